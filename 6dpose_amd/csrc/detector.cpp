@@ -1,0 +1,766 @@
+// libamdlinemod.so — host orchestration + C ABI (include/amd_linemod.h) of the MI355X LINE-MOD
+// detector.  Mirrors linemodLevelup::Detector (LL.cpp:1663-2146): bank bookkeeping and the greedy
+// template extraction on the host, every per-pixel / per-template stage in HIP kernels
+// (frontend.hip, match.hip).  No CPU fallback: creation fails without a HIP device.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/amd_linemod.h"
+#include "host_templates.h"
+#include "lm_kernels.h"
+
+using namespace lm;
+
+// ---- errors -----------------------------------------------------------------------------------
+static thread_local std::string g_err;
+int lm_set_error(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return lm_set_error(LM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                                  __FILE__, __LINE__);                                        \
+    } while (0)
+
+extern "C" const char* lm_last_error(void) { return g_err.c_str(); }
+extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
+extern "C" int lm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" void lm_free(void* p) { free(p); }
+
+// ---- device buffer helper ---------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return LM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return LM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct LevelBufs {
+    int W = 0, H = 0;
+    DevBuf<uint8_t> rgb;      // level>0 only (level 0 aliases the frame)
+    DevBuf<float> mag;
+    DevBuf<uint8_t> ang;      // one-hot quantised orientation (unmasked)
+    DevBuf<uint8_t> nrm;      // one-hot quantised normal (unmasked)
+    DevBuf<uint8_t> mask[2];  // per modality, optional
+};
+
+struct lm_detector {
+    // parameters (LL.cpp:1663-1692 + modality defaults :645-650, :968-974)
+    int num_features = 63;
+    std::vector<int> T_at_level{5, 8};
+    int pyramid_levels = 2;
+    float weak_threshold = 10.0f, strong_threshold = 55.0f;
+    int distance_threshold = 2000, difference_threshold = 50, extract_threshold = 2;
+    TemplatesMap class_templates;
+
+    // device
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int shard_rank = 0, shard_world = 1;
+
+    // frame
+    int fW = 0, fH = 0;
+    bool frame_valid = false, have_mask[2] = {false, false};
+    DevBuf<uint8_t> frame_rgb;
+    DevBuf<uint16_t> frame_depth;
+    DevBuf<uint16_t> tmp16;
+    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena;
+    LevelBufs lvl[kMaxLevels];
+    FrameGeom geom{};
+    size_t lm_block_bytes[kMaxLevels] = {};
+    void* pinned = nullptr;          // staging for H2D frame and D2H results
+    size_t pinned_bytes = 0;
+    float last_h2d_ms = 0.f;
+
+    // bank on device
+    bool bank_dirty = true;
+    int bank_geom_W = -1, bank_geom_H = -1;
+    std::vector<std::string> bank_classes;          // sorted
+    std::vector<int> bank_class_base;               // first flat pyramid index per class
+    std::vector<int> bank_class_count;
+    std::vector<TemplEntry> h_entries;
+    DevBuf<TemplEntry> d_entries;
+    DevBuf<int32_t> d_feat_off;
+    DevBuf<uint32_t> d_feat_xy;
+    // work list
+    std::vector<int32_t> work_pyr, work_cls, work_tid;
+    DevBuf<int32_t> d_work;
+    DevBuf<Candidate> d_cands, d_matches;
+    DevBuf<unsigned long long> d_counters;
+    uint32_t cand_cap = 1u << 20;
+
+    lm_timings timings{};
+};
+
+static int ensure_pinned(lm_detector* d, size_t bytes) {
+    if (bytes <= d->pinned_bytes) return LM_OK;
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    d->pinned = nullptr; d->pinned_bytes = 0;
+    HIP_TRY(hipHostMalloc(&d->pinned, bytes, hipHostMallocDefault));
+    d->pinned_bytes = bytes;
+    return LM_OK;
+}
+
+// NORMAL_LUT plane (normal_lut.i): round(atan2(y-10, x-10)/45deg) mod 8, one-hot (z-independent)
+static void make_normal_lut(uint8_t lut[400]) {
+    const double PI = 3.14159265358979323846;
+    for (int iy = 0; iy < 20; ++iy)
+        for (int ix = 0; ix < 20; ++ix) {
+            double ang = atan2((double)(iy - 10), (double)(ix - 10)) * 180.0 / PI;
+            if (ang < 0) ang += 360.0;
+            int lab = ((int)floor(ang / 45.0 + 0.5)) % 8;
+            lut[iy * 20 + ix] = (uint8_t)(1u << lab);
+        }
+}
+
+extern "C" int lm_detector_create(int num_features, const int* T, int num_levels, int device, lm_detector** out) {
+    if (!out) return lm_set_error(LM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return lm_set_error(LM_ERR_NO_DEVICE, "no HIP device visible (%s); libamdlinemod has no CPU fallback",
+                            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return lm_set_error(LM_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    if (T && (num_levels < 1 || num_levels > kMaxLevels))
+        return lm_set_error(LM_ERR_INVALID, "num_levels must be in 1..%d", kMaxLevels);
+    lm_detector* d = new lm_detector();
+    if (num_features > 0) d->num_features = num_features;
+    if (T) {
+        d->T_at_level.assign(T, T + num_levels);
+        for (int t : d->T_at_level)
+            if (t < 1) { delete d; return lm_set_error(LM_ERR_INVALID, "T must be >= 1"); }
+    }
+    d->pyramid_levels = (int)d->T_at_level.size();
+    d->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete d;
+        return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
+    }
+    for (auto& ev : d->ev) (void)hipEventCreate(&ev);
+    uint8_t lut[400];
+    make_normal_lut(lut);
+    upload_normal_lut(lut);
+    *out = d;
+    return LM_OK;
+}
+
+extern "C" void lm_detector_destroy(lm_detector* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipStreamSynchronize(d->stream);
+    d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
+    d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release();
+    for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
+    d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_work.release();
+    d->d_cands.release(); d->d_matches.release(); d->d_counters.release();
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+// ---- frame upload + front end --------------------------------------------------------------------
+static size_t lm_tail_pad(int Wd, int Hd) {
+    size_t a = (size_t)Wd * Hd, b = (size_t)16 * Wd + 16;
+    return std::max(a, b) + 64;
+}
+
+// (Re)allocates per-level buffers and the LM arena for a W x H frame; validates the reference's
+// preconditions (LL.cpp:1136, 1217-1218).
+static int setup_geometry(lm_detector* d, int W, int H, bool check_match_preconditions) {
+    const int L = d->pyramid_levels;
+    FrameGeom g{};
+    g.levels = L;
+    int w = W, h = H;
+    size_t arena = 0;
+    for (int l = 0; l < L; ++l) {
+        if (l > 0) { w /= 2; h /= 2; }
+        if (w < 1 || h < 1) return lm_set_error(LM_ERR_INVALID, "image too small for %d pyramid levels", L);
+        int T = d->T_at_level[l];
+        if (check_match_preconditions) {
+            if (((long)w * h) % 16 != 0)
+                return lm_set_error(LM_ERR_INVALID, "(src.rows * src.cols) %% 16 == 0 violated at level %d (%dx%d) [LL.cpp:1136]", l, w, h);
+            if (h % T != 0 || w % T != 0)
+                return lm_set_error(LM_ERR_INVALID, "response_map.rows/cols %% T == 0 violated at level %d (%dx%d, T=%d) [LL.cpp:1217-1218]", l, w, h, T);
+        }
+        LevelGeom& lv = g.lv[l];
+        lv.W = w; lv.H = h; lv.T = T; lv.Wd = w / T; lv.Hd = h / T;
+        size_t block = (size_t)8 * T * T * lv.Wd * lv.Hd + lm_tail_pad(lv.Wd, lv.Hd);
+        block = (block + 255) & ~(size_t)255;
+        d->lm_block_bytes[l] = block;
+        for (int m = 0; m < 2; ++m) {
+            if (arena + block > 0xFFFFFFFFull) return lm_set_error(LM_ERR_INVALID, "frame too large for the LM arena");
+            lv.lm_off[m] = (uint32_t)arena;
+            arena += block;
+        }
+    }
+    const size_t n0 = (size_t)W * H;
+    int rc;
+    if ((rc = d->frame_rgb.ensure(n0 * 3))) return rc;
+    if ((rc = d->frame_depth.ensure(n0))) return rc;
+    if ((rc = d->tmp16.ensure(n0 * 3))) return rc;
+    if ((rc = d->smoothed.ensure(n0 * 3))) return rc;
+    if ((rc = d->q16.ensure(n0))) return rc;
+    if ((rc = d->nrm_raw.ensure(n0))) return rc;
+    if ((rc = d->rowor.ensure(n0))) return rc;
+    bool realloc_arena = arena > d->lm_arena.cap;
+    if ((rc = d->lm_arena.ensure(arena))) return rc;
+    if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
+        HIP_TRY(hipMemsetAsync(d->lm_arena.p, 0, d->lm_arena.cap, d->stream));
+    for (int l = 0; l < L; ++l) {
+        LevelBufs& b = d->lvl[l];
+        b.W = g.lv[l].W; b.H = g.lv[l].H;
+        size_t n = (size_t)b.W * b.H;
+        if (l > 0 && (rc = b.rgb.ensure(n * 3))) return rc;
+        if ((rc = b.mag.ensure(n))) return rc;
+        if ((rc = b.ang.ensure(n))) return rc;
+        if ((rc = b.nrm.ensure(n))) return rc;
+    }
+    d->geom = g;
+    d->fW = W; d->fH = H;
+    return LM_OK;
+}
+
+static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int W, int H,
+                        const uint8_t* const* masks, bool check_match_preconditions) {
+    if (!rgb || !depth) return lm_set_error(LM_ERR_INVALID, "rgb/depth is null");
+    if (W < 16 || H < 16 || W > 16384 || H > 16384) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", W, H);
+    HIP_TRY(hipSetDevice(d->device));
+    d->frame_valid = false;
+    int rc = setup_geometry(d, W, H, check_match_preconditions);
+    if (rc) return rc;
+    const size_t n = (size_t)W * H;
+    const bool m0 = masks && masks[0], m1 = masks && masks[1];
+    size_t bytes = n * 3 + n * 2 + (m0 ? n : 0) + (m1 ? n : 0);
+    if ((rc = ensure_pinned(d, bytes))) return rc;
+    uint8_t* st = (uint8_t*)d->pinned;
+    memcpy(st, rgb, n * 3);
+    memcpy(st + n * 3, depth, n * 2);
+    HIP_TRY(hipEventRecord(d->ev[6], d->stream));
+    HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, st, n * 3, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->frame_depth.p, st + n * 3, n * 2, hipMemcpyHostToDevice, d->stream));
+    size_t off = n * 5;
+    for (int m = 0; m < 2; ++m) {
+        d->have_mask[m] = masks && masks[m];
+        if (!d->have_mask[m]) continue;
+        memcpy(st + off, masks[m], n);
+        if ((rc = d->lvl[0].mask[m].ensure(n))) return rc;
+        HIP_TRY(hipMemcpyAsync(d->lvl[0].mask[m].p, st + off, n, hipMemcpyHostToDevice, d->stream));
+        off += n;
+        for (int l = 1; l < d->pyramid_levels; ++l) {       // resize(INTER_NEAREST), LL.cpp:573-578, 874-879
+            const LevelBufs& a = d->lvl[l - 1];
+            LevelBufs& b = d->lvl[l];
+            if ((rc = b.mask[m].ensure((size_t)b.W * b.H))) return rc;
+            launch_nn_down2(a.mask[m].p, b.mask[m].p, a.W, a.H, d->stream);
+        }
+    }
+    HIP_TRY(hipEventRecord(d->ev[7], d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));   // staging buffer is reused by the next call
+    (void)hipEventElapsedTime(&d->last_h2d_ms, d->ev[6], d->ev[7]);
+    d->frame_valid = true;
+    return LM_OK;
+}
+
+// quantise every level; build_lm=false for addTemplate (only the quantised maps are needed)
+static int run_frontend(lm_detector* d, bool build_lm) {
+    hipStream_t s = d->stream;
+    const int L = d->pyramid_levels;
+    const float thr_sq = d->weak_threshold * d->weak_threshold;
+    for (int l = 0; l < L; ++l) {
+        LevelBufs& b = d->lvl[l];
+        const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
+        if (l > 0) {
+            const LevelBufs& a = d->lvl[l - 1];
+            launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
+            launch_nn_down2(a.nrm.p, b.nrm.p, a.W, a.H, s);                                   // LL.cpp:857-880
+        } else {
+            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+                           d->difference_threshold, s);                                       // LL.cpp:729-819
+        }
+        launch_blur7(src, d->tmp16.p, d->smoothed.p, b.W, b.H, s);                            // LL.cpp:367
+        launch_sobel_quant(d->smoothed.p, b.mag.p, d->q16.p, b.W, b.H, s);                    // LL.cpp:368-455
+        launch_hysteresis(d->q16.p, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                   // LL.cpp:457-504
+        if (build_lm) {
+            const LevelGeom& lv = d->geom.lv[l];
+            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[0],
+                            b.W, b.H, lv.T, s);
+            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[1],
+                            b.W, b.H, lv.T, s);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return LM_OK;
+}
+
+// ---- bank -----------------------------------------------------------------------------------------
+static int validate_pyramid(const lm_detector* d, const TemplatePyramid& tp) {
+    if ((int)tp.size() != d->pyramid_levels * 2)
+        return lm_set_error(LM_ERR_INVALID, "template pyramid has %d entries, detector expects %d", (int)tp.size(),
+                            d->pyramid_levels * 2);
+    for (const Template& t : tp) {
+        if (t.features.size() > 8191) return lm_set_error(LM_ERR_INVALID, "templ.features.size() <= 8191 [LL.cpp:1291]");
+        for (const Feature& f : t.features) {
+            if (f.label < 0 || f.label > 7) return lm_set_error(LM_ERR_INVALID, "feature label %d outside [0,8)", f.label);
+            if (f.x < -32768 || f.x > 32767 || f.y < -32768 || f.y > 32767)
+                return lm_set_error(LM_ERR_INVALID, "feature coordinate outside the supported int16 range");
+        }
+    }
+    return LM_OK;
+}
+
+extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, const uint8_t* mask,
+                                        int width, int height, const char* class_id) {
+    if (!d || !class_id) return lm_set_error(LM_ERR_INVALID, "null argument");
+    // quantise() in addTemplate passes object_mask to every modality (LL.cpp:1957), but the masked
+    // quantised image is not used by extractTemplate; only the unmasked maps + the mask are.
+    int rc = upload_frame(d, rgb, depth, width, height, nullptr, false);
+    if (rc) return rc;
+    if ((rc = run_frontend(d, false))) return rc;
+    d->frame_valid = false;   // LM arena not built for this frame
+    const int L = d->pyramid_levels;
+    std::vector<TemplatePyramid>& tps = d->class_templates[class_id];   // created even on failure, LL.cpp:1947
+    d->bank_dirty = true;
+    TemplatePyramid tp((size_t)2 * L);
+    std::vector<uint8_t> hmask, nmask;
+    if (mask) hmask.assign(mask, mask + (size_t)width * height);
+    size_t nf = (size_t)d->num_features;
+    int ext = d->extract_threshold;
+    std::vector<float> mag;
+    std::vector<uint8_t> ang, nrm;
+    for (int l = 0; l < L; ++l) {
+        const LevelBufs& b = d->lvl[l];
+        const size_t n = (size_t)b.W * b.H;
+        if (l > 0) {
+            nf /= 2;            // LL.cpp:560, 860
+            ext /= 2;           // LL.cpp:861
+            if (mask) {         // resize(mask, INTER_NEAREST)
+                const LevelBufs& a = d->lvl[l - 1];
+                nmask.resize(n);
+                for (int y = 0; y < b.H; ++y)
+                    for (int x = 0; x < b.W; ++x) nmask[(size_t)y * b.W + x] = hmask[(size_t)(2 * y) * a.W + 2 * x];
+                hmask.swap(nmask);
+            }
+        }
+        mag.resize(n); ang.resize(n); nrm.resize(n);
+        HIP_TRY(hipMemcpyAsync(mag.data(), b.mag.p, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(ang.data(), b.ang.p, n, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(nrm.data(), b.nrm.p, n, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        const uint8_t* mp = mask ? hmask.data() : nullptr;
+        // reference order is modality-major (LL.cpp:1954-1968); the outcome (-1 on any failure) is the same
+        if (!extract_color_template(mag.data(), ang.data(), mp, b.W, b.H, nf, d->strong_threshold, l, tp[2 * l])) return -1;
+        if (!extract_normal_template(nrm.data(), mp, b.W, b.H, nf, ext, l, tp[2 * l + 1])) return -1;
+    }
+    crop_templates(tp);
+    if ((rc = validate_pyramid(d, tp))) return rc;
+    tps.push_back(std::move(tp));
+    return (int)tps.size() - 1;
+}
+
+extern "C" int lm_detector_read_class(lm_detector* d, const char* path, const char* class_id_override) {
+    if (!d || !path) return lm_set_error(LM_ERR_INVALID, "null argument");
+    std::string cid, err;
+    std::vector<std::string> mods;
+    int levels = 0;
+    std::vector<TemplatePyramid> tps;
+    if (!read_class_yaml(path, cid, mods, levels, tps, err)) {
+        bool assertion = err.find("LL.cpp") != std::string::npos;
+        return lm_set_error(assertion ? LM_ERR_INVALID : LM_ERR_IO, "%s", err.c_str());
+    }
+    if (mods.size() != 2 || mods[0] != "ColorGradient" || mods[1] != "DepthNormal")
+        return lm_set_error(LM_ERR_INVALID, "modalities mismatch [LL.cpp:2047-2051]");
+    if (levels != d->pyramid_levels)
+        return lm_set_error(LM_ERR_INVALID, "(int)fn[\"pyramid_levels\"] == pyramid_levels violated (%d vs %d) [LL.cpp:2052]",
+                            levels, d->pyramid_levels);
+    if (class_id_override && class_id_override[0]) cid = class_id_override;
+    else if (d->class_templates.count(cid))
+        return lm_set_error(LM_ERR_INVALID, "class '%s' already present [LL.cpp:2059]", cid.c_str());
+    for (const TemplatePyramid& tp : tps) { int rc = validate_pyramid(d, tp); if (rc) return rc; }
+    if (!d->class_templates.count(cid)) d->class_templates[cid] = std::move(tps);   // map::insert keeps an existing key
+    d->bank_dirty = true;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_write_class(lm_detector* d, const char* class_id, const char* path) {
+    if (!d || !class_id || !path) return lm_set_error(LM_ERR_INVALID, "null argument");
+    auto it = d->class_templates.find(class_id);
+    if (it == d->class_templates.end()) return lm_set_error(LM_ERR_NOT_FOUND, "unknown class '%s' [LL.cpp:2096]", class_id);
+    std::string err;
+    if (!write_class_yaml(path, it->first, it->second, d->pyramid_levels, err)) return lm_set_error(LM_ERR_IO, "%s", err.c_str());
+    return LM_OK;
+}
+
+extern "C" int lm_detector_add_class_packed(lm_detector* d, const char* class_id, int num_pyramids, const int32_t* features,
+                                            const int32_t* tmpl_offsets, const int32_t* tmpl_wh) {
+    if (!d || !class_id || num_pyramids < 0 || (num_pyramids && (!features || !tmpl_offsets || !tmpl_wh)))
+        return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (d->class_templates.count(class_id)) return lm_set_error(LM_ERR_INVALID, "class '%s' already present", class_id);
+    const int E = d->pyramid_levels * 2;
+    std::vector<TemplatePyramid> tps((size_t)num_pyramids);
+    for (int p = 0; p < num_pyramids; ++p) {
+        TemplatePyramid& tp = tps[p];
+        tp.resize(E);
+        for (int e = 0; e < E; ++e) {
+            size_t k = (size_t)p * E + e;
+            Template& t = tp[e];
+            t.width = tmpl_wh[2 * k]; t.height = tmpl_wh[2 * k + 1]; t.pyramid_level = e / 2;
+            int a = tmpl_offsets[k], b = tmpl_offsets[k + 1];
+            if (a < 0 || b < a) return lm_set_error(LM_ERR_INVALID, "tmpl_offsets not monotone");
+            t.features.resize((size_t)(b - a));
+            for (int i = a; i < b; ++i) t.features[i - a] = Feature{features[3 * (size_t)i], features[3 * (size_t)i + 1], features[3 * (size_t)i + 2]};
+        }
+        int rc = validate_pyramid(d, tp);
+        if (rc) return rc;
+    }
+    d->class_templates[class_id] = std::move(tps);
+    d->bank_dirty = true;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_num_classes(const lm_detector* d) { return d ? (int)d->class_templates.size() : 0; }
+extern "C" const char* lm_detector_class_id(const lm_detector* d, int index) {
+    if (!d || index < 0 || index >= (int)d->class_templates.size()) return nullptr;
+    auto it = d->class_templates.begin();
+    std::advance(it, index);
+    return it->first.c_str();
+}
+extern "C" int lm_detector_num_templates(const lm_detector* d, const char* class_id) {
+    if (!d) return 0;
+    if (!class_id) { int n = 0; for (auto& kv : d->class_templates) n += (int)kv.second.size(); return n; }
+    auto it = d->class_templates.find(class_id);
+    return it == d->class_templates.end() ? 0 : (int)it->second.size();
+}
+extern "C" int lm_detector_pyramid_levels(const lm_detector* d) { return d ? d->pyramid_levels : 0; }
+extern "C" int lm_detector_get_T(const lm_detector* d, int level) {
+    return (d && level >= 0 && level < d->pyramid_levels) ? d->T_at_level[level] : -1;
+}
+
+extern "C" int lm_detector_get_template(const lm_detector* d, const char* class_id, int template_id, int index, int32_t* width,
+                                        int32_t* height, int32_t* pyramid_level, int32_t* num_features, int32_t* features,
+                                        int capacity) {
+    if (!d || !class_id) return lm_set_error(LM_ERR_INVALID, "null argument");
+    auto it = d->class_templates.find(class_id);
+    if (it == d->class_templates.end()) return lm_set_error(LM_ERR_NOT_FOUND, "unknown class '%s' [LL.cpp:1979]", class_id);
+    if (template_id < 0 || (size_t)template_id >= it->second.size())
+        return lm_set_error(LM_ERR_INVALID, "template_id out of range [LL.cpp:1980]");
+    const TemplatePyramid& tp = it->second[template_id];
+    if (index < 0 || index >= (int)tp.size()) return lm_set_error(LM_ERR_INVALID, "template index out of range");
+    const Template& t = tp[index];
+    if (width) *width = t.width;
+    if (height) *height = t.height;
+    if (pyramid_level) *pyramid_level = t.pyramid_level;
+    if (num_features) *num_features = (int32_t)t.features.size();
+    if (features)
+        for (int i = 0; i < capacity && i < (int)t.features.size(); ++i) {
+            features[3 * i] = t.features[i].x; features[3 * i + 1] = t.features[i].y; features[3 * i + 2] = t.features[i].label;
+        }
+    return LM_OK;
+}
+
+extern "C" int lm_detector_set_shard(lm_detector* d, int rank, int world) {
+    if (!d || world < 1 || rank < 0 || rank >= world) return lm_set_error(LM_ERR_INVALID, "bad shard (%d of %d)", rank, world);
+    d->shard_rank = rank; d->shard_world = world;
+    return LM_OK;
+}
+
+static inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+// Flatten the bank for the current frame geometry and upload it: TemplEntry per (pyramid, level),
+// per feature the signed byte offset of its linear-memory run (accessLinearMemory, LL.cpp:1248-1271)
+// and packed int16 x,y.
+static int upload_bank(lm_detector* d) {
+    const int L = d->pyramid_levels;
+    d->bank_classes.clear(); d->bank_class_base.clear(); d->bank_class_count.clear();
+    d->h_entries.clear();
+    std::vector<int32_t> off;
+    std::vector<uint32_t> xy;
+    int flat = 0;
+    for (auto& kv : d->class_templates) {
+        d->bank_classes.push_back(kv.first);
+        d->bank_class_base.push_back(flat);
+        d->bank_class_count.push_back((int)kv.second.size());
+        for (const TemplatePyramid& tp : kv.second) {
+            for (int l = 0; l < L; ++l) {
+                const LevelGeom& lv = d->geom.lv[l];
+                const long npos = (long)lv.Wd * lv.Hd;
+                TemplEntry e{};
+                e.feat_start = (uint32_t)off.size();
+                e.n0 = (uint16_t)tp[2 * l].features.size();
+                e.n1 = (uint16_t)tp[2 * l + 1].features.size();
+                e.width = tp[2 * l].width;      // matchClass uses tp[start] (first modality) for the clamp,
+                e.height = tp[2 * l].height;    // similarity() each template's own size: checked equal below
+                if (tp[2 * l + 1].width != e.width || tp[2 * l + 1].height != e.height)
+                    return lm_set_error(LM_ERR_INVALID, "modalities of one pyramid level disagree on width/height");
+                for (int m = 0; m < 2; ++m)
+                    for (const Feature& f : tp[2 * l + m].features) {
+                        int T = lv.T;
+                        int gx = f.x - floordiv(f.x, T) * T, gy = f.y - floordiv(f.y, T) * T;   // floor modulo
+                        long o = ((long)f.label * T * T + (gy * T + gx)) * npos + (long)floordiv(f.y, T) * lv.Wd + floordiv(f.x, T);
+                        if (o < -(1L << 30) || o > (1L << 30)) return lm_set_error(LM_ERR_INVALID, "feature offset overflow");
+                        off.push_back((int32_t)o);
+                        xy.push_back((uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16));
+                    }
+                d->h_entries.push_back(e);
+            }
+            ++flat;
+        }
+    }
+    int rc;
+    if ((rc = d->d_entries.ensure(std::max<size_t>(1, d->h_entries.size())))) return rc;
+    if ((rc = d->d_feat_off.ensure(std::max<size_t>(1, off.size())))) return rc;
+    if ((rc = d->d_feat_xy.ensure(std::max<size_t>(1, xy.size())))) return rc;
+    if (!d->h_entries.empty())
+        HIP_TRY(hipMemcpy(d->d_entries.p, d->h_entries.data(), d->h_entries.size() * sizeof(TemplEntry), hipMemcpyHostToDevice));
+    if (!off.empty()) {
+        HIP_TRY(hipMemcpy(d->d_feat_off.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_feat_xy.p, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    d->bank_dirty = false;
+    d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
+    return LM_OK;
+}
+
+// ---- canonical merge (LL.cpp:1771-1776 with the total order of SURVEY A12) ---------------------------
+static bool match_less(const lm_match& a, const lm_match& b) {
+    if (a.similarity != b.similarity) return a.similarity > b.similarity;
+    if (a.template_id != b.template_id) return a.template_id < b.template_id;
+    if (a.class_index != b.class_index) return a.class_index < b.class_index;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+}
+static bool match_eq(const lm_match& a, const lm_match& b) {   // Match::operator== (LL.h:243-246)
+    return a.x == b.x && a.y == b.y && a.similarity == b.similarity && a.class_index == b.class_index;
+}
+extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
+    if (!m || n == 0) return 0;
+    std::sort(m, m + n, match_less);
+    return (size_t)(std::unique(m, m + n, match_eq) - m);
+}
+
+// numpy nms of the driver (linemod_and_levelup_test.py:34-61)
+extern "C" int lm_nms_boxes(const double* boxes, const double* scores, int n, double thresh, int32_t* keep) {
+    if (n <= 0 || !boxes || !scores || !keep) return 0;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    // scores.argsort()[::-1]: ascending stable-ish sort reversed -> among equal scores higher index first
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] < scores[b]; });
+    std::reverse(order.begin(), order.end());
+    std::vector<char> dead((size_t)n, 0);
+    int kept = 0;
+    for (int oi = 0; oi < n; ++oi) {
+        int i = order[oi];
+        if (dead[i]) continue;
+        keep[kept++] = i;
+        double ai = (boxes[4 * i + 2] - boxes[4 * i] + 1) * (boxes[4 * i + 3] - boxes[4 * i + 1] + 1);
+        for (int oj = oi + 1; oj < n; ++oj) {
+            int j = order[oj];
+            if (dead[j]) continue;
+            double xx1 = std::max(boxes[4 * i], boxes[4 * j]), yy1 = std::max(boxes[4 * i + 1], boxes[4 * j + 1]);
+            double xx2 = std::min(boxes[4 * i + 2], boxes[4 * j + 2]), yy2 = std::min(boxes[4 * i + 3], boxes[4 * j + 3]);
+            double w = std::max(0.0, xx2 - xx1 + 1), h = std::max(0.0, yy2 - yy1 + 1);
+            double inter = w * h;
+            double aj = (boxes[4 * j + 2] - boxes[4 * j] + 1) * (boxes[4 * j + 3] - boxes[4 * j + 1] + 1);
+            double ovr = inter / (ai + aj - inter);
+            if (!(ovr <= thresh)) dead[j] = 1;
+        }
+    }
+    return kept;
+}
+
+// ---- match ----------------------------------------------------------------------------------------
+extern "C" int lm_detector_set_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int width, int height,
+                                     const uint8_t* const* masks) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    return upload_frame(d, rgb, depth, width, height, masks, true);
+}
+
+static int build_work(lm_detector* d, const char* const* class_ids, int num_class_ids) {
+    d->work_pyr.clear(); d->work_cls.clear(); d->work_tid.clear();
+    std::vector<int> order;   // bank class index per position (-1 unknown)
+    if (!class_ids || num_class_ids <= 0) {
+        for (size_t i = 0; i < d->bank_classes.size(); ++i) order.push_back((int)i);   // std::map order, LL.cpp:1756
+    } else {
+        for (int i = 0; i < num_class_ids; ++i) {
+            int found = -1;
+            if (class_ids[i])
+                for (size_t k = 0; k < d->bank_classes.size(); ++k)
+                    if (d->bank_classes[k] == class_ids[i]) { found = (int)k; break; }
+            order.push_back(found);   // unknown classes are skipped, LL.cpp:1765-1767
+        }
+    }
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        int k = order[pos];
+        if (k < 0) continue;
+        for (int t = 0; t < d->bank_class_count[k]; ++t) {
+            d->work_pyr.push_back(d->bank_class_base[k] + t);
+            d->work_cls.push_back((int)pos);
+            d->work_tid.push_back(t);
+        }
+    }
+    // contiguous shard of the work list; template ids stay global
+    const long N = (long)d->work_pyr.size();
+    const long a = N * d->shard_rank / d->shard_world, b = N * (d->shard_rank + 1) / d->shard_world;
+    if (d->shard_world > 1) {
+        d->work_pyr = std::vector<int32_t>(d->work_pyr.begin() + a, d->work_pyr.begin() + b);
+        d->work_cls = std::vector<int32_t>(d->work_cls.begin() + a, d->work_cls.begin() + b);
+        d->work_tid = std::vector<int32_t>(d->work_tid.begin() + a, d->work_tid.begin() + b);
+    }
+    int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
+    if (rc) return rc;
+    if (!d->work_pyr.empty())
+        HIP_TRY(hipMemcpyAsync(d->d_work.p, d->work_pyr.data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    return LM_OK;
+}
+
+extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids,
+                                          int sort_unique, lm_match** out, size_t* n_out) {
+    if (!d || !out || !n_out) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *out = nullptr; *n_out = 0;
+    if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame first");
+    HIP_TRY(hipSetDevice(d->device));
+    int rc;
+    if (d->bank_dirty || d->bank_geom_W != d->fW || d->bank_geom_H != d->fH)
+        if ((rc = upload_bank(d))) return rc;
+    if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
+    const int num_work = (int)d->work_pyr.size();
+    if ((rc = d->d_counters.ensure(8))) return rc;
+    if ((rc = ensure_pinned(d, 4096))) return rc;
+    hipStream_t s = d->stream;
+    lm_timings tm{};
+    tm.h2d_ms = d->last_h2d_ms;
+    tm.templates = num_work;
+
+    HIP_TRY(hipEventRecord(d->ev[0], s));
+    if ((rc = run_frontend(d, true))) return rc;
+    HIP_TRY(hipEventRecord(d->ev[1], s));
+
+    unsigned long long* hc = (unsigned long long*)d->pinned;
+    uint64_t ncand = 0;
+    for (;;) {   // grow-and-rerun on candidate overflow: never drop silently
+        if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+        HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), s));
+        launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, num_work,
+                      threshold, d->d_cands.p, d->cand_cap, d->d_counters.p, s);
+        HIP_TRY(hipEventRecord(d->ev[2], s));
+        HIP_TRY(hipMemcpyAsync(hc, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        ncand = hc[0];
+        if (ncand <= d->cand_cap) break;
+        if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
+        d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024);
+    }
+    if ((rc = d->d_matches.ensure(std::max<size_t>(1, (size_t)ncand)))) return rc;
+    HIP_TRY(hipEventRecord(d->ev[3], s));
+    launch_local(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
+                 (uint32_t)ncand, threshold, d->d_matches.p, (uint32_t)std::max<uint64_t>(1, ncand), d->d_counters.p, s);
+    HIP_TRY(hipEventRecord(d->ev[4], s));
+    HIP_TRY(hipMemcpyAsync(hc, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    const size_t nm = (size_t)hc[1];
+    tm.coarse_candidates = (int64_t)ncand;
+    tm.local_evals = (int64_t)hc[2];
+    tm.local_bytes = (int64_t)hc[3];
+    tm.matches_pre_unique = (int64_t)nm;
+    std::vector<Candidate> hm(nm);
+    if (nm) HIP_TRY(hipMemcpyAsync(hm.data(), d->d_matches.p, nm * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(d->ev[5], s));
+    HIP_TRY(hipStreamSynchronize(s));
+
+    (void)hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]);
+    (void)hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]);
+    (void)hipEventElapsedTime(&tm.local_ms, d->ev[3], d->ev[4]);
+    (void)hipEventElapsedTime(&tm.d2h_ms, d->ev[4], d->ev[5]);
+    (void)hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[5]);
+    // algorithmic bytes of the coarse pass: sum_m nfeat_m * template_positions
+    {
+        const int L = d->pyramid_levels;
+        const LevelGeom& lv = d->geom.lv[L - 1];
+        int64_t bytes = 0;
+        for (int w = 0; w < num_work; ++w) {
+            const TemplEntry& e = d->h_entries[(size_t)d->work_pyr[w] * L + (L - 1)];
+            int wf = (e.width - 1) / lv.T + 1, hf = (e.height - 1) / lv.T + 1;
+            long tp = (long)(lv.Hd - hf) * lv.Wd + (lv.Wd - wf) + 1;
+            if (tp > 0) bytes += (int64_t)(e.n0 + e.n1) * tp;
+        }
+        tm.coarse_bytes = bytes;
+    }
+    d->timings = tm;
+
+    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, nm) * sizeof(lm_match));
+    if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
+    for (size_t i = 0; i < nm; ++i) {
+        const Candidate& c = hm[i];
+        res[i].x = c.x; res[i].y = c.y; res[i].similarity = c.score;
+        res[i].class_index = d->work_cls[c.work];
+        res[i].template_id = d->work_tid[c.work];
+    }
+    size_t n = nm;
+    if (sort_unique) n = lm_merge_matches(res, nm);
+    *out = res; *n_out = n;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_match(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int width, int height, float threshold,
+                                 const char* const* class_ids, int num_class_ids, const uint8_t* const* masks, lm_match** out,
+                                 size_t* n) {
+    int rc = lm_detector_set_frame(d, rgb, depth, width, height, masks);
+    if (rc) return rc;
+    return lm_detector_match_resident(d, threshold, class_ids, num_class_ids, 1, out, n);
+}
+
+extern "C" int lm_detector_last_timings(const lm_detector* d, lm_timings* t) {
+    if (!d || !t) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *t = d->timings;
+    return LM_OK;
+}
+
+extern "C" int64_t lm_detector_read_stage(lm_detector* d, int level, int kind, uint8_t* dst, int64_t capacity) {
+    if (!d || level < 0 || level >= d->pyramid_levels || kind < 0 || kind > 3) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (d->fW <= 0) return lm_set_error(LM_ERR_INVALID, "no frame processed yet");
+    const LevelBufs& b = d->lvl[level];
+    const LevelGeom& lv = d->geom.lv[level];
+    const uint8_t* src = nullptr;
+    int64_t size = 0;
+    switch (kind) {
+        case 0: src = b.ang.p; size = (int64_t)b.W * b.H; break;
+        case 1: src = b.nrm.p; size = (int64_t)b.W * b.H; break;
+        case 2: src = d->lm_arena.p + lv.lm_off[0]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+        default: src = d->lm_arena.p + lv.lm_off[1]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+    }
+    if (dst && capacity > 0) {
+        if (hipSetDevice(d->device) != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipSetDevice failed");
+        (void)hipStreamSynchronize(d->stream);
+        hipError_t e = hipMemcpy(dst, src, (size_t)std::min(size, capacity), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    return size;
+}

@@ -1,0 +1,53 @@
+// Internal interface between the host orchestration (detector.cpp, pose_refine.cpp) and the HIP
+// kernels (frontend.hip, match.hip, icp.hip).  gfx950 only.  Not part of the public C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lm {
+
+// ---- front end (frontend.hip): reference A1-A7, LL.cpp:350-505, 557-581, 729-880, 1026-1243 ----
+void upload_normal_lut(const uint8_t lut400[400]);
+void launch_blur7(const uint8_t* rgb, uint16_t* tmp, uint8_t* smoothed, int W, int H, hipStream_t s);
+void launch_sobel_quant(const uint8_t* smoothed, float* mag, uint8_t* q16, int W, int H, hipStream_t s);
+void launch_hysteresis(const uint8_t* q16, const float* mag, uint8_t* onehot, int W, int H, float thr_sq,
+                       hipStream_t s);
+void launch_pyrdown_rgb(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s);  // dst (W/2,H/2)
+void launch_normals(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr,
+                    hipStream_t s);
+void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s);     // dst (W/2,H/2)
+// spread (T x T OR) -> 8 response maps -> linearised layout LM[8][T*T][(W/T)*(H/T)]; mask may be null
+void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, int W, int H, int T,
+                     hipStream_t s);
+
+// ---- matching (match.hip): reference A8-A11, LL.cpp:1284-1428, 1788-1941 ----
+struct LevelGeom {        // one pyramid level of the current frame
+    int W, H, T, Wd, Hd;  // image size, sampling step, decimated size
+    uint32_t lm_off[2];   // byte offset of the colour / normal LM block inside the LM arena
+};
+constexpr int kMaxLevels = 8;
+struct FrameGeom {
+    int levels;
+    LevelGeom lv[kMaxLevels];
+};
+struct TemplEntry {       // one (pyramid, level): both modalities
+    uint32_t feat_start;  // index into the resolved-feature arrays
+    uint16_t n0, n1;      // colour / normal feature counts
+    int32_t width, height;
+};
+struct Candidate {        // coarse hit, and (same layout) final match record
+    int32_t x, y;
+    float score;
+    int32_t work;         // index into the work list (-> class position, template id)
+};
+
+// counters[0] = number of candidates produced (may exceed cap: nothing is written past cap).
+void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                   const uint32_t* feat_xy, const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
+                   unsigned long long* counters, hipStream_t s);
+// counters[1] = number of matches produced, counters[2] = 16x16 evaluations, counters[3] = their bytes.
+void launch_local(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t num_cands,
+                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, hipStream_t s);
+
+}  // namespace lm

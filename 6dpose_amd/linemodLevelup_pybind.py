@@ -1,0 +1,453 @@
+"""Drop-in replacement for the reference's pybind11 module `linemodLevelup_pybind`
+(/root/reference/linemodLevelup/pybind11.cpp:7-35) on AMD Instinct MI355X.
+
+Same classes, method names, positional order and keywords as the reference binding:
+
+    Detector(), Detector(T), Detector(num_features, T)            pybind11.cpp:26-28
+      .addTemplate(sources, class_id, object_mask) -> int          :29   (LL.cpp:1943)
+      .writeClasses(format) / .readClasses(class_ids, format)      :30-31 (LL.cpp:2124-2146)
+      .match(sources, threshold, class_ids, masks=[]) -> [Match]   :32-33 (LL.cpp:1702)
+      .getTemplates(class_id, template_id)                         :34   (LL.cpp:1976)
+    Match(): x, y, similarity, class_id, template_id               :16-22 (LL.h:225-258)
+    poseRefine(): process(...), getResidual(), getR(), getT()      :9-14  (LL.cpp:27-170)
+
+Everything numeric happens in libamdlinemod.so (hand-written HIP kernels for gfx950 behind the C ABI
+of include/amd_linemod.h), reached through ctypes.  There is no CPU fallback: importing works
+anywhere (so that host-side code can be unit-tested), but constructing a Detector or calling
+poseRefine.process without the library or without a GPU raises RuntimeError.
+
+Errors: the reference turns CV_Assert failures into Python RuntimeError (cv::Exception through
+pybind11's default translator); this module raises RuntimeError with the message of
+lm_last_error() for the same preconditions.  addTemplate keeps the -1 convention, poseRefine the
+residual == -1 convention.
+
+Array conventions (np2mat/ndarray_converter.cpp:159-336 is zero-copy and never checks dtypes, so a
+float depth image is silently reinterpreted — driver comment linemod_and_levelup_test.py:117):
+this wrapper validates instead: sources = [rgb uint8 HxWx3, depth uint16 HxW]; other dtypes raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import gzip
+import os
+import shutil
+import tempfile
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+__all__ = ["Detector", "Match", "poseRefine", "Template", "library_path", "load_library", "nms"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libamdlinemod.so"
+_lib = None
+
+
+class _CMatch(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("similarity", ctypes.c_float),
+                ("class_index", ctypes.c_int32), ("template_id", ctypes.c_int32)]
+
+
+class Timings(ctypes.Structure):
+    """lm_timings (include/amd_linemod.h)."""
+    _fields_ = [("h2d_ms", ctypes.c_float), ("frontend_ms", ctypes.c_float), ("coarse_ms", ctypes.c_float),
+                ("local_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("coarse_candidates", ctypes.c_int64), ("local_evals", ctypes.c_int64),
+                ("matches_pre_unique", ctypes.c_int64), ("templates", ctypes.c_int64),
+                ("coarse_bytes", ctypes.c_int64), ("local_bytes", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _CPoseResult(ctypes.Structure):
+    _fields_ = [("R", ctypes.c_double * 9), ("t", ctypes.c_double * 3), ("residual", ctypes.c_float),
+                ("inlier_rmse", ctypes.c_float), ("iterations", ctypes.c_int32), ("n_source", ctypes.c_int32),
+                ("n_target", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+MATCH_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("similarity", np.float32),
+                        ("class_index", np.int32), ("template_id", np.int32)])
+LM_ICP_SCENE_FROM_SCENE = 1
+
+
+def library_path() -> str:
+    return os.environ.get("AMD_LINEMOD_LIB", os.path.join(_HERE, _LIB_NAME))
+
+
+def load_library():
+    """Loads libamdlinemod.so and declares the C ABI.  Raises RuntimeError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    S = ctypes.c_char_p
+    lib.lm_last_error.restype = S
+    lib.lm_version.restype = S
+    lib.lm_device_count.restype = I
+    lib.lm_detector_create.argtypes = [I, ctypes.POINTER(I), I, I, ctypes.POINTER(P)]
+    lib.lm_detector_destroy.argtypes = [P]
+    lib.lm_detector_destroy.restype = None
+    lib.lm_detector_add_template.argtypes = [P, P, P, P, I, I, S]
+    lib.lm_detector_read_class.argtypes = [P, S, S]
+    lib.lm_detector_write_class.argtypes = [P, S, S]
+    lib.lm_detector_add_class_packed.argtypes = [P, S, I, P, P, P]
+    lib.lm_detector_num_classes.argtypes = [P]
+    lib.lm_detector_class_id.argtypes = [P, I]
+    lib.lm_detector_class_id.restype = S
+    lib.lm_detector_num_templates.argtypes = [P, S]
+    lib.lm_detector_pyramid_levels.argtypes = [P]
+    lib.lm_detector_get_T.argtypes = [P, I]
+    lib.lm_detector_get_template.argtypes = [P, S, I, I, P, P, P, P, P, I]
+    lib.lm_detector_set_shard.argtypes = [P, I, I]
+    lib.lm_detector_match.argtypes = [P, P, P, I, I, F, ctypes.POINTER(S), I, ctypes.POINTER(P),
+                                      ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
+    lib.lm_detector_set_frame.argtypes = [P, P, P, I, I, ctypes.POINTER(P)]
+    lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
+                                               ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
+    lib.lm_detector_last_timings.argtypes = [P, ctypes.POINTER(Timings)]
+    lib.lm_detector_read_stage.argtypes = [P, I, I, P, ctypes.c_int64]
+    lib.lm_detector_read_stage.restype = ctypes.c_int64
+    lib.lm_merge_matches.argtypes = [P, ctypes.c_size_t]
+    lib.lm_merge_matches.restype = ctypes.c_size_t
+    lib.lm_nms_boxes.argtypes = [P, P, I, ctypes.c_double, P]
+    lib.lm_free.argtypes = [P]
+    lib.lm_free.restype = None
+    lib.lm_pose_refine.argtypes = [I, P, P, I, I, P, P, P, P, I, I, I, ctypes.POINTER(_CPoseResult)]
+    lib.lm_pose_refine_batch.argtypes = [I, P, I, I, P, I, ctypes.POINTER(P), P, P, P, P, I,
+                                         ctypes.POINTER(_CPoseResult), ctypes.POINTER(F)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise RuntimeError(load_library().lm_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as_rgb(a) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise RuntimeError("sources[0] must be a uint8 HxWx3 image (got %s %s)" % (a.dtype, a.shape))
+    return np.ascontiguousarray(a)
+
+
+def _as_depth(a, what="sources[1]") -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint16 or a.ndim != 2:
+        raise RuntimeError("%s must be a uint16 HxW depth image in mm (got %s %s); the reference would "
+                           "silently reinterpret the bytes" % (what, a.dtype, a.shape))
+    return np.ascontiguousarray(a)
+
+
+def _as_mask(a, shape) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    a = np.asarray(a)
+    if a.size == 0:
+        return None
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8)
+    if a.dtype != np.uint8 or a.shape != tuple(shape):
+        raise RuntimeError("mask.empty() || mask.size() == source.size() [LL.cpp:1717] (got %s %s)" % (a.dtype, a.shape))
+    return np.ascontiguousarray(a)
+
+
+class Match:
+    """linemodLevelup::Match (LL.h:225-258, pybind11.cpp:16-22)."""
+    __slots__ = ("x", "y", "similarity", "class_id", "template_id")
+
+    def __init__(self, x: int = 0, y: int = 0, similarity: float = 0.0, class_id: str = "", template_id: int = 0):
+        self.x, self.y, self.similarity, self.class_id, self.template_id = x, y, similarity, class_id, template_id
+
+    def __repr__(self):
+        return "Match(x=%d, y=%d, similarity=%r, class_id=%r, template_id=%d)" % (
+            self.x, self.y, self.similarity, self.class_id, self.template_id)
+
+
+class Template:
+    """linemodLevelup::Template (LL.h:36-45); features is an (N,3) int32 array of x,y,label."""
+    __slots__ = ("width", "height", "pyramid_level", "features")
+
+    def __init__(self, width, height, pyramid_level, features):
+        self.width, self.height, self.pyramid_level, self.features = width, height, pyramid_level, features
+
+
+class Detector:
+    """linemodLevelup::Detector (LL.h:264-375) running on one MI355X."""
+
+    def __init__(self, *args, device: Optional[int] = None):
+        lib = load_library()
+        num_features, T = 0, None
+        if len(args) == 1:
+            T = [int(t) for t in args[0]]                          # Detector(std::vector<int> T)
+        elif len(args) == 2:
+            num_features, T = int(args[0]), [int(t) for t in args[1]]   # Detector(int, std::vector<int>)
+        elif len(args) != 0:
+            raise TypeError("Detector(), Detector(T) or Detector(num_features, T)")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if lib.lm_device_count() > 1 else 0
+        self._h = ctypes.c_void_p()
+        Tarr = (ctypes.c_int * len(T))(*T) if T is not None else None
+        _check(lib.lm_detector_create(num_features, Tarr, len(T) if T is not None else 0, device, ctypes.byref(self._h)))
+        self._lib = lib
+        self.device = device
+        self._shard = (0, 1)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value and getattr(self, "_lib", None) is not None:
+            self._lib.lm_detector_destroy(h)
+
+    # ---- training -------------------------------------------------------------------------------
+    def addTemplate(self, sources: Sequence[np.ndarray], class_id: str, object_mask: np.ndarray) -> int:
+        if len(sources) != 2:
+            raise RuntimeError("sources.size() == modalities.size() [LL.cpp:1707]")
+        rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        if rgb.shape[:2] != depth.shape:
+            raise RuntimeError("rgb and depth sizes differ")
+        mask = _as_mask(object_mask, depth.shape)
+        rc = self._lib.lm_detector_add_template(self._h, _ptr(rgb), _ptr(depth), _ptr(mask), depth.shape[1], depth.shape[0],
+                                                class_id.encode())
+        if rc < -1:
+            _check(rc)
+        return rc
+
+    def writeClasses(self, format: str) -> None:
+        for cid in self.classIds():
+            _check(self._lib.lm_detector_write_class(self._h, cid.encode(), (format % cid).encode()))
+
+    def readClasses(self, class_ids: Sequence[str], format: str) -> None:
+        for cid in class_ids:
+            path = format % cid
+            if path.endswith(".gz"):                        # FileStorage reads .gz transparently
+                with tempfile.NamedTemporaryFile(suffix=".yaml", delete=False) as tmp, gzip.open(path, "rb") as src:
+                    shutil.copyfileobj(src, tmp)
+                try:
+                    _check(self._lib.lm_detector_read_class(self._h, tmp.name.encode(), None))
+                finally:
+                    os.unlink(tmp.name)
+            else:
+                _check(self._lib.lm_detector_read_class(self._h, path.encode(), None))
+
+    def addClassPacked(self, class_id: str, features: np.ndarray, tmpl_offsets: np.ndarray, tmpl_wh: np.ndarray) -> None:
+        """Bulk import (lm_detector_add_class_packed): the binary bank path for >=16k templates."""
+        features = np.ascontiguousarray(features, np.int32).reshape(-1, 3)
+        tmpl_offsets = np.ascontiguousarray(tmpl_offsets, np.int32)
+        tmpl_wh = np.ascontiguousarray(tmpl_wh, np.int32).reshape(-1, 2)
+        E = 2 * self.pyramidLevels()
+        if (len(tmpl_offsets) - 1) % E or len(tmpl_wh) != len(tmpl_offsets) - 1:
+            raise RuntimeError("packed bank arrays have inconsistent sizes")
+        _check(self._lib.lm_detector_add_class_packed(self._h, class_id.encode(), (len(tmpl_offsets) - 1) // E,
+                                                      _ptr(features), _ptr(tmpl_offsets), _ptr(tmpl_wh)))
+
+    # ---- queries --------------------------------------------------------------------------------
+    def classIds(self) -> List[str]:
+        return [self._lib.lm_detector_class_id(self._h, i).decode() for i in range(self._lib.lm_detector_num_classes(self._h))]
+
+    def numClasses(self) -> int:
+        return self._lib.lm_detector_num_classes(self._h)
+
+    def numTemplates(self, class_id: Optional[str] = None) -> int:
+        return self._lib.lm_detector_num_templates(self._h, None if class_id is None else class_id.encode())
+
+    def pyramidLevels(self) -> int:
+        return self._lib.lm_detector_pyramid_levels(self._h)
+
+    def getT(self, level: int) -> int:
+        return self._lib.lm_detector_get_T(self._h, level)
+
+    def getTemplates(self, class_id: str, template_id: int) -> List[Template]:
+        out = []
+        for idx in range(2 * self.pyramidLevels()):
+            w, h, lvl, n = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            _check(self._lib.lm_detector_get_template(self._h, class_id.encode(), template_id, idx, ctypes.byref(w), ctypes.byref(h),
+                                                      ctypes.byref(lvl), ctypes.byref(n), None, 0))
+            feats = np.zeros((n.value, 3), np.int32)
+            _check(self._lib.lm_detector_get_template(self._h, class_id.encode(), template_id, idx, None, None, None, None,
+                                                      _ptr(feats), n.value))
+            out.append(Template(w.value, h.value, lvl.value, feats))
+        return out
+
+    # ---- matching -------------------------------------------------------------------------------
+    def setShard(self, rank: int, world: int) -> None:
+        """This process searches slice `rank` of `world` of the selected template pyramids."""
+        _check(self._lib.lm_detector_set_shard(self._h, rank, world))
+        self._shard = (rank, world)
+
+    def _class_args(self, class_ids):
+        ids = [c for c in (class_ids or [])]
+        arr = (ctypes.c_char_p * len(ids))(*[c.encode() for c in ids]) if ids else None
+        names = ids if ids else self.classIds()
+        return arr, len(ids), names
+
+    def _mask_args(self, masks, shape):
+        if masks is None or len(masks) == 0:
+            return None, []
+        if len(masks) != 2:
+            raise RuntimeError("masks.size() == modalities.size() [LL.cpp:1714]")
+        keep = [_as_mask(m, shape) for m in masks]
+        arr = (ctypes.c_void_p * 2)(*[None if m is None else m.ctypes.data for m in keep])
+        return arr, keep
+
+    def setFrame(self, sources, masks=()) -> None:
+        rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        if rgb.shape[:2] != depth.shape:
+            raise RuntimeError("rgb and depth sizes differ")
+        marr, keep = self._mask_args(masks, depth.shape)
+        _check(self._lib.lm_detector_set_frame(self._h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], marr))
+
+    def matchResident(self, threshold: float, class_ids: Sequence[str] = (), sort_unique: bool = True) -> np.ndarray:
+        """Front end + matching on the frame uploaded by setFrame(); returns MATCH_DTYPE records."""
+        carr, n, _names = self._class_args(class_ids)
+        out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
+        _check(self._lib.lm_detector_match_resident(self._h, float(threshold), carr, n, 1 if sort_unique else 0,
+                                                    ctypes.byref(out), ctypes.byref(cnt)))
+        return self._take(out, cnt.value)
+
+    def _take(self, out, n) -> np.ndarray:
+        try:
+            if n == 0:
+                return np.zeros(0, MATCH_DTYPE)
+            buf = ctypes.string_at(out, n * ctypes.sizeof(_CMatch))
+            return np.frombuffer(buf, MATCH_DTYPE).copy()
+        finally:
+            self._lib.lm_free(out)
+
+    def matchArray(self, sources, threshold: float, class_ids: Sequence[str] = (), masks=()) -> np.ndarray:
+        """match() returning a structured array (class_index refers to class_ids / sorted classIds())."""
+        if len(sources) != 2:
+            raise RuntimeError("sources.size() == modalities.size() [LL.cpp:1707]")
+        rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        if rgb.shape[:2] != depth.shape:
+            raise RuntimeError("rgb and depth sizes differ")
+        carr, n, _names = self._class_args(class_ids)
+        marr, keep = self._mask_args(masks, depth.shape)
+        out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
+        _check(self._lib.lm_detector_match(self._h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], float(threshold),
+                                           carr, n, marr, ctypes.byref(out), ctypes.byref(cnt)))
+        return self._take(out, cnt.value)
+
+    def match(self, sources, threshold: float, class_ids: Sequence[str] = (), masks=()) -> List[Match]:
+        """Detector::match (LL.cpp:1702-1777).  With torch.distributed initialised and setShard()
+        called by the caller, use `match_sharded` from `sharded.py` to gather all ranks."""
+        recs = self.matchArray(sources, threshold, class_ids, masks)
+        names = list(class_ids) if class_ids else self.classIds()
+        return [Match(int(r["x"]), int(r["y"]), float(r["similarity"]), names[int(r["class_index"])], int(r["template_id"]))
+                for r in recs]
+
+    def lastTimings(self) -> dict:
+        t = Timings()
+        _check(self._lib.lm_detector_last_timings(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def readStage(self, level: int, kind: int) -> np.ndarray:
+        """Device intermediates of the last front end run (tests): kind 0/1 quantised colour/normal,
+        2/3 linear memories colour/normal."""
+        n = _check(self._lib.lm_detector_read_stage(self._h, level, kind, None, 0))
+        buf = np.zeros(n, np.uint8)
+        _check(self._lib.lm_detector_read_stage(self._h, level, kind, _ptr(buf), n))
+        return buf
+
+
+def merge_matches(records: np.ndarray) -> np.ndarray:
+    """Canonical sort + unique of gathered MATCH_DTYPE records (lm_merge_matches; LL.cpp:1771-1776)."""
+    recs = np.ascontiguousarray(records, MATCH_DTYPE).copy()
+    n = load_library().lm_merge_matches(_ptr(recs), len(recs))
+    return recs[:n]
+
+
+def nms(dets: np.ndarray, thresh: float) -> List[int]:
+    """The driver's box NMS (linemod_and_levelup_test.py:34-61): dets rows = x1,y1,x2,y2,score."""
+    dets = np.ascontiguousarray(dets, np.float64)
+    if len(dets) == 0:
+        return []
+    boxes = np.ascontiguousarray(dets[:, :4])
+    scores = np.ascontiguousarray(dets[:, 4])
+    keep = np.zeros(len(dets), np.int32)
+    n = load_library().lm_nms_boxes(_ptr(boxes), _ptr(scores), len(dets), float(thresh), _ptr(keep))
+    return keep[:n].tolist()
+
+
+class poseRefine:
+    """poseRefine (LL.h:8-19, LL.cpp:27-170).  `scene_from_scene=True` registers against the scene
+    cloud instead of reproducing LL.cpp:109 (which down-samples the model cloud twice)."""
+
+    def __init__(self, device: Optional[int] = None, scene_from_scene: bool = False):
+        self.residual = -1.0                                   # poseRefine(): residual(-1)
+        self._R = None
+        self._t = None
+        self.device = device
+        self.flags = LM_ICP_SCENE_FROM_SCENE if scene_from_scene else 0
+        self.info = {}
+
+    def process(self, sceneDepth, modelDepth, sceneK, modelK, modelR, modelT, detectX: int, detectY: int) -> None:
+        lib = load_library()
+        sd, md = _as_depth(sceneDepth, "sceneDepth"), _as_depth(modelDepth, "modelDepth")
+        if sd.shape != md.shape:
+            raise RuntimeError("sceneDepth and modelDepth sizes differ")
+        def f32(a, n, what):
+            a = np.asarray(a)
+            if a.dtype != np.float32 or a.size != n:
+                raise RuntimeError("%s must be float32 with %d elements (got %s %s)" % (what, n, a.dtype, a.shape))
+            return np.ascontiguousarray(a).reshape(-1)
+        sK, mK, R, t = f32(sceneK, 9, "sceneK"), f32(modelK, 9, "modelK"), f32(modelR, 9, "modelR"), f32(modelT, 3, "modelT")
+        dev = self.device
+        if dev is None:
+            dev = int(os.environ.get("LOCAL_RANK", "0")) if lib.lm_device_count() > 1 else 0
+        res = _CPoseResult()
+        _check(lib.lm_pose_refine(dev, _ptr(sd), _ptr(md), sd.shape[1], sd.shape[0], _ptr(sK), _ptr(mK), _ptr(R), _ptr(t),
+                                  int(detectX), int(detectY), self.flags, ctypes.byref(res)))
+        self.residual = float(res.residual)
+        if self.residual == -1.0:                              # LL.cpp:52-55: outputs untouched
+            return
+        self._R = np.array(res.R, np.float64).reshape(3, 3)
+        self._t = np.array(res.t, np.float64).reshape(3, 1)
+        self.info = {"inlier_rmse": float(res.inlier_rmse), "iterations": int(res.iterations),
+                     "n_source": int(res.n_source), "n_target": int(res.n_target)}
+
+    def getResidual(self) -> float:
+        return self.residual
+
+    def getR(self):
+        return self._R
+
+    def getT(self):
+        return self._t
+
+
+def pose_refine_batch(scene_depth, scene_K, model_depths, model_Ks, model_Rs, model_ts, detect_xy, device=0,
+                      scene_from_scene=False):
+    """lm_pose_refine_batch: top-K hypotheses of one frame in one ICP launch.  Returns (list of dict, device_ms)."""
+    lib = load_library()
+    sd = _as_depth(scene_depth, "scene_depth")
+    n = len(model_depths)
+    mds = [_as_depth(m, "model_depth") for m in model_depths]
+    ptrs = (ctypes.c_void_p * n)(*[m.ctypes.data for m in mds])
+    Ks = np.ascontiguousarray(np.asarray(model_Ks, np.float32).reshape(n, 9))
+    Rs = np.ascontiguousarray(np.asarray(model_Rs, np.float32).reshape(n, 9))
+    ts = np.ascontiguousarray(np.asarray(model_ts, np.float32).reshape(n, 3))
+    xy = np.ascontiguousarray(np.asarray(detect_xy, np.int32).reshape(n, 2))
+    sK = np.ascontiguousarray(np.asarray(scene_K, np.float32).reshape(9))
+    res = (_CPoseResult * n)()
+    ms = ctypes.c_float()
+    _check(lib.lm_pose_refine_batch(device, _ptr(sd), sd.shape[1], sd.shape[0], _ptr(sK), n, ptrs, _ptr(Ks), _ptr(Rs), _ptr(ts),
+                                    _ptr(xy), LM_ICP_SCENE_FROM_SCENE if scene_from_scene else 0, res, ctypes.byref(ms)))
+    out = []
+    for r in res:
+        out.append({"R": np.array(r.R).reshape(3, 3), "t": np.array(r.t), "residual": float(r.residual),
+                    "rmse": float(r.inlier_rmse), "iterations": int(r.iterations), "n_source": int(r.n_source),
+                    "n_target": int(r.n_target)})
+    return out, float(ms.value)

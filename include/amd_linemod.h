@@ -1,0 +1,188 @@
+/*
+ * amd_linemod.h — C ABI of libamdlinemod.so, the MI355X (gfx950) implementation of the
+ * linemodLevelup hot path (LINE-MOD template matching + point-to-plane ICP pose refinement).
+ *
+ * This is the drop-in boundary for the reference's pybind11 module `linemodLevelup_pybind`
+ * (/root/reference/linemodLevelup/pybind11.cpp:7-35).  Every entry point below names the reference
+ * interface it replaces ("pybind11.cpp:N" = binding, "LL.cpp:N"/"LL.h:N" = linemodLevelup.{cpp,h}).
+ * Plain pointers and sizes only; no torch / OpenCV / STL types.  The Python wrapper
+ * 6dpose_amd/linemodLevelup_pybind.py and bench.py are the only intended callers; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every `int` function returns LM_OK (0) or a negative LM_ERR_* code unless stated otherwise;
+ *     lm_last_error() returns a thread-local message (the reference raises cv::Exception ->
+ *     Python RuntimeError for the same preconditions, e.g. LL.cpp:1136,1217-1218,1291,1707).
+ *   - images are C-contiguous host buffers borrowed for the duration of the call:
+ *     rgb  uint8  [height][width][3]  (channel order as given, LL.cpp:391-412 is order-sensitive)
+ *     depth uint16 [height][width]    (millimetres)
+ *     mask uint8  [height][width]     (non-zero = valid), may be NULL
+ *   - a detector owns one HIP stream on one device; handles are not re-entrant.
+ *   - there is NO CPU fallback: creation fails (LM_ERR_NO_DEVICE) when no gfx950 device is visible.
+ */
+#ifndef AMD_LINEMOD_H
+#define AMD_LINEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_OK 0
+#define LM_ERR_INVALID (-2)     /* bad argument / violated reference precondition (CV_Assert) */
+#define LM_ERR_NO_DEVICE (-3)   /* no HIP device / HIP runtime failure at creation */
+#define LM_ERR_HIP (-4)         /* HIP runtime error during a call */
+#define LM_ERR_IO (-5)          /* file could not be read / written / parsed */
+#define LM_ERR_NOT_FOUND (-6)   /* unknown class id */
+
+typedef struct lm_detector lm_detector;
+
+/* linemodLevelup::Match (LL.h:225-258; bound at pybind11.cpp:16-22).  class_index indexes the
+ * class list the match call used (caller's class_ids order, or sorted class order when empty). */
+typedef struct lm_match {
+    int32_t x;
+    int32_t y;
+    float similarity;
+    int32_t class_index;
+    int32_t template_id;
+} lm_match;
+
+/* Per-stage device time of the last match call, HIP events on the detector's stream (ms). */
+typedef struct lm_timings {
+    float h2d_ms;        /* frame upload (0 when the frame was already resident)            */
+    float frontend_ms;   /* quantise + spread + response + linearise, all levels (A1-A7)     */
+    float coarse_ms;     /* similarity over all positions at the top level + threshold (A8-A10) */
+    float local_ms;      /* 16x16 refinement down the pyramid (A11)                          */
+    float d2h_ms;        /* match download                                                   */
+    float total_ms;      /* first event to last event                                        */
+    int64_t coarse_candidates;
+    int64_t local_evals;
+    int64_t matches_pre_unique;
+    int64_t templates;   /* template pyramids searched by this rank                          */
+    int64_t coarse_bytes;/* algorithmic response bytes read by the coarse pass  */
+    int64_t local_bytes; /* algorithmic response bytes read by the local pass                */
+} lm_timings;
+
+const char *lm_last_error(void);
+const char *lm_version(void);
+/* Number of visible HIP devices (0 when none / runtime unavailable). */
+int lm_device_count(void);
+
+/* ---- Detector -------------------------------------------------------------------------------
+ * Detector(), Detector(T), Detector(num_features, T): pybind11.cpp:26-28, LL.cpp:1663-1692.
+ * num_features <= 0 selects the default 63; T==NULL selects {5,8}.  `device` is the HIP ordinal. */
+int lm_detector_create(int num_features, const int *T, int num_levels, int device, lm_detector **out);
+void lm_detector_destroy(lm_detector *d);
+
+/* Detector::addTemplate (pybind11.cpp:29, LL.cpp:1943-1975).  Returns the new template_id (>=0),
+ * -1 when no valid template could be extracted (the reference's own convention, LL.cpp:1964-1966),
+ * or an LM_ERR_* code (< -1).  Quantisation runs on the GPU, the greedy feature selection on host. */
+int lm_detector_add_template(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, const uint8_t *mask,
+                             int width, int height, const char *class_id);
+
+/* Detector::readClasses / writeClasses for ONE class (pybind11.cpp:30-31; LL.cpp:2043-2146):
+ * OpenCV FileStorage YAML 1.0 schema; `.gz` paths are NOT supported by this library (the Python
+ * wrapper decompresses).  read returns LM_ERR_INVALID on the reference's CV_Asserts (modalities,
+ * pyramid_levels, consecutive template ids, class already present). */
+int lm_detector_read_class(lm_detector *d, const char *path, const char *class_id_override);
+int lm_detector_write_class(lm_detector *d, const char *class_id, const char *path);
+
+/* Bulk import of a packed class (binary bank for >=16k templates).
+ * features: [total][3] int32 (x,y,label); tmpl_offsets: [num_pyramids*levels*2+1] prefix offsets in
+ * reference TemplatePyramid order (level-major, modality-minor; LL.h:336-337); tmpl_wh:
+ * [num_pyramids*levels*2][2] width,height. */
+int lm_detector_add_class_packed(lm_detector *d, const char *class_id, int num_pyramids,
+                                 const int32_t *features, const int32_t *tmpl_offsets, const int32_t *tmpl_wh);
+
+/* Detector::numClasses / classIds / numTemplates (LL.h:343, LL.cpp:1984-2011). */
+int lm_detector_num_classes(const lm_detector *d);
+const char *lm_detector_class_id(const lm_detector *d, int index);   /* sorted (std::map) order */
+int lm_detector_num_templates(const lm_detector *d, const char *class_id); /* NULL = all classes */
+int lm_detector_pyramid_levels(const lm_detector *d);
+int lm_detector_get_T(const lm_detector *d, int level);
+
+/* Detector::getTemplates (pybind11.cpp:34, LL.cpp:1976-1982): entry `index` (0..levels*2-1) of
+ * template pyramid `template_id`.  Writes width/height/pyramid_level/num_features; copies at most
+ * `capacity` features (x,y,label triples) into `features` (may be NULL to query the count). */
+int lm_detector_get_template(const lm_detector *d, const char *class_id, int template_id, int index,
+                             int32_t *width, int32_t *height, int32_t *pyramid_level,
+                             int32_t *num_features, int32_t *features, int capacity);
+
+/* Multi-GPU sharding: this rank searches the contiguous slice
+ * [N*rank/world, N*(rank+1)/world) of the N template pyramids a match call selects; template ids
+ * stay global.  Default (0,1). */
+int lm_detector_set_shard(lm_detector *d, int rank, int world);
+
+/* Detector::match (pybind11.cpp:32-33, LL.cpp:1702-1777).  class_ids may be NULL/0 = all classes.
+ * masks: NULL, or two pointers (colour, depth modality), each NULL or a [height][width] uint8 mask.
+ * On success *out is a malloc'd array of *n matches in the canonical order of SURVEY §8a A12
+ * (similarity desc, template_id asc, class position asc, y asc, x asc; then adjacent-unique on
+ * (x,y,similarity,class)), to be released with lm_free().  With world>1 the result holds only
+ * this rank's matches, still sorted+uniqued; lm_merge_matches() merges gathered lists. */
+int lm_detector_match(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
+                      float threshold, const char *const *class_ids, int num_class_ids,
+                      const uint8_t *const *masks, lm_match **out, size_t *n);
+
+/* The same in two steps, so that a benchmark can time the device path with the frame already
+ * resident in HBM: lm_detector_set_frame uploads (and keeps) the frame; lm_detector_match_resident
+ * runs front end + matching on it.  `sort_unique`=0 returns the raw pre-unique list (unordered). */
+int lm_detector_set_frame(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
+                          const uint8_t *const *masks);
+int lm_detector_match_resident(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids,
+                               int sort_unique, lm_match **out, size_t *n);
+int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
+
+/* Test/diagnostic access to the device-resident intermediates of the last front end run (parity
+ * tests compare them byte-for-byte with the oracle).  kind: 0 quantised colour, 1 quantised
+ * normals (W_l*H_l bytes each), 2 linear memories colour, 3 linear memories normals
+ * (8*W_l*H_l bytes each).  Copies min(capacity, size) bytes, returns the full size. */
+int64_t lm_detector_read_stage(lm_detector *d, int level, int kind, uint8_t *dst, int64_t capacity);
+
+/* Canonical merge of match lists gathered from several ranks (LL.cpp:1771-1776 semantics, A12).
+ * In-place on `m` (n entries); returns the new count. */
+size_t lm_merge_matches(lm_match *m, size_t n);
+
+/* Caller-side box NMS of the reference driver (linemod_and_levelup_test.py:34-61), numpy `nms`
+ * semantics (+1 pixel convention, IoU > thresh suppresses, score-descending, stable for ties by
+ * input order as numpy argsort()[::-1] is NOT guaranteed — ties broken by higher index first).
+ * boxes: [n][4] float64 x1,y1,x2,y2; scores [n] float64.  keep: [n] int32 out; returns #kept. */
+int lm_nms_boxes(const double *boxes, const double *scores, int n, double thresh, int32_t *keep);
+
+void lm_free(void *p);
+
+/* ---- poseRefine (pybind11.cpp:9-14, LL.cpp:27-170) ------------------------------------------
+ * scene/model depth: uint16 [height][width] mm; K matrices float32 row-major 3x3; R float32 3x3,
+ * t float32 3 (mm).  Outputs: R_out float64 3x3, t_out float64 3 (mm), residual (= ICP fitness,
+ * or -1 when the detection window leaves the frame, LL.cpp:52-55).
+ * flags: bit0 = LM_ICP_SCENE_FROM_SCENE: register against the SCENE cloud (evident intent) instead
+ * of reproducing LL.cpp:109, which down-samples the model cloud twice. */
+#define LM_ICP_SCENE_FROM_SCENE 1
+typedef struct lm_pose_result {
+    double R[9];
+    double t[3];
+    float residual;      /* fitness; -1 = rejected */
+    float inlier_rmse;
+    int32_t iterations;
+    int32_t n_source;    /* points after voxel down-sampling */
+    int32_t n_target;
+    int32_t reserved;
+} lm_pose_result;
+
+int lm_pose_refine(int device, const uint16_t *scene_depth, const uint16_t *model_depth, int width, int height,
+                   const float *scene_K, const float *model_K, const float *model_R, const float *model_t,
+                   int detect_x, int detect_y, int flags, lm_pose_result *result);
+
+/* Batched form (top-K hypotheses of one frame, BASELINE config 3): `count` model depth images /
+ * poses against one scene depth; one workgroup per hypothesis, all ICP iterations in one launch. */
+int lm_pose_refine_batch(int device, const uint16_t *scene_depth, int width, int height, const float *scene_K,
+                         int count, const uint16_t *const *model_depths, const float *model_Ks /*[count][9]*/,
+                         const float *model_Rs /*[count][9]*/, const float *model_ts /*[count][3]*/,
+                         const int32_t *detect_xy /*[count][2]*/, int flags, lm_pose_result *results,
+                         float *device_ms /* may be NULL: HIP-event time of the ICP launches */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMD_LINEMOD_H */

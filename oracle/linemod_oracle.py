@@ -738,3 +738,198 @@ def nms_boxes(dets: np.ndarray, thresh: float) -> List[int]:
         inds = np.where(ovr <= thresh)[0]
         order = order[inds + 1]
     return keep
+
+
+# --------------------------------------------------------------------------------------
+# poseRefine (LL.cpp:27-170) + Open3D pieces — PARITY UNPINNED
+# --------------------------------------------------------------------------------------
+# Open3D (un-vendored dependency of the reference, version unpinned; API shape implies 0.8/0.9):
+#   VoxelDownSample, EstimateNormals(KNN 30), RegistrationICP + TransformationEstimationPointToPlane.
+# Deterministic choices shared with the GPU path (documented in DESIGN.md):
+#   * voxel output order = ascending (ix, iy, iz) voxel index (Open3D: unordered_map order);
+#   * kNN / NN ties: smaller squared distance first, then lower index;
+#   * 6x6 solve by LU with partial pivoting; update = identity when there are < 6 correspondences
+#     or the solution is not finite (Open3D: LDLT; older versions add a determinant test);
+#   * correspondence accepted when d^2 < max_dist^2.
+
+VOXEL_SIZE = 0.0025          # LL.cpp:106
+ICP_MAX_DIST = 0.01          # LL.cpp:31
+ICP_MAX_ITER = 30            # open3d ICPConvergenceCriteria default
+ICP_REL = 1e-6
+KNN = 30                     # open3d KDTreeSearchParamKNN default
+
+
+def _seq_sum(a: np.ndarray) -> np.ndarray:
+    """Sequential (not pairwise) double summation along axis 0."""
+    return np.cumsum(a, axis=0)[-1] if len(a) else np.zeros(a.shape[1:], a.dtype)
+
+
+def backproject_clouds(scene_depth, model_depth, sceneK, modelK, detect_x, detect_y):
+    """LL.cpp:43-104.  Returns None when the window leaves the frame (residual=-1, :52-55), else
+    (model_pts, scene_pts, init_translation)."""
+    from scipy.ndimage import maximum_filter
+    H, W = model_depth.shape
+    dil = 4
+    mask = maximum_filter((model_depth > 0).astype(np.uint8), size=2 * dil + 1, mode="constant", cval=0)
+    ys, xs = np.nonzero(mask)
+    if len(ys) == 0:
+        raise RuntimeError("empty model depth")
+    bx, by = int(xs.min()), int(ys.min())
+    bw, bh = int(xs.max()) - bx + 1, int(ys.max()) - by + 1
+    if detect_x + bw >= scene_depth.shape[1] or detect_y + bh >= scene_depth.shape[0]:
+        return None
+    anchor = float(model_depth[H // 2, W // 2]) / 1000.0
+    r, c = np.mgrid[0:bh, 0:bw]
+    r = r.reshape(-1); c = c.reshape(-1)                      # raster order of the double loop
+    mr, mc = r + by, c + bx
+    sr = np.maximum(r + detect_y - dil, 0); sc = np.maximum(c + detect_x - dil, 0)
+    inmask = mask[mr, mc] > 0
+    md = model_depth[mr, mc].astype(np.int64)
+    sd = scene_depth[sr, sc].astype(np.int64)
+    mk = np.asarray(modelK, f32).reshape(3, 3); sk = np.asarray(sceneK, f32).reshape(3, 3)
+
+    def proj(cols, rows, dep, K):
+        z = dep.astype(np.float64) / 1000.0
+        # (int - float)/float is evaluated in float, then multiplied by the double z (LL.cpp:79-80)
+        xf = ((cols.astype(f32) - K[0, 2]).astype(f32) / K[0, 0]).astype(f32)
+        yf = ((rows.astype(f32) - K[1, 2]).astype(f32) / K[1, 1]).astype(f32)
+        return np.stack([xf.astype(np.float64) * z, yf.astype(np.float64) * z, z], 1)
+
+    msel = inmask & (md > 0)
+    model_pts = proj(mc[msel], mr[msel], md[msel], mk)
+    ssel = inmask & (sd > 0)
+    scene_pts_all = proj(sc, sr, sd, sk)
+    scene_pts = scene_pts_all[ssel]
+    csel = ssel & (np.abs(sd.astype(np.float64) / 1000.0 - anchor) < 0.4) & (md > 0)
+    center_model = _seq_sum(model_pts) / float(len(model_pts))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        center_scene = _seq_sum(scene_pts_all[csel]) / float(int(csel.sum()))
+    return model_pts, scene_pts, center_scene - center_model
+
+
+def voxel_down_sample(pts: np.ndarray, voxel: float = VOXEL_SIZE) -> np.ndarray:
+    """open3d PointCloud::VoxelDownSample: mean of the points of each voxel; output in ascending
+    (ix,iy,iz) order (deterministic stand-in for unordered_map order)."""
+    if len(pts) == 0:
+        return pts.copy()
+    mn = pts.min(0) - voxel * 0.5
+    idx = np.floor((pts - mn) / voxel).astype(np.int64)
+    order = np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))     # stable: ties keep input order
+    sidx = idx[order]
+    new = np.ones(len(pts), bool)
+    new[1:] = np.any(sidx[1:] != sidx[:-1], axis=1)
+    starts = np.nonzero(new)[0]
+    ends = np.append(starts[1:], len(pts))
+    out = np.zeros((len(starts), 3))
+    sp = pts[order]
+    for k, (a, b) in enumerate(zip(starts, ends)):
+        acc = np.zeros(3)
+        for p in sp[a:b]:
+            acc = acc + p
+        out[k] = acc / float(b - a)
+    return out
+
+
+def estimate_normals(pts: np.ndarray, knn: int = KNN) -> np.ndarray:
+    """open3d EstimateNormals(KDTreeSearchParamKNN(30)): eigenvector of the smallest eigenvalue of
+    the covariance (E[xx^T] - E[x]E[x]^T) of the k nearest neighbours (self included)."""
+    n = len(pts)
+    out = np.zeros((n, 3))
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2)
+    d2 = d2[..., 0] + d2[..., 1] + d2[..., 2]
+    k = min(knn, n)
+    for i in range(n):
+        nb = np.lexsort((np.arange(n), d2[i]))[:k]
+        if k < 3:
+            out[i] = (0, 0, 1)
+            continue
+        q = pts[nb]
+        mean = _seq_sum(q) / k
+        cum = _seq_sum(q[:, :, None] * q[:, None, :]) / k
+        cov = cum - np.outer(mean, mean)
+        w, v = np.linalg.eigh(cov)
+        nrm = v[:, 0]
+        out[i] = nrm if np.linalg.norm(nrm) > 0 else (0, 0, 1)
+    return out
+
+
+def _rot_xyz(x):
+    """TransformVector6dToMatrix4d: Rz(x2) * Ry(x1) * Rx(x0), translation x3..5."""
+    cx, sx, cy, sy, cz, sz = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = x[3:6]
+    return T
+
+
+def _icp_eval(src, tgt, nrm, max_dist):
+    """GetRegistrationResultAndCorrespondences + the JtJ/Jtr accumulation of
+    TransformationEstimationPointToPlane::ComputeTransformation for the same correspondences."""
+    d2 = ((src[:, None, :] - tgt[None, :, :]) ** 2)
+    d2 = d2[..., 0] + d2[..., 1] + d2[..., 2]
+    j = d2.argmin(1)                                          # first minimum = lowest index on ties
+    best = d2[np.arange(len(src)), j]
+    ok = best < max_dist * max_dist
+    n = int(ok.sum())
+    if n == 0:
+        return 0.0, 0.0, 0, None, None
+    p, q, nt = src[ok], tgt[j[ok]], nrm[j[ok]]
+    r = ((p - q) * nt).sum(1)
+    J = np.concatenate([np.cross(p, nt), nt], 1)
+    JTJ = _seq_sum(J[:, :, None] * J[:, None, :])
+    JTr = _seq_sum(J * r[:, None])
+    fitness = n / float(len(src))
+    rmse = float(np.sqrt(_seq_sum(best[ok][:, None])[0] / n))
+    return fitness, rmse, n, JTJ, JTr
+
+
+def icp_point_to_plane(src, tgt, tgt_normals, init, max_dist=ICP_MAX_DIST, max_iter=ICP_MAX_ITER):
+    """open3d RegistrationICP(source, target, max_dist, init, PointToPlane, default criteria)."""
+    T = np.array(init, np.float64)
+    pts = src @ T[:3, :3].T + T[:3, 3]
+    fit, rmse, n, JTJ, JTr = _icp_eval(pts, tgt, tgt_normals, max_dist)
+    iters = 0
+    for _ in range(max_iter):
+        iters += 1
+        upd = np.eye(4)
+        if n >= 6:
+            try:
+                x = np.linalg.solve(JTJ, -JTr)
+                if np.all(np.isfinite(x)):
+                    upd = _rot_xyz(x)
+            except np.linalg.LinAlgError:
+                pass
+        T = upd @ T
+        pts = pts @ upd[:3, :3].T + upd[:3, 3]
+        bfit, brmse = fit, rmse
+        fit, rmse, n, JTJ, JTr = _icp_eval(pts, tgt, tgt_normals, max_dist)
+        if abs(bfit - fit) < ICP_REL and abs(brmse - rmse) < ICP_REL:
+            break
+    return T, fit, rmse, iters
+
+
+def pose_refine(scene_depth, model_depth, sceneK, modelK, modelR, modelT, detect_x, detect_y,
+                scene_from_scene: bool = False):
+    """poseRefine::process (LL.cpp:27-155).  Returns dict(R (3,3) f64, t (3,) f64 mm, residual, ...)."""
+    init_base = np.zeros((4, 4), f32)
+    init_base[:3, :3] = np.asarray(modelR, f32).reshape(3, 3)
+    init_base[:3, 3] = np.asarray(modelT, f32).reshape(3)
+    init_base[2, 3] = init_base[2, 3] / f32(1000.0)          # only t.z is converted (LL.cpp:37)
+    init_base[3, 3] = 1
+    bp = backproject_clouds(np.asarray(scene_depth), np.asarray(model_depth), sceneK, modelK, detect_x, detect_y)
+    if bp is None:
+        return {"residual": -1.0, "R": None, "t": None}
+    model_pts, scene_pts, tr = bp
+    init_guess = np.eye(4)
+    init_guess[:3, 3] = tr
+    src = voxel_down_sample(model_pts)
+    tgt = voxel_down_sample(scene_pts if scene_from_scene else model_pts)   # LL.cpp:109 (sic: model)
+    nrm = estimate_normals(tgt)
+    T, fit, rmse, iters = icp_point_to_plane(src, tgt, nrm, init_guess)
+    result = T @ init_base.astype(np.float64)
+    return {"residual": float(f32(fit)), "R": result[:3, :3].copy(), "t": result[:3, 3] * 1000.0,
+            "T_icp": T, "rmse": rmse, "iterations": iters, "n_source": len(src), "n_target": len(tgt),
+            "src": src, "tgt": tgt, "normals": nrm, "init_guess": init_guess}
