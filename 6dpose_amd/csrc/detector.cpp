@@ -95,6 +95,9 @@ struct lm_detector {
     LevelBufs lvl[kMaxLevels];
     FrameGeom geom{};
     size_t lm_block_bytes[kMaxLevels] = {};
+    std::vector<DevBuf<uint8_t>> slot_rgb;      // frames parked in HBM (lm_detector_store_frame)
+    std::vector<DevBuf<uint16_t>> slot_depth;
+    std::vector<int> slot_w, slot_h;
     void* pinned = nullptr;          // staging for H2D frame and D2H results
     size_t pinned_bytes = 0;
     float last_h2d_ms = 0.f;
@@ -178,6 +181,8 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipStreamSynchronize(d->stream);
     d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
     d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release();
+    for (auto& b : d->slot_rgb) b.release();
+    for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_work.release();
     d->d_cands.release(); d->d_matches.release(); d->d_counters.release();
@@ -600,6 +605,42 @@ extern "C" int lm_detector_set_frame(lm_detector* d, const uint8_t* rgb, const u
                                      const uint8_t* const* masks) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
     return upload_frame(d, rgb, depth, width, height, masks, true);
+}
+
+extern "C" int lm_detector_store_frame(lm_detector* d, int slot, const uint8_t* rgb, const uint16_t* depth, int width, int height) {
+    if (!d || !rgb || !depth || slot < 0 || slot > 4095) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(d->device));
+    if ((size_t)slot >= d->slot_rgb.size()) {
+        d->slot_rgb.resize(slot + 1); d->slot_depth.resize(slot + 1);
+        d->slot_w.resize(slot + 1, 0); d->slot_h.resize(slot + 1, 0);
+    }
+    const size_t n = (size_t)width * height;
+    int rc;
+    if ((rc = d->slot_rgb[slot].ensure(n * 3))) return rc;
+    if ((rc = d->slot_depth[slot].ensure(n))) return rc;
+    HIP_TRY(hipMemcpy(d->slot_rgb[slot].p, rgb, n * 3, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->slot_depth[slot].p, depth, n * 2, hipMemcpyHostToDevice));
+    d->slot_w[slot] = width; d->slot_h[slot] = height;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_select_frame(lm_detector* d, int slot) {
+    if (!d || slot < 0 || (size_t)slot >= d->slot_rgb.size() || d->slot_w[slot] <= 0)
+        return lm_set_error(LM_ERR_INVALID, "no frame stored in slot %d", slot);
+    HIP_TRY(hipSetDevice(d->device));
+    d->frame_valid = false;
+    const int W = d->slot_w[slot], H = d->slot_h[slot];
+    if (W != d->fW || H != d->fH || d->lm_arena.cap == 0) {
+        int rc = setup_geometry(d, W, H, true);
+        if (rc) return rc;
+    }
+    const size_t n = (size_t)W * H;
+    HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, d->slot_rgb[slot].p, n * 3, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->frame_depth.p, d->slot_depth[slot].p, n * 2, hipMemcpyDeviceToDevice, d->stream));
+    d->have_mask[0] = d->have_mask[1] = false;
+    d->last_h2d_ms = 0.f;
+    d->frame_valid = true;
+    return LM_OK;
 }
 
 static int build_work(lm_detector* d, const char* const* class_ids, int num_class_ids) {

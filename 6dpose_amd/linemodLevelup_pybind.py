@@ -108,6 +108,8 @@ def load_library():
     lib.lm_detector_match.argtypes = [P, P, P, I, I, F, ctypes.POINTER(S), I, ctypes.POINTER(P),
                                       ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_set_frame.argtypes = [P, P, P, I, I, ctypes.POINTER(P)]
+    lib.lm_detector_store_frame.argtypes = [P, I, P, P, I, I]
+    lib.lm_detector_select_frame.argtypes = [P, I]
     lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
                                                ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_last_timings.argtypes = [P, ctypes.POINTER(Timings)]
@@ -308,6 +310,15 @@ class Detector:
             raise RuntimeError("rgb and depth sizes differ")
         marr, keep = self._mask_args(masks, depth.shape)
         _check(self._lib.lm_detector_set_frame(self._h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], marr))
+
+    def storeFrame(self, slot: int, sources) -> None:
+        """Parks a frame in HBM slot `slot` (lm_detector_store_frame)."""
+        rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        _check(self._lib.lm_detector_store_frame(self._h, slot, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0]))
+
+    def selectFrame(self, slot: int) -> None:
+        """Makes a parked frame current with a device-to-device copy (lm_detector_select_frame)."""
+        _check(self._lib.lm_detector_select_frame(self._h, slot))
 
     def matchResident(self, threshold: float, class_ids: Sequence[str] = (), sort_unique: bool = True) -> np.ndarray:
         """Front end + matching on the frame uploaded by setFrame(); returns MATCH_DTYPE records."""

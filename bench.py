@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X linemodLevelup hot path (BASELINE.json metric:
+templates·Mpixels matched/sec on 640x480 RGB-D).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of Detector.match's device path over one synthetic 640x480 RGB-D frame with
+the template bank resident: front end (quantise, spread, response, linearise) + coarse similarity
+over all templates + 16x16 refinement of every candidate + download of the match records (+, for
+N>1, the all-gather of the per-rank records over RCCL and the canonical merge).  Frames are parked
+in HBM before the timed region (lm_detector_store_frame) and made current with a device-to-device
+copy, so `value` is the rate with inputs resident in HBM (DESIGN.md notes the PCIe-inclusive rate).
+
+Workload (N=1): BASELINE configs[1] — 1 object x 2000 template pyramids, Detector(150,[4,8])
+(150+150 features at level 0, 75+75 at level 1), threshold 75, planted synthetic bank (6dpose_amd/
+synth.py).  N>1: configs[3] shape — N objects x 2000 templates, one object per rank (weak scaling),
+every rank searches its contiguous slice of the bank and the match records are all-gathered.
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel (k_local or k_coarse):
+algorithmic response bytes per launch (sum nfeat*256 per 16x16 evaluation, resp.
+sum nfeat*template_positions per template) / that kernel's mean duration from HIP events on the
+detector's stream; peak = 8000 GB/s (HBM3E spec).  `cpu_baseline` times the oracle's SSE C port of
+the same matching step on the host (rank 0, N=1 only), single thread like the reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "6dpose_amd"))
+
+W, H = 640, 480
+T_LEVELS = [4, 8]
+NFEAT = (150, 75)
+N_TEMPLATES = 2000
+THRESHOLD = 75.0
+N_FRAMES = 4
+HBM_PEAK_GBS = 8000.0
+
+
+def noisy_frames(n):
+    """A short synthetic stream: one scene (seed 0), fresh sensor noise per frame."""
+    import synth
+    rgb0, dep0 = synth.make_frame(0, W, H)
+    frames = [(rgb0, dep0)]
+    for k in range(1, n):
+        rng = np.random.default_rng(1000 + k)
+        rgb = np.clip(rgb0.astype(np.int16) + rng.integers(-2, 3, rgb0.shape), 0, 255).astype(np.uint8)
+        dn = dep0.astype(np.int32) + rng.integers(-1, 2, dep0.shape)
+        dep = np.where(dep0 > 0, np.clip(dn, 300, 65535), 0).astype(np.uint16)
+        frames.append((np.ascontiguousarray(rgb), np.ascontiguousarray(dep)))
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--templates", type=int, default=N_TEMPLATES, help="template pyramids per object (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import linemodLevelup_pybind as lm
+    import sharded
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU (libamdlinemod has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_obj = max(1, world)
+
+    det = lm.Detector(NFEAT[0], T_LEVELS, device=local_rank)
+    frames = noisy_frames(N_FRAMES)
+    for k, f in enumerate(frames):
+        det.storeFrame(k, f)
+    # quantised maps of frame 0 from the GPU front end -> planted bank (one object per rank)
+    det.addClassPacked("_probe", np.zeros((0, 3), np.int32), np.zeros(1, np.int32), np.zeros((0, 2), np.int32))
+    det.selectFrame(0)
+    det.matchResident(THRESHOLD, ["_probe"])
+    quant = [(det.readStage(l, 0).reshape(H >> l, W >> l), det.readStage(l, 1).reshape(H >> l, W >> l)) for l in range(2)]
+    classes = []
+    banks = {}
+    for o in range(n_obj):
+        cid = "obj%02d" % o
+        banks[cid] = synth.make_planted_bank(1234 + o, args.templates, quant, T_LEVELS, NFEAT)
+        det.addClassPacked(cid, *banks[cid])
+        classes.append(cid)
+    det.setShard(rank, world)
+
+    def step(k):
+        det.selectFrame(k % N_FRAMES)
+        local = det.matchResident(THRESHOLD, classes, sort_unique=False)
+        allrec = sharded.gather_records(local, device=dev) if world > 1 else local
+        return lm.merge_matches(allrec)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms", "coarse_candidates", "local_evals",
+            "matches_pre_unique", "coarse_bytes", "local_bytes")
+    acc = {k: 0.0 for k in keys}
+    fence()
+    t0 = time.perf_counter()
+    n_final = 0
+    for k in range(args.steps):
+        n_final = len(step(k))
+        tm = det.lastTimings()
+        for q in keys:
+            acc[q] += tm[q]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    K = max(1, args.steps)
+    mean = {k: acc[k] / K for k in keys}
+    total_templates = args.templates * n_obj
+    value = total_templates * (W * H / 1e6) * K / dt
+
+    if rank == 0:
+        # dominant kernel of this rank
+        if mean["local_ms"] >= mean["coarse_ms"]:
+            kname, kms, kbytes = "k_local", mean["local_ms"], mean["local_bytes"]
+        else:
+            kname, kms, kbytes = "k_coarse", mean["coarse_ms"], mean["coarse_bytes"]
+        achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out = {
+            "metric": "templates*Mpixels matched/sec on 640x480 RGB-D",
+            "value": value, "unit": "templates*Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1 object x %d templates per GPU, 640x480 RGB-D, Detector(150,[4,8]), threshold 75, planted synthetic bank"
+                                   % args.templates,
+                       "templates_total": total_templates, "objects": n_obj, "frames_in_stream": N_FRAMES,
+                       "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world,
+                       "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
+                       "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
+            "stages_ms": {k: mean[k] for k in ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms,
+                         "other": {"k_coarse_GBps": (mean["coarse_bytes"] / (mean["coarse_ms"] * 1e-3) / 1e9) if mean["coarse_ms"] > 0 else 0.0,
+                                   "k_local_GBps": (mean["local_bytes"] / (mean["local_ms"] * 1e-3) / 1e9) if mean["local_ms"] > 0 else 0.0}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, banks[classes[0]], args.templates)
+            out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames, bank, n_templates):
+    """The oracle's C (SSE2/SSSE3) port of the matching step, single thread like the reference,
+    on the host cores of this box: spread/response/linearise + coarse + local for the same bank on
+    the first two frames of the stream.  Quantisation (numpy in the oracle) is NOT timed, which can
+    only flatter the CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    od = lo.OracleDetector(NFEAT[0], T_LEVELS)
+    feat, offs, wh = bank
+    pb = lo.PackedBank(n_templates, 2, feat, offs, wh)
+    times, cands = [], 0
+    use = frames[:2]
+    for rgb, dep in use:
+        pyr = od.quantize_pyramid(rgb, dep)
+        t0 = time.perf_counter()
+        lms = [[lo.build_linear_memories(p[0], T_LEVELS[l]), lo.build_linear_memories(p[1], T_LEVELS[l])] for l, p in enumerate(pyr)]
+        sizes = [(p[0].shape[1], p[0].shape[0]) for p in pyr]
+        m, st = lo.match_bank_c(pb, lms, sizes, T_LEVELS, THRESHOLD, 1)
+        times.append(time.perf_counter() - t0)
+        cands += st["coarse_candidates"]
+    ncores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    lo.match_bank_c(pb, lms, sizes, T_LEVELS, THRESHOLD, ncores)
+    t_mt = time.perf_counter() - t0
+    sec = float(np.median(times))
+    cpu = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n_templates * (W * H / 1e6) / sec, "unit": "templates*Mpx/s", "cores": 1, "kind": "port",
+            "sample": "%d frames x %d templates (same bank/frames as the GPU run), SSE C port of LL.cpp:1026-1941, "
+                      "linear memories + coarse + local timed, numpy quantisation excluded; median %.3f s/frame, %.1f coarse candidates/template"
+                      % (len(use), n_templates, sec, cands / len(use) / n_templates),
+            "host_cpu": cpu, "host_cores": ncores,
+            "all_cores_variant": {"threads": ncores, "value": n_templates * (W * H / 1e6) / t_mt,
+                                  "note": "templates split across pthreads, match loops only (not what the reference does)"}}
+
+
+if __name__ == "__main__":
+    main()

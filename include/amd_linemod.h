@@ -130,6 +130,10 @@ int lm_detector_match(lm_detector *d, const uint8_t *rgb, const uint16_t *depth,
  * runs front end + matching on it.  `sort_unique`=0 returns the raw pre-unique list (unordered). */
 int lm_detector_set_frame(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
                           const uint8_t *const *masks);
+/* Stream support: park frames in HBM slots once, then make one current with a
+ * device-to-device copy on the detector's stream (no host traffic inside a timed region). */
+int lm_detector_store_frame(lm_detector *d, int slot, const uint8_t *rgb, const uint16_t *depth, int width, int height);
+int lm_detector_select_frame(lm_detector *d, int slot);
 int lm_detector_match_resident(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids,
                                int sort_unique, lm_match **out, size_t *n);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);

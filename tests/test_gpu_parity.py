@@ -1,0 +1,412 @@
+"""GPU parity tests (`-m gpu`): the HIP path, called through the C ABI, against the CPU oracle on
+the same inputs — bit-exact for every integer/byte stage and for (x, y, similarity, template_id);
+ICP within 1e-4 on R and t (metres) as BASELINE.json's north_star states."""
+import os
+
+import numpy as np
+import pytest
+
+import linemod_oracle as lo
+import synth
+from helpers import GOLDEN, load_bgr, load_gray, load_u16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lm():
+    import __graft_entry__ as g
+    import linemodLevelup_pybind as mod
+    if not os.path.exists(mod.library_path()):
+        g.build()
+    lib = mod.load_library()
+    assert lib.lm_device_count() >= 1, "GPU tests need a visible MI355X (no CPU fallback)"
+    return mod
+
+
+def oracle_matches(od, rgb, dep, bank_arrays, T, thr, cls=0):
+    feat, offs, wh = bank_arrays
+    lms, sizes = od.linear_memories(rgb, dep)
+    P = (len(offs) - 1) // (2 * len(T))
+    raw, st = lo.match_bank_c(lo.PackedBank(P, len(T), feat, offs, wh), lms, sizes, T, thr)
+    raw["cls"] = cls
+    return raw, st
+
+
+def same_records(got, want):
+    """got: product MATCH_DTYPE, want: oracle MATCH_DTYPE; exact comparison field by field."""
+    assert len(got) == len(want), (len(got), len(want))
+    for g, w in (("x", "x"), ("y", "y"), ("similarity", "sim"), ("class_index", "cls"), ("template_id", "tid")):
+        assert np.array_equal(got[g], want[w]), g
+
+
+def as_multiset(rec, names):
+    return sorted(zip(*[rec[n].tolist() for n in names]))
+
+
+# ---------------------------------------------------------------------------------------------
+# front end: quantised maps and linear memories, byte for byte
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["fixture_T58", "synth_T48", "synth_small_T48", "synth_3level", "synth_1280"])
+def test_frontend_stages_bit_exact(lm, case):
+    if case == "fixture_T58":
+        rgb, dep, T, nf = load_bgr("0000_rgb.png"), load_u16("0000_dep.png"), [5, 8], 127
+    elif case == "synth_T48":
+        (rgb, dep), T, nf = synth.make_frame(0), [4, 8], 150
+    elif case == "synth_small_T48":
+        (rgb, dep), T, nf = synth.make_frame(5, 320, 240, 12), [4, 8], 64
+    elif case == "synth_3level":
+        (rgb, dep), T, nf = synth.make_frame(6, 640, 480), [4, 4, 8], 64
+    else:
+        (rgb, dep), T, nf = synth.make_frame(7, 1280, 960, 60), [4, 8], 150
+    od = lo.OracleDetector(nf, T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    det = lm.Detector(nf, T, device=0)
+    det.addClassPacked("e", np.zeros((0, 3), np.int32), np.zeros(1, np.int32), np.zeros((0, 2), np.int32))
+    det.setFrame([rgb, dep])
+    det.matchResident(75.0, ["e"])
+    for l, (qc, qn, *_r) in enumerate(pyr):
+        assert np.array_equal(det.readStage(l, 0).reshape(qc.shape), qc), "orientations level %d" % l
+        assert np.array_equal(det.readStage(l, 1).reshape(qn.shape), qn), "normals level %d" % l
+        n = 8 * qc.size
+        assert np.array_equal(det.readStage(l, 2), lo.build_linear_memories(qc, T[l])[:n]), "LM colour level %d" % l
+        assert np.array_equal(det.readStage(l, 3), lo.build_linear_memories(qn, T[l])[:n]), "LM normal level %d" % l
+
+
+def test_frontend_masks(lm):
+    rgb, dep = synth.make_frame(2, 320, 240, 12)
+    T = [4, 8]
+    rng = np.random.default_rng(0)
+    m0 = (rng.uniform(0, 1, dep.shape) < 0.7).astype(np.uint8) * 255
+    m1 = np.zeros(dep.shape, np.uint8)
+    m1[40:200, 30:290] = 1
+    od = lo.OracleDetector(64, T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    det = lm.Detector(64, T, device=0)
+    det.addClassPacked("e", np.zeros((0, 3), np.int32), np.zeros(1, np.int32), np.zeros((0, 2), np.int32))
+    det.setFrame([rgb, dep], [m0, m1])
+    det.matchResident(75.0, [])
+    a, b = m0, m1
+    for l, (qc, qn, *_r) in enumerate(pyr):
+        if l > 0:
+            a, b = lo.nn_down2(a), lo.nn_down2(b)
+        n = 8 * qc.size
+        assert np.array_equal(det.readStage(l, 2), lo.build_linear_memories(np.where(a > 0, qc, 0).astype(np.uint8), T[l])[:n])
+        assert np.array_equal(det.readStage(l, 3), lo.build_linear_memories(np.where(b > 0, qn, 0).astype(np.uint8), T[l])[:n])
+
+
+def test_precondition_errors_like_cv_assert(lm):
+    det = lm.Detector(63, [5, 8], device=0)
+    rgb, dep = synth.make_frame(1, 320, 240, 4)                 # 160x120 at level 1: 120 % 8 == 0 but 320 % 5 == 0, 240%5==0 ok
+    bad_rgb, bad_dep = rgb[:, :318].copy(), dep[:, :318].copy()    # 318 % 5 != 0
+    with pytest.raises(RuntimeError, match=r"% T == 0|% 16 == 0"):
+        det.match([np.ascontiguousarray(bad_rgb), np.ascontiguousarray(bad_dep)], 75.0, [])
+    with pytest.raises(RuntimeError):
+        det.match([rgb, dep.astype(np.float32)], 75.0, [])
+    with pytest.raises(RuntimeError):
+        det.match([rgb], 75.0, [])
+
+
+# ---------------------------------------------------------------------------------------------
+# match: fixture banks (reference detect_test inputs) and synthetic banks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bank,nfeat", [("127", 127), ("63", 63)])
+def test_match_fixture_banks(lm, bank, nfeat):
+    rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
+    fmt = os.path.join(GOLDEN, "bank" + bank + "_%s.yaml.gz")
+    od = lo.OracleDetector(nfeat, [5, 8])
+    od.readClasses(["06_template"], fmt)
+    det = lm.Detector(nfeat, [5, 8], device=0)
+    det.readClasses(["06_template"], fmt)
+    assert det.numTemplates("06_template") == 89 and det.classIds() == ["06_template"]
+    # bank round trip: what the product parsed equals what the oracle parsed
+    for tid in (0, 34, 88):
+        for a, b in zip(det.getTemplates("06_template", tid), od.class_templates["06_template"][tid]):
+            assert (a.width, a.height, a.pyramid_level) == (b.width, b.height, b.pyramid_level)
+            assert np.array_equal(a.features, b.features)
+    for thr in (75.0, 60.0):
+        got = det.matchArray([rgb, dep], thr, ["06_template"])
+        lms, sizes = od.linear_memories(rgb, dep)
+        raw = od.match_raw(lms, sizes, thr, ["06_template"])
+        same_records(got, lo.canonical_sort_unique(raw))
+        tm = det.lastTimings()
+        assert tm["coarse_candidates"] == od.last_stats["coarse_candidates"]
+        assert tm["matches_pre_unique"] == len(raw)
+        # pre-unique multiset
+        det.setFrame([rgb, dep])
+        pre = det.matchResident(thr, ["06_template"], sort_unique=False)
+        assert as_multiset(pre, ["x", "y", "similarity", "template_id"]) == as_multiset(raw, ["x", "y", "sim", "tid"])
+    ms = det.match([rgb, dep], 75.0, ["06_template"], masks=[])
+    assert (ms[0].x, ms[0].y, ms[0].template_id, ms[0].class_id) == (332, 127, 34, "06_template")
+
+
+@pytest.mark.parametrize("W,H,T,nfeat,n,thr", [
+    (640, 480, [4, 8], (150, 75), 300, 75.0),       # Detector(150,[4,8]) of the driver script
+    (640, 480, [4, 8], (63, 31), 200, 70.0),        # < 64 features: the reference's 8-bit path
+    (320, 240, [4, 8], (64, 32), 100, 65.0),
+    (640, 480, [4, 4, 8], (64, 32, 16), 120, 70.0), # three pyramid levels
+    (640, 480, [8], (75,), 150, 75.0),              # single level: no refinement
+    (1280, 960, [4, 8], (150, 75), 120, 75.0),
+])
+def test_match_planted_and_random_banks(lm, W, H, T, nfeat, n, thr):
+    rgb, dep = synth.make_frame(11, W, H, 40 if W <= 640 else 80)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    planted = synth.make_planted_bank(21, n, [(p[0], p[1]) for p in pyr], T, nfeat)
+    random = synth.make_random_bank(22, n // 2, W, H, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("planted", *planted)
+    det.addClassPacked("random", *random)
+    ra, sa = oracle_matches(od, rgb, dep, planted, T, thr, 0)
+    rb, sb = oracle_matches(od, rgb, dep, random, T, thr, 1)
+    assert sa["coarse_candidates"] > n, "planted bank must exercise the refinement"
+    want = lo.canonical_sort_unique(np.concatenate([ra, rb]))
+    got = det.matchArray([rgb, dep], thr, ["planted", "random"])
+    same_records(got, want)
+    assert det.lastTimings()["coarse_candidates"] == sa["coarse_candidates"] + sb["coarse_candidates"]
+    # class order given by the caller; unknown classes are skipped; empty list = sorted class order
+    got2 = det.matchArray([rgb, dep], thr, ["random", "nope", "planted"])
+    rb2, ra2 = rb.copy(), ra.copy()
+    rb2["cls"] = 0; ra2["cls"] = 2
+    same_records(got2, lo.canonical_sort_unique(np.concatenate([rb2, ra2])))
+    same_records(det.matchArray([rgb, dep], thr, []), want)     # sorted: planted < random
+    # idempotence, and the HBM frame-slot path gives the same result
+    same_records(det.matchArray([rgb, dep], thr, ["planted", "random"]), want)
+    det.storeFrame(1, [rgb, dep])
+    det.storeFrame(0, synth.make_frame(99, W, H, 5))
+    det.selectFrame(0)
+    det.matchResident(thr, ["planted", "random"])
+    det.selectFrame(1)
+    same_records(det.matchResident(thr, ["planted", "random"]), want)
+
+
+def test_match_edge_cases(lm):
+    W, H, T = 320, 240, [4, 8]
+    rgb, dep = synth.make_frame(4, W, H, 14)
+    od = lo.OracleDetector(32, T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    det = lm.Detector(32, T, device=0)
+    # empty detector / empty class / unknown class
+    assert len(det.matchArray([rgb, dep], 75.0, [])) == 0
+    det.addClassPacked("empty", np.zeros((0, 3), np.int32), np.zeros(1, np.int32), np.zeros((0, 2), np.int32))
+    assert len(det.matchArray([rgb, dep], 75.0, ["empty", "unknown"])) == 0
+    # hand-made pyramids: template larger than the image (template_positions <= 0), negative and
+    # out-of-image feature coordinates (discarded by LL.cpp:1330 / :1394), features at x==width
+    qc1 = pyr[1][0]
+    ys, xs = np.nonzero(qc1)
+    lab = np.log2(qc1[ys, xs]).astype(np.int32)
+    def entry(fe, w, h):
+        return np.asarray(fe, np.int32).reshape(-1, 3), (w, h)
+    base0 = [[int(x) * 2, int(y) * 2, int(l)] for x, y, l in zip(xs[:40] % 60, ys[:40] % 60, lab[:40])]
+    base1 = [[int(x), int(y), int(l)] for x, y, l in zip(xs[:20] % 30, ys[:20] % 30, lab[:20])]
+    pyrs = [
+        [entry(base0, 120, 120), entry(base0, 120, 120), entry(base1, 60, 60), entry(base1, 60, 60)],
+        [entry(base0, 400, 300), entry(base0, 400, 300), entry(base1, 200, 150), entry(base1, 200, 150)],      # too large
+        [entry(base0 + [[-3, 5, 1], [5000, 2, 2]], 120, 120), entry(base0, 120, 120),
+         entry(base1 + [[-1, -1, 0], [161, 3, 3]], 60, 60), entry(base1 + [[60, 60, 7]], 60, 60)],
+        [entry([[0, 0, 0]], 0, 0), entry([[0, 0, 1]], 0, 0), entry([[0, 0, 0]], 0, 0), entry([[0, 0, 1]], 0, 0)],   # 1-feature, size 0
+    ]
+    feats, offs, whs = [], [0], []
+    for p in pyrs:
+        for f, wh in p:
+            feats.append(f); offs.append(offs[-1] + len(f)); whs.append(wh)
+    bank = (np.concatenate(feats), np.asarray(offs, np.int32), np.asarray(whs, np.int32))
+    det.addClassPacked("hand", *bank)
+    for thr in (10.0, 50.0, 100.0, 0.0):
+        want, _ = oracle_matches(od, rgb, dep, bank, T, thr, 0)
+        same_records(det.matchArray([rgb, dep], thr, ["hand"]), lo.canonical_sort_unique(want))
+    # candidate-buffer growth path: threshold 0 on a bigger bank overflows the initial capacity? (count only)
+    assert det.lastTimings()["matches_pre_unique"] == len(want)
+    # invalid banks are rejected like the reference's CV_Asserts
+    with pytest.raises(RuntimeError, match="8191"):
+        big = np.zeros((8192, 3), np.int32)
+        det.addClassPacked("big", np.concatenate([big, big, big, big]), np.arange(5, dtype=np.int32) * 8192,
+                           np.full((4, 2), 10, np.int32))
+    with pytest.raises(RuntimeError):
+        det.addClassPacked("hand", *bank)               # class already present
+
+
+def test_sharded_equals_unsharded_on_one_device(lm):
+    """N logical shards on one device through the same slice + merge code the multi-GPU path uses."""
+    W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+    rgb, dep = synth.make_frame(13, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    a = synth.make_planted_bank(31, 130, [(p[0], p[1]) for p in pyr], T, nfeat)
+    b = synth.make_planted_bank(32, 77, [(p[0], p[1]) for p in pyr], T, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("a", *a)
+    det.addClassPacked("b", *b)
+    whole = det.matchArray([rgb, dep], 75.0, ["b", "a"])
+    assert len(whole) > 0
+    for world in (2, 3, 8):
+        parts = []
+        det.setFrame([rgb, dep])
+        for r in range(world):
+            det.setShard(r, world)
+            parts.append(det.matchResident(75.0, ["b", "a"], sort_unique=False))
+        det.setShard(0, 1)
+        merged = lm.merge_matches(np.concatenate(parts))
+        assert merged.tobytes() == whole.tobytes()
+
+
+def test_config1_size_2k_templates_bit_exact(lm):
+    """BASELINE configs[1]: 1 object x 2k templates, 640x480 — compared directly (the C oracle takes
+    ~0.3 s) plus size-independent properties: threshold monotonicity and bank-permutation invariance."""
+    W, H, T, nfeat, n = 640, 480, [4, 8], (150, 75), 2000
+    rgb, dep = synth.make_frame(0, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    bank = synth.make_planted_bank(1234, n, [(p[0], p[1]) for p in pyr], T, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("obj", *bank)
+    want, st = oracle_matches(od, rgb, dep, bank, T, 75.0)
+    got = det.matchArray([rgb, dep], 75.0, ["obj"])
+    same_records(got, lo.canonical_sort_unique(want))
+    tm = det.lastTimings()
+    assert tm["coarse_candidates"] == st["coarse_candidates"] and tm["local_evals"] == st["local_evals"]
+    hi = det.matchArray([rgb, dep], 85.0, ["obj"])
+    key = lambda r: set(zip(r["x"].tolist(), r["y"].tolist(), r["similarity"].tolist(), r["template_id"].tolist()))
+    assert key(hi) <= key(got) and all(hi["similarity"] >= 85.0)
+    # permuting the template pyramids permutes template ids and nothing else
+    feat, offs, wh = bank
+    perm = np.random.default_rng(3).permutation(n)
+    E = 4
+    pf, po, pw = [], [0], []
+    for p in perm:
+        for e in range(E):
+            k = p * E + e
+            pf.append(feat[offs[k]:offs[k + 1]]); po.append(po[-1] + offs[k + 1] - offs[k]); pw.append(wh[k])
+    det2 = lm.Detector(nfeat[0], T, device=0)
+    det2.addClassPacked("obj", np.concatenate(pf), np.asarray(po, np.int32), np.asarray(pw, np.int32))
+    det2.setFrame([rgb, dep])
+    pre2 = det2.matchResident(75.0, ["obj"], sort_unique=False)
+    back = pre2.copy()
+    back["template_id"] = perm[pre2["template_id"]]
+    assert as_multiset(back, ["x", "y", "similarity", "template_id"]) == as_multiset(want, ["x", "y", "sim", "tid"])
+
+
+# ---------------------------------------------------------------------------------------------
+# addTemplate / YAML through the product
+# ---------------------------------------------------------------------------------------------
+def test_add_template_reproduces_reference_golden(lm, tmp_path):
+    rgb, dep, mask = load_bgr("train_rgb.png"), load_u16("train_dep.png"), load_gray("train_mask.png")
+    det = lm.Detector(device=0)                      # Detector(): 63 features, T={5,8}
+    assert det.addTemplate([rgb, dep], "06_template", mask) == 0
+    _, _, _, pyr = lo.read_class_yaml(os.path.join(GOLDEN, "writeClasses_06_template.yaml"))
+    for a, b in zip(det.getTemplates("06_template", 0), pyr[0]):
+        assert (a.width, a.height, a.pyramid_level) == (b.width, b.height, b.pyramid_level)
+        assert np.array_equal(a.features, b.features)
+    # a frame without enough features fails with -1 and adds nothing (LL.cpp:1964-1966)
+    assert det.addTemplate([np.zeros_like(rgb), np.zeros_like(dep)], "06_template", mask) == -1
+    assert det.numTemplates("06_template") == 1
+    # no-mask variant equals the oracle
+    od = lo.OracleDetector()
+    srgb, sdep = synth.make_frame(9, 320, 240, 10)
+    t_o = od.addTemplate([srgb, sdep], "s", None)
+    t_g = det.addTemplate([srgb, sdep], "s", np.zeros((0, 0), np.uint8))
+    assert t_o == t_g == 0
+    for a, b in zip(det.getTemplates("s", 0), od.class_templates["s"][0]):
+        assert (a.width, a.height) == (b.width, b.height) and np.array_equal(a.features, b.features)
+    # writeClasses -> readClasses round trip (oracle reader parses the product's YAML too)
+    det.writeClasses(str(tmp_path / "%s.yaml"))
+    _, mods, levels, pyr2 = lo.read_class_yaml(str(tmp_path / "06_template.yaml"))
+    assert mods == ["ColorGradient", "DepthNormal"] and levels == 2
+    assert np.array_equal(pyr2[0][0].features, pyr[0][0].features)
+    det2 = lm.Detector(device=0)
+    det2.readClasses(["06_template", "s"], str(tmp_path / "%s.yaml"))
+    assert det2.classIds() == ["06_template", "s"]
+    with pytest.raises(RuntimeError):
+        det2.readClasses(["s"], str(tmp_path / "%s.yaml"))             # already present, LL.cpp:2059
+    with pytest.raises(RuntimeError):
+        lm.Detector([5, 8, 8], device=0).readClasses(["s"], str(tmp_path / "%s.yaml"))   # pyramid_levels, LL.cpp:2052
+
+
+# ---------------------------------------------------------------------------------------------
+# poseRefine / ICP  (parity unpinned by the reference: GPU vs the oracle's Open3D restatement)
+# ---------------------------------------------------------------------------------------------
+K_CAM = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32).reshape(3, 3)
+
+
+def _perturbed_scene(md, K, rot_deg, t_mm, seed):
+    """Scene depth = model surface moved by a small SE(3) (re-rendered by forward splatting) + 1 mm noise."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.nonzero(md)
+    z = md[ys, xs].astype(np.float64)
+    P = np.stack([(xs - K[0, 2]) / K[0, 0] * z, (ys - K[1, 2]) / K[1, 1] * z, z], 1)
+    a = np.radians(rot_deg)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    c = P.mean(0)
+    Q = (P - c) @ Rz.T + c + np.asarray(t_mm, np.float64)
+    u = np.rint(Q[:, 0] / Q[:, 2] * K[0, 0] + K[0, 2]).astype(int)
+    v = np.rint(Q[:, 1] / Q[:, 2] * K[1, 1] + K[1, 2]).astype(int)
+    sd = np.zeros(md.shape, np.float64)
+    ok = (u >= 0) & (u < md.shape[1]) & (v >= 0) & (v < md.shape[0])
+    sd[v[ok], u[ok]] = Q[ok, 2] + rng.normal(0, 1.0, int(ok.sum()))
+    return np.clip(np.rint(sd), 0, 65535).astype(np.uint16)
+
+
+def _check_pose(lm, sd, md, dx, dy, intended, tol=1e-4):
+    R, t = np.eye(3, dtype=np.float32), np.array([0, 0, 1000], np.float32)
+    pr = lm.poseRefine(device=0, scene_from_scene=intended)
+    pr.process(sd, md, K_CAM, K_CAM, R, t, dx, dy)
+    ref = lo.pose_refine(sd, md, K_CAM, K_CAM, R, t, dx, dy, scene_from_scene=intended)
+    assert pr.info["n_source"] == ref["n_source"] and pr.info["n_target"] == ref["n_target"]
+    assert pr.info["iterations"] == ref["iterations"]
+    assert abs(pr.getResidual() - ref["residual"]) < 1e-6
+    assert np.abs(pr.getR() - ref["R"]).max() < tol                       # rotation entries
+    assert np.abs(pr.getT().ravel() - ref["t"]).max() / 1000.0 < tol      # translation in metres
+    assert pr.getR().dtype == np.float64 and pr.getT().shape == (3, 1)
+    return pr, ref
+
+
+@pytest.mark.parametrize("seed,rot,tmm", [(1, 1.0, (2.0, -1.5, 3.0)), (2, -2.5, (-3.0, 2.0, -4.0)), (3, 0.0, (0.0, 0.0, 5.0))])
+def test_pose_refine_intended_mode(lm, seed, rot, tmm):
+    md = synth.synth_model_depth(seed)
+    sd = _perturbed_scene(md, K_CAM.astype(np.float64), rot, tmm, seed)
+    ys, xs = np.nonzero(md)
+    pr, ref = _check_pose(lm, sd, md, int(xs.min()), int(ys.min()), True)
+    assert ref["residual"] > 0.9 and ref["iterations"] >= 1               # a well-posed registration
+
+
+def test_pose_refine_reference_fixture_images(lm):
+    md, sd = load_u16("pose_depth_ren.png"), load_u16("pose_0003.png")
+    ys, xs = np.nonzero(md)
+    # verbatim (LL.cpp:109: target = model cloud) in its two well-posed regimes:
+    scene_small = np.where(md > 0, md + 2, 0).astype(np.uint16)           # centroid offset 2 mm -> identity, fitness 1
+    pr, ref = _check_pose(lm, scene_small, md, int(xs.min()) - 4, int(ys.min()) - 4, False)
+    assert pr.getResidual() == 1.0 and ref["n_source"] == 1316
+    scene_far = np.where(md > 0, md + 250, 0).astype(np.uint16)           # 250 mm: no correspondences -> init_guess, fitness 0
+    pr, ref = _check_pose(lm, scene_far, md, int(xs.min()) - 4, int(ys.min()) - 4, False)
+    assert pr.getResidual() == 0.0 and pr.info["iterations"] == 1
+    # the real scene depth image of the fixture in intended mode (well-conditioned registration)
+    _check_pose(lm, scene_small, md, int(xs.min()) - 4, int(ys.min()) - 4, True)
+
+
+def test_pose_refine_rejects_window_outside_frame(lm):
+    md = synth.synth_model_depth(4)
+    pr = lm.poseRefine(device=0)
+    pr.process(md, md, K_CAM, K_CAM, np.eye(3, dtype=np.float32), np.array([0, 0, 1000], np.float32), 620, 10)
+    assert pr.getResidual() == -1 and pr.getR() is None                    # LL.cpp:52-55
+    assert lo.pose_refine(md, md, K_CAM, K_CAM, np.eye(3), np.zeros(3), 620, 10)["residual"] == -1.0
+
+
+def test_pose_refine_batch_equals_single_calls(lm):
+    import linemodLevelup_pybind as mod
+    mds, sds, xy = [], [], []
+    base = synth.synth_model_depth(10)
+    scene = _perturbed_scene(base, K_CAM.astype(np.float64), 1.5, (2.0, 1.0, -3.0), 10)
+    for s in range(4):
+        md = synth.synth_model_depth(10 + s)
+        ys, xs = np.nonzero(md)
+        mds.append(md); xy.append((int(xs.min()), int(ys.min())))
+    xy.append((630, 470)); mds.append(mds[0])                               # one rejected hypothesis
+    n = len(mds)
+    Ks = np.tile(K_CAM.reshape(1, 9), (n, 1)); Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    ts = np.tile(np.array([[0, 0, 1000]], np.float32), (n, 1))
+    res, ms = mod.pose_refine_batch(scene, K_CAM, mds, Ks, Rs, ts, xy, device=0, scene_from_scene=True)
+    assert ms > 0 and res[-1]["residual"] == -1.0
+    for i in range(n - 1):
+        pr = mod.poseRefine(device=0, scene_from_scene=True)
+        pr.process(scene, mds[i], K_CAM, K_CAM, Rs[i].reshape(3, 3), ts[i], xy[i][0], xy[i][1])
+        assert np.array_equal(pr.getR(), res[i]["R"]) and np.array_equal(pr.getT().ravel(), res[i]["t"])
