@@ -115,9 +115,17 @@ struct lm_detector {
     // work list
     std::vector<int32_t> work_pyr, work_cls, work_tid;
     DevBuf<int32_t> d_work;
-    DevBuf<Candidate> d_cands, d_matches;
+    std::vector<std::string> work_key;              // class_ids the cached work list was built for
+    int work_key_rank = -1, work_key_world = -1;
+    bool work_valid = false;
+    int64_t work_coarse_bytes = 0;
+    DevBuf<Candidate> d_cands;
     DevBuf<unsigned long long> d_counters;
-    uint32_t cand_cap = 1u << 20;
+    uint32_t cand_cap = 1u << 18;
+    Candidate* h_matches = nullptr;                 // pinned, device-visible: k_local writes matches here
+    uint32_t match_cap = 0;
+    unsigned long long* h_counters = nullptr;       // pinned
+    int num_cus = 256;
 
     lm_timings timings{};
 };
@@ -168,6 +176,10 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
+    }
     uint8_t lut[400];
     make_normal_lut(lut);
     upload_normal_lut(lut);
@@ -185,7 +197,9 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_work.release();
-    d->d_cands.release(); d->d_matches.release(); d->d_counters.release();
+    d->d_cands.release(); d->d_counters.release();
+    if (d->h_matches) (void)hipHostFree(d->h_matches);
+    if (d->h_counters) (void)hipHostFree(d->h_counters);
     if (d->pinned) (void)hipHostFree(d->pinned);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -193,10 +207,10 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
 }
 
 // ---- frame upload + front end --------------------------------------------------------------------
-static size_t lm_tail_pad(int Wd, int Hd) {
-    size_t a = (size_t)Wd * Hd, b = (size_t)16 * Wd + 16;
-    return std::max(a, b) + 64;
-}
+// Zero tail after the 8 labels of one (level, modality) block: covers the reference's reads past a
+// phase row and the reads of padded / out-of-image features redirected to it, for any
+// position offset < Wd*Hd plus one 16-row window.
+static size_t lm_tail_pad(int Wd, int Hd) { return (size_t)Wd * Hd + (size_t)16 * Wd + 16 + 64; }
 
 // (Re)allocates per-level buffers and the LM arena for a W x H frame; validates the reference's
 // preconditions (LL.cpp:1136, 1217-1218).
@@ -498,15 +512,19 @@ extern "C" int lm_detector_set_shard(lm_detector* d, int rank, int world) {
 
 static inline int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
-// Flatten the bank for the current frame geometry and upload it: TemplEntry per (pyramid, level),
-// per feature the signed byte offset of its linear-memory run (accessLinearMemory, LL.cpp:1248-1271)
-// and packed int16 x,y.
+// Flatten the bank for the current frame geometry and upload it: TemplEntry per (pyramid, level);
+// per feature the byte offset of its linear-memory run from the arena start (accessLinearMemory,
+// LL.cpp:1248-1271; floor division so that window offsets that are multiples of T stay exact) and
+// packed int16 x,y.  Entries are padded to a multiple of kFeatBatch with features that read the
+// level's zero tail; at the top level features outside the image (LL.cpp:1330) are redirected there too.
 static int upload_bank(lm_detector* d) {
     const int L = d->pyramid_levels;
     d->bank_classes.clear(); d->bank_class_base.clear(); d->bank_class_count.clear();
     d->h_entries.clear();
+    d->work_valid = false;
     std::vector<int32_t> off;
     std::vector<uint32_t> xy;
+    const uint32_t pad_xy = 0x80008000u;   // x = y = -32768: never inside an image
     int flat = 0;
     for (auto& kv : d->class_templates) {
         d->bank_classes.push_back(kv.first);
@@ -516,23 +534,33 @@ static int upload_bank(lm_detector* d) {
             for (int l = 0; l < L; ++l) {
                 const LevelGeom& lv = d->geom.lv[l];
                 const long npos = (long)lv.Wd * lv.Hd;
+                const long zero_off = (long)lv.lm_off[1] + (long)8 * lv.T * lv.T * npos;   // tail of the normal block
                 TemplEntry e{};
                 e.feat_start = (uint32_t)off.size();
-                e.n0 = (uint16_t)tp[2 * l].features.size();
-                e.n1 = (uint16_t)tp[2 * l + 1].features.size();
+                const size_t n0 = tp[2 * l].features.size(), n1 = tp[2 * l + 1].features.size();
+                e.nf = (uint16_t)(n0 + n1);
                 e.width = tp[2 * l].width;      // matchClass uses tp[start] (first modality) for the clamp,
                 e.height = tp[2 * l].height;    // similarity() each template's own size: checked equal below
                 if (tp[2 * l + 1].width != e.width || tp[2 * l + 1].height != e.height)
                     return lm_set_error(LM_ERR_INVALID, "modalities of one pyramid level disagree on width/height");
+                int mnx = 32767, mny = 32767, mxx = -32768, mxy = -32768;
                 for (int m = 0; m < 2; ++m)
                     for (const Feature& f : tp[2 * l + m].features) {
-                        int T = lv.T;
-                        int gx = f.x - floordiv(f.x, T) * T, gy = f.y - floordiv(f.y, T) * T;   // floor modulo
-                        long o = ((long)f.label * T * T + (gy * T + gx)) * npos + (long)floordiv(f.y, T) * lv.Wd + floordiv(f.x, T);
-                        if (o < -(1L << 30) || o > (1L << 30)) return lm_set_error(LM_ERR_INVALID, "feature offset overflow");
+                        const int T = lv.T;
+                        const int gx = f.x - floordiv(f.x, T) * T, gy = f.y - floordiv(f.y, T) * T;   // floor modulo
+                        long o = (long)lv.lm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * npos + (long)floordiv(f.y, T) * lv.Wd +
+                                 floordiv(f.x, T);
+                        const bool inside = f.x >= 0 && f.x < lv.W && f.y >= 0 && f.y < lv.H;
+                        if (l == L - 1 && !inside) o = zero_off;                        // LL.cpp:1330
+                        if (o < -(1L << 31) || o >= (1L << 31)) return lm_set_error(LM_ERR_INVALID, "feature offset overflow");
                         off.push_back((int32_t)o);
                         xy.push_back((uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16));
+                        mnx = std::min(mnx, f.x); mny = std::min(mny, f.y); mxx = std::max(mxx, f.x); mxy = std::max(mxy, f.y);
                     }
+                if (e.nf == 0) mnx = mny = mxx = mxy = 0;
+                e.min_x = (int16_t)mnx; e.min_y = (int16_t)mny; e.max_x = (int16_t)mxx; e.max_y = (int16_t)mxy;
+                while ((off.size() - e.feat_start) % kFeatBatch) { off.push_back((int32_t)zero_off); xy.push_back(pad_xy); }
+                e.nf_padded = (uint16_t)(off.size() - e.feat_start);
                 d->h_entries.push_back(e);
             }
             ++flat;
@@ -564,10 +592,80 @@ static bool match_less(const lm_match& a, const lm_match& b) {
 static bool match_eq(const lm_match& a, const lm_match& b) {   // Match::operator== (LL.h:243-246)
     return a.x == b.x && a.y == b.y && a.similarity == b.similarity && a.class_index == b.class_index;
 }
+// LSD radix sort on the 112-bit key (~similarity bits, template_id | class, y, x), 11-bit digits,
+// digits that are constant over the input are skipped.  Equivalent to std::sort(match_less).
 extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
     if (!m || n == 0) return 0;
-    std::sort(m, m + n, match_less);
-    return (size_t)(std::unique(m, m + n, match_eq) - m);
+    if (n < 64) {
+        std::sort(m, m + n, match_less);
+        return (size_t)(std::unique(m, m + n, match_eq) - m);
+    }
+    struct Key { uint64_t hi, lo; };
+    std::vector<Key> keys(n);
+    bool radix_ok = true;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t sb;
+        memcpy(&sb, &m[i].similarity, 4);
+        if ((sb >> 31) || m[i].similarity != m[i].similarity || m[i].template_id < 0 || m[i].class_index < 0 || m[i].class_index > 0xFFFF ||
+            m[i].x < -32768 || m[i].x > 32767 || m[i].y < -32768 || m[i].y > 32767) { radix_ok = false; break; }
+        if (sb == 0x80000000u) sb = 0;
+        keys[i].hi = ((uint64_t)(~sb) << 32) | (uint32_t)m[i].template_id;
+        keys[i].lo = ((uint64_t)m[i].class_index << 32) | ((uint64_t)(uint16_t)(m[i].y + 32768) << 16) | (uint16_t)(m[i].x + 32768);
+    }
+    if (!radix_ok) {   // negative / NaN similarities or out-of-range fields: comparison sort
+        std::sort(m, m + n, match_less);
+        return (size_t)(std::unique(m, m + n, match_eq) - m);
+    }
+    // Exact duplicates (same x, y, similarity, class AND template: several coarse candidates of one
+    // template refined to the same position) are adjacent in the canonical order and removed by the
+    // unique step anyway: drop them first with an open-addressing hash so that the sort sees ~n/5.
+    std::vector<uint32_t> idx;
+    idx.reserve(n);
+    {
+        size_t cap = 64;
+        while (cap < 2 * n) cap <<= 1;
+        std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t h = (keys[i].hi * 0x9E3779B97F4A7C15ull) ^ (keys[i].lo * 0xC2B2AE3D27D4EB4Full);
+            size_t slot = (size_t)(h ^ (h >> 29)) & (cap - 1);
+            for (;;) {
+                uint32_t j = table[slot];
+                if (j == 0xFFFFFFFFu) { table[slot] = (uint32_t)i; idx.push_back((uint32_t)i); break; }
+                if (keys[j].hi == keys[i].hi && keys[j].lo == keys[i].lo) break;
+                slot = (slot + 1) & (cap - 1);
+            }
+        }
+    }
+    const size_t nu = idx.size();
+    std::vector<uint32_t> tmp(nu);
+    constexpr int BITS = 11, NB = 1 << BITS;
+    std::vector<uint32_t> hist(NB);
+    for (int word = 0; word < 2; ++word)          // lo word first (least significant)
+        for (int shift = 0; shift < (word == 0 ? 48 : 64); shift += BITS) {
+            std::fill(hist.begin(), hist.end(), 0u);
+            for (size_t i = 0; i < nu; ++i) {
+                uint64_t k = word == 0 ? keys[idx[i]].lo : keys[idx[i]].hi;
+                ++hist[(k >> shift) & (NB - 1)];
+            }
+            uint64_t k0 = word == 0 ? keys[idx[0]].lo : keys[idx[0]].hi;
+            if (hist[(k0 >> shift) & (NB - 1)] == nu) continue;   // constant digit
+            uint32_t sum = 0;
+            for (int b = 0; b < NB; ++b) { uint32_t c = hist[b]; hist[b] = sum; sum += c; }
+            for (size_t i = 0; i < nu; ++i) {
+                uint32_t id = idx[i];
+                uint64_t k = word == 0 ? keys[id].lo : keys[id].hi;
+                tmp[hist[(k >> shift) & (NB - 1)]++] = id;
+            }
+            idx.swap(tmp);
+        }
+    std::vector<lm_match> out;
+    out.reserve(nu);
+    for (size_t i = 0; i < nu; ++i) {
+        const lm_match& c = m[idx[i]];
+        if (out.empty() || !match_eq(out.back(), c)) out.push_back(c);
+    }
+    memcpy(m, out.data(), out.size() * sizeof(lm_match));
+    return out.size();
 }
 
 // numpy nms of the driver (linemod_and_levelup_test.py:34-61)
@@ -644,16 +742,20 @@ extern "C" int lm_detector_select_frame(lm_detector* d, int slot) {
 }
 
 static int build_work(lm_detector* d, const char* const* class_ids, int num_class_ids) {
+    std::vector<std::string> key;
+    if (class_ids && num_class_ids > 0)
+        for (int i = 0; i < num_class_ids; ++i) key.push_back(class_ids[i] ? class_ids[i] : "");
+    if (d->work_valid && key == d->work_key && d->work_key_rank == d->shard_rank && d->work_key_world == d->shard_world)
+        return LM_OK;   // same selection as the previous call: the device-resident work list is reused
     d->work_pyr.clear(); d->work_cls.clear(); d->work_tid.clear();
     std::vector<int> order;   // bank class index per position (-1 unknown)
-    if (!class_ids || num_class_ids <= 0) {
+    if (key.empty()) {
         for (size_t i = 0; i < d->bank_classes.size(); ++i) order.push_back((int)i);   // std::map order, LL.cpp:1756
     } else {
-        for (int i = 0; i < num_class_ids; ++i) {
+        for (const std::string& c : key) {
             int found = -1;
-            if (class_ids[i])
-                for (size_t k = 0; k < d->bank_classes.size(); ++k)
-                    if (d->bank_classes[k] == class_ids[i]) { found = (int)k; break; }
+            for (size_t k = 0; k < d->bank_classes.size(); ++k)
+                if (d->bank_classes[k] == c) { found = (int)k; break; }
             order.push_back(found);   // unknown classes are skipped, LL.cpp:1765-1767
         }
     }
@@ -677,7 +779,33 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
     if (rc) return rc;
     if (!d->work_pyr.empty())
-        HIP_TRY(hipMemcpyAsync(d->d_work.p, d->work_pyr.data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpy(d->d_work.p, d->work_pyr.data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // algorithmic bytes of the coarse pass over this work list: sum_m nfeat_m * template_positions
+    {
+        const int L = d->pyramid_levels;
+        const LevelGeom& lv = d->geom.lv[L - 1];
+        int64_t bytes = 0;
+        for (int32_t p : d->work_pyr) {
+            const TemplEntry& e = d->h_entries[(size_t)p * L + (L - 1)];
+            int wf = (e.width - 1) / lv.T + 1, hf = (e.height - 1) / lv.T + 1;
+            long tp = (long)(lv.Hd - hf) * lv.Wd + (lv.Wd - wf) + 1;
+            if (tp > 0) bytes += (int64_t)e.nf * tp;
+        }
+        d->work_coarse_bytes = bytes;
+    }
+    d->work_key = key; d->work_key_rank = d->shard_rank; d->work_key_world = d->shard_world;
+    d->work_valid = true;
+    return LM_OK;
+}
+
+static int ensure_match_buffers(lm_detector* d, uint32_t match_cap) {
+    if (!d->h_counters) HIP_TRY(hipHostMalloc((void**)&d->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (match_cap > d->match_cap) {
+        if (d->h_matches) (void)hipHostFree(d->h_matches);
+        d->h_matches = nullptr; d->match_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&d->h_matches, (size_t)match_cap * sizeof(Candidate), hipHostMallocDefault));
+        d->match_cap = match_cap;
+    }
     return LM_OK;
 }
 
@@ -693,79 +821,66 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
     if ((rc = d->d_counters.ensure(8))) return rc;
-    if ((rc = ensure_pinned(d, 4096))) return rc;
+    if ((rc = ensure_match_buffers(d, std::max<uint32_t>(d->match_cap, 1u << 16)))) return rc;
     hipStream_t s = d->stream;
     lm_timings tm{};
     tm.h2d_ms = d->last_h2d_ms;
     tm.templates = num_work;
+    tm.coarse_bytes = d->work_coarse_bytes;
 
     HIP_TRY(hipEventRecord(d->ev[0], s));
     if ((rc = run_frontend(d, true))) return rc;
     HIP_TRY(hipEventRecord(d->ev[1], s));
-
-    unsigned long long* hc = (unsigned long long*)d->pinned;
-    uint64_t ncand = 0;
-    for (;;) {   // grow-and-rerun on candidate overflow: never drop silently
+    Candidate* d_matches = nullptr;
+    uint64_t ncand = 0, nm = 0;
+    for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed: never drop silently
         if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, d->h_matches, 0));
         HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), s));
-        launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, num_work,
-                      threshold, d->d_cands.p, d->cand_cap, d->d_counters.p, s);
+        launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
+                      d->cand_cap, d->d_counters.p, s);
         HIP_TRY(hipEventRecord(d->ev[2], s));
-        HIP_TRY(hipMemcpyAsync(hc, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        // persistent refinement grid; the candidate count is read on the device (no host round trip)
+        launch_local(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
+                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d->num_cus * 8, s);
+        HIP_TRY(hipEventRecord(d->ev[3], s));
+        HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(d->ev[4], s));
         HIP_TRY(hipStreamSynchronize(s));
-        ncand = hc[0];
-        if (ncand <= d->cand_cap) break;
+        HIP_TRY(hipGetLastError());
+        ncand = d->h_counters[0]; nm = d->h_counters[1];
         if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
-        d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024);
+        bool again = false;
+        if (ncand > d->cand_cap) { d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024); again = true; }
+        if (nm > d->match_cap || (again && ncand > d->match_cap)) {
+            uint64_t want = std::max<uint64_t>(nm, ncand);
+            if ((rc = ensure_match_buffers(d, (uint32_t)(want + want / 4 + 1024)))) return rc;
+            again = true;
+        }
+        if (!again) break;
     }
-    if ((rc = d->d_matches.ensure(std::max<size_t>(1, (size_t)ncand)))) return rc;
-    HIP_TRY(hipEventRecord(d->ev[3], s));
-    launch_local(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                 (uint32_t)ncand, threshold, d->d_matches.p, (uint32_t)std::max<uint64_t>(1, ncand), d->d_counters.p, s);
-    HIP_TRY(hipEventRecord(d->ev[4], s));
-    HIP_TRY(hipMemcpyAsync(hc, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
-    const size_t nm = (size_t)hc[1];
     tm.coarse_candidates = (int64_t)ncand;
-    tm.local_evals = (int64_t)hc[2];
-    tm.local_bytes = (int64_t)hc[3];
+    tm.local_evals = (int64_t)d->h_counters[2];
+    tm.local_bytes = (int64_t)d->h_counters[3];
     tm.matches_pre_unique = (int64_t)nm;
-    std::vector<Candidate> hm(nm);
-    if (nm) HIP_TRY(hipMemcpyAsync(hm.data(), d->d_matches.p, nm * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(d->ev[5], s));
-    HIP_TRY(hipStreamSynchronize(s));
-
     (void)hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]);
     (void)hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]);
-    (void)hipEventElapsedTime(&tm.local_ms, d->ev[3], d->ev[4]);
-    (void)hipEventElapsedTime(&tm.d2h_ms, d->ev[4], d->ev[5]);
-    (void)hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[5]);
-    // algorithmic bytes of the coarse pass: sum_m nfeat_m * template_positions
-    {
-        const int L = d->pyramid_levels;
-        const LevelGeom& lv = d->geom.lv[L - 1];
-        int64_t bytes = 0;
-        for (int w = 0; w < num_work; ++w) {
-            const TemplEntry& e = d->h_entries[(size_t)d->work_pyr[w] * L + (L - 1)];
-            int wf = (e.width - 1) / lv.T + 1, hf = (e.height - 1) / lv.T + 1;
-            long tp = (long)(lv.Hd - hf) * lv.Wd + (lv.Wd - wf) + 1;
-            if (tp > 0) bytes += (int64_t)(e.n0 + e.n1) * tp;
-        }
-        tm.coarse_bytes = bytes;
-    }
+    (void)hipEventElapsedTime(&tm.local_ms, d->ev[2], d->ev[3]);
+    (void)hipEventElapsedTime(&tm.d2h_ms, d->ev[3], d->ev[4]);
+    (void)hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[4]);
     d->timings = tm;
 
-    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, nm) * sizeof(lm_match));
+    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
+    const Candidate* hm = d->h_matches;
     for (size_t i = 0; i < nm; ++i) {
         const Candidate& c = hm[i];
         res[i].x = c.x; res[i].y = c.y; res[i].similarity = c.score;
         res[i].class_index = d->work_cls[c.work];
         res[i].template_id = d->work_tid[c.work];
     }
-    size_t n = nm;
-    if (sort_unique) n = lm_merge_matches(res, nm);
+    size_t n = (size_t)nm;
+    if (sort_unique) n = lm_merge_matches(res, (size_t)nm);
     *out = res; *n_out = n;
     return LM_OK;
 }

@@ -30,10 +30,13 @@ struct FrameGeom {
     int levels;
     LevelGeom lv[kMaxLevels];
 };
-struct TemplEntry {       // one (pyramid, level): both modalities
-    uint32_t feat_start;  // index into the resolved-feature arrays
-    uint16_t n0, n1;      // colour / normal feature counts
+constexpr int kFeatBatch = 8;   // features per unrolled batch (independent gathers in flight per lane)
+struct TemplEntry {       // one (pyramid, level): both modalities, colour features first
+    uint32_t feat_start;  // index into feat_off / feat_xy (multiple of kFeatBatch)
+    uint16_t nf;          // true feature count of both modalities (the score denominator)
+    uint16_t nf_padded;   // nf rounded up to a multiple of kFeatBatch; padding reads the zero tail
     int32_t width, height;
+    int16_t min_x, min_y, max_x, max_y;   // bounding box of the features (fast-path test of the refinement)
 };
 struct Candidate {        // coarse hit, and (same layout) final match record
     int32_t x, y;
@@ -43,11 +46,13 @@ struct Candidate {        // coarse hit, and (same layout) final match record
 
 // counters[0] = number of candidates produced (may exceed cap: nothing is written past cap).
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                   const uint32_t* feat_xy, const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
+                   const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
                    unsigned long long* counters, hipStream_t s);
+// Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
 // counters[1] = number of matches produced, counters[2] = 16x16 evaluations, counters[3] = their bytes.
 void launch_local(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t num_cands,
-                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, hipStream_t s);
+                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
+                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
+                  hipStream_t s);
 
 }  // namespace lm

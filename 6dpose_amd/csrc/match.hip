@@ -2,16 +2,19 @@
 // similarityLocal, LL.cpp:1788-1941 matchClass).  Pure integer byte work: every response is a
 // u8 in {0,1,4}, summed per template position.  Nothing here is a dense contraction, so no MFMA;
 // the linear memories of one frame (1.2 MB coarse + 4.9 MB fine at VGA) live in L2 / Infinity
-// Cache and the kernels are bound by L2->L1 gather bandwidth and VALU byte adds.
+// Cache and the kernels are bound by the L2->L1 gather path, so the design goal is to keep many
+// independent gathers in flight per wave (kFeatBatch per batch) rather than arithmetic.
 //
-// Data layout (built by frontend.hip, offsets in FrameGeom):
+// Data layout (built by frontend.hip / detector.cpp, offsets in FrameGeom):
 //   LM arena: per level, per modality: u8 [8 labels][T*T phases][(W/T)*(H/T)] + zero tail.
-//   Bank:     TemplEntry per (pyramid, level); feat_off[] = signed byte offset of each feature's
-//             linear-memory run inside its level block (label / phase / lm_index of
-//             accessLinearMemory, LL.cpp:1248-1271, resolved on the host for the current frame
-//             geometry with floor division so that adding a multiple-of-T window offset stays exact;
-//             colour features first, then normal features);
-//             feat_xy[] = int16 x | int16 y << 16 for the bounds tests (LL.cpp:1330, 1394).
+//   Bank:     TemplEntry per (pyramid, level).  Its features (colour then normal) are padded to a
+//             multiple of kFeatBatch with entries that point at the level's zero tail, so the inner
+//             loops are branch-free.  feat_off[] = byte offset of the feature's linear-memory run
+//             from the arena start (accessLinearMemory, LL.cpp:1248-1271, resolved on the host for
+//             the current frame geometry with floor division, so adding a multiple-of-T window
+//             offset stays exact).  At the top level, features outside the image (LL.cpp:1330) are
+//             already redirected to the zero tail.  feat_xy[] = int16 x | int16 y << 16 is only
+//             read on the slow path of the refinement (bounds test of LL.cpp:1394).
 #include "lm_kernels.h"
 
 namespace lm {
@@ -33,38 +36,36 @@ static __device__ __forceinline__ float score_of(int raw, int nfeat) {
 // accumulated in two packed u16x2 registers (even / odd bytes); 2 x 8191 x 4 < 65536 so neither
 // modality split nor widening is needed (the reference's 8-bit and 16-bit paths give the same sums).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(320)
 k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-         const uint32_t* __restrict__ feat_xy,
          const int32_t* __restrict__ work_pyramids, float threshold, Candidate* __restrict__ cands, uint32_t cap,
          unsigned long long* __restrict__ counters) {
     const int work = blockIdx.x;
     const int pyr = work_pyramids[work];
     const TemplEntry e = entries[(size_t)pyr * levels + level];
-    const int n0 = e.n0, nf = e.n0 + e.n1;
+    const int nf = e.nf, nfp = e.nf_padded;
     const int32_t* fo = feat_off + e.feat_start;
-    const uint32_t* fxy = feat_xy + e.feat_start;
     const int Wd = lv.Wd, Hd = lv.Hd, T = lv.T;
     const int npos = Wd * Hd;
     // LL.cpp:1299-1309
     const int wf = (e.width - 1) / T + 1, hf = (e.height - 1) / T + 1;
     const int tp = (Hd - hf) * Wd + (Wd - wf) + 1;
-    const uint8_t* lm0 = lm_arena + lv.lm_off[0];
-    const uint8_t* lm1 = lm_arena + lv.lm_off[1];
     const int offset = T / 2 + (T % 2 - 1);   // LL.cpp:1846
 
     for (int j0 = threadIdx.x * 4; j0 < npos; j0 += blockDim.x * 4) {
         uint32_t even = 0, odd = 0;
         if (j0 < tp) {
-            for (int f = 0; f < nf; ++f) {
-                int32_t o = fo[f];                        // wave-uniform -> scalar loads
-                uint32_t xy = fxy[f];
-                int fx = (int16_t)(xy & 0xFFFF), fy = (int16_t)(xy >> 16);
-                if (fx < 0 || fx >= lv.W || fy < 0 || fy >= lv.H) continue;   // LL.cpp:1330
-                uint32_t v = ld_u32((f < n0 ? lm0 : lm1) + o + j0);
-                even += v & 0x00FF00FFu;
-                odd += (v >> 8) & 0x00FF00FFu;
+            const uint8_t* base = lm_arena + j0;
+            for (int f = 0; f < nfp; f += kFeatBatch) {
+                uint32_t v[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u32(base + fo[f + u]);   // fo[]: wave-uniform -> SMEM
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) {
+                    even += v[u] & 0x00FF00FFu;
+                    odd += (v[u] >> 8) & 0x00FF00FFu;
+                }
             }
         }
         int raw[4] = {(int)(even & 0xFFFF), (int)(odd & 0xFFFF), (int)(even >> 16), (int)(odd >> 16)};
@@ -88,24 +89,26 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
 }
 
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                   const uint32_t* feat_xy, const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
+                   const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
                    unsigned long long* counters, hipStream_t s) {
     if (num_work <= 0) return;
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
     int npos = lv.Wd * lv.Hd;
     int threads = ((npos + 3) / 4 + 63) / 64 * 64;
-    if (threads > 256) threads = 256;
+    if (threads > 320) threads = 320;
     if (threads < 64) threads = 64;
     hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(threads), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
-                       feat_xy, work_pyramids, threshold, cands, cap, counters);
+                       work_pyramids, threshold, cands, cap, counters);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Local refinement: one wave64 per candidate, marching up the pyramid (LL.cpp:1855-1938).  Lane l
 // owns row l/4, columns 4*(l%4)..+3 of the 16x16 patch; per feature it adds one dword of the linear
 // memory at  run + (y/T-8)*Wd + (x/T-8) + row*Wd + col.  First strict maximum (LL.cpp:1920) is found
-// with a packed key (raw<<8 | 255-index) and a wave max-reduction.
+// with a packed key (raw<<8 | 255-index) and a wave max-reduction.  The grid is persistent: waves
+// stride over the candidate list whose length is read from device memory (no host round trip
+// between the coarse and the local pass).
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -119,74 +122,90 @@ static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 __global__ void __launch_bounds__(256)
 k_local(const uint8_t* __restrict__ lm_arena, FrameGeom g, const TemplEntry* __restrict__ entries,
         const int32_t* __restrict__ feat_off, const uint32_t* __restrict__ feat_xy,
-        const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t num_cands,
+        const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
         float threshold, Candidate* __restrict__ matches, uint32_t cap, unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
-    const uint32_t ci = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ci >= num_cands) return;
-    const Candidate cd = cands[ci];
-    const int work = __builtin_amdgcn_readfirstlane(cd.work);
-    const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
-    int mx = __builtin_amdgcn_readfirstlane(cd.x), my = __builtin_amdgcn_readfirstlane(cd.y);
-    float sim = cd.score;
+    const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    unsigned long long nc = counters[0];
+    const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
     const int row = lane >> 2, col = (lane & 3) * 4;
-    bool alive = true;
     unsigned long long evals = 0, bytes = 0;
 
-    for (int l = g.levels - 2; l >= 0 && alive; --l) {
-        const LevelGeom lv = g.lv[l];
-        const TemplEntry e = entries[(size_t)pyr * g.levels + l];
-        const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd;
-        const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-        const int max_x = W - e.width - border, max_y = H - e.height - border;
-        int x = mx * 2 + 1, y = my * 2 + 1;               // LL.cpp:1871-1880
-        x = x > border ? x : border;  y = y > border ? y : border;
-        x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
-        const int gx = x / T - 8, gy = y / T - 8;          // C division (truncation), LL.cpp:1380-1381
-        const int off_x = gx * T, off_y = gy * T;
-        const int shift = gy * Wd + gx + row * Wd + col;
-        const int n0 = e.n0, nf = e.n0 + e.n1;
-        const int32_t* fo = feat_off + e.feat_start;
-        const uint32_t* fxy = feat_xy + e.feat_start;
-        const uint8_t* lm0 = lm_arena + lv.lm_off[0];
-        const uint8_t* lm1 = lm_arena + lv.lm_off[1];
-        uint32_t even = 0, odd = 0;
-        for (int f = 0; f < nf; ++f) {
-            int32_t o = fo[f];
-            uint32_t xy = fxy[f];
-            int fx = (int16_t)(xy & 0xFFFF) + off_x, fy = (int16_t)(xy >> 16) + off_y;
-            if (fx < 0 || fy < 0 || fx >= W || fy >= H) continue;   // LL.cpp:1394
-            uint32_t v = ld_u32((f < n0 ? lm0 : lm1) + ((int64_t)o + shift));
-            even += v & 0x00FF00FFu;
-            odd += (v >> 8) & 0x00FF00FFu;
+    for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
+        const Candidate cd = cands[ci];
+        const int work = __builtin_amdgcn_readfirstlane(cd.work);
+        const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
+        int mx = __builtin_amdgcn_readfirstlane(cd.x), my = __builtin_amdgcn_readfirstlane(cd.y);
+        float sim = cd.score;
+        bool alive = true;
+
+        for (int l = g.levels - 2; l >= 0 && alive; --l) {
+            const LevelGeom lv = g.lv[l];
+            const TemplEntry e = entries[(size_t)pyr * g.levels + l];
+            const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd;
+            const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+            const int max_x = W - e.width - border, max_y = H - e.height - border;
+            int x = mx * 2 + 1, y = my * 2 + 1;               // LL.cpp:1871-1880
+            x = x > border ? x : border;  y = y > border ? y : border;
+            x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
+            const int gx = x / T - 8, gy = y / T - 8;          // C division (truncation), LL.cpp:1380-1381
+            const int off_x = gx * T, off_y = gy * T;
+            const int nf = e.nf, nfp = e.nf_padded;
+            const int32_t* fo = feat_off + e.feat_start;
+            const uint8_t* base = lm_arena + ((int64_t)gy * Wd + gx + row * Wd + col);
+            uint32_t even = 0, odd = 0;
+            // every feature stays inside the image after the window offset (LL.cpp:1394)?  Decided once
+            // per candidate from the entry's feature bounding box; true unless the template is huge.
+            // (gx,gy inside [0, Wd-16] x [0, Hd-16] also keeps the zero-tail padding reads inside the tail.)
+            const bool all_in = (e.min_x + off_x >= 0) && (e.min_y + off_y >= 0) && (e.max_x + off_x < W) && (e.max_y + off_y < H) &&
+                                gx >= 0 && gy >= 0 && gx + 16 <= Wd && gy + 16 <= lv.Hd;
+            if (all_in) {
+                for (int f = 0; f < nfp; f += kFeatBatch) {
+                    uint32_t v[kFeatBatch];
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u32(base + fo[f + u]);
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) {
+                        even += v[u] & 0x00FF00FFu;
+                        odd += (v[u] >> 8) & 0x00FF00FFu;
+                    }
+                }
+            } else {
+                const uint32_t* fxy = feat_xy + e.feat_start;
+                for (int f = 0; f < nfp; ++f) {
+                    uint32_t xy = fxy[f];
+                    int fx = (int16_t)(xy & 0xFFFF) + off_x, fy = (int16_t)(xy >> 16) + off_y;
+                    if (fx < 0 || fy < 0 || fx >= W || fy >= H) continue;   // LL.cpp:1394 (padding: x = y = -32768)
+                    uint32_t v = ld_u32(base + fo[f]);
+                    even += v & 0x00FF00FFu;
+                    odd += (v >> 8) & 0x00FF00FFu;
+                }
+            }
+            ++evals;
+            bytes += 256ull * nf;   // algorithmic response bytes of this 16x16 evaluation
+            const uint32_t idx0 = (uint32_t)(row * 16 + col);
+            uint32_t k0 = ((even & 0xFFFF) << 8) | (255u - idx0);
+            uint32_t k1 = ((odd & 0xFFFF) << 8) | (255u - (idx0 + 1));
+            uint32_t k2 = ((even >> 16) << 8) | (255u - (idx0 + 2));
+            uint32_t k3 = ((odd >> 16) << 8) | (255u - (idx0 + 3));
+            uint32_t k = k0 > k1 ? k0 : k1;
+            uint32_t kk = k2 > k3 ? k2 : k3;
+            k = wave_max_u32(k > kk ? k : kk);
+            const int raw = (int)(k >> 8);
+            int br = -1, bc = -1;                               // LL.cpp:1910-1911
+            float best = 0.f;
+            if (raw > 0) {
+                int idx = 255 - (int)(k & 0xFF);
+                br = idx >> 4; bc = idx & 15;
+                best = score_of(raw, nf);
+            }
+            sim = best;
+            mx = (x / T - 8 + bc) * T + offset;                 // LL.cpp:1930-1931
+            my = (y / T - 8 + br) * T + offset;
+            if (sim < threshold) alive = false;                 // remove_if(MatchPredicate), LL.cpp:1935
         }
-        ++evals;
-        bytes += 256ull * nf;   // algorithmic response bytes of this 16x16 evaluation
-        const uint32_t idx0 = (uint32_t)(row * 16 + col);
-        uint32_t k0 = ((even & 0xFFFF) << 8) | (255u - idx0);
-        uint32_t k1 = ((odd & 0xFFFF) << 8) | (255u - (idx0 + 1));
-        uint32_t k2 = ((even >> 16) << 8) | (255u - (idx0 + 2));
-        uint32_t k3 = ((odd >> 16) << 8) | (255u - (idx0 + 3));
-        uint32_t k = k0 > k1 ? k0 : k1;
-        uint32_t kk = k2 > k3 ? k2 : k3;
-        k = wave_max_u32(k > kk ? k : kk);
-        const int raw = (int)(k >> 8);
-        int br = -1, bc = -1;                               // LL.cpp:1910-1911
-        float best = 0.f;
-        if (raw > 0) {
-            int idx = 255 - (int)(k & 0xFF);
-            br = idx >> 4; bc = idx & 15;
-            best = score_of(raw, nf);
-        }
-        sim = best;
-        mx = (x / T - 8 + bc) * T + offset;                 // LL.cpp:1930-1931
-        my = (y / T - 8 + br) * T + offset;
-        if (sim < threshold) alive = false;                 // remove_if(MatchPredicate), LL.cpp:1935
-    }
-    if (lane == 0) {
-        atomicAdd(&counters[2], evals);
-        atomicAdd(&counters[3], bytes);
-        if (alive) {
+        if (lane == 0 && alive) {
             unsigned long long slot = atomicAdd(&counters[1], 1ull);
             if (slot < cap) {
                 Candidate m;
@@ -195,15 +214,19 @@ k_local(const uint8_t* __restrict__ lm_arena, FrameGeom g, const TemplEntry* __r
             }
         }
     }
+    if (lane == 0 && evals) {
+        atomicAdd(&counters[2], evals);
+        atomicAdd(&counters[3], bytes);
+    }
 }
 
 void launch_local(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t num_cands,
-                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, hipStream_t s) {
-    if (num_cands == 0) return;
-    const int waves = 4;
-    hipLaunchKernelGGL(k_local, dim3((num_cands + waves - 1) / waves), dim3(64 * waves), 0, s, lm_arena, g, entries,
-                       feat_off, feat_xy, work_pyramids, cands, num_cands, threshold, matches, cap, counters);
+                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
+                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
+                  hipStream_t s) {
+    if (cand_cap == 0 || grid_blocks <= 0) return;
+    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, g, entries, feat_off, feat_xy,
+                       work_pyramids, cands, cand_cap, threshold, matches, cap, counters);
 }
 
 }  // namespace lm
