@@ -91,7 +91,7 @@ struct lm_detector {
     DevBuf<uint8_t> frame_rgb;
     DevBuf<uint16_t> frame_depth;
     DevBuf<uint16_t> tmp16;
-    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena;
+    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
     LevelBufs lvl[kMaxLevels];
     FrameGeom geom{};
     size_t lm_block_bytes[kMaxLevels] = {};
@@ -112,6 +112,7 @@ struct lm_detector {
     DevBuf<TemplEntry> d_entries;
     DevBuf<int32_t> d_feat_off;
     DevBuf<uint32_t> d_feat_xy;
+    DevBuf<FeatStrip> d_feat_strip;
     // work list
     std::vector<int32_t> work_pyr, work_cls, work_tid;
     DevBuf<int32_t> d_work;
@@ -192,11 +193,11 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
     d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
-    d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release();
+    d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release(); d->sm_arena.release();
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
-    d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_work.release();
+    d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
     d->d_cands.release(); d->d_counters.release();
     if (d->h_matches) (void)hipHostFree(d->h_matches);
     if (d->h_counters) (void)hipHostFree(d->h_counters);
@@ -219,7 +220,7 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     FrameGeom g{};
     g.levels = L;
     int w = W, h = H;
-    size_t arena = 0;
+    size_t arena = 0, sarena = 0;
     for (int l = 0; l < L; ++l) {
         if (l > 0) { w /= 2; h /= 2; }
         if (w < 1 || h < 1) return lm_set_error(LM_ERR_INVALID, "image too small for %d pyramid levels", L);
@@ -240,6 +241,19 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
             lv.lm_off[m] = (uint32_t)arena;
             arena += block;
         }
+        // strip-major copy for the refinement (levels below the top): [8 labels][T*T phases][NS strips][Hd rows][16 B]
+        // per modality, then one all-zero plane (read by padded features) and slack for the second aligned dword.
+        lv.NS = (lv.Wd + 15) / 16;
+        lv.sm_off[0] = lv.sm_off[1] = 0;
+        if (l < L - 1) {
+            const size_t splane = (size_t)lv.NS * lv.Hd * 16;
+            const size_t sblock = (size_t)8 * T * T * splane;
+            if (sarena + 2 * sblock + 3 * splane + 4096 > 0xFFFFFFFFull) return lm_set_error(LM_ERR_INVALID, "frame too large for the strip arena");
+            lv.sm_off[0] = (uint32_t)sarena;
+            lv.sm_off[1] = (uint32_t)(sarena + sblock);
+            sarena += 2 * sblock + 3 * splane + 4096;
+            sarena = (sarena + 255) & ~(size_t)255;
+        }
     }
     const size_t n0 = (size_t)W * H;
     int rc;
@@ -254,6 +268,9 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     if ((rc = d->lm_arena.ensure(arena))) return rc;
     if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
         HIP_TRY(hipMemsetAsync(d->lm_arena.p, 0, d->lm_arena.cap, d->stream));
+    bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena.cap;
+    if ((rc = d->sm_arena.ensure(std::max<size_t>(sarena, 256)))) return rc;
+    if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena.p, 0, d->sm_arena.cap, d->stream));
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
         b.W = g.lv[l].W; b.H = g.lv[l].H;
@@ -329,10 +346,11 @@ static int run_frontend(lm_detector* d, bool build_lm) {
         launch_hysteresis(d->q16.p, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                   // LL.cpp:457-504
         if (build_lm) {
             const LevelGeom& lv = d->geom.lv[l];
+            const bool strips = l < L - 1;
             launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[0],
-                            b.W, b.H, lv.T, s);
+                            strips ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, s);
             launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[1],
-                            b.W, b.H, lv.T, s);
+                            strips ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -524,6 +542,7 @@ static int upload_bank(lm_detector* d) {
     d->work_valid = false;
     std::vector<int32_t> off;
     std::vector<uint32_t> xy;
+    std::vector<FeatStrip> strip;
     const uint32_t pad_xy = 0x80008000u;   // x = y = -32768: never inside an image
     int flat = 0;
     for (auto& kv : d->class_templates) {
@@ -535,6 +554,8 @@ static int upload_bank(lm_detector* d) {
                 const LevelGeom& lv = d->geom.lv[l];
                 const long npos = (long)lv.Wd * lv.Hd;
                 const long zero_off = (long)lv.lm_off[1] + (long)8 * lv.T * lv.T * npos;   // tail of the normal block
+                const long splane = (long)lv.NS * lv.Hd * 16;
+                const uint32_t szero = (uint32_t)((long)lv.sm_off[1] + (long)8 * lv.T * lv.T * splane);   // the all-zero strip plane
                 TemplEntry e{};
                 e.feat_start = (uint32_t)off.size();
                 const size_t n0 = tp[2 * l].features.size(), n1 = tp[2 * l + 1].features.size();
@@ -555,11 +576,19 @@ static int upload_bank(lm_detector* d) {
                         if (o < -(1L << 31) || o >= (1L << 31)) return lm_set_error(LM_ERR_INVALID, "feature offset overflow");
                         off.push_back((int32_t)o);
                         xy.push_back((uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16));
+                        FeatStrip fs{0, 0};
+                        if (l < L - 1 && f.x >= 0 && f.y >= 0) {   // only read on the fast path, where x, y >= 0
+                            fs.sbase = (uint32_t)((long)lv.sm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * splane);
+                            fs.cell = (uint32_t)(f.x / T) | ((uint32_t)(f.y / T) << 16);
+                        }
+                        strip.push_back(fs);
                         mnx = std::min(mnx, f.x); mny = std::min(mny, f.y); mxx = std::max(mxx, f.x); mxy = std::max(mxy, f.y);
                     }
                 if (e.nf == 0) mnx = mny = mxx = mxy = 0;
                 e.min_x = (int16_t)mnx; e.min_y = (int16_t)mny; e.max_x = (int16_t)mxx; e.max_y = (int16_t)mxy;
-                while ((off.size() - e.feat_start) % kFeatBatch) { off.push_back((int32_t)zero_off); xy.push_back(pad_xy); }
+                while ((off.size() - e.feat_start) % kFeatBatch) {
+                    off.push_back((int32_t)zero_off); xy.push_back(pad_xy); strip.push_back(FeatStrip{szero, 0});
+                }
                 e.nf_padded = (uint16_t)(off.size() - e.feat_start);
                 d->h_entries.push_back(e);
             }
@@ -570,11 +599,13 @@ static int upload_bank(lm_detector* d) {
     if ((rc = d->d_entries.ensure(std::max<size_t>(1, d->h_entries.size())))) return rc;
     if ((rc = d->d_feat_off.ensure(std::max<size_t>(1, off.size())))) return rc;
     if ((rc = d->d_feat_xy.ensure(std::max<size_t>(1, xy.size())))) return rc;
+    if ((rc = d->d_feat_strip.ensure(std::max<size_t>(1, strip.size())))) return rc;
     if (!d->h_entries.empty())
         HIP_TRY(hipMemcpy(d->d_entries.p, d->h_entries.data(), d->h_entries.size() * sizeof(TemplEntry), hipMemcpyHostToDevice));
     if (!off.empty()) {
         HIP_TRY(hipMemcpy(d->d_feat_off.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->d_feat_xy.p, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_feat_strip.p, strip.data(), strip.size() * sizeof(FeatStrip), hipMemcpyHostToDevice));
     }
     d->bank_dirty = false;
     d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
@@ -841,7 +872,7 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
                       d->cand_cap, d->d_counters.p, s);
         HIP_TRY(hipEventRecord(d->ev[2], s));
         // persistent refinement grid; the candidate count is read on the device (no host round trip)
-        launch_local(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
+        launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
                      num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d->num_cus * 8, s);
         HIP_TRY(hipEventRecord(d->ev[3], s));
         HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -280,8 +280,11 @@ __global__ void k_spread_rows(const uint8_t* __restrict__ q, const uint8_t* __re
 
 // pass 2: one thread per linear-memory position (phase, decimated index): OR the T rows, derive the
 // 8 responses (4 / 1 / 0), store to LM[label][phase][idx] — consecutive lanes write consecutive
-// bytes of each label's plane.
-__global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restrict__ lm, int W, int H, int T, int Wd, int Hd) {
+// bytes of each label's plane.  Levels below the top also get the "strip" copy the refinement kernel
+// gathers from: every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so
+// that a 16x16 window touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.
+__global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restrict__ lm, uint8_t* __restrict__ strips,
+                           int W, int H, int T, int Wd, int Hd, int NS) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;   // decimated raster index
     int phase = blockIdx.y;                              // r_start*T + c_start
     int npos = Wd * Hd;
@@ -295,18 +298,21 @@ __global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restric
     uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
     size_t plane = (size_t)T * T * npos;
     uint8_t* o = lm + (size_t)phase * npos + idx;
+    const size_t splane1 = (size_t)NS * Hd * 16;             // one (label, phase) plane in strip form
+    uint8_t* so = strips ? strips + (size_t)phase * splane1 + ((size_t)(rx >> 4) * Hd + ry) * 16 + (rx & 15) : nullptr;
 #pragma unroll
     for (int ori = 0; ori < 8; ++ori) {
         uint8_t r = ((v >> ori) & 1u) ? 4 : (((adj >> ori) & 1u) ? 1 : 0);
         o[plane * ori] = r;
+        if (so) so[splane1 * T * T * ori] = r;
     }
 }
 
-void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, int W, int H, int T,
-                     hipStream_t s) {
-    int Wd = W / T, Hd = H / T;
+void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, uint8_t* strips, int W, int H,
+                     int T, hipStream_t s) {
+    int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
     hipLaunchKernelGGL(k_spread_rows, dim3((W + 255) / 256, H), dim3(256), 0, s, quant, mask, rowor, W, H, T);
-    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T), dim3(256), 0, s, rowor, lm, W, H, T, Wd, Hd);
+    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T), dim3(256), 0, s, rowor, lm, strips, W, H, T, Wd, Hd, NS);
 }
 
 }  // namespace lm

@@ -17,13 +17,16 @@ void launch_normals(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, in
                     hipStream_t s);
 void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s);     // dst (W/2,H/2)
 // spread (T x T OR) -> 8 response maps -> linearised layout LM[8][T*T][(W/T)*(H/T)]; mask may be null
-void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, int W, int H, int T,
-                     hipStream_t s);
+// `strips` (may be null) receives the strip-major copy used by the refinement kernel.
+void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, uint8_t* strips, int W, int H,
+                     int T, hipStream_t s);
 
 // ---- matching (match.hip): reference A8-A11, LL.cpp:1284-1428, 1788-1941 ----
 struct LevelGeom {        // one pyramid level of the current frame
     int W, H, T, Wd, Hd;  // image size, sampling step, decimated size
     uint32_t lm_off[2];   // byte offset of the colour / normal LM block inside the LM arena
+    uint32_t sm_off[2];   // byte offset of the strip-major copy inside the strip arena (levels below the top)
+    int NS;               // 16-column strips per plane row = ceil(Wd / 16)
 };
 constexpr int kMaxLevels = 8;
 struct FrameGeom {
@@ -50,8 +53,12 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
                    unsigned long long* counters, hipStream_t s);
 // Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
 // counters[1] = number of matches produced, counters[2] = 16x16 evaluations, counters[3] = their bytes.
-void launch_local(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
+struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
+    uint32_t sbase;       // byte offset of the feature's (label, phase) plane inside the strip arena
+    uint32_t cell;        // lx | ly << 16   (x / T, y / T)
+};
+void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
+                  const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
                   hipStream_t s);
 

@@ -31,12 +31,22 @@ static __device__ __forceinline__ float score_of(int raw, int nfeat) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Coarse pass: one workgroup per template pyramid; each lane owns 4 consecutive positions of the
-// decimated top-level grid and adds one (unaligned) dword of responses per feature.  Bytes are
-// accumulated in two packed u16x2 registers (even / odd bytes); 2 x 8191 x 4 < 65536 so neither
-// modality split nor widening is needed (the reference's 8-bit and 16-bit paths give the same sums).
+// Coarse pass: one workgroup per template pyramid; each lane owns 16 consecutive positions of the
+// decimated top-level grid and adds one (unaligned) 16-byte run of responses per feature, 8 features
+// (8 x dwordx4) in flight, with the next batch of run offsets prefetched through the scalar cache
+// while the gathers are outstanding.  Bytes are accumulated in packed u16x2 registers (even / odd
+// bytes); 2 x 8191 x 4 < 65536 so neither modality split nor widening is needed (the reference's
+// 8-bit and 16-bit paths give the same sums).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(320)
+static __device__ __forceinline__ uint4 ld_u128(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);   // unaligned global_load_dwordx4
+    return v;
+}
+
+constexpr int kCoarsePos = 16;     // positions per lane
+
+__global__ void __launch_bounds__(1024)
 k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
          const int32_t* __restrict__ work_pyramids, float threshold, Candidate* __restrict__ cands, uint32_t cap,
@@ -53,35 +63,48 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
     const int tp = (Hd - hf) * Wd + (Wd - wf) + 1;
     const int offset = T / 2 + (T % 2 - 1);   // LL.cpp:1846
 
-    for (int j0 = threadIdx.x * 4; j0 < npos; j0 += blockDim.x * 4) {
-        uint32_t even = 0, odd = 0;
-        if (j0 < tp) {
+    for (int j0 = threadIdx.x * kCoarsePos; j0 < npos; j0 += blockDim.x * kCoarsePos) {
+        uint32_t even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0};
+        if (j0 < tp && nfp > 0) {
             const uint8_t* base = lm_arena + j0;
-            for (int f = 0; f < nfp; f += kFeatBatch) {
-                uint32_t v[kFeatBatch];
+            int32_t o[kFeatBatch];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u32(base + fo[f + u]);   // fo[]: wave-uniform -> SMEM
+            for (int u = 0; u < kFeatBatch; ++u) o[u] = fo[u];                      // wave-uniform -> SMEM
+            for (int f = 0; f < nfp; f += kFeatBatch) {
+                const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;             // prefetch next batch of offsets
+                int32_t on[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) on[u] = fo[fn + u];
+                uint4 v[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u128(base + o[u]);
 #pragma unroll
                 for (int u = 0; u < kFeatBatch; ++u) {
-                    even += v[u] & 0x00FF00FFu;
-                    odd += (v[u] >> 8) & 0x00FF00FFu;
+                    even[0] += v[u].x & 0x00FF00FFu; odd[0] += (v[u].x >> 8) & 0x00FF00FFu;
+                    even[1] += v[u].y & 0x00FF00FFu; odd[1] += (v[u].y >> 8) & 0x00FF00FFu;
+                    even[2] += v[u].z & 0x00FF00FFu; odd[2] += (v[u].z >> 8) & 0x00FF00FFu;
+                    even[3] += v[u].w & 0x00FF00FFu; odd[3] += (v[u].w >> 8) & 0x00FF00FFu;
                 }
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) o[u] = on[u];
             }
         }
-        int raw[4] = {(int)(even & 0xFFFF), (int)(odd & 0xFFFF), (int)(even >> 16), (int)(odd >> 16)};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int j = j0 + k;
-            if (j >= npos) break;
-            int r = j < tp ? raw[k] : 0;                  // positions >= template_positions stay 0
-            float sc = score_of(r, nf);
-            if (sc > threshold) {                         // LL.cpp:1844
-                unsigned long long slot = atomicAdd(&counters[0], 1ull);
-                if (slot < cap) {
-                    int cy = j / Wd, cx = j - cy * Wd;
-                    Candidate c;
-                    c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc; c.work = work;
-                    cands[slot] = c;
+        for (int k = 0; k < kCoarsePos; ++k) {
+            const int j = j0 + k;
+            const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
+            const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
+            if (j < npos) {
+                int r = j < tp ? rawk : 0;                // positions >= template_positions stay 0
+                float sc = score_of(r, nf);
+                if (sc > threshold) {                     // LL.cpp:1844
+                    unsigned long long slot = atomicAdd(&counters[0], 1ull);
+                    if (slot < cap) {
+                        int cy = j / Wd, cx = j - cy * Wd;
+                        Candidate c;
+                        c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc; c.work = work;
+                        cands[slot] = c;
+                    }
                 }
             }
         }
@@ -95,8 +118,8 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
     int npos = lv.Wd * lv.Hd;
-    int threads = ((npos + 3) / 4 + 63) / 64 * 64;
-    if (threads > 320) threads = 320;
+    int threads = ((npos + kCoarsePos - 1) / kCoarsePos + 63) / 64 * 64;
+    if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
     hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(threads), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
                        work_pyramids, threshold, cands, cap, counters);
@@ -109,6 +132,13 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
 // with a packed key (raw<<8 | 255-index) and a wave max-reduction.  The grid is persistent: waves
 // stride over the candidate list whose length is read from device memory (no host round trip
 // between the coarse and the local pass).
+//
+// Fast path (every window inside its plane, i.e. always except for oversized templates): the gather
+// reads the strip-major copy of the linear memories ([strip of 16 columns][row][16 B]).  A window row
+// is then two aligned-dword pieces inside at most two strips whose 16 rows are contiguous, so one
+// feature costs ~5 L2 lines instead of ~16 (PMC: the flat layout was L1-miss bound at 14 L2 requests
+// per gather instruction).  Each lane loads the two aligned dwords around its 4 window bytes and
+// funnel-shifts them (v_alignbyte) by the wave-uniform byte phase of the window start.
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -120,8 +150,9 @@ static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 __global__ void __launch_bounds__(256)
-k_local(const uint8_t* __restrict__ lm_arena, FrameGeom g, const TemplEntry* __restrict__ entries,
-        const int32_t* __restrict__ feat_off, const uint32_t* __restrict__ feat_xy,
+k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_arena, FrameGeom g,
+        const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
+        const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
         float threshold, Candidate* __restrict__ matches, uint32_t cap, unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
@@ -155,23 +186,48 @@ k_local(const uint8_t* __restrict__ lm_arena, FrameGeom g, const TemplEntry* __r
             const int32_t* fo = feat_off + e.feat_start;
             const uint8_t* base = lm_arena + ((int64_t)gy * Wd + gx + row * Wd + col);
             uint32_t even = 0, odd = 0;
-            // every feature stays inside the image after the window offset (LL.cpp:1394)?  Decided once
-            // per candidate from the entry's feature bounding box; true unless the template is huge.
-            // (gx,gy inside [0, Wd-16] x [0, Hd-16] also keeps the zero-tail padding reads inside the tail.)
-            const bool all_in = (e.min_x + off_x >= 0) && (e.min_y + off_y >= 0) && (e.max_x + off_x < W) && (e.max_y + off_y < H) &&
-                                gx >= 0 && gy >= 0 && gx + 16 <= Wd && gy + 16 <= lv.Hd;
-            if (all_in) {
-                for (int f = 0; f < nfp; f += kFeatBatch) {
-                    uint32_t v[kFeatBatch];
+            // Fast path iff every feature's 16x16 window lies inside its plane (no feature is discarded by
+            // LL.cpp:1394, no row wrap, no spill into the next phase) — decided once per candidate from the
+            // entry's feature bounding box; true unless the template is oversized for the frame.
+            const bool all_in = (e.min_x + off_x >= 0) && (e.min_y + off_y >= 0) && gx >= 0 && gy >= 0 &&
+                                ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= lv.Hd);
+            if (all_in && nfp > 0) {
+                const FeatStrip* fs = feat_strip + e.feat_start;
+                const uint8_t* sm = sm_arena;
+                const int Hd = lv.Hd, HS = Hd * 16;
+                const int q = lane & 3, r16 = row * 16;
+                FeatStrip c[kFeatBatch];
 #pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u32(base + fo[f + u]);
+                for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
+                for (int f = 0; f < nfp; f += kFeatBatch) {
+                    const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
+                    FeatStrip cn[kFeatBatch];
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
+                    uint32_t va[kFeatBatch], vb[kFeatBatch];
+                    int sh[kFeatBatch];
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) {
-                        even += v[u] & 0x00FF00FFu;
-                        odd += (v[u] >> 8) & 0x00FF00FFu;
+                        const int X0 = (int)(c[u].cell & 0xFFFF) + gx, Y0 = (int)(c[u].cell >> 16) + gy;   // window origin in the plane
+                        const int A4 = X0 >> 2;                           // first aligned dword of the window row
+                        const uint32_t sbase = c[u].sbase + (uint32_t)(((A4 >> 2) * Hd + Y0) * 16);
+                        const int t = q + (A4 & 3), tb = t + 1;           // aligned dword index inside the 2-strip span
+                        const uint8_t* pa = sm + sbase + ((t >> 2) * HS + (t & 3) * 4 + r16);
+                        const uint8_t* pb = sm + sbase + ((tb >> 2) * HS + (tb & 3) * 4 + r16);
+                        va[u] = *(const uint32_t*)pa;
+                        vb[u] = *(const uint32_t*)pb;
+                        sh[u] = X0 & 3;
                     }
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) {
+                        const uint32_t v = __builtin_amdgcn_alignbyte(vb[u], va[u], (uint32_t)sh[u]);
+                        even += v & 0x00FF00FFu;
+                        odd += (v >> 8) & 0x00FF00FFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
                 }
-            } else {
+            } else if (!all_in) {
                 const uint32_t* fxy = feat_xy + e.feat_start;
                 for (int f = 0; f < nfp; ++f) {
                     uint32_t xy = fxy[f];
@@ -220,13 +276,14 @@ k_local(const uint8_t* __restrict__ lm_arena, FrameGeom g, const TemplEntry* __r
     }
 }
 
-void launch_local(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
+void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
+                  const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
+                  const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
                   hipStream_t s) {
     if (cand_cap == 0 || grid_blocks <= 0) return;
-    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, g, entries, feat_off, feat_xy,
-                       work_pyramids, cands, cand_cap, threshold, matches, cap, counters);
+    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
+                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, cap, counters);
 }
 
 }  // namespace lm
