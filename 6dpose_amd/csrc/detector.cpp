@@ -211,7 +211,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
 // Zero tail after the 8 labels of one (level, modality) block: covers the reference's reads past a
 // phase row and the reads of padded / out-of-image features redirected to it, for any
 // position offset < Wd*Hd plus one 16-row window.
-static size_t lm_tail_pad(int Wd, int Hd) { return (size_t)Wd * Hd + (size_t)16 * Wd + 16 + 64; }
+static size_t lm_tail_pad(int Wd, int Hd) { return (size_t)Wd * Hd + (size_t)16 * Wd + 2048; }
 
 // (Re)allocates per-level buffers and the LM arena for a W x H frame; validates the reference's
 // preconditions (LL.cpp:1136, 1217-1218).
@@ -565,6 +565,10 @@ static int upload_bank(lm_detector* d) {
                 if (tp[2 * l + 1].width != e.width || tp[2 * l + 1].height != e.height)
                     return lm_set_error(LM_ERR_INVALID, "modalities of one pyramid level disagree on width/height");
                 int mnx = 32767, mny = 32767, mxx = -32768, mxy = -32768;
+                struct Rec { int32_t off; uint32_t xy; FeatStrip fs; int cls; };
+                std::vector<Rec> recs;
+                const bool top = (l == L - 1);
+                const long zero16 = (zero_off + 15) & ~15L;      // 16-aligned start of the zero tail
                 for (int m = 0; m < 2; ++m)
                     for (const Feature& f : tp[2 * l + m].features) {
                         const int T = lv.T;
@@ -572,23 +576,39 @@ static int upload_bank(lm_detector* d) {
                         long o = (long)lv.lm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * npos + (long)floordiv(f.y, T) * lv.Wd +
                                  floordiv(f.x, T);
                         const bool inside = f.x >= 0 && f.x < lv.W && f.y >= 0 && f.y < lv.H;
-                        if (l == L - 1 && !inside) o = zero_off;                        // LL.cpp:1330
+                        if (top && !inside) o = zero16;                                 // LL.cpp:1330
                         if (o < -(1L << 31) || o >= (1L << 31)) return lm_set_error(LM_ERR_INVALID, "feature offset overflow");
-                        off.push_back((int32_t)o);
-                        xy.push_back((uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16));
-                        FeatStrip fs{0, 0};
-                        if (l < L - 1 && f.x >= 0 && f.y >= 0) {   // only read on the fast path, where x, y >= 0
-                            fs.sbase = (uint32_t)((long)lv.sm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * splane);
-                            fs.cell = (uint32_t)(f.x / T) | ((uint32_t)(f.y / T) << 16);
+                        Rec r{};
+                        r.off = (int32_t)o;
+                        r.xy = (uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16);
+                        r.fs = FeatStrip{0, 0};
+                        if (!top && f.x >= 0 && f.y >= 0) {   // only read on the fast path, where x, y >= 0
+                            r.fs.sbase = (uint32_t)((long)lv.sm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * splane);
+                            r.fs.cell = (uint32_t)(f.x / T) | ((uint32_t)(f.y / T) << 16);
                         }
-                        strip.push_back(fs);
+                        // alignment class: byte phase of the run start (top level: flat offset; below: plane column)
+                        r.cls = top ? (int)(o & 15) : (f.x >= 0 ? (f.x / T) & 15 : 0);
+                        recs.push_back(r);
                         mnx = std::min(mnx, f.x); mny = std::min(mny, f.y); mxx = std::max(mxx, f.x); mxy = std::max(mxy, f.y);
                     }
                 if (e.nf == 0) mnx = mny = mxx = mxy = 0;
                 e.min_x = (int16_t)mnx; e.min_y = (int16_t)mny; e.max_x = (int16_t)mxx; e.max_y = (int16_t)mxy;
-                while ((off.size() - e.feat_start) % kFeatBatch) {
-                    off.push_back((int32_t)zero_off); xy.push_back(pad_xy); strip.push_back(FeatStrip{szero, 0});
+                std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.cls < b.cls; });
+                auto push_pad = [&](int cls) {           // a feature that reads zeros, in alignment class `cls`
+                    off.push_back((int32_t)(zero16 + (top ? cls : 0)));
+                    xy.push_back(pad_xy);
+                    strip.push_back(FeatStrip{szero, (uint32_t)cls});
+                };
+                int last_cls = 0;
+                for (size_t i = 0; i < recs.size();) {
+                    size_t j = i;
+                    while (j < recs.size() && recs[j].cls == recs[i].cls) ++j;
+                    for (size_t k = i; k < j; ++k) { off.push_back(recs[k].off); xy.push_back(recs[k].xy); strip.push_back(recs[k].fs); }
+                    last_cls = recs[i].cls;
+                    if (!top && ((j - i) & 1)) push_pad(last_cls);   // the refinement consumes features in same-class pairs
+                    i = j;
                 }
+                while ((off.size() - e.feat_start) % kFeatBatch) push_pad(last_cls);
                 e.nf_padded = (uint16_t)(off.size() - e.feat_start);
                 d->h_entries.push_back(e);
             }

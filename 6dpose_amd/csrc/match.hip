@@ -2,13 +2,13 @@
 // similarityLocal, LL.cpp:1788-1941 matchClass).  Pure integer byte work: every response is a
 // u8 in {0,1,4}, summed per template position.  Nothing here is a dense contraction, so no MFMA;
 // the linear memories of one frame (1.2 MB coarse + 4.9 MB fine at VGA) live in L2 / Infinity
-// Cache and the kernels are bound by the L2->L1 gather path, so the design goal is to keep many
-// independent gathers in flight per wave (kFeatBatch per batch) rather than arithmetic.
+// Cache; the kernels are bound by the vector-L1 access rate (see "Gather discipline" below), not by
+// HBM and not by arithmetic.
 //
 // Data layout (built by frontend.hip / detector.cpp, offsets in FrameGeom):
 //   LM arena: per level, per modality: u8 [8 labels][T*T phases][(W/T)*(H/T)] + zero tail.
-//   Bank:     TemplEntry per (pyramid, level).  Its features (colour then normal) are padded to a
-//             multiple of kFeatBatch with entries that point at the level's zero tail, so the inner
+//   Bank:     TemplEntry per (pyramid, level).  Its features (both modalities) are sorted by alignment
+//             class and padded to a multiple of kFeatBatch with entries that read zeros, so the inner
 //             loops are branch-free.  feat_off[] = byte offset of the feature's linear-memory run
 //             from the arena start (accessLinearMemory, LL.cpp:1248-1271, resolved on the host for
 //             the current frame geometry with floor division, so adding a multiple-of-T window
@@ -31,20 +31,31 @@ static __device__ __forceinline__ float score_of(int raw, int nfeat) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Coarse pass: one workgroup per template pyramid; each lane owns 16 consecutive positions of the
-// decimated top-level grid and adds one (unaligned) 16-byte run of responses per feature, 8 features
-// (8 x dwordx4) in flight, with the next batch of run offsets prefetched through the scalar cache
-// while the gathers are outstanding.  Bytes are accumulated in packed u16x2 registers (even / odd
-// bytes); 2 x 8191 x 4 < 65536 so neither modality split nor widening is needed (the reference's
-// 8-bit and 16-bit paths give the same sums).
+// Gather discipline (measured, profiles/r01_pmc_*.txt): the vector L1 (TCP) services one access per
+// cycle and an access moves at most 64 aligned bytes.  Unaligned or narrow per-lane gathers explode
+// into 3-4 accesses per quad of lanes and the kernels become TCP-access bound, so both kernels only
+// issue ALIGNED 16-byte loads (1 KB per wave instruction in 16 accesses).  The byte misalignment of
+// a feature's run is handled without per-feature shifting: the host sorts the features of every
+// template entry by their alignment class (run offset mod 16), the kernel adds the aligned chunks of
+// one class into packed-u8 accumulators (<= 63 features x 4 < 256, the reference's own no-overflow
+// argument, README.md:67-69) and realigns ONCE per class run (v_alignbyte + one neighbour exchange)
+// into the u16 position accumulators.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ uint4 ld_u128(const uint8_t* p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);   // unaligned global_load_dwordx4
-    return v;
+static __device__ __forceinline__ uint4 ld_aligned16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// widen 4 packed bytes of `v` into two packed u16x2 accumulators: e gets bytes 0,2 ; o gets bytes 1,3
+static __device__ __forceinline__ void add_bytes(uint32_t v, uint32_t& e, uint32_t& o) {
+    e += v & 0x00FF00FFu;
+    o += (v >> 8) & 0x00FF00FFu;
 }
 
-constexpr int kCoarsePos = 16;     // positions per lane
+// ---------------------------------------------------------------------------------------------
+// Coarse pass (LL.cpp:1284-1354 similarity + :1835-1852 scan): one workgroup per template pyramid.
+// Lane i of wave w owns the 16 positions [16*(63w+i), +16) of the decimated top-level grid and loads
+// the aligned 16-byte chunk that starts at or before them; the tail of its positions lives in lane
+// i+1's chunk, hence 63 producing lanes per wave plus one feeder lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunksPerWave = 63;
 
 __global__ void __launch_bounds__(1024)
 k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
@@ -62,11 +73,43 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
     const int wf = (e.width - 1) / T + 1, hf = (e.height - 1) / T + 1;
     const int tp = (Hd - hf) * Wd + (Wd - wf) + 1;
     const int offset = T / 2 + (T % 2 - 1);   // LL.cpp:1846
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 
-    for (int j0 = threadIdx.x * kCoarsePos; j0 < npos; j0 += blockDim.x * kCoarsePos) {
+    for (int chunk0 = wave * kChunksPerWave; chunk0 * 16 < npos; chunk0 += nwaves * kChunksPerWave) {
+        const int j0 = (chunk0 + lane) * 16;                   // first position owned by this lane
         uint32_t even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0};
-        if (j0 < tp && nfp > 0) {
+        if (chunk0 * 16 < tp && nfp > 0) {                     // wave-uniform
             const uint8_t* base = lm_arena + j0;
+            uint32_t r8[4] = {0, 0, 0, 0};                      // packed-u8 sums of the current class run
+            int cur = -1, cnt = 0;
+            auto flush = [&](int cls) {                         // realign the run: bytes [cls, cls+16) of {own, next lane}
+                uint32_t x[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x[k] = r8[k]; x[4 + k] = (uint32_t)__shfl_down((int)r8[k], 1, 64); r8[k] = 0; }
+                const int d = cls >> 2;
+                const uint32_t sb = (uint32_t)(cls & 3);
+                uint32_t o4[4];
+                switch (d) {                                    // wave-uniform
+                    case 0:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 1], x[k], sb);
+                        break;
+                    case 1:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 2], x[k + 1], sb);
+                        break;
+                    case 2:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 3], x[k + 2], sb);
+                        break;
+                    default:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 4], x[k + 3], sb);
+                        break;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) add_bytes(o4[k], even[k], odd[k]);
+            };
             int32_t o[kFeatBatch];
 #pragma unroll
             for (int u = 0; u < kFeatBatch; ++u) o[u] = fo[u];                      // wave-uniform -> SMEM
@@ -77,33 +120,39 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
                 for (int u = 0; u < kFeatBatch; ++u) on[u] = fo[fn + u];
                 uint4 v[kFeatBatch];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_u128(base + o[u]);
+                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_aligned16(base + (o[u] & ~15));
 #pragma unroll
                 for (int u = 0; u < kFeatBatch; ++u) {
-                    even[0] += v[u].x & 0x00FF00FFu; odd[0] += (v[u].x >> 8) & 0x00FF00FFu;
-                    even[1] += v[u].y & 0x00FF00FFu; odd[1] += (v[u].y >> 8) & 0x00FF00FFu;
-                    even[2] += v[u].z & 0x00FF00FFu; odd[2] += (v[u].z >> 8) & 0x00FF00FFu;
-                    even[3] += v[u].w & 0x00FF00FFu; odd[3] += (v[u].w >> 8) & 0x00FF00FFu;
+                    const int cls = o[u] & 15;
+                    if (cls != cur || cnt == 63) {
+                        if (cur >= 0) flush(cur);
+                        cur = cls; cnt = 0;
+                    }
+                    r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // bytes never carry (<= 252)
+                    ++cnt;
                 }
 #pragma unroll
                 for (int u = 0; u < kFeatBatch; ++u) o[u] = on[u];
             }
+            if (cur >= 0) flush(cur);
         }
+        if (lane < kChunksPerWave) {
 #pragma unroll
-        for (int k = 0; k < kCoarsePos; ++k) {
-            const int j = j0 + k;
-            const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
-            const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
-            if (j < npos) {
-                int r = j < tp ? rawk : 0;                // positions >= template_positions stay 0
-                float sc = score_of(r, nf);
-                if (sc > threshold) {                     // LL.cpp:1844
-                    unsigned long long slot = atomicAdd(&counters[0], 1ull);
-                    if (slot < cap) {
-                        int cy = j / Wd, cx = j - cy * Wd;
-                        Candidate c;
-                        c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc; c.work = work;
-                        cands[slot] = c;
+            for (int k = 0; k < 16; ++k) {
+                const int j = j0 + k;
+                const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
+                const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
+                if (j < npos) {
+                    int r = j < tp ? rawk : 0;                // positions >= template_positions stay 0
+                    float sc = score_of(r, nf);
+                    if (sc > threshold) {                     // LL.cpp:1844
+                        unsigned long long slot = atomicAdd(&counters[0], 1ull);
+                        if (slot < cap) {
+                            int cy = j / Wd, cx = j - cy * Wd;
+                            Candidate c;
+                            c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc; c.work = work;
+                            cands[slot] = c;
+                        }
                     }
                 }
             }
@@ -118,27 +167,27 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
     int npos = lv.Wd * lv.Hd;
-    int threads = ((npos + kCoarsePos - 1) / kCoarsePos + 63) / 64 * 64;
-    if (threads > 1024) threads = 1024;
-    if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(threads), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
+    int waves = (npos + kChunksPerWave * 16 - 1) / (kChunksPerWave * 16);
+    if (waves > 16) waves = 16;
+    if (waves < 1) waves = 1;
+    hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(waves * 64), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
                        work_pyramids, threshold, cands, cap, counters);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Local refinement: one wave64 per candidate, marching up the pyramid (LL.cpp:1855-1938).  Lane l
-// owns row l/4, columns 4*(l%4)..+3 of the 16x16 patch; per feature it adds one dword of the linear
-// memory at  run + (y/T-8)*Wd + (x/T-8) + row*Wd + col.  First strict maximum (LL.cpp:1920) is found
-// with a packed key (raw<<8 | 255-index) and a wave max-reduction.  The grid is persistent: waves
-// stride over the candidate list whose length is read from device memory (no host round trip
-// between the coarse and the local pass).
+// Local refinement (LL.cpp:1855-1938, similarityLocal :1366-1428): one wave64 per candidate, marching
+// up the pyramid; the grid is persistent and strides over the candidate list whose length is read
+// from device memory (no host round trip between the coarse and the local pass).
 //
-// Fast path (every window inside its plane, i.e. always except for oversized templates): the gather
-// reads the strip-major copy of the linear memories ([strip of 16 columns][row][16 B]).  A window row
-// is then two aligned-dword pieces inside at most two strips whose 16 rows are contiguous, so one
-// feature costs ~5 L2 lines instead of ~16 (PMC: the flat layout was L1-miss bound at 14 L2 requests
-// per gather instruction).  Each lane loads the two aligned dwords around its 4 window bytes and
-// funnel-shifts them (v_alignbyte) by the wave-uniform byte phase of the window start.
+// Fast path (every feature's 16x16 window inside its plane — always, except for oversized templates):
+// gathers from the strip-major copy of the linear memories ([strip of 16 columns][row][16 B]).  A
+// window spans two strips, so 32 lanes x one aligned 16-byte load cover it: lane (row r, strip h).
+// The two half-waves work on two features of the same alignment class at a time; class runs are
+// accumulated in packed u8 and realigned once per run: half-waves combined (lane ^ 32), strip pairs
+// exchanged (lane ^ 1), v_alignbyte by the run's byte phase, widened into the u16 window
+// accumulators (lane (r,h) keeps window columns 8h..8h+7 of row r).
+// Slow path: flat layout, per-feature bounds test, exactly the reference's reads (wrap-around included).
+// First strict maximum (LL.cpp:1920) = wave max-reduction of the packed key (raw << 8 | 255 - index).
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -160,7 +209,6 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     unsigned long long nc = counters[0];
     const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
-    const int row = lane >> 2, col = (lane & 3) * 4;
     unsigned long long evals = 0, bytes = 0;
 
     for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
@@ -174,7 +222,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         for (int l = g.levels - 2; l >= 0 && alive; --l) {
             const LevelGeom lv = g.lv[l];
             const TemplEntry e = entries[(size_t)pyr * g.levels + l];
-            const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd;
+            const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
             const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
             const int max_x = W - e.width - border, max_y = H - e.height - border;
             int x = mx * 2 + 1, y = my * 2 + 1;               // LL.cpp:1871-1880
@@ -183,71 +231,111 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             const int gx = x / T - 8, gy = y / T - 8;          // C division (truncation), LL.cpp:1380-1381
             const int off_x = gx * T, off_y = gy * T;
             const int nf = e.nf, nfp = e.nf_padded;
-            const int32_t* fo = feat_off + e.feat_start;
-            const uint8_t* base = lm_arena + ((int64_t)gy * Wd + gx + row * Wd + col);
-            uint32_t even = 0, odd = 0;
+            uint32_t key;                                        // lane-local best (raw << 8 | 255 - index)
             // Fast path iff every feature's 16x16 window lies inside its plane (no feature is discarded by
             // LL.cpp:1394, no row wrap, no spill into the next phase) — decided once per candidate from the
             // entry's feature bounding box; true unless the template is oversized for the frame.
-            const bool all_in = (e.min_x + off_x >= 0) && (e.min_y + off_y >= 0) && gx >= 0 && gy >= 0 &&
-                                ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= lv.Hd);
-            if (all_in && nfp > 0) {
-                const FeatStrip* fs = feat_strip + e.feat_start;
-                const uint8_t* sm = sm_arena;
-                const int Hd = lv.Hd, HS = Hd * 16;
-                const int q = lane & 3, r16 = row * 16;
-                FeatStrip c[kFeatBatch];
+            const bool all_in = e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 &&
+                                ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= Hd);
+            if (all_in) {
+                const int half = lane >> 5, l5 = lane & 31, r = l5 >> 1, h = l5 & 1;
+                const uint32_t HS = (uint32_t)Hd * 16u;
+                const uint8_t* smp = sm_arena + (h * HS + r * 16);
+                uint32_t w[4] = {0, 0, 0, 0};                   // u16x2: cols (0,2) (1,3) (4,6) (5,7) of this lane's 8 columns
+                if (nfp > 0) {
+                    const FeatStrip* fs = feat_strip + e.feat_start;
+                    uint32_t r8[4] = {0, 0, 0, 0};
+                    int cur = -1, cnt = 0;
+                    auto flush = [&](int cls) {
+                        uint32_t own[4], par[4];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
-                for (int f = 0; f < nfp; f += kFeatBatch) {
-                    const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
-                    FeatStrip cn[kFeatBatch];
+                        for (int k = 0; k < 4; ++k) {
+                            own[k] = r8[k] + (uint32_t)__shfl_xor((int)r8[k], 32, 64);   // both features of the pair
+                            par[k] = (uint32_t)__shfl_xor((int)own[k], 1, 64);            // the other strip of this row
+                            r8[k] = 0;
+                        }
+                        // bytes [c0 + 8h, +8) of the 32-byte row {strip S0, strip S0+1}; c0 = window start inside strip S0
+                        const int c0 = (cls + gx) & 15;
+                        uint32_t u6[6];
+                        u6[0] = h ? par[2] : own[0]; u6[1] = h ? par[3] : own[1]; u6[2] = h ? own[0] : own[2];
+                        u6[3] = h ? own[1] : own[3]; u6[4] = h ? own[2] : par[0]; u6[5] = h ? own[3] : par[1];
+                        const uint32_t sb = (uint32_t)(c0 & 3);
+                        uint32_t o0, o1;
+                        switch (c0 >> 2) {                       // wave-uniform
+                            case 0: o0 = __builtin_amdgcn_alignbyte(u6[1], u6[0], sb); o1 = __builtin_amdgcn_alignbyte(u6[2], u6[1], sb); break;
+                            case 1: o0 = __builtin_amdgcn_alignbyte(u6[2], u6[1], sb); o1 = __builtin_amdgcn_alignbyte(u6[3], u6[2], sb); break;
+                            case 2: o0 = __builtin_amdgcn_alignbyte(u6[3], u6[2], sb); o1 = __builtin_amdgcn_alignbyte(u6[4], u6[3], sb); break;
+                            default: o0 = __builtin_amdgcn_alignbyte(u6[4], u6[3], sb); o1 = __builtin_amdgcn_alignbyte(u6[5], u6[4], sb); break;
+                        }
+                        add_bytes(o0, w[0], w[1]);
+                        add_bytes(o1, w[2], w[3]);
+                    };
+                    FeatStrip c[kFeatBatch];
 #pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
-                    uint32_t va[kFeatBatch], vb[kFeatBatch];
-                    int sh[kFeatBatch];
+                    for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
+                    for (int f = 0; f < nfp; f += kFeatBatch) {
+                        const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
+                        FeatStrip cn[kFeatBatch];
 #pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) {
-                        const int X0 = (int)(c[u].cell & 0xFFFF) + gx, Y0 = (int)(c[u].cell >> 16) + gy;   // window origin in the plane
-                        const int A4 = X0 >> 2;                           // first aligned dword of the window row
-                        const uint32_t sbase = c[u].sbase + (uint32_t)(((A4 >> 2) * Hd + Y0) * 16);
-                        const int t = q + (A4 & 3), tb = t + 1;           // aligned dword index inside the 2-strip span
-                        const uint8_t* pa = sm + sbase + ((t >> 2) * HS + (t & 3) * 4 + r16);
-                        const uint8_t* pb = sm + sbase + ((tb >> 2) * HS + (tb & 3) * 4 + r16);
-                        va[u] = *(const uint32_t*)pa;
-                        vb[u] = *(const uint32_t*)pb;
-                        sh[u] = X0 & 3;
+                        for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
+                        uint4 v[kFeatBatch / 2];
+#pragma unroll
+                        for (int k = 0; k < kFeatBatch / 2; ++k) {
+                            // features 2k (lanes 0-31) and 2k+1 (lanes 32-63): same alignment class by construction
+                            const uint32_t xa = (c[2 * k].cell & 0xFFFF) + gx, ya = (c[2 * k].cell >> 16) + gy;
+                            const uint32_t xb = (c[2 * k + 1].cell & 0xFFFF) + gx, yb = (c[2 * k + 1].cell >> 16) + gy;
+                            const uint32_t ba = c[2 * k].sbase + ((xa >> 4) * Hd + ya) * 16u;
+                            const uint32_t bb = c[2 * k + 1].sbase + ((xb >> 4) * Hd + yb) * 16u;
+                            v[k] = ld_aligned16(smp + (half ? bb : ba));
+                        }
+#pragma unroll
+                        for (int k = 0; k < kFeatBatch / 2; ++k) {
+                            const int cls = (int)(c[2 * k].cell & 15);
+                            if (cls != cur || cnt == 31) {
+                                if (cur >= 0) flush(cur);
+                                cur = cls; cnt = 0;
+                            }
+                            r8[0] += v[k].x; r8[1] += v[k].y; r8[2] += v[k].z; r8[3] += v[k].w;   // <= 31 x 4 per byte and half
+                            ++cnt;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
                     }
-#pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) {
-                        const uint32_t v = __builtin_amdgcn_alignbyte(vb[u], va[u], (uint32_t)sh[u]);
-                        even += v & 0x00FF00FFu;
-                        odd += (v >> 8) & 0x00FF00FFu;
-                    }
-#pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
+                    if (cur >= 0) flush(cur);
                 }
-            } else if (!all_in) {
+                const uint32_t idx0 = (uint32_t)(r * 16 + 8 * h);
+                const uint32_t raws[8] = {w[0] & 0xFFFF, w[1] & 0xFFFF, w[0] >> 16, w[1] >> 16,
+                                          w[2] & 0xFFFF, w[3] & 0xFFFF, w[2] >> 16, w[3] >> 16};
+                key = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t kk = (raws[k] << 8) | (255u - (idx0 + k));
+                    key = kk > key ? kk : key;
+                }
+            } else {
+                const int row = lane >> 2, col = (lane & 3) * 4;
+                const int32_t* fo = feat_off + e.feat_start;
                 const uint32_t* fxy = feat_xy + e.feat_start;
+                const uint8_t* base = lm_arena + ((int64_t)gy * Wd + gx + row * Wd + col);
+                uint32_t even = 0, odd = 0;
                 for (int f = 0; f < nfp; ++f) {
                     uint32_t xy = fxy[f];
                     int fx = (int16_t)(xy & 0xFFFF) + off_x, fy = (int16_t)(xy >> 16) + off_y;
                     if (fx < 0 || fy < 0 || fx >= W || fy >= H) continue;   // LL.cpp:1394 (padding: x = y = -32768)
                     uint32_t v = ld_u32(base + fo[f]);
-                    even += v & 0x00FF00FFu;
-                    odd += (v >> 8) & 0x00FF00FFu;
+                    add_bytes(v, even, odd);
                 }
+                const uint32_t idx0 = (uint32_t)(row * 16 + col);
+                uint32_t k0 = ((even & 0xFFFF) << 8) | (255u - idx0);
+                uint32_t k1 = ((odd & 0xFFFF) << 8) | (255u - (idx0 + 1));
+                uint32_t k2 = ((even >> 16) << 8) | (255u - (idx0 + 2));
+                uint32_t k3 = ((odd >> 16) << 8) | (255u - (idx0 + 3));
+                uint32_t ka = k0 > k1 ? k0 : k1, kb = k2 > k3 ? k2 : k3;
+                key = ka > kb ? ka : kb;
             }
             ++evals;
             bytes += 256ull * nf;   // algorithmic response bytes of this 16x16 evaluation
-            const uint32_t idx0 = (uint32_t)(row * 16 + col);
-            uint32_t k0 = ((even & 0xFFFF) << 8) | (255u - idx0);
-            uint32_t k1 = ((odd & 0xFFFF) << 8) | (255u - (idx0 + 1));
-            uint32_t k2 = ((even >> 16) << 8) | (255u - (idx0 + 2));
-            uint32_t k3 = ((odd >> 16) << 8) | (255u - (idx0 + 3));
-            uint32_t k = k0 > k1 ? k0 : k1;
-            uint32_t kk = k2 > k3 ? k2 : k3;
-            k = wave_max_u32(k > kk ? k : kk);
+            const uint32_t k = wave_max_u32(key);
             const int raw = (int)(k >> 8);
             int br = -1, bc = -1;                               // LL.cpp:1910-1911
             float best = 0.f;
