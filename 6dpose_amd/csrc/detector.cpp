@@ -125,7 +125,9 @@ struct lm_detector {
     uint32_t cand_cap = 1u << 18;
     Candidate* h_matches = nullptr;                 // pinned, device-visible: k_local writes matches here
     uint32_t match_cap = 0;
-    unsigned long long* h_counters = nullptr;       // pinned
+    unsigned long long* h_counters = nullptr;       // pinned: 8 counters + 2 words of statistics per refinement block
+    DevBuf<unsigned long long> d_block_stats;
+    int local_blocks = 0;
     int num_cus = 256;
 
     lm_timings timings{};
@@ -198,7 +200,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_block_stats.release();
     if (d->h_matches) (void)hipHostFree(d->h_matches);
     if (d->h_counters) (void)hipHostFree(d->h_counters);
     if (d->pinned) (void)hipHostFree(d->pinned);
@@ -850,7 +852,12 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
 }
 
 static int ensure_match_buffers(lm_detector* d, uint32_t match_cap) {
-    if (!d->h_counters) HIP_TRY(hipHostMalloc((void**)&d->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!d->h_counters) {
+        d->local_blocks = d->num_cus * 8;
+        HIP_TRY(hipHostMalloc((void**)&d->h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
+        int rc = d->d_block_stats.ensure(2 * (size_t)d->local_blocks);
+        if (rc) return rc;
+    }
     if (match_cap > d->match_cap) {
         if (d->h_matches) (void)hipHostFree(d->h_matches);
         d->h_matches = nullptr; d->match_cap = 0;
@@ -872,7 +879,7 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
     if ((rc = d->d_counters.ensure(8))) return rc;
-    if ((rc = ensure_match_buffers(d, std::max<uint32_t>(d->match_cap, 1u << 16)))) return rc;
+    if ((rc = ensure_match_buffers(d, std::max<uint32_t>(d->match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream;
     lm_timings tm{};
     tm.h2d_ms = d->last_h2d_ms;
@@ -893,26 +900,28 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
         HIP_TRY(hipEventRecord(d->ev[2], s));
         // persistent refinement grid; the candidate count is read on the device (no host round trip)
         launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d->num_cus * 8, s);
+                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d->d_block_stats.p,
+                     d->local_blocks, s);
         HIP_TRY(hipEventRecord(d->ev[3], s));
         HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d->h_counters + 8, d->d_block_stats.p, 2 * (size_t)d->local_blocks * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(d->ev[4], s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
-        ncand = d->h_counters[0]; nm = d->h_counters[1];
+        ncand = d->h_counters[0];
         if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
-        bool again = false;
-        if (ncand > d->cand_cap) { d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024); again = true; }
-        if (nm > d->match_cap || (again && ncand > d->match_cap)) {
-            uint64_t want = std::max<uint64_t>(nm, ncand);
-            if ((rc = ensure_match_buffers(d, (uint32_t)(want + want / 4 + 1024)))) return rc;
-            again = true;
-        }
-        if (!again) break;
+        if (ncand <= d->cand_cap && ncand <= d->match_cap) break;
+        // a buffer overflowed: grow both (every candidate owns one match slot) and rerun the frame
+        d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024);
+        if ((rc = ensure_match_buffers(d, d->cand_cap))) return rc;
     }
+    uint64_t evals = 0, lbytes = 0;
+    for (int b = 0; b < d->local_blocks; ++b) { evals += d->h_counters[8 + 2 * b]; lbytes += d->h_counters[8 + 2 * b + 1]; }
+    for (uint64_t i = 0; i < ncand; ++i) nm += d->h_matches[i].work >= 0;
     tm.coarse_candidates = (int64_t)ncand;
-    tm.local_evals = (int64_t)d->h_counters[2];
-    tm.local_bytes = (int64_t)d->h_counters[3];
+    tm.local_evals = (int64_t)evals;
+    tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;
     (void)hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]);
     (void)hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]);
@@ -924,11 +933,14 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
     const Candidate* hm = d->h_matches;
-    for (size_t i = 0; i < nm; ++i) {
+    size_t w = 0;
+    for (uint64_t i = 0; i < ncand; ++i) {
         const Candidate& c = hm[i];
-        res[i].x = c.x; res[i].y = c.y; res[i].similarity = c.score;
-        res[i].class_index = d->work_cls[c.work];
-        res[i].template_id = d->work_tid[c.work];
+        if (c.work < 0) continue;                     // dropped below the threshold during refinement
+        res[w].x = c.x; res[w].y = c.y; res[w].similarity = c.score;
+        res[w].class_index = d->work_cls[c.work];
+        res[w].template_id = d->work_tid[c.work];
+        ++w;
     }
     size_t n = (size_t)nm;
     if (sort_unique) n = lm_merge_matches(res, (size_t)nm);

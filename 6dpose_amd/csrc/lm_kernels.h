@@ -52,14 +52,14 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
                    unsigned long long* counters, hipStream_t s);
 // Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
-// counters[1] = number of matches produced, counters[2] = 16x16 evaluations, counters[3] = their bytes.
+// matches[ci] = refined candidate ci (work = -1: dropped); block_stats[2*b], [2*b+1] = 16x16 evaluations / bytes of block b.
 struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
     uint32_t sbase;       // byte offset of the feature's (label, phase) plane inside the strip arena
     uint32_t cell;        // lx | ly << 16   (x / T, y / T)
 };
 void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
-                  hipStream_t s);
+                  float threshold, Candidate* matches, uint32_t cap, const unsigned long long* counters,
+                  unsigned long long* block_stats, int grid_blocks, hipStream_t s);
 
 }  // namespace lm

@@ -136,24 +136,43 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
             }
             if (cur >= 0) flush(cur);
         }
-        if (lane < kChunksPerWave) {
+        // Threshold scan (LL.cpp:1835-1852).  One atomicAdd per WAVE reserves the slots of all its hits (a
+        // single counter word saturates at ~90 atomics/us on this chip: per-candidate atomics made the pass
+        // atomic-bound), then every lane writes its hits at the reserved base + its exclusive prefix.
+        uint32_t hit_mask = 0;
+        float sc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = j0 + k;
+            const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
+            const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
+            const int r = j < tp ? rawk : 0;                  // positions >= template_positions stay 0
+            sc[k] = score_of(r, nf);
+            if (lane < kChunksPerWave && j < npos && sc[k] > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
+        }
+        int mine = __popc(hit_mask), incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total > 0) {                                       // wave-uniform
+            unsigned long long wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&counters[0], (unsigned long long)total);
+            wbase = ((unsigned long long)(uint32_t)__shfl((int)(wbase >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0, 64);
+            unsigned long long slot = wbase + (unsigned long long)(incl - mine);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int j = j0 + k;
-                const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
-                const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
-                if (j < npos) {
-                    int r = j < tp ? rawk : 0;                // positions >= template_positions stay 0
-                    float sc = score_of(r, nf);
-                    if (sc > threshold) {                     // LL.cpp:1844
-                        unsigned long long slot = atomicAdd(&counters[0], 1ull);
-                        if (slot < cap) {
-                            int cy = j / Wd, cx = j - cy * Wd;
-                            Candidate c;
-                            c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc; c.work = work;
-                            cands[slot] = c;
-                        }
+                if (hit_mask & (1u << k)) {
+                    if (slot < cap) {
+                        const int j = j0 + k;
+                        const int cy = j / Wd, cx = j - cy * Wd;
+                        Candidate c;
+                        c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc[k]; c.work = work;
+                        cands[slot] = c;
                     }
+                    ++slot;
                 }
             }
         }
@@ -203,7 +222,9 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
         const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
-        float threshold, Candidate* __restrict__ matches, uint32_t cap, unsigned long long* __restrict__ counters) {
+        float threshold, Candidate* __restrict__ matches, uint32_t cap, const unsigned long long* __restrict__ counters,
+        unsigned long long* __restrict__ block_stats) {
+    __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -349,29 +370,33 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             my = (y / T - 8 + br) * T + offset;
             if (sim < threshold) alive = false;                 // remove_if(MatchPredicate), LL.cpp:1935
         }
-        if (lane == 0 && alive) {
-            unsigned long long slot = atomicAdd(&counters[1], 1ull);
-            if (slot < cap) {
-                Candidate m;
-                m.x = mx; m.y = my; m.score = sim; m.work = work;
-                matches[slot] = m;
-            }
+        // No atomics: the result of candidate ci goes to slot ci (work = -1 when it dropped below the
+        // threshold on the way up, LL.cpp:1935); the host compacts.  matches[] is pinned host memory.
+        if (lane == 0 && ci < cap) {
+            Candidate m;
+            m.x = mx; m.y = my; m.score = sim; m.work = alive ? work : -1;
+            matches[ci] = m;
         }
     }
-    if (lane == 0 && evals) {
-        atomicAdd(&counters[2], evals);
-        atomicAdd(&counters[3], bytes);
+    // per-block statistics (16x16 evaluations, their algorithmic bytes): plain stores, summed on the host
+    if (lane == 0) { s_stats[threadIdx.x >> 6][0] = evals; s_stats[threadIdx.x >> 6][1] = bytes; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_stats[w][0]; b += s_stats[w][1]; }
+        block_stats[2 * blockIdx.x] = a;
+        block_stats[2 * blockIdx.x + 1] = b;
     }
 }
 
 void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
                   const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, uint32_t cap, unsigned long long* counters, int grid_blocks,
-                  hipStream_t s) {
-    if (cand_cap == 0 || grid_blocks <= 0) return;
+                  float threshold, Candidate* matches, uint32_t cap, const unsigned long long* counters,
+                  unsigned long long* block_stats, int grid_blocks, hipStream_t s) {
+    if (grid_blocks <= 0) return;
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
-                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, cap, counters);
+                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, cap, counters, block_stats);
 }
 
 }  // namespace lm
