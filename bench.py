@@ -101,11 +101,20 @@ def main():
         classes.append(cid)
     det.setShard(rank, world)
 
+    host_t = {"select": 0.0, "match_call": 0.0, "gather": 0.0, "merge": 0.0}
+
     def step(k):
+        t0 = time.perf_counter()
         det.selectFrame(k % N_FRAMES)
+        t1 = time.perf_counter()
         local = det.matchResident(THRESHOLD, classes, sort_unique=False)
+        t2 = time.perf_counter()
         allrec = sharded.gather_records(local, device=dev) if world > 1 else local
-        return lm.merge_matches(allrec)
+        t3 = time.perf_counter()
+        out = lm.merge_matches(allrec)
+        t4 = time.perf_counter()
+        host_t["select"] += t1 - t0; host_t["match_call"] += t2 - t1; host_t["gather"] += t3 - t2; host_t["merge"] += t4 - t3
+        return out
 
     def fence():
         if world > 1:
@@ -118,6 +127,8 @@ def main():
             "matches_pre_unique", "coarse_bytes", "local_bytes")
     acc = {k: 0.0 for k in keys}
     fence()
+    for q in host_t:
+        host_t[q] = 0.0
     t0 = time.perf_counter()
     n_final = 0
     for k in range(args.steps):
@@ -155,6 +166,7 @@ def main():
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
             "stages_ms": {k: mean[k] for k in ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
+            "host_wall_ms": {q: host_t[q] / K * 1e3 for q in host_t},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms,
