@@ -130,6 +130,13 @@ struct lm_detector {
     int local_blocks = 0;
     int num_cus = 256;
 
+    // the whole per-frame device pipeline captured once into a hipGraph (launch-bound: ~30 small launches)
+    bool use_graph = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key[8] = {};
+    bool graph_events_ok = true;
+
     lm_timings timings{};
 };
 
@@ -179,6 +186,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
+    if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
@@ -204,6 +212,8 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (d->h_matches) (void)hipHostFree(d->h_matches);
     if (d->h_counters) (void)hipHostFree(d->h_counters);
     if (d->pinned) (void)hipHostFree(d->pinned);
+    if (d->graph_exec) (void)hipGraphExecDestroy(d->graph_exec);
+    if (d->graph) (void)hipGraphDestroy(d->graph);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -886,14 +896,14 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     tm.templates = num_work;
     tm.coarse_bytes = d->work_coarse_bytes;
 
-    HIP_TRY(hipEventRecord(d->ev[0], s));
-    if ((rc = run_frontend(d, true))) return rc;
-    HIP_TRY(hipEventRecord(d->ev[1], s));
     Candidate* d_matches = nullptr;
     uint64_t ncand = 0, nm = 0;
-    for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed: never drop silently
-        if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
-        HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, d->h_matches, 0));
+    // front end + coarse + refinement + counter download, all on the detector's stream
+    auto enqueue = [&]() -> int {
+        HIP_TRY(hipEventRecord(d->ev[0], s));
+        int r = run_frontend(d, true);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(d->ev[1], s));
         HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), s));
         launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
                       d->cand_cap, d->d_counters.p, s);
@@ -907,6 +917,39 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
         HIP_TRY(hipMemcpyAsync(d->h_counters + 8, d->d_block_stats.p, 2 * (size_t)d->local_blocks * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(d->ev[4], s));
+        return LM_OK;
+    };
+    for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed: never drop silently
+        if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, d->h_matches, 0));
+        bool launched = false;
+        if (d->use_graph) {
+            uint32_t thr_bits;
+            memcpy(&thr_bits, &threshold, 4);
+            const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, d->match_cap,
+                                     ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
+                                     (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p};
+            if (!d->graph_exec || memcmp(key, d->graph_key, sizeof(key)) != 0) {
+                if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+                if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+                bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    int r = enqueue();
+                    hipError_t ee = hipStreamEndCapture(s, &d->graph);
+                    ok = (r == LM_OK) && ee == hipSuccess && d->graph &&
+                         hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0) == hipSuccess;
+                }
+                if (ok) memcpy(d->graph_key, key, sizeof(key));
+                else {   // capture unavailable: fall back to plain launches for good
+                    (void)hipGetLastError();
+                    if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+                    if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+                    d->use_graph = false;
+                }
+            }
+            if (d->graph_exec) { HIP_TRY(hipGraphLaunch(d->graph_exec, s)); launched = true; }
+        }
+        if (!launched && (rc = enqueue())) return rc;
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
         ncand = d->h_counters[0];
@@ -923,11 +966,18 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;
-    (void)hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]);
-    (void)hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]);
-    (void)hipEventElapsedTime(&tm.local_ms, d->ev[2], d->ev[3]);
-    (void)hipEventElapsedTime(&tm.d2h_ms, d->ev[3], d->ev[4]);
-    (void)hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[4]);
+    if (hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, d->ev[2], d->ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.d2h_ms, d->ev[3], d->ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[4]) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d->use_graph && d->graph_events_ok) {   // event nodes of a graph are not timeable here: time with plain launches
+            d->graph_events_ok = false;
+            d->use_graph = false;
+        }
+        tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;
+    }
     d->timings = tm;
 
     lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));

@@ -107,12 +107,16 @@ def main():
         t0 = time.perf_counter()
         det.selectFrame(k % N_FRAMES)
         t1 = time.perf_counter()
-        local = det.matchResident(THRESHOLD, classes, sort_unique=False)
-        t2 = time.perf_counter()
-        allrec = sharded.gather_records(local, device=dev) if world > 1 else local
-        t3 = time.perf_counter()
-        out = lm.merge_matches(allrec)
-        t4 = time.perf_counter()
+        if world == 1:        # Detector.match semantics: canonical sort + unique inside the library call
+            out = det.matchResident(THRESHOLD, classes, sort_unique=True)
+            t2 = t3 = t4 = time.perf_counter()
+        else:                 # pre-unique records of this rank's shard -> all-gather -> merge on every rank
+            local = det.matchResident(THRESHOLD, classes, sort_unique=False)
+            t2 = time.perf_counter()
+            allrec = sharded.gather_records(local, device=dev)
+            t3 = time.perf_counter()
+            out = lm.merge_matches(allrec)
+            t4 = time.perf_counter()
         host_t["select"] += t1 - t0; host_t["match_call"] += t2 - t1; host_t["gather"] += t3 - t2; host_t["merge"] += t4 - t3
         return out
 
