@@ -177,6 +177,18 @@ def main():
                          "other": {"k_coarse_GBps": (mean["coarse_bytes"] / (mean["coarse_ms"] * 1e-3) / 1e9) if mean["coarse_ms"] > 0 else 0.0,
                                    "k_local_GBps": (mean["local_bytes"] / (mean["local_ms"] * 1e-3) / 1e9) if mean["local_ms"] > 0 else 0.0}},
         }
+        if world == 1:
+            out["extras"] = {"pcie_inclusive": pcie_inclusive(det, frames, classes, args.templates),
+                             "icp": icp_bench(local_rank)}
+        traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
+        if os.path.exists(traffic):
+            try:
+                tj = json.load(open(traffic))
+                if tj.get("kernel") == kname:
+                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = tj.get("source")
+            except (OSError, ValueError):
+                pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
@@ -185,6 +197,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pcie_inclusive(det, frames, classes, n_templates, steps=20):
+    """Detector.match as the drop-in boundary hands it over: host numpy frames in, Match records out
+    (H2D of the frame through pinned staging included).  Never the headline `value`."""
+    for k in range(3):
+        det.matchArray(list(frames[k % len(frames)]), THRESHOLD, classes)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        det.matchArray(list(frames[k % len(frames)]), THRESHOLD, classes)
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_frame": dt * 1e3, "value": n_templates * (W * H / 1e6) / dt, "unit": "templates*Mpx/s"}
+
+
+def icp_bench(device, hypotheses=16, reps=5):
+    """BASELINE configs[2]: poseRefine on the top-16 hypotheses of a frame, one ICP launch (one workgroup
+    per hypothesis, <=30 point-to-plane iterations each).  Reports ICP iterations/sec."""
+    import linemodLevelup_pybind as lm
+    import synth
+    K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
+    rng = np.random.default_rng(7)
+    scene_model = synth.synth_model_depth(100)
+    scene = np.where(scene_model > 0, scene_model + 4, 0).astype(np.uint16)
+    scene = np.where(scene > 0, scene + rng.integers(-1, 2, scene.shape), 0).astype(np.uint16)
+    mds, xy = [], []
+    for h in range(hypotheses):
+        md = synth.synth_model_depth(100 + (h % 4))
+        ys, xs = np.nonzero(md)
+        mds.append(md)
+        xy.append((int(xs.min()) + int(rng.integers(-2, 3)), int(ys.min()) + int(rng.integers(-2, 3))))
+    Ks = np.tile(K.reshape(1, 9), (hypotheses, 1))
+    Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (hypotheses, 1))
+    ts = np.tile(np.array([[0, 0, 1000]], np.float32), (hypotheses, 1))
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res, dev_ms = lm.pose_refine_batch(scene, K, mds, Ks, Rs, ts, xy, device=device, scene_from_scene=True)
+        wall = time.perf_counter() - t0
+        iters = sum(r["iterations"] for r in res if r["residual"] >= 0)
+        cur = {"hypotheses": hypotheses, "iterations_total": iters, "device_ms": dev_ms, "wall_ms": wall * 1e3,
+               "icp_iters_per_sec_device": iters / (dev_ms * 1e-3) if dev_ms > 0 else 0.0,
+               "icp_iters_per_sec_wall": iters / wall, "points_source_mean": float(np.mean([r["n_source"] for r in res])),
+               "points_target_mean": float(np.mean([r["n_target"] for r in res])),
+               "mean_fitness": float(np.mean([r["residual"] for r in res]))}
+        if best is None or cur["device_ms"] < best["device_ms"]:
+            best = cur
+    return best
 
 
 def cpu_baseline(frames, bank, n_templates):
