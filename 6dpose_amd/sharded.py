@@ -18,11 +18,14 @@ import numpy as np
 import linemodLevelup_pybind as lm
 
 
-def gather_records(local: np.ndarray, device=None, group=None) -> np.ndarray:
-    """all-gather of MATCH_DTYPE records from every rank (concatenated in rank order)."""
+def gather_records(local: np.ndarray, device=None, group=None, force: bool = False) -> np.ndarray:
+    """all-gather of MATCH_DTYPE records from every rank (concatenated in rank order).  `force` runs
+    the collective even with a single rank (used to exercise the RCCL path on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size(group) == 1 and not force:
         return local
     world = dist.get_world_size(group)
     dev = torch.device("cpu") if device is None else torch.device(device)

@@ -410,3 +410,59 @@ def test_pose_refine_batch_equals_single_calls(lm):
         pr = mod.poseRefine(device=0, scene_from_scene=True)
         pr.process(scene, mds[i], K_CAM, K_CAM, Rs[i].reshape(3, 3), ts[i], xy[i][0], xy[i][1])
         assert np.array_equal(pr.getR(), res[i]["R"]) and np.array_equal(pr.getT().ravel(), res[i]["t"])
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-process sharding on the one visible GPU
+# ---------------------------------------------------------------------------------------------
+_SHARD_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+root, port, rank, world, backend = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+sys.path[:0] = [os.path.join(root, "6dpose_amd"), os.path.join(root, "oracle")]
+import linemodLevelup_pybind as lm, sharded, synth, linemod_oracle as lo
+kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+dist.init_process_group(backend, init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world, **kw)
+W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+rgb, dep = synth.make_frame(13, W, H)
+od = lo.OracleDetector(nfeat[0], T)
+pyr = od.quantize_pyramid(rgb, dep)
+banks = {c: synth.make_planted_bank(41 + i, 90 + 20 * i, [(p[0], p[1]) for p in pyr], T, nfeat) for i, c in enumerate(["a", "b", "c"])}
+det = lm.Detector(nfeat[0], T, device=0)
+for c in banks:
+    det.addClassPacked(c, *banks[c])
+dev = "cuda:0" if backend == "nccl" else None
+got = sharded.match_sharded(det, [rgb, dep], 75.0, ["c", "a", "b"], device=dev)
+if backend == "nccl":   # single rank: also push the records through the RCCL all-gather explicitly
+    det.setFrame([rgb, dep])
+    pre = det.matchResident(75.0, ["c", "a", "b"], sort_unique=False)
+    again = lm.merge_matches(sharded.gather_records(pre, device=dev, force=True))
+    assert again.tobytes() == got.tobytes()
+det.setShard(0, 1)
+whole = det.matchArray([rgb, dep], 75.0, ["c", "a", "b"])
+assert len(whole) > 0 and got.tobytes() == whole.tobytes(), (rank, len(got), len(whole))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", len(got))
+'''
+
+
+def _run_workers(tmp_path, world, backend):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    port = str(29800 + os.getpid() % 1500)
+    procs = [subprocess.Popen([sys.executable, str(script), root, port, str(r), str(world), backend],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=500)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+def test_match_sharded_two_processes_one_gpu_gloo(lm, tmp_path):
+    """world_size 2, both ranks computing on cuda:0, records exchanged over gloo: equals the unsharded result."""
+    _run_workers(tmp_path, 2, "gloo")
+
+
+def test_match_sharded_rccl_single_rank(lm, tmp_path):
+    """The RCCL (backend "nccl") all-gather path with the one rank a 1-GPU box allows."""
+    _run_workers(tmp_path, 1, "nccl")
