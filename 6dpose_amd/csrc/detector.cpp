@@ -92,6 +92,12 @@ struct lm_detector {
     DevBuf<uint16_t> frame_depth;
     DevBuf<uint16_t> tmp16;
     DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
+    // second scratch set (colour chain of the levels >= 1) and the depth chain's row-OR scratch: the three
+    // chains of the front end run concurrently on three streams (forked/joined with events, also inside the graph)
+    DevBuf<uint16_t> tmp16_b;
+    DevBuf<uint8_t> smoothed_b, q16_b, rowor_b, rowor_d;
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     LevelBufs lvl[kMaxLevels];
     FrameGeom geom{};
     size_t lm_block_bytes[kMaxLevels] = {};
@@ -126,7 +132,6 @@ struct lm_detector {
     Candidate* h_matches = nullptr;                 // pinned, device-visible: k_local writes matches here
     uint32_t match_cap = 0;
     unsigned long long* h_counters = nullptr;       // pinned: 8 counters + 2 words of statistics per refinement block
-    DevBuf<unsigned long long> d_block_stats;
     int local_blocks = 0;
     int num_cus = 256;
 
@@ -186,6 +191,9 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
+    for (auto& a : d->aux) (void)hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+    for (auto& e : d->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     {
         hipDeviceProp_t prop;
@@ -204,11 +212,15 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipStreamSynchronize(d->stream);
     d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
     d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release(); d->sm_arena.release();
+    d->tmp16_b.release(); d->smoothed_b.release(); d->q16_b.release(); d->rowor_b.release(); d->rowor_d.release();
+    for (auto& a : d->aux) if (a) (void)hipStreamDestroy(a);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    for (auto& e : d->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_block_stats.release();
+    d->d_cands.release(); d->d_counters.release();
     if (d->h_matches) (void)hipHostFree(d->h_matches);
     if (d->h_counters) (void)hipHostFree(d->h_counters);
     if (d->pinned) (void)hipHostFree(d->pinned);
@@ -276,6 +288,14 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     if ((rc = d->q16.ensure(n0))) return rc;
     if ((rc = d->nrm_raw.ensure(n0))) return rc;
     if ((rc = d->rowor.ensure(n0))) return rc;
+    if ((rc = d->rowor_d.ensure(n0))) return rc;
+    {
+        const size_t n1 = std::max<size_t>(1, (size_t)(W / 2) * (H / 2));
+        if ((rc = d->tmp16_b.ensure(n1 * 3))) return rc;
+        if ((rc = d->smoothed_b.ensure(n1 * 3))) return rc;
+        if ((rc = d->q16_b.ensure(n1))) return rc;
+        if ((rc = d->rowor_b.ensure(n1))) return rc;
+    }
     bool realloc_arena = arena > d->lm_arena.cap;
     if ((rc = d->lm_arena.ensure(arena))) return rc;
     if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
@@ -339,32 +359,50 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
 
 // quantise every level; build_lm=false for addTemplate (only the quantised maps are needed)
 static int run_frontend(lm_detector* d, bool build_lm) {
-    hipStream_t s = d->stream;
+    // Three independent chains, forked from / joined into the detector's stream:
+    //   s  : colour, level 0          (blur -> sobel/phase -> hysteresis -> spread -> linear memories)
+    //   s1 : pyrDown + colour, levels >= 1
+    //   s2 : depth normals of every level (+ their linear memories)
+    hipStream_t s = d->stream, s1 = d->aux[0], s2 = d->aux[1];
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
-    for (int l = 0; l < L; ++l) {
+    HIP_TRY(hipEventRecord(d->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(s1, d->ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(s2, d->ev_fork, 0));
+    auto colour = [&](int l, hipStream_t st, uint16_t* tmp16, uint8_t* smoothed, uint8_t* q16, uint8_t* rowor) {
         LevelBufs& b = d->lvl[l];
         const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
-        if (l > 0) {
-            const LevelBufs& a = d->lvl[l - 1];
-            launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
-            launch_nn_down2(a.nrm.p, b.nrm.p, a.W, a.H, s);                                   // LL.cpp:857-880
-        } else {
-            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
-                           d->difference_threshold, s);                                       // LL.cpp:729-819
-        }
-        launch_blur7(src, d->tmp16.p, d->smoothed.p, b.W, b.H, s);                            // LL.cpp:367
-        launch_sobel_quant(d->smoothed.p, b.mag.p, d->q16.p, b.W, b.H, s);                    // LL.cpp:368-455
-        launch_hysteresis(d->q16.p, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                   // LL.cpp:457-504
+        launch_blur7(src, tmp16, smoothed, b.W, b.H, st);                                     // LL.cpp:367
+        launch_sobel_quant(smoothed, b.mag.p, q16, b.W, b.H, st);                             // LL.cpp:368-455
+        launch_hysteresis(q16, b.mag.p, b.ang.p, b.W, b.H, thr_sq, st);                       // LL.cpp:457-504
         if (build_lm) {
             const LevelGeom& lv = d->geom.lv[l];
-            const bool strips = l < L - 1;
-            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[0],
-                            strips ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, s);
-            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[1],
-                            strips ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s);
+            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, rowor, d->lm_arena.p + lv.lm_off[0],
+                            l < L - 1 ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, st);
+        }
+    };
+    colour(0, s, d->tmp16.p, d->smoothed.p, d->q16.p, d->rowor.p);
+    for (int l = 1; l < L; ++l) {
+        const LevelBufs& a = d->lvl[l - 1];
+        launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, d->lvl[l].rgb.p, a.W, a.H, s1);   // LL.cpp:557-581
+        colour(l, s1, d->tmp16_b.p, d->smoothed_b.p, d->q16_b.p, d->rowor_b.p);
+    }
+    for (int l = 0; l < L; ++l) {
+        LevelBufs& b = d->lvl[l];
+        if (l == 0)
+            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold, d->difference_threshold, s2);   // LL.cpp:729-819
+        else
+            launch_nn_down2(d->lvl[l - 1].nrm.p, b.nrm.p, d->lvl[l - 1].W, d->lvl[l - 1].H, s2);                                       // LL.cpp:857-880
+        if (build_lm) {
+            const LevelGeom& lv = d->geom.lv[l];
+            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor_d.p, d->lm_arena.p + lv.lm_off[1],
+                            l < L - 1 ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s2);
         }
     }
+    HIP_TRY(hipEventRecord(d->ev_join[0], s1));
+    HIP_TRY(hipEventRecord(d->ev_join[1], s2));
+    HIP_TRY(hipStreamWaitEvent(s, d->ev_join[0], 0));
+    HIP_TRY(hipStreamWaitEvent(s, d->ev_join[1], 0));
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
@@ -865,8 +903,6 @@ static int ensure_match_buffers(lm_detector* d, uint32_t match_cap) {
     if (!d->h_counters) {
         d->local_blocks = d->num_cus * 8;
         HIP_TRY(hipHostMalloc((void**)&d->h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
-        int rc = d->d_block_stats.ensure(2 * (size_t)d->local_blocks);
-        if (rc) return rc;
     }
     if (match_cap > d->match_cap) {
         if (d->h_matches) (void)hipHostFree(d->h_matches);
@@ -897,6 +933,8 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     tm.coarse_bytes = d->work_coarse_bytes;
 
     Candidate* d_matches = nullptr;
+    unsigned long long* d_hcounters = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, d->h_counters, 0));
     uint64_t ncand = 0, nm = 0;
     // front end + coarse + refinement + counter download, all on the detector's stream
     auto enqueue = [&]() -> int {
@@ -909,13 +947,11 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
                       d->cand_cap, d->d_counters.p, s);
         HIP_TRY(hipEventRecord(d->ev[2], s));
         // persistent refinement grid; the candidate count is read on the device (no host round trip)
+        // (candidate count and per-block statistics are stored straight into pinned host memory: no copy nodes)
         launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d->d_block_stats.p,
+                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d_hcounters,
                      d->local_blocks, s);
         HIP_TRY(hipEventRecord(d->ev[3], s));
-        HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(d->h_counters + 8, d->d_block_stats.p, 2 * (size_t)d->local_blocks * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(d->ev[4], s));
         return LM_OK;
     };

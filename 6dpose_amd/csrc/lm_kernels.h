@@ -52,7 +52,8 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
                    unsigned long long* counters, hipStream_t s);
 // Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
-// matches[ci] = refined candidate ci (work = -1: dropped); block_stats[2*b], [2*b+1] = 16x16 evaluations / bytes of block b.
+// matches[ci] = refined candidate ci (work = -1: dropped); block_stats (pinned host memory): [0] = candidate count,
+// [8+2*b], [8+2*b+1] = 16x16 evaluations / their algorithmic bytes of block b.
 struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
     uint32_t sbase;       // byte offset of the feature's (label, phase) plane inside the strip arena
     uint32_t cell;        // lx | ly << 16   (x / T, y / T)

@@ -231,6 +231,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     unsigned long long nc = counters[0];
     const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
     unsigned long long evals = 0, bytes = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) block_stats[0] = nc;   // candidate count for the host (pinned memory)
 
     for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
         const Candidate cd = cands[ci];
@@ -384,8 +385,8 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     if (threadIdx.x == 0) {
         unsigned long long a = 0, b = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_stats[w][0]; b += s_stats[w][1]; }
-        block_stats[2 * blockIdx.x] = a;
-        block_stats[2 * blockIdx.x + 1] = b;
+        block_stats[8 + 2 * blockIdx.x] = a;
+        block_stats[8 + 2 * blockIdx.x + 1] = b;
     }
 }
 
