@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -92,12 +93,7 @@ struct lm_detector {
     DevBuf<uint16_t> frame_depth;
     DevBuf<uint16_t> tmp16;
     DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
-    // second scratch set (colour chain of the levels >= 1) and the depth chain's row-OR scratch: the three
-    // chains of the front end run concurrently on three streams (forked/joined with events, also inside the graph)
-    DevBuf<uint16_t> tmp16_b;
-    DevBuf<uint8_t> smoothed_b, q16_b, rowor_b, rowor_d;
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+
     LevelBufs lvl[kMaxLevels];
     FrameGeom geom{};
     size_t lm_block_bytes[kMaxLevels] = {};
@@ -191,9 +187,6 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
-    for (auto& a : d->aux) (void)hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
-    for (auto& e : d->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     {
         hipDeviceProp_t prop;
@@ -212,10 +205,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipStreamSynchronize(d->stream);
     d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
     d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release(); d->sm_arena.release();
-    d->tmp16_b.release(); d->smoothed_b.release(); d->q16_b.release(); d->rowor_b.release(); d->rowor_d.release();
-    for (auto& a : d->aux) if (a) (void)hipStreamDestroy(a);
-    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
-    for (auto& e : d->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
@@ -288,14 +277,7 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     if ((rc = d->q16.ensure(n0))) return rc;
     if ((rc = d->nrm_raw.ensure(n0))) return rc;
     if ((rc = d->rowor.ensure(n0))) return rc;
-    if ((rc = d->rowor_d.ensure(n0))) return rc;
-    {
-        const size_t n1 = std::max<size_t>(1, (size_t)(W / 2) * (H / 2));
-        if ((rc = d->tmp16_b.ensure(n1 * 3))) return rc;
-        if ((rc = d->smoothed_b.ensure(n1 * 3))) return rc;
-        if ((rc = d->q16_b.ensure(n1))) return rc;
-        if ((rc = d->rowor_b.ensure(n1))) return rc;
-    }
+
     bool realloc_arena = arena > d->lm_arena.cap;
     if ((rc = d->lm_arena.ensure(arena))) return rc;
     if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
@@ -359,50 +341,35 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
 
 // quantise every level; build_lm=false for addTemplate (only the quantised maps are needed)
 static int run_frontend(lm_detector* d, bool build_lm) {
-    // Three independent chains, forked from / joined into the detector's stream:
-    //   s  : colour, level 0          (blur -> sobel/phase -> hysteresis -> spread -> linear memories)
-    //   s1 : pyrDown + colour, levels >= 1
-    //   s2 : depth normals of every level (+ their linear memories)
-    hipStream_t s = d->stream, s1 = d->aux[0], s2 = d->aux[1];
+    // One stream: measured on MI355X, forking the colour / pyramid / depth chains onto three streams
+    // (events, also inside the hipGraph) cost more in cross-stream synchronisation (+26 us) than the
+    // ~3 us kernels could overlap.
+    hipStream_t s = d->stream;
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
-    HIP_TRY(hipEventRecord(d->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(s1, d->ev_fork, 0));
-    HIP_TRY(hipStreamWaitEvent(s2, d->ev_fork, 0));
-    auto colour = [&](int l, hipStream_t st, uint16_t* tmp16, uint8_t* smoothed, uint8_t* q16, uint8_t* rowor) {
-        LevelBufs& b = d->lvl[l];
-        const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
-        launch_blur7(src, tmp16, smoothed, b.W, b.H, st);                                     // LL.cpp:367
-        launch_sobel_quant(smoothed, b.mag.p, q16, b.W, b.H, st);                             // LL.cpp:368-455
-        launch_hysteresis(q16, b.mag.p, b.ang.p, b.W, b.H, thr_sq, st);                       // LL.cpp:457-504
-        if (build_lm) {
-            const LevelGeom& lv = d->geom.lv[l];
-            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, rowor, d->lm_arena.p + lv.lm_off[0],
-                            l < L - 1 ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, st);
-        }
-    };
-    colour(0, s, d->tmp16.p, d->smoothed.p, d->q16.p, d->rowor.p);
-    for (int l = 1; l < L; ++l) {
-        const LevelBufs& a = d->lvl[l - 1];
-        launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, d->lvl[l].rgb.p, a.W, a.H, s1);   // LL.cpp:557-581
-        colour(l, s1, d->tmp16_b.p, d->smoothed_b.p, d->q16_b.p, d->rowor_b.p);
-    }
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
-        if (l == 0)
-            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold, d->difference_threshold, s2);   // LL.cpp:729-819
-        else
-            launch_nn_down2(d->lvl[l - 1].nrm.p, b.nrm.p, d->lvl[l - 1].W, d->lvl[l - 1].H, s2);                                       // LL.cpp:857-880
+        const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
+        if (l > 0) {
+            const LevelBufs& a = d->lvl[l - 1];
+            launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
+            launch_nn_down2(a.nrm.p, b.nrm.p, a.W, a.H, s);                                   // LL.cpp:857-880
+        } else {
+            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+                           d->difference_threshold, s);                                       // LL.cpp:729-819
+        }
+        launch_blur7(src, d->tmp16.p, d->smoothed.p, b.W, b.H, s);                            // LL.cpp:367
+        launch_sobel_quant(d->smoothed.p, b.mag.p, d->q16.p, b.W, b.H, s);                    // LL.cpp:368-455
+        launch_hysteresis(d->q16.p, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                   // LL.cpp:457-504
         if (build_lm) {
             const LevelGeom& lv = d->geom.lv[l];
-            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor_d.p, d->lm_arena.p + lv.lm_off[1],
-                            l < L - 1 ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s2);
+            const bool strips = l < L - 1;
+            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[0],
+                            strips ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, s);
+            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[1],
+                            strips ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s);
         }
     }
-    HIP_TRY(hipEventRecord(d->ev_join[0], s1));
-    HIP_TRY(hipEventRecord(d->ev_join[1], s2));
-    HIP_TRY(hipStreamWaitEvent(s, d->ev_join[0], 0));
-    HIP_TRY(hipStreamWaitEvent(s, d->ev_join[1], 0));
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
@@ -928,6 +895,7 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     if ((rc = ensure_match_buffers(d, std::max<uint32_t>(d->match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream;
     lm_timings tm{};
+    const auto t_host0 = std::chrono::steady_clock::now();
     tm.h2d_ms = d->last_h2d_ms;
     tm.templates = num_work;
     tm.coarse_bytes = d->work_coarse_bytes;
@@ -955,6 +923,7 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
         HIP_TRY(hipEventRecord(d->ev[4], s));
         return LM_OK;
     };
+    auto t_host1 = t_host0, t_host2 = t_host0;
     for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed: never drop silently
         if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
         HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, d->h_matches, 0));
@@ -986,7 +955,9 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
             if (d->graph_exec) { HIP_TRY(hipGraphLaunch(d->graph_exec, s)); launched = true; }
         }
         if (!launched && (rc = enqueue())) return rc;
+        t_host1 = std::chrono::steady_clock::now();
         HIP_TRY(hipStreamSynchronize(s));
+        t_host2 = std::chrono::steady_clock::now();
         HIP_TRY(hipGetLastError());
         ncand = d->h_counters[0];
         if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
@@ -1029,7 +1000,16 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
         ++w;
     }
     size_t n = (size_t)nm;
+    const auto t_host3 = std::chrono::steady_clock::now();
     if (sort_unique) n = lm_merge_matches(res, (size_t)nm);
+    const auto t_host4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::milli>(b - a).count();
+    };
+    d->timings.host_submit_ms = ms(t_host0, t_host1);
+    d->timings.host_wait_ms = ms(t_host1, t_host2);
+    d->timings.host_collect_ms = ms(t_host2, t_host3);
+    d->timings.host_merge_ms = ms(t_host3, t_host4);
     *out = res; *n_out = n;
     return LM_OK;
 }

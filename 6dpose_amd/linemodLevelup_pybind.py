@@ -54,7 +54,9 @@ class Timings(ctypes.Structure):
                 ("local_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("coarse_candidates", ctypes.c_int64), ("local_evals", ctypes.c_int64),
                 ("matches_pre_unique", ctypes.c_int64), ("templates", ctypes.c_int64),
-                ("coarse_bytes", ctypes.c_int64), ("local_bytes", ctypes.c_int64)]
+                ("coarse_bytes", ctypes.c_int64), ("local_bytes", ctypes.c_int64),
+                ("host_submit_ms", ctypes.c_float), ("host_wait_ms", ctypes.c_float),
+                ("host_collect_ms", ctypes.c_float), ("host_merge_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

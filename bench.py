@@ -128,7 +128,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms", "coarse_candidates", "local_evals",
-            "matches_pre_unique", "coarse_bytes", "local_bytes")
+            "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")
     acc = {k: 0.0 for k in keys}
     fence()
     for q in host_t:
@@ -170,7 +170,8 @@ def main():
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
             "stages_ms": {k: mean[k] for k in ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
-            "host_wall_ms": {q: host_t[q] / K * 1e3 for q in host_t},
+            "host_wall_ms": dict({q: host_t[q] / K * 1e3 for q in host_t},
+                                 **{q: mean[q] for q in ("host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")}),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms,

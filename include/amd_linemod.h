@@ -63,6 +63,10 @@ typedef struct lm_timings {
     int64_t templates;   /* template pyramids searched by this rank                          */
     int64_t coarse_bytes;/* algorithmic response bytes read by the coarse pass  */
     int64_t local_bytes; /* algorithmic response bytes read by the local pass                */
+    float host_submit_ms;  /* host wall time: call entry -> everything enqueued               */
+    float host_wait_ms;    /* host wall time blocked in the stream synchronisation            */
+    float host_collect_ms; /* host wall time: read-back bookkeeping + record conversion       */
+    float host_merge_ms;   /* host wall time: canonical sort + unique (0 when not requested)  */
 } lm_timings;
 
 const char *lm_last_error(void);
