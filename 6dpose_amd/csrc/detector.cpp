@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -116,7 +117,8 @@ struct lm_detector {
     DevBuf<uint32_t> d_feat_xy;
     DevBuf<FeatStrip> d_feat_strip;
     // work list
-    std::vector<int32_t> work_pyr, work_cls, work_tid;
+    std::vector<int32_t> work_pyr;
+    std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;   // shared with in-flight result slots
     DevBuf<int32_t> d_work;
     std::vector<std::string> work_key;              // class_ids the cached work list was built for
     int work_key_rank = -1, work_key_world = -1;
@@ -125,17 +127,28 @@ struct lm_detector {
     DevBuf<Candidate> d_cands;
     DevBuf<unsigned long long> d_counters;
     uint32_t cand_cap = 1u << 18;
-    Candidate* h_matches = nullptr;                 // pinned, device-visible: k_local writes matches here
-    uint32_t match_cap = 0;
-    unsigned long long* h_counters = nullptr;       // pinned: 8 counters + 2 words of statistics per refinement block
+    // Two result slots: the refinement kernel of frame k+1 writes into one pinned buffer while the host
+    // collects frame k from the other (lm_detector_submit / lm_detector_collect).
+    struct Slot {
+        Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
+        uint32_t match_cap = 0;
+        unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [8..] 2 words of statistics per refinement block
+        hipGraph_t graph = nullptr;                 // the whole per-frame device pipeline, captured once
+        hipGraphExec_t exec = nullptr;
+        uint64_t key[8] = {};
+        hipEvent_t ev[5] = {};
+        bool pending = false;
+        float threshold = 0.f, h2d_ms = 0.f;
+        int num_work = 0;
+        int64_t coarse_bytes = 0;
+        std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
+        std::chrono::steady_clock::time_point t0, t1;
+    } slot[2];
+    uint64_t n_submitted = 0, n_collected = 0;
     int local_blocks = 0;
     int num_cus = 256;
 
-    // the whole per-frame device pipeline captured once into a hipGraph (launch-bound: ~30 small launches)
     bool use_graph = true;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    uint64_t graph_key[8] = {};
     bool graph_events_ok = true;
 
     lm_timings timings{};
@@ -187,6 +200,9 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
+    for (auto& sl : d->slot) for (auto& e : sl.ev) (void)hipEventCreate(&e);
+    d->work_cls = std::make_shared<std::vector<int32_t>>();
+    d->work_tid = std::make_shared<std::vector<int32_t>>();
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     {
         hipDeviceProp_t prop;
@@ -210,11 +226,14 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
     d->d_cands.release(); d->d_counters.release();
-    if (d->h_matches) (void)hipHostFree(d->h_matches);
-    if (d->h_counters) (void)hipHostFree(d->h_counters);
+    for (auto& sl : d->slot) {
+        if (sl.h_matches) (void)hipHostFree(sl.h_matches);
+        if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
+        if (sl.graph) (void)hipGraphDestroy(sl.graph);
+        for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
+    }
     if (d->pinned) (void)hipHostFree(d->pinned);
-    if (d->graph_exec) (void)hipGraphExecDestroy(d->graph_exec);
-    if (d->graph) (void)hipGraphDestroy(d->graph);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -815,7 +834,9 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
         for (int i = 0; i < num_class_ids; ++i) key.push_back(class_ids[i] ? class_ids[i] : "");
     if (d->work_valid && key == d->work_key && d->work_key_rank == d->shard_rank && d->work_key_world == d->shard_world)
         return LM_OK;   // same selection as the previous call: the device-resident work list is reused
-    d->work_pyr.clear(); d->work_cls.clear(); d->work_tid.clear();
+    d->work_pyr.clear();
+    d->work_cls = std::make_shared<std::vector<int32_t>>();    // in-flight slots keep the old vectors alive
+    d->work_tid = std::make_shared<std::vector<int32_t>>();
     std::vector<int> order;   // bank class index per position (-1 unknown)
     if (key.empty()) {
         for (size_t i = 0; i < d->bank_classes.size(); ++i) order.push_back((int)i);   // std::map order, LL.cpp:1756
@@ -832,8 +853,8 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
         if (k < 0) continue;
         for (int t = 0; t < d->bank_class_count[k]; ++t) {
             d->work_pyr.push_back(d->bank_class_base[k] + t);
-            d->work_cls.push_back((int)pos);
-            d->work_tid.push_back(t);
+            d->work_cls->push_back((int)pos);
+            d->work_tid->push_back(t);
         }
     }
     // contiguous shard of the work list; template ids stay global
@@ -841,8 +862,8 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     const long a = N * d->shard_rank / d->shard_world, b = N * (d->shard_rank + 1) / d->shard_world;
     if (d->shard_world > 1) {
         d->work_pyr = std::vector<int32_t>(d->work_pyr.begin() + a, d->work_pyr.begin() + b);
-        d->work_cls = std::vector<int32_t>(d->work_cls.begin() + a, d->work_cls.begin() + b);
-        d->work_tid = std::vector<int32_t>(d->work_tid.begin() + a, d->work_tid.begin() + b);
+        *d->work_cls = std::vector<int32_t>(d->work_cls->begin() + a, d->work_cls->begin() + b);
+        *d->work_tid = std::vector<int32_t>(d->work_tid->begin() + a, d->work_tid->begin() + b);
     }
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
     if (rc) return rc;
@@ -866,118 +887,129 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     return LM_OK;
 }
 
-static int ensure_match_buffers(lm_detector* d, uint32_t match_cap) {
-    if (!d->h_counters) {
-        d->local_blocks = d->num_cus * 8;
-        HIP_TRY(hipHostMalloc((void**)&d->h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
-    }
-    if (match_cap > d->match_cap) {
-        if (d->h_matches) (void)hipHostFree(d->h_matches);
-        d->h_matches = nullptr; d->match_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&d->h_matches, (size_t)match_cap * sizeof(Candidate), hipHostMallocDefault));
-        d->match_cap = match_cap;
+static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t match_cap) {
+    if (!d->local_blocks) d->local_blocks = d->num_cus * 8;
+    if (!sl.h_counters)
+        HIP_TRY(hipHostMalloc((void**)&sl.h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
+    if (match_cap > sl.match_cap) {
+        if (sl.h_matches) (void)hipHostFree(sl.h_matches);
+        sl.h_matches = nullptr; sl.match_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&sl.h_matches, (size_t)match_cap * sizeof(Candidate), hipHostMallocDefault));
+        sl.match_cap = match_cap;
     }
     return LM_OK;
 }
 
-extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids,
-                                          int sort_unique, lm_match** out, size_t* n_out) {
-    if (!d || !out || !n_out) return lm_set_error(LM_ERR_INVALID, "null argument");
-    *out = nullptr; *n_out = 0;
-    if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame first");
+// Enqueue the whole device pipeline of the current frame into a free result slot (asynchronous).
+static int submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
+    if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame / select_frame first");
+    if (d->n_submitted - d->n_collected >= 2)
+        return lm_set_error(LM_ERR_INVALID, "two frames already in flight: call lm_detector_collect first");
     HIP_TRY(hipSetDevice(d->device));
+    lm_detector::Slot& sl = d->slot[d->n_submitted & 1];
     int rc;
-    if (d->bank_dirty || d->bank_geom_W != d->fW || d->bank_geom_H != d->fH)
+    if (d->bank_dirty || d->bank_geom_W != d->fW || d->bank_geom_H != d->fH) {
+        if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "bank or frame geometry changed with a frame in flight");
         if ((rc = upload_bank(d))) return rc;
+    }
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
     if ((rc = d->d_counters.ensure(8))) return rc;
-    if ((rc = ensure_match_buffers(d, std::max<uint32_t>(d->match_cap, d->cand_cap)))) return rc;
+    if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+    if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream;
-    lm_timings tm{};
-    const auto t_host0 = std::chrono::steady_clock::now();
-    tm.h2d_ms = d->last_h2d_ms;
-    tm.templates = num_work;
-    tm.coarse_bytes = d->work_coarse_bytes;
+    sl.t0 = std::chrono::steady_clock::now();
+    sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
+    sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
 
     Candidate* d_matches = nullptr;
     unsigned long long* d_hcounters = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, d->h_counters, 0));
-    uint64_t ncand = 0, nm = 0;
-    // front end + coarse + refinement + counter download, all on the detector's stream
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, sl.h_counters, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, sl.h_matches, 0));
+    // front end + coarse + refinement, all on the detector's stream
     auto enqueue = [&]() -> int {
-        HIP_TRY(hipEventRecord(d->ev[0], s));
+        HIP_TRY(hipEventRecord(sl.ev[0], s));
         int r = run_frontend(d, true);
         if (r) return r;
-        HIP_TRY(hipEventRecord(d->ev[1], s));
+        HIP_TRY(hipEventRecord(sl.ev[1], s));
         HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), s));
         launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
                       d->cand_cap, d->d_counters.p, s);
-        HIP_TRY(hipEventRecord(d->ev[2], s));
-        // persistent refinement grid; the candidate count is read on the device (no host round trip)
-        // (candidate count and per-block statistics are stored straight into pinned host memory: no copy nodes)
+        HIP_TRY(hipEventRecord(sl.ev[2], s));
+        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
+        // the per-block statistics and the results, stored straight into this slot's pinned host memory
         launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->match_cap, d->d_counters.p, d_hcounters,
+                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, sl.match_cap, d->d_counters.p, d_hcounters,
                      d->local_blocks, s);
-        HIP_TRY(hipEventRecord(d->ev[3], s));
-        HIP_TRY(hipEventRecord(d->ev[4], s));
+        HIP_TRY(hipEventRecord(sl.ev[3], s));
+        HIP_TRY(hipEventRecord(sl.ev[4], s));
         return LM_OK;
     };
-    auto t_host1 = t_host0, t_host2 = t_host0;
-    for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed: never drop silently
-        if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
-        HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, d->h_matches, 0));
-        bool launched = false;
-        if (d->use_graph) {
-            uint32_t thr_bits;
-            memcpy(&thr_bits, &threshold, 4);
-            const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, d->match_cap,
-                                     ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
-                                     (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p};
-            if (!d->graph_exec || memcmp(key, d->graph_key, sizeof(key)) != 0) {
-                if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
-                if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
-                bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-                if (ok) {
-                    int r = enqueue();
-                    hipError_t ee = hipStreamEndCapture(s, &d->graph);
-                    ok = (r == LM_OK) && ee == hipSuccess && d->graph &&
-                         hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0) == hipSuccess;
-                }
-                if (ok) memcpy(d->graph_key, key, sizeof(key));
-                else {   // capture unavailable: fall back to plain launches for good
-                    (void)hipGetLastError();
-                    if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
-                    if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
-                    d->use_graph = false;
-                }
+    bool launched = false;
+    if (d->use_graph) {
+        uint32_t thr_bits;
+        memcpy(&thr_bits, &threshold, 4);
+        const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
+                                 ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
+                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p};
+        if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
+            if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+            if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                int r = enqueue();
+                hipError_t ee = hipStreamEndCapture(s, &sl.graph);
+                ok = (r == LM_OK) && ee == hipSuccess && sl.graph && hipGraphInstantiate(&sl.exec, sl.graph, nullptr, nullptr, 0) == hipSuccess;
             }
-            if (d->graph_exec) { HIP_TRY(hipGraphLaunch(d->graph_exec, s)); launched = true; }
+            if (ok) memcpy(sl.key, key, sizeof(key));
+            else {   // capture unavailable: fall back to plain launches for good
+                (void)hipGetLastError();
+                if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+                if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
+                d->use_graph = false;
+            }
         }
-        if (!launched && (rc = enqueue())) return rc;
-        t_host1 = std::chrono::steady_clock::now();
-        HIP_TRY(hipStreamSynchronize(s));
-        t_host2 = std::chrono::steady_clock::now();
-        HIP_TRY(hipGetLastError());
-        ncand = d->h_counters[0];
-        if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
-        if (ncand <= d->cand_cap && ncand <= d->match_cap) break;
-        // a buffer overflowed: grow both (every candidate owns one match slot) and rerun the frame
-        d->cand_cap = (uint32_t)(ncand + ncand / 4 + 1024);
-        if ((rc = ensure_match_buffers(d, d->cand_cap))) return rc;
+        if (sl.exec) { HIP_TRY(hipGraphLaunch(sl.exec, s)); launched = true; }
     }
-    uint64_t evals = 0, lbytes = 0;
-    for (int b = 0; b < d->local_blocks; ++b) { evals += d->h_counters[8 + 2 * b]; lbytes += d->h_counters[8 + 2 * b + 1]; }
-    for (uint64_t i = 0; i < ncand; ++i) nm += d->h_matches[i].work >= 0;
+    if (!launched && (rc = enqueue())) return rc;
+    sl.t1 = std::chrono::steady_clock::now();
+    sl.pending = true;
+    ++d->n_submitted;
+    return LM_OK;
+}
+
+// Wait for the oldest frame in flight and turn its records into lm_match.  Returns 1 when a buffer
+// overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
+static int collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
+    if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
+    lm_detector::Slot& sl = d->slot[d->n_collected & 1];
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventSynchronize(sl.ev[4]));
+    const auto t2 = std::chrono::steady_clock::now();
+    sl.pending = false;
+    ++d->n_collected;
+    HIP_TRY(hipGetLastError());
+    const uint64_t ncand = sl.h_counters[0];
+    if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
+    if (ncand > d->cand_cap || ncand > sl.match_cap) {   // never drop silently: grow, caller reruns the frame
+        d->cand_cap = std::max<uint32_t>(d->cand_cap, (uint32_t)(ncand + ncand / 4 + 1024));
+        return 1;
+    }
+    lm_timings tm{};
+    tm.h2d_ms = sl.h2d_ms; tm.templates = sl.num_work; tm.coarse_bytes = sl.coarse_bytes;
+    uint64_t evals = 0, lbytes = 0, nm = 0;
+    for (int b = 0; b < d->local_blocks; ++b) { evals += sl.h_counters[8 + 2 * b]; lbytes += sl.h_counters[8 + 2 * b + 1]; }
+    const Candidate* hm = sl.h_matches;
+    for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0;
     tm.coarse_candidates = (int64_t)ncand;
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;
-    if (hipEventElapsedTime(&tm.frontend_ms, d->ev[0], d->ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&tm.coarse_ms, d->ev[1], d->ev[2]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, d->ev[2], d->ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.d2h_ms, d->ev[3], d->ev[4]) != hipSuccess ||
-        hipEventElapsedTime(&tm.total_ms, d->ev[0], d->ev[4]) != hipSuccess) {
+    if (hipEventElapsedTime(&tm.frontend_ms, sl.ev[0], sl.ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, sl.ev[1], sl.ev[2]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, sl.ev[2], sl.ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.d2h_ms, sl.ev[3], sl.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.total_ms, sl.ev[0], sl.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
         if (d->use_graph && d->graph_events_ok) {   // event nodes of a graph are not timeable here: time with plain launches
             d->graph_events_ok = false;
@@ -985,33 +1017,61 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
         }
         tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;
     }
-    d->timings = tm;
-
     lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
-    const Candidate* hm = d->h_matches;
+    const std::vector<int32_t>& wcls = *sl.work_cls;
+    const std::vector<int32_t>& wtid = *sl.work_tid;
     size_t w = 0;
     for (uint64_t i = 0; i < ncand; ++i) {
         const Candidate& c = hm[i];
         if (c.work < 0) continue;                     // dropped below the threshold during refinement
         res[w].x = c.x; res[w].y = c.y; res[w].similarity = c.score;
-        res[w].class_index = d->work_cls[c.work];
-        res[w].template_id = d->work_tid[c.work];
+        res[w].class_index = wcls[c.work];
+        res[w].template_id = wtid[c.work];
         ++w;
     }
     size_t n = (size_t)nm;
-    const auto t_host3 = std::chrono::steady_clock::now();
+    const auto t3 = std::chrono::steady_clock::now();
     if (sort_unique) n = lm_merge_matches(res, (size_t)nm);
-    const auto t_host4 = std::chrono::steady_clock::now();
+    const auto t4 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<float, std::milli>(b - a).count();
     };
-    d->timings.host_submit_ms = ms(t_host0, t_host1);
-    d->timings.host_wait_ms = ms(t_host1, t_host2);
-    d->timings.host_collect_ms = ms(t_host2, t_host3);
-    d->timings.host_merge_ms = ms(t_host3, t_host4);
+    tm.host_submit_ms = ms(sl.t0, sl.t1);
+    tm.host_wait_ms = ms(sl.t1, t2);       // includes whatever the caller did between submit and collect
+    tm.host_collect_ms = ms(t2, t3);
+    tm.host_merge_ms = ms(t3, t4);
+    d->timings = tm;
     *out = res; *n_out = n;
     return LM_OK;
+}
+
+extern "C" int lm_detector_submit(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    return submit_frame(d, threshold, class_ids, num_class_ids);
+}
+
+extern "C" int lm_detector_collect(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
+    if (!d || !out || !n_out) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *out = nullptr; *n_out = 0;
+    int rc = collect_frame(d, sort_unique, out, n_out);
+    if (rc == 1)
+        return lm_set_error(LM_ERR_OVERFLOW, "candidate buffer overflow: capacity raised to %u, submit the frame again "
+                            "(lm_detector_match_resident does this by itself)", d->cand_cap);
+    return rc;
+}
+
+extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids,
+                                          int sort_unique, lm_match** out, size_t* n_out) {
+    if (!d || !out || !n_out) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *out = nullptr; *n_out = 0;
+    if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them first");
+    for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed
+        int rc = submit_frame(d, threshold, class_ids, num_class_ids);
+        if (rc) return rc;
+        rc = collect_frame(d, sort_unique, out, n_out);
+        if (rc != 1) return rc;
+    }
 }
 
 extern "C" int lm_detector_match(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int width, int height, float threshold,

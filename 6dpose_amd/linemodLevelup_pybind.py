@@ -114,6 +114,8 @@ def load_library():
     lib.lm_detector_select_frame.argtypes = [P, I]
     lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
                                                ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
+    lib.lm_detector_submit.argtypes = [P, F, ctypes.POINTER(S), I]
+    lib.lm_detector_collect.argtypes = [P, I, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_last_timings.argtypes = [P, ctypes.POINTER(Timings)]
     lib.lm_detector_read_stage.argtypes = [P, I, I, P, ctypes.c_int64]
     lib.lm_detector_read_stage.restype = ctypes.c_int64
@@ -328,6 +330,17 @@ class Detector:
         out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
         _check(self._lib.lm_detector_match_resident(self._h, float(threshold), carr, n, 1 if sort_unique else 0,
                                                     ctypes.byref(out), ctypes.byref(cnt)))
+        return self._take(out, cnt.value)
+
+    def submit(self, threshold: float, class_ids: Sequence[str] = ()) -> None:
+        """Pipelined mode: enqueue front end + matching of the current frame and return (lm_detector_submit)."""
+        carr, n, _names = self._class_args(class_ids)
+        _check(self._lib.lm_detector_submit(self._h, float(threshold), carr, n))
+
+    def collect(self, sort_unique: bool = True) -> np.ndarray:
+        """Pipelined mode: matches of the oldest submitted frame (lm_detector_collect)."""
+        out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
+        _check(self._lib.lm_detector_collect(self._h, 1 if sort_unique else 0, ctypes.byref(out), ctypes.byref(cnt)))
         return self._take(out, cnt.value)
 
     def _take(self, out, n) -> np.ndarray:

@@ -101,47 +101,61 @@ def main():
         classes.append(cid)
     det.setShard(rank, world)
 
-    host_t = {"select": 0.0, "match_call": 0.0, "gather": 0.0, "merge": 0.0}
+    host_t = {"submit": 0.0, "collect": 0.0, "gather": 0.0, "merge": 0.0}
+    keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms", "coarse_candidates", "local_evals",
+            "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")
+    acc = {k: 0.0 for k in keys}
+    last = {"n": 0}
 
-    def step(k):
+    # Pipelined stream (depth 2): the GPU runs frame k+1 while the host collects / sorts / gathers frame k.
+    def submit(k):
         t0 = time.perf_counter()
-        det.selectFrame(k % N_FRAMES)
-        t1 = time.perf_counter()
+        det.selectFrame(k % N_FRAMES)            # device-to-device copy of a frame parked in HBM
+        det.submit(THRESHOLD, classes)
+        host_t["submit"] += time.perf_counter() - t0
+
+    def finish():
+        t0 = time.perf_counter()
         if world == 1:        # Detector.match semantics: canonical sort + unique inside the library call
-            out = det.matchResident(THRESHOLD, classes, sort_unique=True)
-            t2 = t3 = t4 = time.perf_counter()
+            out = det.collect(sort_unique=True)
+            t1 = t2 = t3 = time.perf_counter()
         else:                 # pre-unique records of this rank's shard -> all-gather -> merge on every rank
-            local = det.matchResident(THRESHOLD, classes, sort_unique=False)
-            t2 = time.perf_counter()
+            local = det.collect(sort_unique=False)
+            t1 = time.perf_counter()
             allrec = sharded.gather_records(local, device=dev)
-            t3 = time.perf_counter()
+            t2 = time.perf_counter()
             out = lm.merge_matches(allrec)
-            t4 = time.perf_counter()
-        host_t["select"] += t1 - t0; host_t["match_call"] += t2 - t1; host_t["gather"] += t3 - t2; host_t["merge"] += t4 - t3
-        return out
+            t3 = time.perf_counter()
+        host_t["collect"] += t1 - t0; host_t["gather"] += t2 - t1; host_t["merge"] += t3 - t2
+        tm = det.lastTimings()
+        for q in keys:
+            acc[q] += tm[q]
+        last["n"] = len(out)
+
+    def run(nsteps):
+        for k in range(nsteps):
+            submit(k)
+            if k > 0:
+                finish()
+        if nsteps > 0:
+            finish()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms", "coarse_candidates", "local_evals",
-            "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")
-    acc = {k: 0.0 for k in keys}
+    run(args.warmup)
     fence()
     for q in host_t:
         host_t[q] = 0.0
+    for q in acc:
+        acc[q] = 0.0
     t0 = time.perf_counter()
-    n_final = 0
-    for k in range(args.steps):
-        n_final = len(step(k))
-        tm = det.lastTimings()
-        for q in keys:
-            acc[q] += tm[q]
+    run(args.steps)                              # exactly K submits and K collects inside the timed region
     fence()
     dt = time.perf_counter() - t0
+    n_final = last["n"]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -167,6 +181,7 @@ def main():
                                    % args.templates,
                        "templates_total": total_templates, "objects": n_obj, "frames_in_stream": N_FRAMES,
                        "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world,
+                       "pipeline_depth": 2,
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
             "stages_ms": {k: mean[k] for k in ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
@@ -179,7 +194,8 @@ def main():
                                    "k_local_GBps": (mean["local_bytes"] / (mean["local_ms"] * 1e-3) / 1e9) if mean["local_ms"] > 0 else 0.0}},
         }
         if world == 1:
-            out["extras"] = {"pcie_inclusive": pcie_inclusive(det, frames, classes, args.templates),
+            out["extras"] = {"synchronous_call": sync_latency(det, classes, args.templates),
+                             "pcie_inclusive": pcie_inclusive(det, frames, classes, args.templates),
                              "icp": icp_bench(local_rank)}
         traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
         if os.path.exists(traffic):
@@ -198,6 +214,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sync_latency(det, classes, n_templates, steps=20):
+    """One frame at a time (submit + collect back to back, frame resident in HBM): the latency of a
+    synchronous Detector.match call without the host<->device frame copy."""
+    for k in range(3):
+        det.selectFrame(k % N_FRAMES)
+        det.matchResident(THRESHOLD, classes)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        det.selectFrame(k % N_FRAMES)
+        det.matchResident(THRESHOLD, classes)
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_frame": dt * 1e3, "value": n_templates * (W * H / 1e6) / dt, "unit": "templates*Mpx/s"}
 
 
 def pcie_inclusive(det, frames, classes, n_templates, steps=20):

@@ -36,6 +36,7 @@ extern "C" {
 #define LM_ERR_HIP (-4)         /* HIP runtime error during a call */
 #define LM_ERR_IO (-5)          /* file could not be read / written / parsed */
 #define LM_ERR_NOT_FOUND (-6)   /* unknown class id */
+#define LM_ERR_OVERFLOW (-7)    /* pipelined mode only: candidate buffer overflow, capacity raised, resubmit the frame */
 
 typedef struct lm_detector lm_detector;
 
@@ -140,6 +141,13 @@ int lm_detector_store_frame(lm_detector *d, int slot, const uint8_t *rgb, const 
 int lm_detector_select_frame(lm_detector *d, int slot);
 int lm_detector_match_resident(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids,
                                int sort_unique, lm_match **out, size_t *n);
+/* Pipelined stream mode: lm_detector_submit enqueues front end + matching of the current
+ * frame and returns; lm_detector_collect waits for the OLDEST submitted frame and returns its matches.
+ * Up to two frames may be in flight (the GPU works on frame k+1 while the host sorts frame k):
+ *   select_frame(k+1); submit(); collect() -> frame k; ...
+ * lm_detector_match_resident == submit + collect. */
+int lm_detector_submit(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids);
+int lm_detector_collect(lm_detector *d, int sort_unique, lm_match **out, size_t *n);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity

@@ -250,6 +250,36 @@ def test_sharded_equals_unsharded_on_one_device(lm):
         assert merged.tobytes() == whole.tobytes()
 
 
+def test_pipelined_submit_collect_equals_synchronous(lm):
+    """Stream mode: two frames in flight (submit k+1 before collecting k) returns exactly what the
+    synchronous calls return, frame by frame; a third submit without a collect is refused."""
+    W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+    frames = [synth.make_frame(50 + i, W, H) for i in range(3)]
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(*frames[0])
+    bank = synth.make_planted_bank(61, 150, [(p[0], p[1]) for p in pyr], T, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("o", *bank)
+    want = []
+    for i, f in enumerate(frames):
+        det.storeFrame(i, f)
+        want.append(det.matchArray(list(f), 70.0, ["o"]))
+    assert len(want[0]) > 0
+    got = []
+    det.selectFrame(0); det.submit(70.0, ["o"])
+    det.selectFrame(1); det.submit(70.0, ["o"])
+    with pytest.raises(RuntimeError, match="in flight"):
+        det.submit(70.0, ["o"])
+    got.append(det.collect())
+    det.selectFrame(2); det.submit(70.0, ["o"])
+    got.append(det.collect())
+    got.append(det.collect())
+    with pytest.raises(RuntimeError, match="no frame in flight"):
+        det.collect()
+    for g, w in zip(got, want):
+        assert g.tobytes() == w.tobytes()
+
+
 def test_config1_size_2k_templates_bit_exact(lm):
     """BASELINE configs[1]: 1 object x 2k templates, 640x480 — compared directly (the C oracle takes
     ~0.3 s) plus size-independent properties: threshold monotonicity and bank-permutation invariance."""
