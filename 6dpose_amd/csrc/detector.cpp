@@ -136,7 +136,8 @@ struct lm_detector {
         hipGraph_t graph = nullptr;                 // the whole per-frame device pipeline, captured once
         hipGraphExec_t exec = nullptr;
         uint64_t key[8] = {};
-        hipEvent_t ev[5] = {};
+        hipEvent_t ev[5] = {};                      // stage timing (recorded inside the graph)
+        hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
         bool pending = false;
         float threshold = 0.f, h2d_ms = 0.f;
         int num_work = 0;
@@ -200,7 +201,10 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
-    for (auto& sl : d->slot) for (auto& e : sl.ev) (void)hipEventCreate(&e);
+    for (auto& sl : d->slot) {
+        for (auto& e : sl.ev) (void)hipEventCreate(&e);
+        (void)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+    }
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
@@ -232,6 +236,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.graph) (void)hipGraphDestroy(sl.graph);
         for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
+        if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (d->pinned) (void)hipHostFree(d->pinned);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
@@ -972,6 +977,9 @@ static int submit_frame(lm_detector* d, float threshold, const char* const* clas
         if (sl.exec) { HIP_TRY(hipGraphLaunch(sl.exec, s)); launched = true; }
     }
     if (!launched && (rc = enqueue())) return rc;
+    // An event recorded by a graph node keeps its previous (completed) state until that node runs, so waiting
+    // on sl.ev[4] could return before the frame is done: the host waits on an eagerly recorded event instead.
+    HIP_TRY(hipEventRecord(sl.done, s));
     sl.t1 = std::chrono::steady_clock::now();
     sl.pending = true;
     ++d->n_submitted;
@@ -984,7 +992,7 @@ static int collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t
     if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
     lm_detector::Slot& sl = d->slot[d->n_collected & 1];
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(sl.ev[4]));
+    HIP_TRY(hipEventSynchronize(sl.done));
     const auto t2 = std::chrono::steady_clock::now();
     sl.pending = false;
     ++d->n_collected;
