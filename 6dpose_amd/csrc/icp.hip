@@ -1,20 +1,533 @@
-// ICP inner loops of poseRefine::process on gfx950 (reference call sites LL.cpp:127-130; the
-// arithmetic is Open3D's — EstimateNormals(KNN 30), RegistrationICP with
-// TransformationEstimationPointToPlane — restated per SURVEY Appendix B).
+// poseRefine::process on gfx950 (reference LL.cpp:27-155).  The cloud arithmetic is Open3D's
+// (un-vendored): VoxelDownSample (LL.cpp:108-109), EstimateNormals(KNN 30) (LL.cpp:127),
+// RegistrationICP + TransformationEstimationPointToPlane (LL.cpp:128-130), restated per SURVEY
+// Appendix B with the deterministic rules of DESIGN.md §5 (shared with oracle/linemod_oracle.py).
 //
-// One workgroup per pose hypothesis; the whole ICP (<= 30 iterations: nearest-neighbour
-// correspondence + 6x6 point-to-plane normal equations + solve + transform + convergence test)
-// runs inside ONE launch.  Clouds are ~1.3k points, so brute-force NN with the target streamed
-// through the scalar cache (the inner index is wave-uniform) beats any tree; all arithmetic is
-// double like Open3D's (f64 VALU, no MFMA: nothing here is a dense contraction).  The 29 partial
-// sums are reduced with wave shuffles, then across the 4 waves through LDS.
+// Six launches per batch of hypotheses, no host round trip in between:
+//   k_icp_bbox     bounding box of modelDepth > 0                                   (LL.cpp:43-50)
+//   k_icp_points   dilated mask, back-projection, raster-order compaction, centroids (LL.cpp:52-104)
+//   k_icp_voxel    VoxelDownSample: 64-bit (voxel, index) keys, bitonic sort in LDS, segment means
+//   k_icp_grid     bins the target cloud into <= 64 x 64 xy columns (cell >= 5 mm), sorted by cell
+//   k_icp_knn      one wave per target point: ring search over the columns, the k nearest in
+//                  (distance, index) order, cumulants accumulated in that order;
+//   k_icp_normals  covariance + Jacobi eigenvector, one thread per point
+//   k_icp_loop     one 1024-thread workgroup per hypothesis, all <= 30 iterations in one launch:
+//                  exact nearest neighbour through the grid (search radius = distance to the previous
+//                  correspondence, so later iterations touch a handful of candidates), 29 double sums
+//                  reduced by wave shuffles + LDS, 6x6 LU, Rz*Ry*Rx update, convergence test.
+// All arithmetic is double like Open3D's (f64 VALU; nothing here is a dense contraction, so no MFMA).
+// The grid only prunes: candidate distances are the same expression the oracle evaluates and ties go
+// to the lower original index, so correspondences equal a brute-force search.
+#include <limits.h>
+
 #include "icp_kernels.h"
 
 namespace lm {
 
+constexpr int kWG = 1024;          // workgroup size of the per-hypothesis kernels
+constexpr int kSortLds = 16384;    // 64-bit keys sorted in LDS (128 KiB); longer lists use the global scratch
+constexpr int kDilate = 4;         // LL.cpp:45 (9x9 dilation)
+constexpr double kCellMin = 0.005; // search-grid cell edge (m), grown when the target extent exceeds 64 cells
+constexpr int kKnnCache = 768;     // candidates cached in LDS per wave by k_icp_knn
+constexpr int kIdxBits = 22;       // point-index bits of the grid sort key
+
 static __device__ __forceinline__ double sqdist(double ax, double ay, double az, double bx, double by, double bz) {
     double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by), dz = __dsub_rn(az, bz);
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+static __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+static __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Exclusive prefix of a per-thread flag in thread order; `total` = number of flags set in the workgroup.
+static __device__ __forceinline__ int block_scan_flag(bool flag, int* s_wave, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long b = __ballot(flag);
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int c = s_wave[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + within;
+}
+
+// min / max of K doubles over the workgroup; result in s_out[0..K) (min) and s_out[K..2K) (max), visible after return.
+template <int K>
+static __device__ __forceinline__ void block_minmax(const double (&mn)[K], const double (&mx)[K], double* s_part /*[16][2K]*/,
+                                                    double* s_out /*[2K]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double a[K], b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        a[k] = mn[k]; b[k] = mx[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a[k] = fmin(a[k], shfl_xor_d(a[k], o));
+            b[k] = fmax(b[k], shfl_xor_d(b[k], o));
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { s_part[wave * 2 * K + k] = a[k]; s_part[wave * 2 * K + K + k] = b[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * K) {
+        double v = s_part[threadIdx.x];
+        for (int w = 1; w < nw; ++w) {
+            const double u = s_part[w * 2 * K + threadIdx.x];
+            v = threadIdx.x < K ? fmin(v, u) : fmax(v, u);
+        }
+        s_out[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+// Ascending bitonic sort of npad (power of two) 64-bit keys by one workgroup.
+template <typename P>
+static __device__ __forceinline__ void bitonic_sort(P A, int npad) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = A[i], b = A[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { A[i] = b; A[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static __device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+static __device__ __forceinline__ int bits_for(long long vmax) {   // bits needed for values 0..vmax
+    return vmax <= 0 ? 1 : 64 - __clzll((unsigned long long)vmax);
+}
+
+static __device__ __forceinline__ int grid_coord(double v, double mn, double inv, int g) {
+    const double f = floor((v - mn) * inv);
+    return f >= 0.0 ? (f < (double)g ? (int)f : g - 1) : 0;      // NaN -> 0, never UB
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_bbox: bounding rectangle of modelDepth > 0 (the 9x9 dilation only grows it by 4, LL.cpp:43-50)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_icp_bbox(IcpBuffers B, int W, int H) {
+    const int h = blockIdx.y;
+    const uint16_t* img = B.models + (size_t)B.in[h].model_slot * W * H;
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+    const bool vec = (W & 7) == 0;
+    for (int y = blockIdx.x; y < H; y += gridDim.x) {
+        const uint16_t* row = img + (size_t)y * W;
+        for (int x = threadIdx.x * 8; x < W; x += blockDim.x * 8) {
+            uint16_t px[8];
+            if (vec) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + x);
+                px[0] = v.x & 0xFFFF; px[1] = v.x >> 16; px[2] = v.y & 0xFFFF; px[3] = v.y >> 16;
+                px[4] = v.z & 0xFFFF; px[5] = v.z >> 16; px[6] = v.w & 0xFFFF; px[7] = v.w >> 16;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) px[k] = x + k < W ? row[x + k] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (px[k]) {
+                    x0 = min(x0, x + k); x1 = max(x1, x + k);
+                    y0 = min(y0, y); y1 = max(y1, y);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        int* bb = B.st[h].bbox;
+        atomicMin(&bb[0], x0); atomicMin(&bb[1], y0); atomicMax(&bb[2], x1); atomicMax(&bb[3], y1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_points (LL.cpp:52-104): raster scan of the dilated bounding box; model point where
+// modelDepth > 0, scene point where the dilated mask is set and sceneDepth (window shifted by
+// detect - 4, clamped at 0) > 0; compaction keeps raster order; centroid difference = init_guess.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWG)
+k_icp_points(IcpBuffers B, int W, int H, int flags) {
+    __shared__ int s_wave[32];
+    __shared__ double s_red[16][7];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    IcpState& S = B.st[h];
+    const IcpIn I = B.in[h];
+    const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
+    if (x1 < 0) {
+        if (tid == 0) { S.status = 2; S.n_model = 0; S.n_scene = 0; }
+        return;
+    }
+    const int bx0 = max(x0 - kDilate, 0), by0 = max(y0 - kDilate, 0);
+    const int bx1 = min(x1 + kDilate, W - 1), by1 = min(y1 + kDilate, H - 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    if (I.dx + bw >= W || I.dy + bh >= H) {                       // LL.cpp:52-55
+        if (tid == 0) { S.status = 1; S.n_model = 0; S.n_scene = 0; }
+        return;
+    }
+    const uint16_t* model = B.models + (size_t)I.model_slot * W * H;
+    const uint16_t* scene = B.scene;
+    const double anchor = model[(size_t)(H / 2) * W + W / 2] / 1000.0;   // LL.cpp:62
+    double* mp = B.model_pts + (size_t)h * B.cap * 3;
+    double* sp = B.scene_pts + (size_t)h * B.cap * 3;
+    const bool keep_scene = (flags & 1) != 0;
+    int nm = 0, nsn = 0;
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};     // model xyz, scene-near-anchor xyz, its count
+    const int area = bw * bh;
+    for (int base = 0; base < area; base += kWG) {
+        const int p = base + tid;
+        bool is_m = false, is_s = false;
+        double mx = 0, my = 0, mz = 0, sx = 0, sy = 0, sz = 0;
+        if (p < area) {
+            const int r = p / bw, c = p - r * bw;
+            const int mr = r + by0, mc = c + bx0;
+            const int sr = max(r + I.dy - kDilate, 0), sc = max(c + I.dx - kDilate, 0);
+            const uint16_t md = model[(size_t)mr * W + mc];
+            const uint16_t sd = scene[(size_t)sr * W + sc];
+            if (md > 0) {
+                is_m = true;
+                mz = md / 1000.0;
+                // (int - float) / float evaluated in float, then * double (LL.cpp:79-80)
+                mx = (double)__fdiv_rn(__fsub_rn((float)mc, I.mK[2]), I.mK[0]) * mz;
+                my = (double)__fdiv_rn(__fsub_rn((float)mr, I.mK[5]), I.mK[4]) * mz;
+                acc[0] += mx; acc[1] += my; acc[2] += mz;
+            }
+            if (sd > 0) {
+                bool in_mask = md > 0;
+                if (!in_mask) {                                   // dilate(modelDepth > 0, 9x9) at (mr, mc)
+                    const int ya = max(mr - kDilate, 0), yb = min(mr + kDilate, H - 1);
+                    const int xa = max(mc - kDilate, 0), xb = min(mc + kDilate, W - 1);
+                    for (int yy = ya; yy <= yb && !in_mask; ++yy)
+                        for (int xx = xa; xx <= xb; ++xx)
+                            if (model[(size_t)yy * W + xx]) { in_mask = true; break; }
+                }
+                if (in_mask) {
+                    is_s = true;
+                    sz = sd / 1000.0;
+                    sx = (double)__fdiv_rn(__fsub_rn((float)sc, B.sK[2]), B.sK[0]) * sz;
+                    sy = (double)__fdiv_rn(__fsub_rn((float)sr, B.sK[5]), B.sK[4]) * sz;
+                    if (fabs(sz - anchor) < 0.4 && md > 0) { acc[3] += sx; acc[4] += sy; acc[5] += sz; acc[6] += 1.0; }
+                }
+            }
+        }
+        int tot;
+        const int pm = nm + block_scan_flag(is_m, s_wave, tot);
+        nm += tot;
+        if (is_m) { mp[3 * (size_t)pm] = mx; mp[3 * (size_t)pm + 1] = my; mp[3 * (size_t)pm + 2] = mz; }
+        if (keep_scene) {
+            const int ps = nsn + block_scan_flag(is_s, s_wave, tot);
+            nsn += tot;
+            if (is_s) { sp[3 * (size_t)ps] = sx; sp[3 * (size_t)ps + 1] = sy; sp[3 * (size_t)ps + 2] = sz; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t[7];
+        for (int k = 0; k < 7; ++k) {
+            double v = 0;
+            for (int w = 0; w < (kWG >> 6); ++w) v += s_red[w][k];
+            t[k] = v;
+        }
+        const double n = (double)nm;
+        S.init[0] = t[3] / t[6] - t[0] / n;      // NaN when no scene point is near the anchor, as the reference
+        S.init[1] = t[4] / t[6] - t[1] / n;
+        S.init[2] = t[5] / t[6] - t[2] / n;
+        S.n_model = nm; S.n_scene = nsn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_voxel: open3d PointCloud::VoxelDownSample — mean per voxel, output in ascending
+// (ix,iy,iz) order, the points of a voxel summed in input order.  key = voxel index | point index
+// with just enough bits per field; one workgroup sorts its cloud (LDS up to 16k points).
+// blockIdx.y: 0 = model cloud -> src (and tgt in verbatim mode, LL.cpp:109), 1 = scene cloud -> tgt.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWG)
+k_icp_voxel(IcpBuffers B, int flags, double voxel) {
+    __shared__ unsigned long long s_keys[kSortLds];
+    __shared__ int s_wave[32];
+    __shared__ double s_part[16 * 6];
+    __shared__ double s_mm[6];
+    const int h = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+    IcpState& S = B.st[h];
+    const bool scene_mode = (flags & 1) != 0;
+    if (S.status != 0) {
+        if (tid == 0) { if (which == 0) { S.n_src = 0; if (!scene_mode) S.n_tgt = 0; } else S.n_tgt = 0; }
+        return;
+    }
+    const int n = which ? S.n_scene : S.n_model;
+    const double* pts = (which ? B.scene_pts : B.model_pts) + (size_t)h * B.cap * 3;
+    double* out = (which ? B.tgt : B.src) + (size_t)h * B.cap * 3;
+    if (n == 0) {
+        if (tid == 0) { if (which == 0) { S.n_src = 0; if (!scene_mode) S.n_tgt = 0; } else S.n_tgt = 0; }
+        return;
+    }
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int i = tid; i < n; i += kWG) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double v = pts[3 * (size_t)i + k]; mn[k] = fmin(mn[k], v); mx[k] = fmax(mx[k], v); }
+    }
+    block_minmax<3>(mn, mx, s_part, s_mm);
+    const double mnx = s_mm[0] - voxel * 0.5, mny = s_mm[1] - voxel * 0.5, mnz = s_mm[2] - voxel * 0.5;
+    const double fx = floor(__ddiv_rn(s_mm[3] - mnx, voxel)), fy = floor(__ddiv_rn(s_mm[4] - mny, voxel)),
+                 fz = floor(__ddiv_rn(s_mm[5] - mnz, voxel));
+    const bool finite = fx >= 0 && fx < 4e18 && fy >= 0 && fy < 4e18 && fz >= 0 && fz < 4e18;
+    const int bx = finite ? bits_for((long long)fx) : 64, by = finite ? bits_for((long long)fy) : 64,
+              bz = finite ? bits_for((long long)fz) : 64, bi = bits_for(n - 1);
+    if (bx + by + bz + bi > 64) {
+        if (tid == 0) S.status = 3;
+        return;
+    }
+    const int npad = next_pow2(n < 2 ? 2 : n);
+    const bool in_lds = npad <= kSortLds;
+    unsigned long long* gk = B.keys + ((size_t)h * 2 + which) * B.cap2;
+    for (int i = tid; i < npad; i += kWG) {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            const unsigned long long ix = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i] - mnx, voxel));
+            const unsigned long long iy = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 1] - mny, voxel));
+            const unsigned long long iz = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 2] - mnz, voxel));
+            key = ((((ix << by) | iy) << bz | iz) << bi) | (unsigned long long)i;
+        }
+        if (in_lds) s_keys[i] = key; else gk[i] = key;
+    }
+    __syncthreads();
+    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort(gk, npad);
+    const unsigned long long imask = (1ull << bi) - 1ull;
+    int nout = 0;
+    for (int base = 0; base < n; base += kWG) {
+        const int i = base + tid;
+        bool head = false;
+        unsigned long long vox = 0;
+        if (i < n) {
+            const unsigned long long k = in_lds ? s_keys[i] : gk[i];
+            vox = k >> bi;
+            head = i == 0 || ((in_lds ? s_keys[i - 1] : gk[i - 1]) >> bi) != vox;
+        }
+        int tot;
+        const int pos = nout + block_scan_flag(head, s_wave, tot);
+        nout += tot;
+        if (head) {
+            double sx = 0, sy = 0, sz = 0;
+            int cnt = 0, j = i;
+            for (;;) {
+                const unsigned long long k = in_lds ? s_keys[j] : gk[j];
+                if ((k >> bi) != vox) break;
+                const size_t idx = (size_t)(k & imask);
+                sx += pts[3 * idx]; sy += pts[3 * idx + 1]; sz += pts[3 * idx + 2];
+                ++cnt; ++j;
+                if (j >= n) break;
+            }
+            const double c = (double)cnt;
+            out[3 * (size_t)pos] = sx / c; out[3 * (size_t)pos + 1] = sy / c; out[3 * (size_t)pos + 2] = sz / c;
+        }
+    }
+    if (tid == 0) {
+        if (which == 0) { S.n_src = nout; if (!scene_mode) S.n_tgt = nout; }
+        else S.n_tgt = nout;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_grid: the target cloud binned into xy columns (cell edge >= 5 mm, <= 64 x 64 columns),
+// points reordered by (row, column, original index); cell_start[c] = first sorted position of column c.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWG)
+k_icp_grid(IcpBuffers B, int flags) {
+    __shared__ unsigned long long s_keys[kSortLds];
+    __shared__ double s_part[16 * 4];
+    __shared__ double s_mm[4];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    IcpState& S = B.st[h];
+    int* cs = B.cell_start + (size_t)h * kIcpCells;
+    const int nt = S.status == 0 ? S.n_tgt : 0;
+    if (nt == 0 || nt >= (1 << kIdxBits)) {
+        if (tid == 0) {
+            if (nt > 0) { S.status = 3; S.n_tgt = 0; }
+            S.gx = 1; S.gy = 1; S.gminx = 0; S.gminy = 0; S.cell = kCellMin; S.inv_cell = 1.0 / kCellMin;
+            cs[0] = 0; cs[1] = 0;
+        }
+        return;
+    }
+    const double* T = ((flags & 1) ? B.tgt : B.src) + (size_t)h * B.cap * 3;
+    double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
+    for (int i = tid; i < nt; i += kWG) {
+        const double x = T[3 * (size_t)i], y = T[3 * (size_t)i + 1];
+        mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x); mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+    }
+    block_minmax<2>(mn, mx, s_part, s_mm);
+    const double minx = s_mm[0], miny = s_mm[1];
+    const double ext = fmax(s_mm[2] - minx, s_mm[3] - miny);
+    double cell = ext / (double)kIcpGrid;
+    if (!(cell > kCellMin)) cell = kCellMin;                       // also catches NaN
+    const double inv = 1.0 / cell;
+    const int gx = grid_coord(s_mm[2], minx, inv, kIcpGrid) + 1, gy = grid_coord(s_mm[3], miny, inv, kIcpGrid) + 1;
+    const int npad = next_pow2(nt < 2 ? 2 : nt);
+    const bool in_lds = npad <= kSortLds;
+    unsigned long long* gk = B.keys + (size_t)h * 2 * B.cap2;
+    for (int i = tid; i < npad; i += kWG) {
+        unsigned long long key = ~0ull;
+        if (i < nt) {
+            const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy);
+            key = ((unsigned long long)(cy * gx + cx) << kIdxBits) | (unsigned long long)i;
+        }
+        if (in_lds) s_keys[i] = key; else gk[i] = key;
+    }
+    __syncthreads();
+    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort(gk, npad);
+    double* Ts = B.tgt_sorted + (size_t)h * B.cap * 3;
+    int* orig = B.tgt_orig + (size_t)h * B.cap;
+    for (int p = tid; p < nt; p += kWG) {
+        const unsigned long long k = in_lds ? s_keys[p] : gk[p];
+        const size_t i = (size_t)(k & ((1ull << kIdxBits) - 1ull));
+        Ts[3 * (size_t)p] = T[3 * i]; Ts[3 * (size_t)p + 1] = T[3 * i + 1]; Ts[3 * (size_t)p + 2] = T[3 * i + 2];
+        orig[p] = (int)i;
+    }
+    const int ncell = gx * gy;
+    for (int c = tid; c <= ncell; c += kWG) {                       // lower_bound of (c << kIdxBits)
+        const unsigned long long want = (unsigned long long)c << kIdxBits;
+        int lo = 0, hi = nt;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long k = in_lds ? s_keys[mid] : gk[mid];
+            if (k < want) lo = mid + 1; else hi = mid;
+        }
+        cs[c] = lo;
+    }
+    if (tid == 0) { S.gx = gx; S.gy = gy; S.gminx = minx; S.gminy = miny; S.cell = cell; S.inv_cell = inv; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_knn: open3d EstimateNormals(KDTreeSearchParamKNN(30)), neighbour search part.  One wave per
+// target point.  Ring R of grid columns around the point holds every point closer than R*cell, so
+// once >= k candidates are closer than that the k nearest of the ring are the k nearest of the
+// cloud.  Candidates are cached in LDS; k selection passes pick them in (distance, original index)
+// order and the cumulants are accumulated in that order (the oracle's sequential sums).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_icp_knn(IcpBuffers B, int knn) {
+    __shared__ double s_d[4][kKnnCache];
+    __shared__ int s_pos[4][kKnnCache];
+    __shared__ int s_org[4][kKnnCache];
+    const int h = blockIdx.y;
+    const IcpState& S = B.st[h];
+    const int nt = S.status == 0 ? S.n_tgt : 0;
+    if (nt == 0) return;
+    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
+    const int* orig = B.tgt_orig + (size_t)h * B.cap;
+    const int* cs = B.cell_start + (size_t)h * kIcpCells;
+    double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    const int gx = S.gx, gy = S.gy;
+    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell, cell = S.cell;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    const int k = knn < nt ? knn : nt;
+    double* cd = s_d[wave];
+    int* cp = s_pos[wave];
+    int* co = s_org[wave];
+
+    for (int pos = blockIdx.x * 4 + wave; pos < nt; pos += nwaves) {
+        const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
+        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
+        int R = 2, M = 0, xa = 0, xb = 0, ya = 0, yb = 0;
+        for (;;) {
+            xa = max(cx - R, 0); xb = min(cx + R, gx - 1); ya = max(cy - R, 0); yb = min(cy + R, gy - 1);
+            const bool all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1;
+            const double g = (double)R * cell * (1.0 - 1e-9), g2 = g * g;   // margin >> the rounding of grid_coord
+            M = 0;
+            int inside = 0;
+            for (int y = ya; y <= yb; ++y) {
+                const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
+                for (int j0 = a; j0 < b; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool valid = j < b;
+                    double d = 1e300;
+                    if (valid) {
+                        d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
+                        const int slot = M + (j - a);
+                        if (slot < kKnnCache) { cd[slot] = d; cp[slot] = j; co[slot] = orig[j]; }
+                    }
+                    inside += __popcll(__ballot(valid && d < g2));
+                }
+                M += b - a;
+            }
+            if (inside >= k || all) break;
+            ++R;
+        }
+        const bool cached = M <= kKnnCache;
+        double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double prev_d = -1.0;
+        int prev_o = -1, taken = 0;
+        for (int pass = 0; pass < k; ++pass) {
+            double bd = 1e300;
+            int bo = INT_MAX, bp = -1;
+            if (cached) {
+                for (int m = lane; m < M; m += 64) {
+                    const double d = cd[m];
+                    const int o = co[m];
+                    const bool after = d > prev_d || (d == prev_d && o > prev_o);
+                    if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = cp[m]; }
+                }
+            } else {
+                for (int y = ya; y <= yb; ++y) {
+                    const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
+                    for (int j = a + lane; j < b; j += 64) {
+                        const double d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
+                        const int o = orig[j];
+                        const bool after = d > prev_d || (d == prev_d && o > prev_o);
+                        if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = shfl_xor_d(bd, off);
+                const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
+                if (od < bd || (od == bd && oo < bo)) { bd = od; bo = oo; bp = op; }
+            }
+            if (bp < 0) break;
+            prev_d = bd; prev_o = bo;
+            const double qx = T[3 * (size_t)bp], qy = T[3 * (size_t)bp + 1], qz = T[3 * (size_t)bp + 2];
+            sum[0] += qx; sum[1] += qy; sum[2] += qz;
+            sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
+            ++taken;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cov[(size_t)pos * kIcpCovStride + q] = sum[q];
+            cov[(size_t)pos * kIcpCovStride + 9] = (double)taken;
+        }
+    }
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----
@@ -54,67 +567,35 @@ static __device__ void smallest_eigvec(double a00, double a01, double a02, doubl
     n[0] = V[0][m]; n[1] = V[1][m]; n[2] = V[2][m];
 }
 
-// ---- EstimateNormals(KNN): one thread per target point; k passes, each selecting the next
-// neighbour in (distance, index) order — no per-thread arrays, target streamed via scalar loads ----
+// k_icp_normals: open3d ComputeNormal from the cumulants: covariance = E[xx^T] - E[x]E[x]^T,
+// normal = eigenvector of its smallest eigenvalue ((0,0,1) for fewer than 3 neighbours).
 __global__ void __launch_bounds__(256)
-k_knn_normals(const double* __restrict__ pts, double* __restrict__ normals, const IcpProblem* __restrict__ probs, int knn) {
-    const IcpProblem pb = probs[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x >= pb.n_tgt) return;
-    const bool active = i < pb.n_tgt;
-    const double* T = pts + 3 * (size_t)pb.tgt_off;
-    const int ii = active ? i : 0;
-    const double px = T[3 * ii], py = T[3 * ii + 1], pz = T[3 * ii + 2];
-    const int n = pb.n_tgt;
-    const int k = knn < n ? knn : n;
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    double prev_d = -1.0;
-    int prev_j = -1;
-    for (int pass = 0; pass < k; ++pass) {
-        double bd = 1e300;
-        int bj = -1;
-        for (int j = 0; j < n; ++j) {
-            double qx = T[3 * j], qy = T[3 * j + 1], qz = T[3 * j + 2];
-            double d = sqdist(px, py, pz, qx, qy, qz);
-            bool after = d > prev_d || (d == prev_d && j > prev_j);
-            if (after && d < bd) { bd = d; bj = j; }       // strict '<': lowest index wins ties
+k_icp_normals(IcpBuffers B) {
+    const int h = blockIdx.y;
+    const IcpState& S = B.st[h];
+    const int nt = S.status == 0 ? S.n_tgt : 0;
+    const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    double* N = B.normals + (size_t)h * B.cap * 3;
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < nt; pos += gridDim.x * blockDim.x) {
+        const double* c = cov + (size_t)pos * kIcpCovStride;
+        const double k = c[9];
+        double nrm[3] = {0, 0, 1};
+        if (k >= 3.0) {
+            const double mx = c[0] / k, my = c[1] / k, mz = c[2] / k;
+            smallest_eigvec(c[3] / k - mx * mx, c[4] / k - mx * my, c[5] / k - mx * mz, c[6] / k - my * my, c[7] / k - my * mz,
+                            c[8] / k - mz * mz, nrm);
+            if (nrm[0] == 0 && nrm[1] == 0 && nrm[2] == 0) nrm[2] = 1;
         }
-        prev_d = bd; prev_j = bj;
-        if (bj < 0) break;
-        double qx = T[3 * bj], qy = T[3 * bj + 1], qz = T[3 * bj + 2];
-        sx += qx; sy += qy; sz += qz;
-        sxx += qx * qx; sxy += qx * qy; sxz += qx * qz; syy += qy * qy; syz += qy * qz; szz += qz * qz;
+        N[3 * (size_t)pos] = nrm[0]; N[3 * (size_t)pos + 1] = nrm[1]; N[3 * (size_t)pos + 2] = nrm[2];
     }
-    double nrm[3] = {0, 0, 1};
-    if (k >= 3) {
-        double mx = sx / k, my = sy / k, mz = sz / k;
-        smallest_eigvec(sxx / k - mx * mx, sxy / k - mx * my, sxz / k - mx * mz, syy / k - my * my, syz / k - my * mz,
-                        szz / k - mz * mz, nrm);
-        if (nrm[0] == 0 && nrm[1] == 0 && nrm[2] == 0) nrm[2] = 1;
-    }
-    if (active) {
-        double* o = normals + 3 * ((size_t)pb.tgt_off + i);
-        o[0] = nrm[0]; o[1] = nrm[1]; o[2] = nrm[2];
-    }
-}
-
-void launch_knn_normals(const double* pts, double* normals, const IcpProblem* probs, int count, int max_tgt, int knn,
-                        hipStream_t s) {
-    if (count <= 0 || max_tgt <= 0) return;
-    hipLaunchKernelGGL(k_knn_normals, dim3((max_tgt + 255) / 256, count), dim3(256), 0, s, pts, normals, probs, knn);
 }
 
 // ---- RegistrationICP ------------------------------------------------------------------------------
 constexpr int kNSum = 29;   // 21 JtJ (upper) + 6 Jtr + sum d^2 + count
 
-static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-// Gaussian elimination with partial pivoting, A x = b (6x6).  Returns false if singular / non-finite.
-static __device__ bool solve6(double A[6][6], double b[6], double x[6]) {
+// Gaussian elimination with partial pivoting, A x = b (6x6), on LDS arrays (one thread; keeps the
+// dynamically indexed rows out of scratch).  Returns false if singular / non-finite.
+static __device__ bool solve6(double (*A)[6], double* b, double* x) {
     for (int c = 0; c < 6; ++c) {
         int piv = c;
         double best = fabs(A[c][c]);
@@ -141,35 +622,45 @@ static __device__ bool solve6(double A[6][6], double b[6], double x[6]) {
     return true;
 }
 
-__global__ void __launch_bounds__(256)
-k_icp(const double* __restrict__ pts, const double* __restrict__ normals, double* __restrict__ work /* transformed src */,
-      const IcpProblem* __restrict__ probs, IcpResult* __restrict__ results, double max_dist, int max_iter, double rel_tol) {
-    __shared__ double s_part[4][kNSum];
+__global__ void __launch_bounds__(kWG)
+k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
+    __shared__ double s_part[kWG / 64][kNSum];
     __shared__ double s_sum[kNSum];
     __shared__ double s_upd[12];     // 3x4 update
     __shared__ int s_stop;
     __shared__ double s_T[16];
     __shared__ double s_fit, s_rmse;
     __shared__ int s_iters, s_ncorr;
+    __shared__ double s_A[6][6], s_b[6], s_x[6];
 
-    const IcpProblem pb = probs[blockIdx.x];
+    const int h = blockIdx.x;
+    IcpState& S = B.st[h];
+    if (S.status != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* S = pts + 3 * (size_t)pb.src_off;
-    const double* T = pts + 3 * (size_t)pb.tgt_off;
-    const double* N = normals + 3 * (size_t)pb.tgt_off;
-    double* P = work + 3 * (size_t)pb.src_off;
-    const int ns = pb.n_src, nt = pb.n_tgt;
+    const double* Src = B.src + (size_t)h * B.cap * 3;
+    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
+    const double* N = B.normals + (size_t)h * B.cap * 3;
+    const int* orig = B.tgt_orig + (size_t)h * B.cap;
+    const int* cs = B.cell_start + (size_t)h * kIcpCells;
+    double* P = B.work + (size_t)h * B.cap * 3;
+    int* prev = B.prev_nn + (size_t)h * B.cap;
+    const int ns = S.n_src, nt = S.n_tgt;
+    const int gx = S.gx, gy = S.gy;
+    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell;
     const double r2 = max_dist * max_dist;
 
-    if (tid < 16) s_T[tid] = pb.init[tid];
+    if (tid < 16) s_T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid < 3) s_T[4 * tid + 3] = S.init[tid];
     if (tid == 0) { s_stop = 0; s_iters = 0; s_fit = 0; s_rmse = 0; s_ncorr = 0; }
     __syncthreads();
     // pcd.Transform(init)
-    for (int i = tid; i < ns; i += blockDim.x) {
-        double x = S[3 * i], y = S[3 * i + 1], z = S[3 * i + 2];
-        P[3 * i] = s_T[0] * x + s_T[1] * y + s_T[2] * z + s_T[3];
-        P[3 * i + 1] = s_T[4] * x + s_T[5] * y + s_T[6] * z + s_T[7];
-        P[3 * i + 2] = s_T[8] * x + s_T[9] * y + s_T[10] * z + s_T[11];
+    for (int i = tid; i < ns; i += kWG) {
+        const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
+        P[3 * (size_t)i] = s_T[0] * x + s_T[1] * y + s_T[2] * z + s_T[3];
+        P[3 * (size_t)i + 1] = s_T[4] * x + s_T[5] * y + s_T[6] * z + s_T[7];
+        P[3 * (size_t)i + 2] = s_T[8] * x + s_T[9] * y + s_T[10] * z + s_T[11];
+        prev[i] = -1;
     }
     __syncthreads();
 
@@ -178,22 +669,36 @@ k_icp(const double* __restrict__ pts, const double* __restrict__ normals, double
         double acc[kNSum];
 #pragma unroll
         for (int k = 0; k < kNSum; ++k) acc[k] = 0.0;
-        for (int i0 = 0; i0 < ns; i0 += blockDim.x) {
-            const int i = i0 + tid;
-            const bool act = i < ns;
-            const int ii = act ? i : 0;
-            const double px = P[3 * ii], py = P[3 * ii + 1], pz = P[3 * ii + 2];
-            double bd = 1e300;
-            int bj = -1;
-            for (int j = 0; j < nt; ++j) {                       // wave-uniform index: scalar loads
-                double d = sqdist(px, py, pz, T[3 * j], T[3 * j + 1], T[3 * j + 2]);
-                if (d < bd) { bd = d; bj = j; }
+        for (int i = tid; i < ns; i += kWG) {
+            const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+            // best = lexicographic minimum of (d, original index) over targets with d < r2
+            double bd = r2;
+            int bo = -1, bp = -1;
+            const int pj = prev[i];
+            if (pj >= 0) {
+                const double d = sqdist(px, py, pz, T[3 * (size_t)pj], T[3 * (size_t)pj + 1], T[3 * (size_t)pj + 2]);
+                if (d < bd) { bd = d; bo = orig[pj]; bp = pj; }
             }
-            if (act && bj >= 0 && bd < r2) {
-                const double qx = T[3 * bj], qy = T[3 * bj + 1], qz = T[3 * bj + 2];
-                const double nx = N[3 * bj], ny = N[3 * bj + 1], nz = N[3 * bj + 2];
+            if (nt > 0 && px == px && py == py) {
+                // every target with d <= bd has |dx|,|dy| <= sqrt(bd): the columns overlapping that square suffice
+                const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
+                const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
+                const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
+                for (int y = ya; y <= yb; ++y) {
+                    const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
+                    for (int j = a; j < b; ++j) {
+                        const double d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
+                        if (d < bd) { bd = d; bo = orig[j]; bp = j; }
+                        else if (d == bd && bp >= 0 && bp != j) { const int o = orig[j]; if (o < bo) { bo = o; bp = j; } }
+                    }
+                }
+            }
+            prev[i] = bp;
+            if (bp >= 0) {
+                const double qx = T[3 * (size_t)bp], qy = T[3 * (size_t)bp + 1], qz = T[3 * (size_t)bp + 2];
+                const double nx = N[3 * (size_t)bp], ny = N[3 * (size_t)bp + 1], nz = N[3 * (size_t)bp + 2];
                 const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
-                double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+                const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
                 int k = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
@@ -207,13 +712,13 @@ k_icp(const double* __restrict__ pts, const double* __restrict__ normals, double
         }
 #pragma unroll
         for (int k = 0; k < kNSum; ++k) {
-            double v = wave_sum(acc[k]);
+            const double v = wave_sum(acc[k]);
             if (lane == 0) s_part[wave][k] = v;
         }
         __syncthreads();
         if (tid < kNSum) {
             double v = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_part[w][tid];
+            for (int w = 0; w < kWG / 64; ++w) v += s_part[w][tid];
             s_sum[tid] = v;
         }
         __syncthreads();
@@ -226,7 +731,8 @@ k_icp(const double* __restrict__ pts, const double* __restrict__ normals, double
             if (it == max_iter) s_stop = 1;
             if (!s_stop) {
                 // TransformationEstimationPointToPlane::ComputeTransformation
-                double A[6][6], b[6], x[6];
+                double (*A)[6] = s_A;
+                double *b = s_b, *x = s_x;
                 int k = 0;
                 for (int a = 0; a < 6; ++a)
                     for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
@@ -252,25 +758,31 @@ k_icp(const double* __restrict__ pts, const double* __restrict__ normals, double
         __syncthreads();
         if (s_stop) break;
         // pcd.Transform(update)
-        for (int i = tid; i < ns; i += blockDim.x) {
-            double x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
-            P[3 * i] = s_upd[0] * x + s_upd[1] * y + s_upd[2] * z + s_upd[3];
-            P[3 * i + 1] = s_upd[4] * x + s_upd[5] * y + s_upd[6] * z + s_upd[7];
-            P[3 * i + 2] = s_upd[8] * x + s_upd[9] * y + s_upd[10] * z + s_upd[11];
+        for (int i = tid; i < ns; i += kWG) {
+            const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+            P[3 * (size_t)i] = s_upd[0] * x + s_upd[1] * y + s_upd[2] * z + s_upd[3];
+            P[3 * (size_t)i + 1] = s_upd[4] * x + s_upd[5] * y + s_upd[6] * z + s_upd[7];
+            P[3 * (size_t)i + 2] = s_upd[8] * x + s_upd[9] * y + s_upd[10] * z + s_upd[11];
         }
         __syncthreads();
     }
     if (tid == 0) {
-        IcpResult& r = results[blockIdx.x];
-        for (int a = 0; a < 16; ++a) r.T[a] = s_T[a];
-        r.fitness = s_fit; r.rmse = s_rmse; r.iterations = s_iters; r.n_corr = s_ncorr;
+        for (int a = 0; a < 16; ++a) S.T[a] = s_T[a];
+        S.fitness = s_fit; S.rmse = s_rmse; S.iterations = s_iters; S.n_corr = s_ncorr;
     }
 }
 
-void launch_icp(const double* pts, const double* normals, double* work, const IcpProblem* probs, IcpResult* results,
-                int count, double max_dist, int max_iter, double rel_tol, hipStream_t s) {
+void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
+                         double rel_tol, int knn, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_icp, dim3(count), dim3(256), 0, s, pts, normals, work, probs, results, max_dist, max_iter, rel_tol);
+    const int scene_mode = flags & 1;
+    hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
+    hipLaunchKernelGGL(k_icp_points, dim3(count), dim3(kWG), 0, s, B, W, H, flags);
+    hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
+    hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
+    hipLaunchKernelGGL(k_icp_knn, dim3(64, count), dim3(256), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_icp_loop, dim3(count), dim3(kWG), 0, s, B, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

@@ -1,24 +1,63 @@
 // Internal interface between pose_refine.cpp (host) and icp.hip (kernels).  gfx950 only.
+// The whole of poseRefine::process (LL.cpp:27-155) after the argument checks runs on the device:
+// bounding box + dilated mask + back-projection + centroid init (LL.cpp:43-104), the two
+// VoxelDownSample calls (LL.cpp:108-109), EstimateNormals (LL.cpp:127) and RegistrationICP
+// (LL.cpp:128-130).  All buffers are sized for the worst case (every pixel of the frame a point):
+// 288 GB of HBM makes that free and removes every host round trip between the stages.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace lm {
 
-struct IcpProblem {          // one pose hypothesis; clouds are xyz triples of doubles in one arena
-    int src_off, n_src;      // source cloud (voxel-down-sampled model), point index into the arena
-    int tgt_off, n_tgt;      // target cloud
-    double init[16];         // row-major 4x4 initial guess
-};
-struct IcpResult {
-    double T[16];            // final transformation_ (row-major)
-    double fitness, rmse;    // fitness_, inlier_rmse_
-    int iterations, n_corr;
+constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 x 64 columns over the target's xy extent
+constexpr int kIcpCells = kIcpGrid * kIcpGrid + 1;
+constexpr int kIcpCovStride = 10;                 // 9 cumulants + neighbour count per target point
+
+struct IcpIn {               // one pose hypothesis (uploaded)
+    float mK[9];             // model camera matrix (row-major 3x3, float like the reference's cv::Mat_<float>)
+    int dx, dy;              // detectX, detectY
+    int model_slot;          // which resident model depth image
+    int pad;
 };
 
-void launch_knn_normals(const double* pts, double* normals, const IcpProblem* probs, int count, int max_tgt, int knn,
-                        hipStream_t s);
-void launch_icp(const double* pts, const double* normals, double* work, const IcpProblem* probs, IcpResult* results,
-                int count, double max_dist, int max_iter, double rel_tol, hipStream_t s);
+struct IcpState {            // one pose hypothesis (device-written, downloaded after the run)
+    int bbox[4];             // x0,y0,x1,y1 of modelDepth > 0 (uploaded as INT_MAX,INT_MAX,-1,-1)
+    int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys
+    int n_model, n_scene;    // back-projected points
+    int n_src, n_tgt;        // after voxel down-sampling
+    int gx, gy;              // search grid dimensions
+    int iterations, n_corr;
+    int pad;
+    double init[3];          // init_guess translation (LL.cpp:101-104)
+    double gminx, gminy, cell, inv_cell;
+    double T[16];            // final transformation_ (row-major)
+    double fitness, rmse;    // fitness_, inlier_rmse_
+};
+
+struct IcpBuffers {
+    const uint16_t* scene;   // [H][W]
+    const uint16_t* models;  // [slots][H][W]
+    const IcpIn* in;         // [count]
+    IcpState* st;            // [count]
+    float sK[9];             // scene camera matrix
+    size_t cap;              // points per hypothesis and cloud (= W*H)
+    size_t cap2;             // cap rounded up to a power of two (sort scratch)
+    double* model_pts;       // [count][cap][3]
+    double* scene_pts;       // [count][cap][3]
+    double* src;             // [count][cap][3]  VoxelDownSample(model)
+    double* tgt;             // [count][cap][3]  VoxelDownSample(scene) (scene-from-scene mode only)
+    double* tgt_sorted;      // [count][cap][3]  target points in grid-cell order
+    int* tgt_orig;           // [count][cap]     original index of the point at a sorted position
+    int* cell_start;         // [count][kIcpCells]
+    double* cov;             // [count][cap][kIcpCovStride] cumulants of the k nearest neighbours (sorted positions)
+    double* normals;         // [count][cap][3]  per sorted position
+    double* work;            // [count][cap][3]  transformed source cloud
+    int* prev_nn;            // [count][cap]     previous correspondence (sorted position) of every source point
+    unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
+};
+
+void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
+                         double rel_tol, int knn, hipStream_t s);
 
 }  // namespace lm

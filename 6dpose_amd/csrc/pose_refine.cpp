@@ -1,13 +1,16 @@
-// poseRefine::process (LL.cpp:27-155) behind the C ABI: host-side cloud preparation (dilate, bbox,
-// back-projection, centroid init, voxel down-sampling — a few thousand points, sequential
-// bookkeeping) and the GPU ICP (icp.hip: kNN normals + the whole point-to-plane loop in one launch,
-// one workgroup per hypothesis).  Deterministic rules shared with oracle/linemod_oracle.py are
-// listed in DESIGN.md §ICP.
+// poseRefine::process (LL.cpp:27-155) behind the C ABI.  The host only validates arguments, stages
+// the depth images through pinned memory and composes the final [R|t] from the device result
+// (LL.cpp:146-154); everything between — bounding box, dilated mask, back-projection, centroid
+// init, both VoxelDownSample calls, EstimateNormals and the whole ICP loop — runs in icp.hip with
+// no host round trip.  An `lm_icp` context owns one HIP stream, the resident depth images and the
+// worst-case-sized arenas (W*H points per hypothesis and cloud: 288 GB of HBM make that free).
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/amd_linemod.h"
@@ -25,129 +28,331 @@ int lm_set_error(int code, const char* fmt, ...);   // detector.cpp
     } while (0)
 
 namespace {
-
 constexpr double kVoxel = 0.0025;     // LL.cpp:106
 constexpr double kMaxDist = 0.01;     // LL.cpp:31
 constexpr int kMaxIter = 30;          // open3d ICPConvergenceCriteria default
 constexpr double kRelTol = 1e-6;
 constexpr int kKnn = 30;              // open3d KDTreeSearchParamKNN default
-constexpr int kDilate = 4;            // LL.cpp:45
 
-struct P3 { double x, y, z; };
+size_t pow2_at_least(size_t n) {
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+}  // namespace
 
-struct Prepared {
-    bool rejected = false;            // residual = -1 (LL.cpp:52-55)
-    std::vector<P3> src, tgt;         // voxel-down-sampled clouds
-    double init[16];
-    float base[16];                   // init_base (float, LL.cpp:34-41)
+struct lm_icp {
+    int device = 0;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int W = 0, H = 0;
+    bool have_scene = false;
+    float sK[9] = {0};
+    int slots = 0;                 // resident model depth images
+    int max_count = 0;             // hypotheses the arenas hold
+    int last_count = 0, last_flags = 0;
+    uint16_t* d_scene = nullptr;
+    uint16_t* d_models = nullptr;
+    IcpIn* d_in = nullptr;
+    IcpState* d_st = nullptr;
+    IcpBuffers B{};
+    void* pinned = nullptr;        // staging for images
+    size_t pinned_bytes = 0;
+    IcpIn* h_in = nullptr;         // pinned
+    IcpState* h_st = nullptr;      // pinned
+    int h_cap = 0;
 };
 
-// open3d PointCloud::VoxelDownSample: mean per voxel; output in ascending (ix,iy,iz) order, points of
-// one voxel summed in input order.
-std::vector<P3> voxel_down_sample(const std::vector<P3>& pts, double voxel) {
-    std::vector<P3> out;
-    if (pts.empty()) return out;
-    double mnx = pts[0].x, mny = pts[0].y, mnz = pts[0].z;
-    for (const P3& p : pts) { mnx = std::min(mnx, p.x); mny = std::min(mny, p.y); mnz = std::min(mnz, p.z); }
-    mnx -= voxel * 0.5; mny -= voxel * 0.5; mnz -= voxel * 0.5;
-    struct Key { long long ix, iy, iz; int idx; };
-    std::vector<Key> keys(pts.size());
-    for (size_t i = 0; i < pts.size(); ++i) {
-        keys[i].ix = (long long)floor((pts[i].x - mnx) / voxel);
-        keys[i].iy = (long long)floor((pts[i].y - mny) / voxel);
-        keys[i].iz = (long long)floor((pts[i].z - mnz) / voxel);
-        keys[i].idx = (int)i;
-    }
-    std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-        if (a.ix != b.ix) return a.ix < b.ix;
-        if (a.iy != b.iy) return a.iy < b.iy;
-        return a.iz < b.iz;
-    });
-    size_t a = 0;
-    while (a < keys.size()) {
-        size_t b = a;
-        double sx = 0, sy = 0, sz = 0;
-        while (b < keys.size() && keys[b].ix == keys[a].ix && keys[b].iy == keys[a].iy && keys[b].iz == keys[a].iz) {
-            const P3& p = pts[keys[b].idx];
-            sx += p.x; sy += p.y; sz += p.z;
-            ++b;
-        }
-        double n = (double)(b - a);
-        out.push_back(P3{sx / n, sy / n, sz / n});
-        a = b;
-    }
-    return out;
+namespace {
+
+void free_arenas(lm_icp* c) {
+    void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.keys, c->d_in, c->d_st};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->B = IcpBuffers{};
+    c->d_in = nullptr; c->d_st = nullptr;
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_st) (void)hipHostFree(c->h_st);
+    c->h_in = nullptr; c->h_st = nullptr; c->h_cap = 0;
+    c->max_count = 0;
 }
 
-// LL.cpp:34-109 for one hypothesis
-int prepare(const uint16_t* scene, const uint16_t* model, int W, int H, const float* sK, const float* mK, const float* R,
-            const float* t, int dx, int dy, int flags, Prepared& out) {
-    // init_base (float): [R|t], only t.z / 1000 (LL.cpp:34-39)
-    float* B = out.base;
-    for (int i = 0; i < 16; ++i) B[i] = 0.f;
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) B[4 * r + c] = R[3 * r + c];
-        B[4 * r + 3] = t[r];
-    }
-    B[11] = B[11] / 1000.0f;
-    B[15] = 1.f;
-    // modelMask = dilate(modelDepth > 0, 9x9) ; bbox (LL.cpp:43-50)
-    std::vector<uint8_t> m0((size_t)W * H), mrow((size_t)W * H), mask((size_t)W * H);
-    for (size_t i = 0; i < m0.size(); ++i) m0[i] = model[i] > 0;
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            uint8_t v = 0;
-            for (int k = std::max(0, x - kDilate); k <= std::min(W - 1, x + kDilate) && !v; ++k) v |= m0[(size_t)y * W + k];
-            mrow[(size_t)y * W + x] = v;
-        }
-    int bx0 = W, by0 = H, bx1 = -1, by1 = -1;
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            uint8_t v = 0;
-            for (int k = std::max(0, y - kDilate); k <= std::min(H - 1, y + kDilate) && !v; ++k) v |= mrow[(size_t)k * W + x];
-            mask[(size_t)y * W + x] = v;
-            if (v) { bx0 = std::min(bx0, x); bx1 = std::max(bx1, x); by0 = std::min(by0, y); by1 = std::max(by1, y); }
-        }
-    if (bx1 < 0) return lm_set_error(LM_ERR_INVALID, "model depth image is empty");
-    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-    if (dx + bw >= W || dy + bh >= H) { out.rejected = true; return LM_OK; }   // LL.cpp:52-55
-    const double anchor = model[(size_t)(H / 2) * W + W / 2] / 1000.0;          // LL.cpp:62
-    std::vector<P3> mp, sp;
-    double cmx = 0, cmy = 0, cmz = 0, csx = 0, csy = 0, csz = 0;
-    long cs_n = 0;
-    for (int r = 0; r < bh; ++r)
-        for (int c = 0; c < bw; ++c) {
-            int mr = r + by0, mc = c + bx0;
-            int sr = std::max(r + dy - kDilate, 0), sc = std::max(c + dx - kDilate, 0);
-            if (!mask[(size_t)mr * W + mc]) continue;
-            uint16_t md = model[(size_t)mr * W + mc];
-            if (md > 0) {
-                double z = md / 1000.0;
-                // (int - float) / float evaluated in float, then * double (LL.cpp:79-80)
-                double x = (double)(((float)mc - mK[2]) / mK[0]) * z;
-                double y = (double)(((float)mr - mK[5]) / mK[4]) * z;
-                mp.push_back(P3{x, y, z});
-                cmx += x; cmy += y; cmz += z;
-            }
-            uint16_t sd = scene[(size_t)sr * W + sc];
-            if (sd > 0) {
-                double z = sd / 1000.0;
-                double x = (double)(((float)sc - sK[2]) / sK[0]) * z;
-                double y = (double)(((float)sr - sK[5]) / sK[4]) * z;
-                sp.push_back(P3{x, y, z});
-                if (fabs(z - anchor) < 0.4 && md > 0) { csx += x; csy += y; csz += z; ++cs_n; }
-            }
-        }
-    const double nm = (double)mp.size();
-    for (int i = 0; i < 16; ++i) out.init[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    out.init[3] = csx / (double)cs_n - cmx / nm;     // NaN when cs_n == 0, as the reference (LL.cpp:101-104)
-    out.init[7] = csy / (double)cs_n - cmy / nm;
-    out.init[11] = csz / (double)cs_n - cmz / nm;
-    out.src = voxel_down_sample(mp, kVoxel);                                              // LL.cpp:108
-    out.tgt = voxel_down_sample((flags & LM_ICP_SCENE_FROM_SCENE) ? sp : mp, kVoxel);    // LL.cpp:109 (sic: model)
+int ensure_pinned(lm_icp* c, size_t bytes) {
+    if (bytes <= c->pinned_bytes) return LM_OK;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinned_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault));
+    c->pinned_bytes = bytes;
     return LM_OK;
 }
 
+int ensure_arenas(lm_icp* c, int count) {
+    if (count <= c->max_count) return LM_OK;
+    HIP_TRY(hipStreamSynchronize(c->s));
+    free_arenas(c);
+    const int n = std::max(count, 16);
+    const size_t cap = (size_t)c->W * c->H, cap2 = pow2_at_least(cap);
+    const size_t pts = (size_t)n * cap * 3 * sizeof(double);
+    IcpBuffers& B = c->B;
+    B.cap = cap; B.cap2 = cap2;
+    HIP_TRY(hipMalloc((void**)&B.model_pts, pts));
+    HIP_TRY(hipMalloc((void**)&B.scene_pts, pts));
+    HIP_TRY(hipMalloc((void**)&B.src, pts));
+    HIP_TRY(hipMalloc((void**)&B.tgt, pts));
+    HIP_TRY(hipMalloc((void**)&B.tgt_sorted, pts));
+    HIP_TRY(hipMalloc((void**)&B.normals, pts));
+    HIP_TRY(hipMalloc((void**)&B.work, pts));
+    HIP_TRY(hipMalloc((void**)&B.cov, (size_t)n * cap * kIcpCovStride * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.tgt_orig, (size_t)n * cap * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&B.prev_nn, (size_t)n * cap * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&B.keys, (size_t)n * 2 * cap2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->d_in, (size_t)n * sizeof(IcpIn)));
+    HIP_TRY(hipMalloc((void**)&c->d_st, (size_t)n * sizeof(IcpState)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_in, (size_t)n * sizeof(IcpIn), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_st, (size_t)n * sizeof(IcpState), hipHostMallocDefault));
+    c->h_cap = n;
+    c->max_count = n;
+    return LM_OK;
+}
+
+int set_geometry(lm_icp* c, int W, int H) {
+    if (W == c->W && H == c->H) return LM_OK;
+    HIP_TRY(hipStreamSynchronize(c->s));
+    free_arenas(c);
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->d_models) (void)hipFree(c->d_models);
+    c->d_scene = nullptr; c->d_models = nullptr; c->slots = 0; c->have_scene = false;
+    c->W = W; c->H = H;
+    HIP_TRY(hipMalloc((void**)&c->d_scene, (size_t)W * H * sizeof(uint16_t)));
+    return LM_OK;
+}
+
+int ensure_slots(lm_icp* c, int slots) {
+    if (slots <= c->slots) return LM_OK;
+    const size_t img = (size_t)c->W * c->H * sizeof(uint16_t);
+    const int n = std::max(slots, std::max(16, c->slots * 2));
+    uint16_t* p = nullptr;
+    HIP_TRY(hipMalloc((void**)&p, (size_t)n * img));
+    if (c->d_models) {
+        HIP_TRY(hipMemcpyAsync(p, c->d_models, (size_t)c->slots * img, hipMemcpyDeviceToDevice, c->s));
+        HIP_TRY(hipStreamSynchronize(c->s));
+        (void)hipFree(c->d_models);
+    }
+    c->d_models = p;
+    c->slots = n;
+    return LM_OK;
+}
+
+}  // namespace
+
+extern "C" int lm_icp_create(int device, lm_icp** out) {
+    if (!out) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return lm_set_error(LM_ERR_NO_DEVICE, "no HIP device visible; libamdlinemod has no CPU fallback");
+    if (device < 0 || device >= ndev) return lm_set_error(LM_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    lm_icp* c = new lm_icp();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->e0) != hipSuccess ||
+        hipEventCreate(&c->e1) != hipSuccess) {
+        delete c;
+        return lm_set_error(LM_ERR_HIP, "could not create the ICP stream / events");
+    }
+    *out = c;
+    return LM_OK;
+}
+
+extern "C" void lm_icp_destroy(lm_icp* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->s) (void)hipStreamSynchronize(c->s);
+    free_arenas(c);
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->d_models) (void)hipFree(c->d_models);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->e0) (void)hipEventDestroy(c->e0);
+    if (c->e1) (void)hipEventDestroy(c->e1);
+    if (c->s) (void)hipStreamDestroy(c->s);
+    delete c;
+}
+
+extern "C" int lm_icp_set_scene(lm_icp* c, const uint16_t* scene_depth, int width, int height, const float* scene_K) {
+    if (!c || !scene_depth || !scene_K || width <= 0 || height <= 0) return lm_set_error(LM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = set_geometry(c, width, height);
+    if (rc) return rc;
+    const size_t img = (size_t)width * height * sizeof(uint16_t);
+    HIP_TRY(hipStreamSynchronize(c->s));                            // the staging buffer may still be in flight
+    if ((rc = ensure_pinned(c, img))) return rc;
+    memcpy(c->pinned, scene_depth, img);
+    HIP_TRY(hipMemcpyAsync(c->d_scene, c->pinned, img, hipMemcpyHostToDevice, c->s));
+    memcpy(c->sK, scene_K, sizeof(c->sK));
+    c->have_scene = true;
+    return LM_OK;
+}
+
+extern "C" int lm_icp_set_models(lm_icp* c, int first_slot, int count, const uint16_t* const* model_depths) {
+    if (!c || first_slot < 0 || count < 0 || (count && !model_depths)) return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (c->W <= 0) return lm_set_error(LM_ERR_INVALID, "lm_icp_set_scene must define the frame geometry first");
+    if (count == 0) return LM_OK;
+    for (int i = 0; i < count; ++i)
+        if (!model_depths[i]) return lm_set_error(LM_ERR_INVALID, "model depth %d is null", i);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_slots(c, first_slot + count);
+    if (rc) return rc;
+    const size_t img = (size_t)c->W * c->H * sizeof(uint16_t);
+    HIP_TRY(hipStreamSynchronize(c->s));
+    // the scene image may sit at the start of the staging buffer and still be copying: keep it, append after it
+    if ((rc = ensure_pinned(c, img * (size_t)(count + 1)))) return rc;
+    uint8_t* stage = (uint8_t*)c->pinned + img;
+    for (int i = 0; i < count; ++i) memcpy(stage + (size_t)i * img, model_depths[i], img);
+    HIP_TRY(hipMemcpyAsync(c->d_models + (size_t)first_slot * c->W * c->H, stage, img * (size_t)count, hipMemcpyHostToDevice, c->s));
+    return LM_OK;
+}
+
+extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, const float* model_Ks, const float* model_Rs,
+                          const float* model_ts, const int32_t* detect_xy, int flags, lm_pose_result* results, float* device_ms) {
+    if (!c || count < 0 || (count && (!model_Ks || !model_Rs || !model_ts || !detect_xy || !results)))
+        return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (device_ms) *device_ms = 0.f;
+    if (count == 0) return LM_OK;
+    if (!c->have_scene) return lm_set_error(LM_ERR_INVALID, "no scene depth resident (lm_icp_set_scene)");
+    for (int i = 0; i < count; ++i) {
+        const int slot = model_slots ? model_slots[i] : i;
+        if (slot < 0 || slot >= c->slots) return lm_set_error(LM_ERR_INVALID, "model slot %d of hypothesis %d is not resident", slot, i);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_arenas(c, count);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i) {
+        IcpIn& in = c->h_in[i];
+        memcpy(in.mK, model_Ks + 9 * i, sizeof(in.mK));
+        in.dx = detect_xy[2 * i]; in.dy = detect_xy[2 * i + 1];
+        in.model_slot = model_slots ? model_slots[i] : i;
+        in.pad = 0;
+        IcpState& st = c->h_st[i];
+        memset(&st, 0, sizeof(st));
+        st.bbox[0] = INT_MAX; st.bbox[1] = INT_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+    }
+    IcpBuffers B = c->B;
+    B.scene = c->d_scene; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
+    memcpy(B.sK, c->sK, sizeof(B.sK));
+    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
+    HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
+    HIP_TRY(hipEventRecord(c->e0, c->s));
+    launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->s);
+    HIP_TRY(hipEventRecord(c->e1, c->s));
+    HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
+    HIP_TRY(hipStreamSynchronize(c->s));
+    HIP_TRY(hipGetLastError());
+    c->last_count = count; c->last_flags = flags;
+    if (device_ms) (void)hipEventElapsedTime(device_ms, c->e0, c->e1);
+    for (int i = 0; i < count; ++i) {
+        const IcpState& st = c->h_st[i];
+        if (st.status == 2) return lm_set_error(LM_ERR_INVALID, "model depth image is empty");
+        if (st.status == 3)
+            return lm_set_error(LM_ERR_INVALID, "hypothesis %d: point cloud too large for 64-bit voxel keys (depth spans tens of metres?)", i);
+    }
+    for (int i = 0; i < count; ++i) {
+        const IcpState& st = c->h_st[i];
+        lm_pose_result& o = results[i];
+        memset(&o, 0, sizeof(o));
+        if (st.status == 1) { o.residual = -1.f; continue; }        // LL.cpp:52-55
+        // init_base (float): [R|t], only t.z / 1000 (LL.cpp:34-39)
+        float base[16];
+        for (int k = 0; k < 16; ++k) base[k] = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            for (int q = 0; q < 3; ++q) base[4 * r + q] = model_Rs[9 * i + 3 * r + q];
+            base[4 * r + 3] = model_ts[3 * i + r];
+        }
+        base[11] = base[11] / 1000.0f;
+        base[15] = 1.f;
+        // result = transformation_ * init_base.cast<double>() (LL.cpp:146); t * 1000 (LL.cpp:154)
+        double M[16];
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                double v = 0;
+                for (int k = 0; k < 4; ++k) v += st.T[4 * a + k] * (double)base[4 * k + b];
+                M[4 * a + b] = v;
+            }
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) o.R[3 * a + b] = M[4 * a + b];
+            o.t[a] = M[4 * a + 3] * 1000.0;
+        }
+        o.residual = (float)st.fitness;       // residual = fitness_ (LL.cpp:148)
+        o.inlier_rmse = (float)st.rmse;
+        o.iterations = st.iterations;
+        o.n_source = st.n_src;
+        o.n_target = st.n_tgt;
+    }
+    return LM_OK;
+}
+
+extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double* dst, int64_t capacity) {
+    if (!c || hypothesis < 0 || hypothesis >= c->last_count) return lm_set_error(LM_ERR_INVALID, "no such hypothesis in the last run");
+    if (hipSetDevice(c->device) != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipSetDevice failed");
+    const IcpState& st = c->h_st[hypothesis];
+    const size_t off = (size_t)hypothesis * c->B.cap;
+    const bool scene_mode = (c->last_flags & LM_ICP_SCENE_FROM_SCENE) != 0;
+    std::vector<double> tmp;
+    int64_t n = 0;
+    switch (kind) {
+        case 0: {   // source cloud
+            n = (int64_t)st.n_src * 3; tmp.resize((size_t)n);
+            if (n && hipMemcpy(tmp.data(), c->B.src + off * 3, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                return lm_set_error(LM_ERR_HIP, "read-back failed");
+            break;
+        }
+        case 1: {   // target cloud, original (voxel) order
+            n = (int64_t)st.n_tgt * 3; tmp.resize((size_t)n);
+            if (n && hipMemcpy(tmp.data(), (scene_mode ? c->B.tgt : c->B.src) + off * 3, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                return lm_set_error(LM_ERR_HIP, "read-back failed");
+            break;
+        }
+        case 2: {   // target normals, original order
+            n = (int64_t)st.n_tgt * 3; tmp.resize((size_t)n);
+            std::vector<double> sorted((size_t)n);
+            std::vector<int> orig((size_t)st.n_tgt);
+            if (n && (hipMemcpy(sorted.data(), c->B.normals + off * 3, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+                      hipMemcpy(orig.data(), c->B.tgt_orig + off, (size_t)st.n_tgt * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess))
+                return lm_set_error(LM_ERR_HIP, "read-back failed");
+            for (int p = 0; p < st.n_tgt; ++p)
+                for (int k = 0; k < 3; ++k) tmp[(size_t)orig[p] * 3 + k] = sorted[(size_t)p * 3 + k];
+            break;
+        }
+        case 3: {   // init_guess translation, final T (16), counters
+            tmp = {st.init[0], st.init[1], st.init[2]};
+            for (int k = 0; k < 16; ++k) tmp.push_back(st.T[k]);
+            tmp.push_back((double)st.n_model); tmp.push_back((double)st.n_scene);
+            tmp.push_back((double)st.gx); tmp.push_back((double)st.gy); tmp.push_back(st.cell);
+            n = (int64_t)tmp.size();
+            break;
+        }
+        default: return lm_set_error(LM_ERR_INVALID, "unknown debug kind %d", kind);
+    }
+    if (dst && capacity > 0) memcpy(dst, tmp.data(), (size_t)std::min<int64_t>(n, capacity) * sizeof(double));
+    return n;
+}
+
+// ---- the reference-shaped entry points: one shared context per device -----------------------------
+namespace {
+std::mutex g_mu;
+std::vector<lm_icp*> g_ctx;
+
+int shared_context(int device, lm_icp** out) {
+    if (device < 0) return lm_set_error(LM_ERR_INVALID, "device %d out of range", device);
+    if ((size_t)device >= g_ctx.size()) g_ctx.resize((size_t)device + 1, nullptr);
+    if (!g_ctx[device]) {
+        int rc = lm_icp_create(device, &g_ctx[device]);
+        if (rc) return rc;
+    }
+    *out = g_ctx[device];
+    return LM_OK;
+}
 }  // namespace
 
 extern "C" int lm_pose_refine_batch(int device, const uint16_t* scene_depth, int width, int height, const float* scene_K,
@@ -158,98 +363,13 @@ extern "C" int lm_pose_refine_batch(int device, const uint16_t* scene_depth, int
         return lm_set_error(LM_ERR_INVALID, "null argument");
     if (device_ms) *device_ms = 0.f;
     if (count == 0) return LM_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return lm_set_error(LM_ERR_NO_DEVICE, "no HIP device visible; libamdlinemod has no CPU fallback");
-    if (device < 0 || device >= ndev) return lm_set_error(LM_ERR_INVALID, "device %d out of range", device);
-    HIP_TRY(hipSetDevice(device));
-
-    std::vector<Prepared> prep((size_t)count);
-    std::vector<IcpProblem> probs;
-    std::vector<int> prob_of((size_t)count, -1);
-    std::vector<double> arena;
-    int max_tgt = 0;
-    for (int i = 0; i < count; ++i) {
-        if (!model_depths[i]) return lm_set_error(LM_ERR_INVALID, "model depth %d is null", i);
-        int rc = prepare(scene_depth, model_depths[i], width, height, scene_K, model_Ks + 9 * i, model_Rs + 9 * i, model_ts + 3 * i,
-                         detect_xy[2 * i], detect_xy[2 * i + 1], flags, prep[i]);
-        if (rc) return rc;
-        if (prep[i].rejected) continue;
-        IcpProblem pb{};
-        pb.src_off = (int)(arena.size() / 3); pb.n_src = (int)prep[i].src.size();
-        for (const P3& p : prep[i].src) { arena.push_back(p.x); arena.push_back(p.y); arena.push_back(p.z); }
-        pb.tgt_off = (int)(arena.size() / 3); pb.n_tgt = (int)prep[i].tgt.size();
-        for (const P3& p : prep[i].tgt) { arena.push_back(p.x); arena.push_back(p.y); arena.push_back(p.z); }
-        memcpy(pb.init, prep[i].init, sizeof(pb.init));
-        max_tgt = std::max(max_tgt, pb.n_tgt);
-        prob_of[i] = (int)probs.size();
-        probs.push_back(pb);
-    }
-    std::vector<IcpResult> res(probs.size());
-    float ms = 0.f;
-    if (!probs.empty()) {
-        double *d_pts = nullptr, *d_nrm = nullptr, *d_work = nullptr;
-        IcpProblem* d_probs = nullptr;
-        IcpResult* d_res = nullptr;
-        hipStream_t s = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const size_t ab = std::max<size_t>(arena.size(), 3) * sizeof(double);
-        int rc = LM_OK;
-        auto cleanup = [&]() {
-            if (d_pts) (void)hipFree(d_pts); if (d_nrm) (void)hipFree(d_nrm); if (d_work) (void)hipFree(d_work);
-            if (d_probs) (void)hipFree(d_probs); if (d_res) (void)hipFree(d_res);
-            if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-            if (s) (void)hipStreamDestroy(s);
-        };
-#define TRY_OR_CLEAN(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return lm_set_error(LM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-        TRY_OR_CLEAN(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        TRY_OR_CLEAN(hipEventCreate(&e0));
-        TRY_OR_CLEAN(hipEventCreate(&e1));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_pts, ab));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_nrm, ab));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_work, ab));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_probs, probs.size() * sizeof(IcpProblem)));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_res, probs.size() * sizeof(IcpResult)));
-        TRY_OR_CLEAN(hipMemcpyAsync(d_pts, arena.data(), arena.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        TRY_OR_CLEAN(hipMemsetAsync(d_nrm, 0, ab, s));
-        TRY_OR_CLEAN(hipMemcpyAsync(d_probs, probs.data(), probs.size() * sizeof(IcpProblem), hipMemcpyHostToDevice, s));
-        TRY_OR_CLEAN(hipEventRecord(e0, s));
-        launch_knn_normals(d_pts, d_nrm, d_probs, (int)probs.size(), max_tgt, kKnn, s);        // LL.cpp:127
-        launch_icp(d_pts, d_nrm, d_work, d_probs, d_res, (int)probs.size(), kMaxDist, kMaxIter, kRelTol, s);   // LL.cpp:128-130
-        TRY_OR_CLEAN(hipEventRecord(e1, s));
-        TRY_OR_CLEAN(hipMemcpyAsync(res.data(), d_res, res.size() * sizeof(IcpResult), hipMemcpyDeviceToHost, s));
-        TRY_OR_CLEAN(hipStreamSynchronize(s));
-        TRY_OR_CLEAN(hipGetLastError());
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        cleanup();
-        (void)rc;
-#undef TRY_OR_CLEAN
-    }
-    if (device_ms) *device_ms = ms;
-    for (int i = 0; i < count; ++i) {
-        lm_pose_result& o = results[i];
-        memset(&o, 0, sizeof(o));
-        if (prep[i].rejected) { o.residual = -1.f; continue; }
-        const IcpResult& r = res[prob_of[i]];
-        // result = transformation_ * init_base.cast<double>() (LL.cpp:146); t * 1000 (LL.cpp:154)
-        double M[16];
-        for (int a = 0; a < 4; ++a)
-            for (int b = 0; b < 4; ++b) {
-                double v = 0;
-                for (int k = 0; k < 4; ++k) v += r.T[4 * a + k] * (double)prep[i].base[4 * k + b];
-                M[4 * a + b] = v;
-            }
-        for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b) o.R[3 * a + b] = M[4 * a + b];
-            o.t[a] = M[4 * a + 3] * 1000.0;
-        }
-        o.residual = (float)r.fitness;       // residual = fitness_ (LL.cpp:148)
-        o.inlier_rmse = (float)r.rmse;
-        o.iterations = r.iterations;
-        o.n_source = (int)prep[i].src.size();
-        o.n_target = (int)prep[i].tgt.size();
-    }
-    return LM_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    lm_icp* c = nullptr;
+    int rc = shared_context(device, &c);
+    if (rc) return rc;
+    if ((rc = lm_icp_set_scene(c, scene_depth, width, height, scene_K))) return rc;
+    if ((rc = lm_icp_set_models(c, 0, count, model_depths))) return rc;
+    return lm_icp_run(c, count, nullptr, model_Ks, model_Rs, model_ts, detect_xy, flags, results, device_ms);
 }
 
 extern "C" int lm_pose_refine(int device, const uint16_t* scene_depth, const uint16_t* model_depth, int width, int height,

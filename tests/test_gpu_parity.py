@@ -442,6 +442,86 @@ def test_pose_refine_batch_equals_single_calls(lm):
         assert np.array_equal(pr.getR(), res[i]["R"]) and np.array_equal(pr.getT().ravel(), res[i]["t"])
 
 
+def test_icp_device_intermediates_match_oracle(lm):
+    """Every device stage of poseRefine against the oracle's intermediates: init_guess, both voxel-down-sampled
+    clouds (same order), the kNN normals (up to sign), in both target modes."""
+    import linemodLevelup_pybind as mod
+    md = synth.synth_model_depth(21)
+    sd = _perturbed_scene(md, K_CAM.astype(np.float64), 2.0, (2.5, -2.0, 4.0), 21)
+    ys, xs = np.nonzero(md)
+    dx, dy = int(xs.min()), int(ys.min())
+    R, t = np.eye(3, dtype=np.float32), np.array([0, 0, 1000], np.float32)
+    for intended in (True, False):
+        ctx = mod.IcpContext(device=0, scene_from_scene=intended)
+        ctx.set_scene(sd, K_CAM)
+        ctx.set_models([md])
+        res, ms = ctx.run(K_CAM.reshape(1, 9), R.reshape(1, 9), t.reshape(1, 3), [(dx, dy)])
+        ref = lo.pose_refine(sd, md, K_CAM, K_CAM, R, t, dx, dy, scene_from_scene=intended)
+        src, tgt, nrm, dbg = (ctx.read_debug(0, k) for k in range(4))
+        assert src.shape == ref["src"].shape and tgt.shape == ref["tgt"].shape
+        assert np.abs(src - ref["src"]).max() < 1e-12 and np.abs(tgt - ref["tgt"]).max() < 1e-12
+        assert np.abs(dbg[:3] - ref["init_guess"][:3, 3]).max() < 1e-12
+        cosang = np.abs((nrm * ref["normals"]).sum(1))
+        assert cosang.min() > 1 - 1e-9, cosang.min()
+        assert res[0]["iterations"] == ref["iterations"] and abs(res[0]["residual"] - ref["residual"]) < 1e-6
+        assert np.abs(res[0]["R"] - ref["R"]).max() < 1e-4 and np.abs(res[0]["t"] - ref["t"]).max() / 1000.0 < 1e-4
+        ctx.close()
+
+
+def test_icp_large_clouds_take_the_global_sort_path(lm):
+    """> 16k points per cloud: the voxel / grid sorts leave LDS for the HBM scratch.  The down-sampled cloud must
+    still equal the oracle's, and registering the cloud to itself (verbatim mode, LL.cpp:109) is the identity."""
+    import linemodLevelup_pybind as mod
+    H, W = 480, 640
+    yy, xx = np.mgrid[0:H, 0:W]
+    inside = (np.abs(xx - W // 2) < 110) & (np.abs(yy - H // 2) < 100)                    # 219 x 199 = 43.6k pixels
+    md = np.where(inside, 2000 + ((xx - W // 2) * 0.5).astype(np.int64) + ((yy % 7) == 0) * 3, 0).astype(np.uint16)
+    ys, xs = np.nonzero(md)
+    dx, dy = int(xs.min()), int(ys.min())
+    bp = lo.backproject_clouds(md, md, K_CAM, K_CAM, dx, dy)
+    want = lo.voxel_down_sample(bp[0])
+    assert len(bp[0]) > 16384 and len(want) > 16384
+    ctx = mod.IcpContext(device=0, scene_from_scene=False)
+    ctx.set_scene(md, K_CAM)
+    ctx.set_models([md])
+    res, ms = ctx.run(K_CAM.reshape(1, 9), np.eye(3, dtype=np.float32).reshape(1, 9), np.array([[0, 0, 2000]], np.float32), [(dx, dy)])
+    src = ctx.read_debug(0, 0)
+    assert src.shape == want.shape and np.abs(src - want).max() < 1e-12
+    dbg = ctx.read_debug(0, 3)
+    assert np.abs(dbg[:3] - bp[2]).max() < 1e-12
+    assert res[0]["residual"] == 1.0 and res[0]["n_source"] == len(want) and res[0]["n_target"] == len(want)
+    T = dbg[3:19].reshape(4, 4)
+    assert np.abs(T[:3, :3] - np.eye(3)).max() < 1e-6 and np.abs(T[:3, 3]).max() < 1e-4
+    ctx.close()
+
+
+def test_icp_context_slots_shared_by_hypotheses(lm):
+    """Hypotheses may share a resident model slot; results equal the one-image-per-hypothesis batch call."""
+    import linemodLevelup_pybind as mod
+    base = synth.synth_model_depth(30)
+    scene = _perturbed_scene(base, K_CAM.astype(np.float64), -1.0, (1.0, 2.0, 3.0), 30)
+    mds = [synth.synth_model_depth(30 + s) for s in range(3)]
+    slots = [0, 2, 1, 2, 0]
+    xy = []
+    for sl in slots:
+        ys, xs = np.nonzero(mds[sl])
+        xy.append((int(xs.min()) + len(xy) - 2, int(ys.min()) + 1))
+    n = len(slots)
+    Ks = np.tile(K_CAM.reshape(1, 9), (n, 1)); Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    ts = np.tile(np.array([[0, 0, 1000]], np.float32), (n, 1))
+    ctx = mod.IcpContext(device=0, scene_from_scene=True)
+    ctx.set_scene(scene, K_CAM)
+    ctx.set_models(mds)
+    got, _ = ctx.run(Ks, Rs, ts, xy, model_slots=slots)
+    want, _ = mod.pose_refine_batch(scene, K_CAM, [mds[sl] for sl in slots], Ks, Rs, ts, xy, device=0, scene_from_scene=True)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["R"], w["R"]) and np.array_equal(g["t"], w["t"]) and g["iterations"] == w["iterations"]
+    again, _ = ctx.run(Ks, Rs, ts, xy, model_slots=slots)                                     # deterministic run to run
+    for g, w in zip(got, again):
+        assert np.array_equal(g["R"], w["R"]) and np.array_equal(g["t"], w["t"])
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-process sharding on the one visible GPU
 # ---------------------------------------------------------------------------------------------
