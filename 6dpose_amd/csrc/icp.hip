@@ -27,8 +27,7 @@ namespace lm {
 constexpr int kWG = 1024;          // workgroup size of the per-hypothesis kernels
 constexpr int kSortLds = 16384;    // 64-bit keys sorted in LDS (128 KiB); longer lists use the global scratch
 constexpr int kDilate = 4;         // LL.cpp:45 (9x9 dilation)
-constexpr double kCellMin = 0.005; // search-grid cell edge (m), grown when the target extent exceeds 64 cells
-constexpr int kKnnCache = 768;     // candidates cached in LDS per wave by k_icp_knn
+constexpr double kCellMin = 0.005; // search-grid cell edge (m), grown until the grid fits kIcpGrid / kIcpCells
 constexpr int kIdxBits = 22;       // point-index bits of the grid sort key
 
 static __device__ __forceinline__ double sqdist(double ax, double ay, double az, double bx, double by, double bz) {
@@ -359,14 +358,18 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_icp_grid: the target cloud binned into xy columns (cell edge >= 5 mm, <= 64 x 64 columns),
-// points reordered by (row, column, original index); cell_start[c] = first sorted position of column c.
+// k_icp_grid: the target cloud binned into a dense 3-D grid (cell edge >= 5 mm, grown until the grid
+// has <= 64 cells per axis and <= 16384 cells), points reordered by (y, x, z cell, original index):
+// the cells of one (x, y) column are contiguous, so a search visits one run per column and only the
+// z range it needs.  cell_start[c] = first sorted position of cell c.
 // ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int pad; };   // LDS copy of a target point
+
 __global__ void __launch_bounds__(kWG)
 k_icp_grid(IcpBuffers B, int flags) {
     __shared__ unsigned long long s_keys[kSortLds];
-    __shared__ double s_part[16 * 4];
-    __shared__ double s_mm[4];
+    __shared__ double s_part[16 * 6];
+    __shared__ double s_mm[6];
     const int h = blockIdx.x, tid = threadIdx.x;
     IcpState& S = B.st[h];
     int* cs = B.cell_start + (size_t)h * kIcpCells;
@@ -374,32 +377,44 @@ k_icp_grid(IcpBuffers B, int flags) {
     if (nt == 0 || nt >= (1 << kIdxBits)) {
         if (tid == 0) {
             if (nt > 0) { S.status = 3; S.n_tgt = 0; }
-            S.gx = 1; S.gy = 1; S.gminx = 0; S.gminy = 0; S.cell = kCellMin; S.inv_cell = 1.0 / kCellMin;
+            S.gx = 1; S.gy = 1; S.gz = 1; S.gminx = 0; S.gminy = 0; S.gminz = 0; S.cell = kCellMin; S.inv_cell = 1.0 / kCellMin;
             cs[0] = 0; cs[1] = 0;
         }
         return;
     }
     const double* T = ((flags & 1) ? B.tgt : B.src) + (size_t)h * B.cap * 3;
-    double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
     for (int i = tid; i < nt; i += kWG) {
-        const double x = T[3 * (size_t)i], y = T[3 * (size_t)i + 1];
-        mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x); mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double v = T[3 * (size_t)i + k]; mn[k] = fmin(mn[k], v); mx[k] = fmax(mx[k], v); }
     }
-    block_minmax<2>(mn, mx, s_part, s_mm);
-    const double minx = s_mm[0], miny = s_mm[1];
-    const double ext = fmax(s_mm[2] - minx, s_mm[3] - miny);
-    double cell = ext / (double)kIcpGrid;
-    if (!(cell > kCellMin)) cell = kCellMin;                       // also catches NaN
-    const double inv = 1.0 / cell;
-    const int gx = grid_coord(s_mm[2], minx, inv, kIcpGrid) + 1, gy = grid_coord(s_mm[3], miny, inv, kIcpGrid) + 1;
+    block_minmax<3>(mn, mx, s_part, s_mm);
+    const double minx = s_mm[0], miny = s_mm[1], minz = s_mm[2];
+    double cell = kCellMin, inv = 1.0 / kCellMin;
+    int gx = 1, gy = 1, gz = 1;
+    bool ok = false;
+    for (int tries = 0; tries < 400; ++tries) {                      // uniform: every thread computes the same grid
+        inv = 1.0 / cell;
+        const double fx = (s_mm[3] - minx) * inv, fy = (s_mm[4] - miny) * inv, fz = (s_mm[5] - minz) * inv;
+        if (fx < (double)kIcpGrid && fy < (double)kIcpGrid && fz < (double)kIcpGrid) {
+            gx = (int)fx + 1; gy = (int)fy + 1; gz = (int)fz + 1;
+            if (gx * gy * gz < kIcpCells) { ok = true; break; }
+        }
+        cell *= 1.25;
+    }
+    if (!ok) {                                                         // non-finite coordinates
+        if (tid == 0) { S.status = 3; S.n_tgt = 0; S.gx = 1; S.gy = 1; S.gz = 1; cs[0] = 0; cs[1] = 0; }
+        return;
+    }
     const int npad = next_pow2(nt < 2 ? 2 : nt);
     const bool in_lds = npad <= kSortLds;
     unsigned long long* gk = B.keys + (size_t)h * 2 * B.cap2;
     for (int i = tid; i < npad; i += kWG) {
         unsigned long long key = ~0ull;
         if (i < nt) {
-            const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy);
-            key = ((unsigned long long)(cy * gx + cx) << kIdxBits) | (unsigned long long)i;
+            const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy),
+                      cz = grid_coord(T[3 * (size_t)i + 2], minz, inv, gz);
+            key = ((unsigned long long)((cy * gx + cx) * gz + cz) << kIdxBits) | (unsigned long long)i;
         }
         if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
@@ -413,7 +428,7 @@ k_icp_grid(IcpBuffers B, int flags) {
         Ts[3 * (size_t)p] = T[3 * i]; Ts[3 * (size_t)p + 1] = T[3 * i + 1]; Ts[3 * (size_t)p + 2] = T[3 * i + 2];
         orig[p] = (int)i;
     }
-    const int ncell = gx * gy;
+    const int ncell = gx * gy * gz;
     for (int c = tid; c <= ncell; c += kWG) {                       // lower_bound of (c << kIdxBits)
         const unsigned long long want = (unsigned long long)c << kIdxBits;
         int lo = 0, hi = nt;
@@ -424,110 +439,262 @@ k_icp_grid(IcpBuffers B, int flags) {
         }
         cs[c] = lo;
     }
-    if (tid == 0) { S.gx = gx; S.gy = gy; S.gminx = minx; S.gminy = miny; S.cell = cell; S.inv_cell = inv; }
+    if (tid == 0) {
+        S.gx = gx; S.gy = gy; S.gz = gz; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_icp_knn: open3d EstimateNormals(KDTreeSearchParamKNN(30)), neighbour search part.  One wave per
-// target point.  Ring R of grid columns around the point holds every point closer than R*cell, so
-// once >= k candidates are closer than that the k nearest of the ring are the k nearest of the
-// cloud.  Candidates are cached in LDS; k selection passes pick them in (distance, original index)
-// order and the cumulants are accumulated in that order (the oracle's sequential sums).
+// target point.  The cube of cells within ring R of the point's cell holds every point closer than
+// R*cell, so once >= k candidates are closer than that, the k nearest of the cube are the k nearest
+// of the cloud.  Candidates sit one per lane-slot in registers; the k-th smallest squared distance is
+// found by bisection on its bit pattern (a ballot + popcount per step, no sorting), ties at the
+// threshold go to the lower original index, and the cumulants of the selected points are wave-reduced.
+// Rings with more than 384 candidates take the generic path: k selection passes over the runs.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_icp_knn(IcpBuffers B, int knn) {
-    __shared__ double s_d[4][kKnnCache];
-    __shared__ int s_pos[4][kKnnCache];
-    __shared__ int s_org[4][kKnnCache];
-    const int h = blockIdx.y;
-    const IcpState& S = B.st[h];
-    const int nt = S.status == 0 ? S.n_tgt : 0;
-    if (nt == 0) return;
+constexpr int kKnnWG = 512;        // 8 waves: 8 target points in flight per workgroup
+constexpr int kKnnCache = 384;     // candidates per point held in registers (6 per lane)
+constexpr int kKnnSlots = kKnnCache / 64;
+constexpr int kLoopLdsPts = 3072;  // target points staged in LDS by k_icp_knn and k_icp_loop (32-byte records, 96 KiB)
+
+template <int N, int OFF>
+static __device__ __forceinline__ void reduce_halve16(double (&v)[16], int lane) {
+    const bool hi = (lane & OFF) != 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double send = hi ? v[k] : v[k + N];
+        const double keep = hi ? v[k + N] : v[k];
+        v[k] = keep + shfl_xor_d(send, OFF);
+    }
+}
+
+template <bool kLds>
+static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpState& S, const int h, const int knn, TgtRec* s_tgt,
+                                                int* s_list) {
+    const int nt = S.n_tgt;
     const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
     const int* orig = B.tgt_orig + (size_t)h * B.cap;
     const int* cs = B.cell_start + (size_t)h * kIcpCells;
     double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-    const int gx = S.gx, gy = S.gy;
-    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell, cell = S.cell;
+    const int gx = S.gx, gy = S.gy, gz = S.gz;
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, cell = S.cell;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * 4;
+    const int nwaves = gridDim.x * (kKnnWG / 64);
     const int k = knn < nt ? knn : nt;
-    double* cd = s_d[wave];
-    int* cp = s_pos[wave];
-    int* co = s_org[wave];
+    if (kLds) {
+        for (int j = threadIdx.x; j < nt; j += kKnnWG) {
+            TgtRec r;
+            r.x = T[3 * (size_t)j]; r.y = T[3 * (size_t)j + 1]; r.z = T[3 * (size_t)j + 2]; r.orig = orig[j]; r.pad = 0;
+            s_tgt[j] = r;
+        }
+        __syncthreads();
+    }
+    auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
+        if (kLds) { const TgtRec& r = s_tgt[j]; x = r.x; y = r.y; z = r.z; }
+        else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
+    };
+    auto tgt_orig = [&](int j) { return kLds ? s_tgt[j].orig : orig[j]; };
+    int* list = s_list + wave * kKnnCache;
+    int R0 = (int)ceil(0.009 / cell);
+    if (R0 < 1) R0 = 1;
 
-    for (int pos = blockIdx.x * 4 + wave; pos < nt; pos += nwaves) {
-        const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
-        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
-        int R = 2, M = 0, xa = 0, xb = 0, ya = 0, yb = 0;
+    for (int pos = blockIdx.x * (kKnnWG / 64) + wave; pos < nt; pos += nwaves) {
+        double px, py, pz;
+        tgt_xyz(pos, px, py, pz);
+        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy), cz = grid_coord(pz, minz, inv, gz);
+        int R = R0, M = 0, xa = 0, xb = 0, ya = 0, yb = 0, za = 0, zb = 0;
+        double dreg[kKnnSlots];
+        int preg[kKnnSlots];
         for (;;) {
             xa = max(cx - R, 0); xb = min(cx + R, gx - 1); ya = max(cy - R, 0); yb = min(cy + R, gy - 1);
-            const bool all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1;
+            za = max(cz - R, 0); zb = min(cz + R, gz - 1);
+            const bool all = xa == 0 && ya == 0 && za == 0 && xb == gx - 1 && yb == gy - 1 && zb == gz - 1;
             const double g = (double)R * cell * (1.0 - 1e-9), g2 = g * g;   // margin >> the rounding of grid_coord
+            const int nx = xb - xa + 1, nruns = nx * (yb - ya + 1);
             M = 0;
-            int inside = 0;
-            for (int y = ya; y <= yb; ++y) {
-                const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
-                for (int j0 = a; j0 < b; j0 += 64) {
-                    const int j = j0 + lane;
-                    const bool valid = j < b;
-                    double d = 1e300;
-                    if (valid) {
-                        d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
-                        const int slot = M + (j - a);
-                        if (slot < kKnnCache) { cd[slot] = d; cp[slot] = j; co[slot] = orig[j]; }
-                    }
-                    inside += __popcll(__ballot(valid && d < g2));
+            for (int r0 = 0; r0 < nruns; r0 += 64) {                // one (x, y) column per lane: its z run
+                const int r = r0 + lane;
+                int a = 0, len = 0;
+                if (r < nruns) {
+                    const int y = ya + r / nx, x = xa + r % nx;
+                    const int c = (y * gx + x) * gz;
+                    a = cs[c + za];
+                    len = cs[c + zb + 1] - a;
                 }
-                M += b - a;
+                int incl = len;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const int off = M + incl - len;
+                for (int t = 0; t < len; ++t)
+                    if (off + t < kKnnCache) list[off + t] = a + t;
+                M += __shfl(incl, 63, 64);
+            }
+            int inside = 0;
+            if (M <= kKnnCache) {
+#pragma unroll
+                for (int s = 0; s < kKnnSlots; ++s) {
+                    const int m = lane + 64 * s;
+                    dreg[s] = __longlong_as_double(0x7FF0000000000000ll);   // +inf: never selected
+                    preg[s] = -1;
+                    if (s * 64 < M) {
+                        if (m < M) {
+                            const int j = list[m];
+                            double qx, qy, qz;
+                            tgt_xyz(j, qx, qy, qz);
+                            dreg[s] = sqdist(px, py, pz, qx, qy, qz);
+                            preg[s] = j;
+                        }
+                        inside += __popcll(__ballot(dreg[s] < g2));
+                    }
+                }
+            } else {
+                for (int y = ya; y <= yb; ++y)
+                    for (int x = xa; x <= xb; ++x) {
+                        const int c = (y * gx + x) * gz;
+                        const int a = cs[c + za], b = cs[c + zb + 1];
+                        for (int j0 = a; j0 < b; j0 += 64) {
+                            const int j = j0 + lane;
+                            bool in = false;
+                            if (j < b) {
+                                double qx, qy, qz;
+                                tgt_xyz(j, qx, qy, qz);
+                                in = sqdist(px, py, pz, qx, qy, qz) < g2;
+                            }
+                            inside += __popcll(__ballot(in));
+                        }
+                    }
             }
             if (inside >= k || all) break;
             ++R;
         }
-        const bool cached = M <= kKnnCache;
-        double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double prev_d = -1.0;
-        int prev_o = -1, taken = 0;
-        for (int pass = 0; pass < k; ++pass) {
-            double bd = 1e300;
-            int bo = INT_MAX, bp = -1;
-            if (cached) {
-                for (int m = lane; m < M; m += 64) {
-                    const double d = cd[m];
-                    const int o = co[m];
-                    const bool after = d > prev_d || (d == prev_d && o > prev_o);
-                    if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = cp[m]; }
+        double sum[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum[q] = 0.0;
+        double sep2 = 1e300;
+        int taken = 0;
+        if (M <= kKnnCache) {
+            const int nslots = (M + 63) >> 6;
+            // k-th smallest squared distance by bisection on the (non-negative) bit pattern
+            unsigned long long v = 0;
+            for (int bit = 62; bit >= 0; --bit) {
+                const unsigned long long t = v | (1ull << bit);
+                int c = 0;
+#pragma unroll
+                for (int s = 0; s < kKnnSlots; ++s)
+                    if (s < nslots) c += __popcll(__ballot((unsigned long long)__double_as_longlong(dreg[s]) < t));
+                if (c < k) v = t;
+            }
+            const double dk = __longlong_as_double((long long)v);
+            int less = 0, eq = 0;
+#pragma unroll
+            for (int s = 0; s < kKnnSlots; ++s)
+                if (s < nslots) { less += __popcll(__ballot(dreg[s] < dk)); eq += __popcll(__ballot(dreg[s] == dk)); }
+            int need = k - less;                                      // how many of the `eq` ties are taken
+            bool sel[kKnnSlots];
+#pragma unroll
+            for (int s = 0; s < kKnnSlots; ++s) sel[s] = s < nslots && dreg[s] < dk;
+            if (eq <= need) {
+#pragma unroll
+                for (int s = 0; s < kKnnSlots; ++s) sel[s] = sel[s] || (s < nslots && dreg[s] == dk);
+            } else {                                                   // ties: lower original index first
+                int last_o = -1;
+                for (int n = 0; n < need; ++n) {
+                    int bo = INT_MAX;
+#pragma unroll
+                    for (int s = 0; s < kKnnSlots; ++s)
+                        if (s < nslots && dreg[s] == dk && preg[s] >= 0) { const int o = tgt_orig(preg[s]); if (o > last_o && o < bo) bo = o; }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) bo = min(bo, __shfl_xor(bo, o, 64));
+#pragma unroll
+                    for (int s = 0; s < kKnnSlots; ++s)
+                        if (s < nslots && dreg[s] == dk && preg[s] >= 0 && tgt_orig(preg[s]) == bo) sel[s] = true;
+                    last_o = bo;
                 }
-            } else {
-                for (int y = ya; y <= yb; ++y) {
-                    const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
-                    for (int j = a + lane; j < b; j += 64) {
-                        const double d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
-                        const int o = orig[j];
-                        const bool after = d > prev_d || (d == prev_d && o > prev_o);
-                        if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
+            }
+            double nearest = 1e300;
+#pragma unroll
+            for (int s = 0; s < kKnnSlots; ++s) {
+                if (s < nslots) {
+                    if (sel[s]) {
+                        double qx, qy, qz;
+                        tgt_xyz(preg[s], qx, qy, qz);
+                        sum[0] += qx; sum[1] += qy; sum[2] += qz;
+                        sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
+                        sum[9] += 1.0;
                     }
+                    if (preg[s] >= 0 && preg[s] != pos) nearest = fmin(nearest, dreg[s]);
                 }
             }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = shfl_xor_d(bd, off);
-                const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
-                if (od < bd || (od == bd && oo < bo)) { bd = od; bo = oo; bp = op; }
-            }
-            if (bp < 0) break;
-            prev_d = bd; prev_o = bo;
-            const double qx = T[3 * (size_t)bp], qy = T[3 * (size_t)bp + 1], qz = T[3 * (size_t)bp + 2];
-            sum[0] += qx; sum[1] += qy; sum[2] += qz;
-            sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
-            ++taken;
-        }
-        if (lane == 0) {
+            for (int o = 32; o > 0; o >>= 1) nearest = fmin(nearest, shfl_xor_d(nearest, o));
+            sep2 = nearest;
+            reduce_halve16<8, 32>(sum, lane);
+            reduce_halve16<4, 16>(sum, lane);
+            reduce_halve16<2, 8>(sum, lane);
+            reduce_halve16<1, 4>(sum, lane);
+            double tot = sum[0] + shfl_xor_d(sum[0], 2);
+            tot += shfl_xor_d(tot, 1);
+            const int q = lane >> 2;                                   // lane l holds the wave total of value l >> 2
+            if ((lane & 3) == 0 && q < 10) cov[(size_t)pos * kIcpCovStride + q] = tot;
+            if (lane == 0) cov[(size_t)pos * kIcpCovStride + 10] = sep2;
+        } else {
+            // generic path: k passes over the runs, each taking the next candidate in (distance, index) order
+            double prev_d = -1.0;
+            int prev_o = -1;
+            for (int pass = 0; pass < k; ++pass) {
+                double bd = 1e300;
+                int bo = INT_MAX, bp = -1;
+                for (int y = ya; y <= yb; ++y)
+                    for (int x = xa; x <= xb; ++x) {
+                        const int c = (y * gx + x) * gz;
+                        const int a = cs[c + za], b = cs[c + zb + 1];
+                        for (int j = a + lane; j < b; j += 64) {
+                            double qx, qy, qz;
+                            tgt_xyz(j, qx, qy, qz);
+                            const double d = sqdist(px, py, pz, qx, qy, qz);
+                            const int o = tgt_orig(j);
+                            const bool after = d > prev_d || (d == prev_d && o > prev_o);
+                            if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
+                        }
+                    }
 #pragma unroll
-            for (int q = 0; q < 9; ++q) cov[(size_t)pos * kIcpCovStride + q] = sum[q];
-            cov[(size_t)pos * kIcpCovStride + 9] = (double)taken;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double od = shfl_xor_d(bd, off);
+                    const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
+                    if (od < bd || (od == bd && oo < bo)) { bd = od; bo = oo; bp = op; }
+                }
+                if (bp < 0) break;
+                if (bp != pos && bd < sep2) sep2 = bd;
+                prev_d = bd; prev_o = bo;
+                double qx, qy, qz;
+                tgt_xyz(bp, qx, qy, qz);
+                sum[0] += qx; sum[1] += qy; sum[2] += qz;
+                sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
+                ++taken;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) cov[(size_t)pos * kIcpCovStride + q] = sum[q];
+                cov[(size_t)pos * kIcpCovStride + 9] = (double)taken;
+                cov[(size_t)pos * kIcpCovStride + 10] = sep2;
+            }
         }
     }
+}
+
+__global__ void __launch_bounds__(kKnnWG)
+k_icp_knn(IcpBuffers B, int knn) {
+    __shared__ TgtRec s_tgt[kLoopLdsPts];
+    __shared__ int s_list[(kKnnWG / 64) * kKnnCache];
+    const int h = blockIdx.y;
+    const IcpState& S = B.st[h];
+    if (S.status != 0 || S.n_tgt == 0) return;
+    if (S.n_tgt <= kLoopLdsPts) knn_body<true>(B, S, h, knn, s_tgt, s_list);
+    else knn_body<false>(B, S, h, knn, s_tgt, s_list);
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----
@@ -591,11 +758,13 @@ k_icp_normals(IcpBuffers B) {
 }
 
 // ---- RegistrationICP ------------------------------------------------------------------------------
-constexpr int kNSum = 29;   // 21 JtJ (upper) + 6 Jtr + sum d^2 + count
+// 29 sums per iteration: 21 JtJ (upper triangle) + 6 Jtr + sum d^2 + count, carried as 32 for the halving reduction
+constexpr int kLoopWG = 512;        // workgroup of k_icp_loop (256 VGPRs per lane: the 32 running sums never spill)
+constexpr int kLoopQueue = 4096;    // source points per round whose correspondence needs a grid search
 
 // Gaussian elimination with partial pivoting, A x = b (6x6), on LDS arrays (one thread; keeps the
 // dynamically indexed rows out of scratch).  Returns false if singular / non-finite.
-static __device__ bool solve6(double (*A)[6], double* b, double* x) {
+static __device__ __forceinline__ bool solve6(double (*A)[6], double* b, double* x) {
     for (int c = 0; c < 6; ++c) {
         int piv = c;
         double best = fabs(A[c][c]);
@@ -622,40 +791,78 @@ static __device__ bool solve6(double (*A)[6], double* b, double* x) {
     return true;
 }
 
-__global__ void __launch_bounds__(kWG)
-k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
-    __shared__ double s_part[kWG / 64][kNSum];
-    __shared__ double s_sum[kNSum];
+// Sum of 32 per-lane values over the wave with 32 shuffles instead of 6 x 32: every step halves the
+// number of values a lane carries (lanes whose bit `off` is set keep the upper half).  Afterwards lane l
+// holds the wave total of value (l >> 1).
+template <int N, int OFF>
+static __device__ __forceinline__ void reduce_halve(double (&v)[32], int lane) {
+    const bool hi = (lane & OFF) != 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double send = hi ? v[k] : v[k + N];
+        const double keep = hi ? v[k + N] : v[k];
+        v[k] = keep + shfl_xor_d(send, OFF);
+    }
+}
+static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane) {
+    reduce_halve<16, 32>(v, lane);
+    reduce_halve<8, 16>(v, lane);
+    reduce_halve<4, 8>(v, lane);
+    reduce_halve<2, 4>(v, lane);
+    reduce_halve<1, 2>(v, lane);
+    return v[0] + shfl_xor_d(v[0], 1);
+}
+
+// One workgroup per hypothesis.  Per iteration:
+//   A1  every source point first re-measures its previous correspondence j: with d = |p - t_j|^2 and
+//       sep2(j) = squared distance from t_j to its nearest other target (from k_icp_knn), 4 d < sep2(j)
+//       proves by the triangle inequality that t_j is still the unique nearest neighbour — no search.
+//       The others are queued in LDS;
+//   A2  queued points search the grid columns overlapping the square of half-width sqrt(min(d, r^2))
+//       (dense over the workgroup: no lane waits for another lane's search);
+//   B   29 sums: halving wave reduction + LDS across the 16 waves;   C  6x6 solve + update (one thread);
+//   D   pcd.Transform(update).
+template <bool kLds>
+static __device__ __forceinline__ void icp_loop_body(const IcpBuffers& B, IcpState& S, const int h, TgtRec* s_tgt, unsigned short* s_cs, int* s_q,
+                                                     const double max_dist, const int max_iter, const double rel_tol) {
+    __shared__ double s_part[kLoopWG / 64][32];
+    __shared__ double s_sum[32];
     __shared__ double s_upd[12];     // 3x4 update
-    __shared__ int s_stop;
+    __shared__ int s_stop, s_nq;
     __shared__ double s_T[16];
     __shared__ double s_fit, s_rmse;
     __shared__ int s_iters, s_ncorr;
     __shared__ double s_A[6][6], s_b[6], s_x[6];
 
-    const int h = blockIdx.x;
-    IcpState& S = B.st[h];
-    if (S.status != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Src = B.src + (size_t)h * B.cap * 3;
     const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
     const double* N = B.normals + (size_t)h * B.cap * 3;
+    const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
     const int* orig = B.tgt_orig + (size_t)h * B.cap;
     const int* cs = B.cell_start + (size_t)h * kIcpCells;
     double* P = B.work + (size_t)h * B.cap * 3;
     int* prev = B.prev_nn + (size_t)h * B.cap;
     const int ns = S.n_src, nt = S.n_tgt;
-    const int gx = S.gx, gy = S.gy;
-    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell;
+    const int gx = S.gx, gy = S.gy, gz = S.gz;
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell;
     const double r2 = max_dist * max_dist;
 
+    if (kLds) {
+        for (int j = tid; j < nt; j += kLoopWG) {
+            TgtRec r;
+            r.x = T[3 * (size_t)j]; r.y = T[3 * (size_t)j + 1]; r.z = T[3 * (size_t)j + 2]; r.orig = orig[j]; r.pad = 0;
+            s_tgt[j] = r;
+        }
+        for (int c = tid; c <= gx * gy * gz; c += kLoopWG) s_cs[c] = (unsigned short)cs[c];
+    }
     if (tid < 16) s_T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
     __syncthreads();
     if (tid < 3) s_T[4 * tid + 3] = S.init[tid];
-    if (tid == 0) { s_stop = 0; s_iters = 0; s_fit = 0; s_rmse = 0; s_ncorr = 0; }
+    if (tid == 0) { s_stop = 0; s_iters = 0; s_fit = 0; s_rmse = 0; s_ncorr = 0; s_nq = 0; }
     __syncthreads();
     // pcd.Transform(init)
-    for (int i = tid; i < ns; i += kWG) {
+    for (int i = tid; i < ns; i += kLoopWG) {
         const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
         P[3 * (size_t)i] = s_T[0] * x + s_T[1] * y + s_T[2] * z + s_T[3];
         P[3 * (size_t)i + 1] = s_T[4] * x + s_T[5] * y + s_T[6] * z + s_T[7];
@@ -664,64 +871,124 @@ k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
     }
     __syncthreads();
 
+    auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
+        if (kLds) { const TgtRec& r = s_tgt[j]; x = r.x; y = r.y; z = r.z; }
+        else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
+    };
+    auto tgt_orig = [&](int j) { return kLds ? s_tgt[j].orig : orig[j]; };
+    auto cell_at = [&](int c) { return kLds ? (int)s_cs[c] : cs[c]; };
+
+    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it <= max_iter; ++it) {
-        // --- GetRegistrationResultAndCorrespondences fused with the JtJ / Jtr accumulation ---
-        double acc[kNSum];
-#pragma unroll
-        for (int k = 0; k < kNSum; ++k) acc[k] = 0.0;
-        for (int i = tid; i < ns; i += kWG) {
-            const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
-            // best = lexicographic minimum of (d, original index) over targets with d < r2
-            double bd = r2;
-            int bo = -1, bp = -1;
-            const int pj = prev[i];
-            if (pj >= 0) {
-                const double d = sqdist(px, py, pz, T[3 * (size_t)pj], T[3 * (size_t)pj + 1], T[3 * (size_t)pj + 2]);
-                if (d < bd) { bd = d; bo = orig[pj]; bp = pj; }
-            }
-            if (nt > 0 && px == px && py == py) {
-                // every target with d <= bd has |dx|,|dy| <= sqrt(bd): the columns overlapping that square suffice
-                const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
-                const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
-                const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
-                for (int y = ya; y <= yb; ++y) {
-                    const int a = cs[y * gx + xa], b = cs[y * gx + xb + 1];
-                    for (int j = a; j < b; ++j) {
-                        const double d = sqdist(px, py, pz, T[3 * (size_t)j], T[3 * (size_t)j + 1], T[3 * (size_t)j + 2]);
-                        if (d < bd) { bd = d; bo = orig[j]; bp = j; }
-                        else if (d == bd && bp >= 0 && bp != j) { const int o = orig[j]; if (o < bo) { bo = o; bp = j; } }
-                    }
+        long long c0 = (long long)__builtin_amdgcn_s_memtime();
+        // --- GetRegistrationResultAndCorrespondences ---
+        for (int base = 0; base < ns; base += kLoopQueue) {
+            const int end = base + kLoopQueue < ns ? base + kLoopQueue : ns;
+            // A1: keep correspondences that are provably unchanged, queue the other points
+            for (int i0 = base; i0 < end; i0 += kLoopWG) {
+                const int i = i0 + tid;
+                const int pj = i < end ? prev[i] : -2;
+                bool need = i < end;
+                if (pj >= 0) {
+                    const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+                    double qx, qy, qz;
+                    tgt_xyz(pj, qx, qy, qz);
+                    const double d = sqdist(px, py, pz, qx, qy, qz);
+                    need = !(d < r2 && 4.0 * d * (1.0 + 1e-9) < cov[(size_t)pj * kIcpCovStride + 10]);
+                }
+                // one LDS atomic per wave reserves the slots of all its queued points
+                const unsigned long long mask = __ballot(need);
+                if (mask) {
+                    int qbase = 0;
+                    if (lane == (int)__ffsll((long long)mask) - 1) qbase = atomicAdd(&s_nq, __popcll(mask));
+                    qbase = __shfl(qbase, (int)__ffsll((long long)mask) - 1, 64);
+                    if (need) s_q[qbase + __popcll(mask & ((1ull << lane) - 1ull))] = i;
                 }
             }
-            prev[i] = bp;
-            if (bp >= 0) {
-                const double qx = T[3 * (size_t)bp], qy = T[3 * (size_t)bp + 1], qz = T[3 * (size_t)bp + 2];
-                const double nx = N[3 * (size_t)bp], ny = N[3 * (size_t)bp + 1], nz = N[3 * (size_t)bp + 2];
-                const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
-                const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-                acc[27] += bd;
-                acc[28] += 1.0;
+            __syncthreads();
+            const int nq = s_nq;
+            const long long ca = (long long)__builtin_amdgcn_s_memtime();
+            clk[6] += nq;
+            // A2: best = lexicographic minimum of (d, original index) over targets with d < r2
+            for (int q = tid; q < nq; q += kLoopWG) {
+                const int i = s_q[q];
+                const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+                double bd = r2;
+                int bo = -1, bp = -1;
+                const int pj = prev[i];
+                if (pj >= 0) {
+                    double qx, qy, qz;
+                    tgt_xyz(pj, qx, qy, qz);
+                    const double d = sqdist(px, py, pz, qx, qy, qz);
+                    if (d < bd) { bd = d; bo = tgt_orig(pj); bp = pj; }
+                }
+                if (nt > 0 && px == px && py == py && pz == pz) {
+                    // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the cells overlapping it suffice
+                    const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
+                    const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
+                    const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
+                    const int za = grid_coord(pz - rad, minz, inv, gz), zb = grid_coord(pz + rad, minz, inv, gz);
+                    for (int y = ya; y <= yb; ++y)
+                        for (int x = xa; x <= xb; ++x) {
+                            const int c = (y * gx + x) * gz;
+                            const int a = cell_at(c + za), b = cell_at(c + zb + 1);
+                            for (int j = a; j < b; ++j) {
+                                double qx, qy, qz;
+                                tgt_xyz(j, qx, qy, qz);
+                                const double d = sqdist(px, py, pz, qx, qy, qz);
+                                if (d < bd) { bd = d; bo = tgt_orig(j); bp = j; }
+                                else if (d == bd && bp >= 0 && bp != j) { const int o = tgt_orig(j); if (o < bo) { bo = o; bp = j; } }
+                            }
+                        }
+                }
+                prev[i] = bp;
             }
-        }
-#pragma unroll
-        for (int k = 0; k < kNSum; ++k) {
-            const double v = wave_sum(acc[k]);
-            if (lane == 0) s_part[wave][k] = v;
+            __syncthreads();
+            clk[4] += (long long)__builtin_amdgcn_s_memtime() - ca;
+            if (tid == 0) s_nq = 0;
         }
         __syncthreads();
-        if (tid < kNSum) {
+        const long long cb = (long long)__builtin_amdgcn_s_memtime();
+        // --- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences ---
+        double acc[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+        for (int i = tid; i < ns; i += kLoopWG) {
+            const int bp = prev[i];
+            if (bp < 0) continue;
+            const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+            double qx, qy, qz;
+            tgt_xyz(bp, qx, qy, qz);
+            const double bd = sqdist(px, py, pz, qx, qy, qz);
+            const double nx = N[3 * (size_t)bp], ny = N[3 * (size_t)bp + 1], nz = N[3 * (size_t)bp + 2];
+            const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+            const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+            acc[27] += bd;
+            acc[28] += 1.0;
+        }
+        long long c1 = (long long)__builtin_amdgcn_s_memtime();
+        clk[0] += c1 - c0;
+        clk[5] += c1 - cb;
+        {
+            const double v = wave_reduce32(acc, lane);
+            if ((lane & 1) == 0) s_part[wave][lane >> 1] = v;
+        }
+        __syncthreads();
+        if (tid < 32) {
             double v = 0;
-            for (int w = 0; w < kWG / 64; ++w) v += s_part[w][tid];
+            for (int w = 0; w < kLoopWG / 64; ++w) v += s_part[w][tid];
             s_sum[tid] = v;
         }
         __syncthreads();
+        long long c2 = (long long)__builtin_amdgcn_s_memtime();
+        clk[1] += c2 - c1;
         if (tid == 0) {
             const int ncorr = (int)s_sum[28];
             const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
@@ -739,7 +1006,8 @@ k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
                 for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
                 double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
                 if (ncorr >= 6 && solve6(A, b, x)) {
-                    const double cx = cos(x[0]), sx = sin(x[0]), cy = cos(x[1]), sy = sin(x[1]), cz = cos(x[2]), sz = sin(x[2]);
+                    double sx, cx, sy, cy, sz, cz;
+                    sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
                     // Rz(x2) * Ry(x1) * Rx(x0)
                     U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
                     U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
@@ -756,20 +1024,36 @@ k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
             }
         }
         __syncthreads();
+        long long c3 = (long long)__builtin_amdgcn_s_memtime();
+        clk[2] += c3 - c2;
         if (s_stop) break;
         // pcd.Transform(update)
-        for (int i = tid; i < ns; i += kWG) {
+        for (int i = tid; i < ns; i += kLoopWG) {
             const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
             P[3 * (size_t)i] = s_upd[0] * x + s_upd[1] * y + s_upd[2] * z + s_upd[3];
             P[3 * (size_t)i + 1] = s_upd[4] * x + s_upd[5] * y + s_upd[6] * z + s_upd[7];
             P[3 * (size_t)i + 2] = s_upd[8] * x + s_upd[9] * y + s_upd[10] * z + s_upd[11];
         }
         __syncthreads();
+        clk[3] += (long long)__builtin_amdgcn_s_memtime() - c3;
     }
     if (tid == 0) {
+        for (int a = 0; a < 8; ++a) S.clk[a] = clk[a];
         for (int a = 0; a < 16; ++a) S.T[a] = s_T[a];
         S.fitness = s_fit; S.rmse = s_rmse; S.iterations = s_iters; S.n_corr = s_ncorr;
     }
+}
+
+__global__ void __launch_bounds__(kLoopWG)
+k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
+    __shared__ TgtRec s_tgt[kLoopLdsPts];
+    __shared__ unsigned short s_cs[kIcpCells];
+    __shared__ int s_q[kLoopQueue];
+    const int h = blockIdx.x;
+    IcpState& S = B.st[h];
+    if (S.status != 0) return;
+    if (S.n_tgt <= kLoopLdsPts) icp_loop_body<true>(B, S, h, s_tgt, s_cs, s_q, max_dist, max_iter, rel_tol);
+    else icp_loop_body<false>(B, S, h, s_tgt, s_cs, s_q, max_dist, max_iter, rel_tol);
 }
 
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
@@ -780,9 +1064,9 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_points, dim3(count), dim3(kWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
-    hipLaunchKernelGGL(k_icp_knn, dim3(64, count), dim3(256), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn, dim3(32, count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
-    hipLaunchKernelGGL(k_icp_loop, dim3(count), dim3(kWG), 0, s, B, max_dist, max_iter, rel_tol);
+    hipLaunchKernelGGL(k_icp_loop, dim3(count), dim3(kLoopWG), 0, s, B, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

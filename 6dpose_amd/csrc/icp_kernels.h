@@ -10,9 +10,9 @@
 
 namespace lm {
 
-constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 x 64 columns over the target's xy extent
-constexpr int kIcpCells = kIcpGrid * kIcpGrid + 1;
-constexpr int kIcpCovStride = 10;                 // 9 cumulants + neighbour count per target point
+constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 cells per axis ...
+constexpr int kIcpCells = 16384 + 1;              // ... and at most 16384 cells (+1 end marker)
+constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
 
 struct IcpIn {               // one pose hypothesis (uploaded)
     float mK[9];             // model camera matrix (row-major 3x3, float like the reference's cv::Mat_<float>)
@@ -26,13 +26,13 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys
     int n_model, n_scene;    // back-projected points
     int n_src, n_tgt;        // after voxel down-sampling
-    int gx, gy;              // search grid dimensions
+    int gx, gy, gz;          // search grid dimensions
     int iterations, n_corr;
-    int pad;
     double init[3];          // init_guess translation (LL.cpp:101-104)
-    double gminx, gminy, cell, inv_cell;
+    double gminx, gminy, gminz, cell, inv_cell;
     double T[16];            // final transformation_ (row-major)
     double fitness, rmse;    // fitness_, inlier_rmse_
+    long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };
 
 struct IcpBuffers {

@@ -329,6 +329,8 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             for (int k = 0; k < 16; ++k) tmp.push_back(st.T[k]);
             tmp.push_back((double)st.n_model); tmp.push_back((double)st.n_scene);
             tmp.push_back((double)st.gx); tmp.push_back((double)st.gy); tmp.push_back(st.cell);
+            tmp.push_back((double)st.iterations);
+            for (int k = 0; k < 8; ++k) tmp.push_back((double)st.clk[k]);
             n = (int64_t)tmp.size();
             break;
         }

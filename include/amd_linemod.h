@@ -218,7 +218,7 @@ int lm_icp_run(lm_icp *c, int count, const int32_t *model_slots, const float *mo
                const int32_t *detect_xy /*[count][2]*/, int flags, lm_pose_result *results, float *device_ms);
 /* Test/diagnostic read-back of the last run's device intermediates of one hypothesis.  kind: 0 source
  * cloud, 1 target cloud, 2 target normals (xyz triples, voxel order), 3 {init_guess t[3], T[16],
- * n_model, n_scene, grid_x, grid_y, cell}.  Copies min(capacity, size) doubles, returns the size. */
+ * n_model, n_scene, grid_x, grid_y, cell, iterations, 4 phase cycle counts of the iteration kernel}.  Copies min(capacity, size) doubles, returns the size. */
 int64_t lm_icp_read_debug(lm_icp *c, int hypothesis, int kind, double *dst, int64_t capacity);
 
 #ifdef __cplusplus
