@@ -3,7 +3,7 @@
 // RegistrationICP + TransformationEstimationPointToPlane (LL.cpp:128-130), restated per SURVEY
 // Appendix B with the deterministic rules of DESIGN.md §5 (shared with oracle/linemod_oracle.py).
 //
-// Six launches per batch of hypotheses, no host round trip in between:
+// One stream of launches per batch of hypotheses, no host round trip in between:
 //   k_icp_bbox     bounding box of modelDepth > 0                                   (LL.cpp:43-50)
 //   k_icp_points   dilated mask, back-projection, raster-order compaction, centroids (LL.cpp:52-104)
 //   k_icp_voxel    VoxelDownSample: 64-bit (voxel, index) keys, bitonic sort in LDS, segment means
@@ -11,10 +11,9 @@
 //   k_icp_knn      one wave per target point: ring search over the columns, the k nearest in
 //                  (distance, index) order, cumulants accumulated in that order;
 //   k_icp_normals  covariance + Jacobi eigenvector, one thread per point
-//   k_icp_loop     one 1024-thread workgroup per hypothesis, all <= 30 iterations in one launch:
-//                  exact nearest neighbour through the grid (search radius = distance to the previous
-//                  correspondence, so later iterations touch a handful of candidates), 29 double sums
-//                  reduced by wave shuffles + LDS, 6x6 LU, Rz*Ry*Rx update, convergence test.
+//   k_icp_search / k_icp_solve, once per ICP evaluation (<= 31): exact nearest neighbours through the
+//                  grid (search radius = distance to the previous correspondence), 29 double sums by a
+//                  halving wave reduction, then 6x6 LU, Rz*Ry*Rx update and the convergence test.
 // All arithmetic is double like Open3D's (f64 VALU; nothing here is a dense contraction, so no MFMA).
 // The grid only prunes: candidate distances are the same expression the oracle evaluates and ties go
 // to the lower original index, so correspondences equal a brute-force search.
@@ -758,8 +757,18 @@ k_icp_normals(IcpBuffers B) {
 }
 
 // ---- RegistrationICP ------------------------------------------------------------------------------
-// 29 sums per iteration: 21 JtJ (upper triangle) + 6 Jtr + sum d^2 + count, carried as 32 for the halving reduction
-constexpr int kLoopWG = 512;        // workgroup of k_icp_loop (256 VGPRs per lane: the 32 running sums never spill)
+// One ICP evaluation = two launches:
+//   k_icp_search  grid (G, hypotheses): workgroup g owns a slice of the source points.  It applies the
+//                 pending update to its slice (pcd.Transform), finds the correspondences (below) and
+//                 writes its 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded);
+//   k_icp_solve   one wave per hypothesis: adds the G partials in fixed order, applies Open3D's
+//                 convergence test, solves the 6x6 system and publishes the update.
+// Splitting a hypothesis over G workgroups is what fills the chip at the batch sizes of the pipeline
+// (16 hypotheses x 16 slices = 256 workgroups = one per CU); the stream order of the launches is the
+// only synchronisation, converged hypotheses return at once.
+constexpr int kSearchWG = 256;      // workgroup of k_icp_search
+constexpr double kFarMargin = 1.5;  // search radius (x max_dist) of a source point that has no correspondence
+constexpr int kClasses = 8;         // search-cost classes of the queue (by overlapped grid columns)
 constexpr int kLoopQueue = 4096;    // source points per round whose correspondence needs a grid search
 
 // Gaussian elimination with partial pivoting, A x = b (6x6), on LDS arrays (one thread; keeps the
@@ -813,26 +822,22 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
     return v[0] + shfl_xor_d(v[0], 1);
 }
 
-// One workgroup per hypothesis.  Per iteration:
+// Correspondences of one slice (GetRegistrationResultAndCorrespondences):
 //   A1  every source point first re-measures its previous correspondence j: with d = |p - t_j|^2 and
 //       sep2(j) = squared distance from t_j to its nearest other target (from k_icp_knn), 4 d < sep2(j)
 //       proves by the triangle inequality that t_j is still the unique nearest neighbour — no search.
-//       The others are queued in LDS;
-//   A2  queued points search the grid columns overlapping the square of half-width sqrt(min(d, r^2))
-//       (dense over the workgroup: no lane waits for another lane's search);
-//   B   29 sums: halving wave reduction + LDS across the 16 waves;   C  6x6 solve + update (one thread);
-//   D   pcd.Transform(update).
+//       A point without correspondence carries a lower bound on its nearest-target distance (what its
+//       last search saw, minus its motion since); while that exceeds max_dist it needs no search either.
+//       The other points are queued in LDS, ordered by the number of grid columns their search cube
+//       overlaps, so that the 64 searches a wave runs in lock-step cost about the same;
+//   A2  queued points search the cells overlapping the cube of half-width sqrt(min(d_prev, r^2)):
+//       exact lexicographic minimum of (d, original index).
 template <bool kLds>
-static __device__ __forceinline__ void icp_loop_body(const IcpBuffers& B, IcpState& S, const int h, TgtRec* s_tgt, unsigned short* s_cs, int* s_q,
-                                                     const double max_dist, const int max_iter, const double rel_tol) {
-    __shared__ double s_part[kLoopWG / 64][32];
-    __shared__ double s_sum[32];
-    __shared__ double s_upd[12];     // 3x4 update
-    __shared__ int s_stop, s_nq;
-    __shared__ double s_T[16];
-    __shared__ double s_fit, s_rmse;
-    __shared__ int s_iters, s_ncorr;
-    __shared__ double s_A[6][6], s_b[6], s_x[6];
+static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
+                                                       unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist) {
+    __shared__ double s_part[kSearchWG / 64][32];
+    __shared__ int s_nq;
+    __shared__ int s_cnt[kClasses], s_cur[kClasses];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Src = B.src + (size_t)h * B.cap * 3;
@@ -843,31 +848,46 @@ static __device__ __forceinline__ void icp_loop_body(const IcpBuffers& B, IcpSta
     const int* cs = B.cell_start + (size_t)h * kIcpCells;
     double* P = B.work + (size_t)h * B.cap * 3;
     int* prev = B.prev_nn + (size_t)h * B.cap;
+    double* lb = B.nn_lb + (size_t)h * B.cap;
     const int ns = S.n_src, nt = S.n_tgt;
     const int gx = S.gx, gy = S.gy, gz = S.gz;
     const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell;
     const double r2 = max_dist * max_dist;
+    const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
+    const int G = gridDim.x, g = blockIdx.x;
+    const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
 
     if (kLds) {
-        for (int j = tid; j < nt; j += kLoopWG) {
+        for (int j = tid; j < nt; j += kSearchWG) {
             TgtRec r;
             r.x = T[3 * (size_t)j]; r.y = T[3 * (size_t)j + 1]; r.z = T[3 * (size_t)j + 2]; r.orig = orig[j]; r.pad = 0;
             s_tgt[j] = r;
         }
-        for (int c = tid; c <= gx * gy * gz; c += kLoopWG) s_cs[c] = (unsigned short)cs[c];
+        for (int c = tid; c <= gx * gy * gz; c += kSearchWG) s_cs[c] = (unsigned short)cs[c];
     }
-    if (tid < 16) s_T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
-    __syncthreads();
-    if (tid < 3) s_T[4 * tid + 3] = S.init[tid];
-    if (tid == 0) { s_stop = 0; s_iters = 0; s_fit = 0; s_rmse = 0; s_ncorr = 0; s_nq = 0; }
-    __syncthreads();
-    // pcd.Transform(init)
-    for (int i = tid; i < ns; i += kLoopWG) {
-        const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
-        P[3 * (size_t)i] = s_T[0] * x + s_T[1] * y + s_T[2] * z + s_T[3];
-        P[3 * (size_t)i + 1] = s_T[4] * x + s_T[5] * y + s_T[6] * z + s_T[7];
-        P[3 * (size_t)i + 2] = s_T[8] * x + s_T[9] * y + s_T[10] * z + s_T[11];
-        prev[i] = -1;
+    // pcd.Transform: the initial guess at evaluation 0, the pending update afterwards
+    if (it == 0) {
+        const double t0 = S.init[0], t1 = S.init[1], t2 = S.init[2];
+        for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
+            const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
+            P[3 * (size_t)i] = 1.0 * x + 0.0 * y + 0.0 * z + t0;
+            P[3 * (size_t)i + 1] = 0.0 * x + 1.0 * y + 0.0 * z + t1;
+            P[3 * (size_t)i + 2] = 0.0 * x + 0.0 * y + 1.0 * z + t2;
+            prev[i] = -1;
+            lb[i] = 0.0;
+        }
+    } else {
+        double U[12];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) U[a] = S.upd[a];
+        for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
+            const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+            const double nx = U[0] * x + U[1] * y + U[2] * z + U[3];
+            const double ny = U[4] * x + U[5] * y + U[6] * z + U[7];
+            const double nz = U[8] * x + U[9] * y + U[10] * z + U[11];
+            P[3 * (size_t)i] = nx; P[3 * (size_t)i + 1] = ny; P[3 * (size_t)i + 2] = nz;
+            if (prev[i] < 0) lb[i] -= sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12;
+        }
     }
     __syncthreads();
 
@@ -878,182 +898,234 @@ static __device__ __forceinline__ void icp_loop_body(const IcpBuffers& B, IcpSta
     auto tgt_orig = [&](int j) { return kLds ? s_tgt[j].orig : orig[j]; };
     auto cell_at = [&](int c) { return kLds ? (int)s_cs[c] : cs[c]; };
 
-    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int it = 0; it <= max_iter; ++it) {
-        long long c0 = (long long)__builtin_amdgcn_s_memtime();
-        // --- GetRegistrationResultAndCorrespondences ---
-        for (int base = 0; base < ns; base += kLoopQueue) {
-            const int end = base + kLoopQueue < ns ? base + kLoopQueue : ns;
-            // A1: keep correspondences that are provably unchanged, queue the other points
-            for (int i0 = base; i0 < end; i0 += kLoopWG) {
-                const int i = i0 + tid;
-                const int pj = i < end ? prev[i] : -2;
-                bool need = i < end;
+    for (int base = i_lo; base < i_hi; base += kLoopQueue) {
+        const int end = base + kLoopQueue < i_hi ? base + kLoopQueue : i_hi;
+        if (tid < kClasses) s_cnt[tid] = 0;
+        __syncthreads();
+        for (int i0 = base; i0 < end; i0 += kSearchWG) {
+            const int i = i0 + tid;
+            const int pj = i < end ? prev[i] : -2;
+            bool need = i < end;
+            int cls = kClasses;
+            if (need) {
+                const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+                double bd0 = far2;
                 if (pj >= 0) {
-                    const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
                     double qx, qy, qz;
                     tgt_xyz(pj, qx, qy, qz);
                     const double d = sqdist(px, py, pz, qx, qy, qz);
                     need = !(d < r2 && 4.0 * d * (1.0 + 1e-9) < cov[(size_t)pj * kIcpCovStride + 10]);
+                    bd0 = d < r2 ? d : r2;
+                } else {
+                    need = !(lb[i] > lb_need);          // nearest target provably beyond max_dist: still no correspondence
                 }
-                // one LDS atomic per wave reserves the slots of all its queued points
-                const unsigned long long mask = __ballot(need);
-                if (mask) {
-                    int qbase = 0;
-                    if (lane == (int)__ffsll((long long)mask) - 1) qbase = atomicAdd(&s_nq, __popcll(mask));
-                    qbase = __shfl(qbase, (int)__ffsll((long long)mask) - 1, 64);
-                    if (need) s_q[qbase + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+                if (need) {
+                    const double rad = sqrt(bd0) * (1.0 + 1e-9) + 1e-12;
+                    const int nxc = grid_coord(px + rad, minx, inv, gx) - grid_coord(px - rad, minx, inv, gx) + 1;
+                    const int nyc = grid_coord(py + rad, miny, inv, gy) - grid_coord(py - rad, miny, inv, gy) + 1;
+                    const int ncol = nxc * nyc;
+                    cls = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 6 ? 3 : ncol <= 9 ? 4 : ncol <= 16 ? 5 : ncol <= 25 ? 6 : 7;
                 }
             }
-            __syncthreads();
-            const int nq = s_nq;
-            const long long ca = (long long)__builtin_amdgcn_s_memtime();
-            clk[6] += nq;
-            // A2: best = lexicographic minimum of (d, original index) over targets with d < r2
-            for (int q = tid; q < nq; q += kLoopWG) {
-                const int i = s_q[q];
-                const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
-                double bd = r2;
-                int bo = -1, bp = -1;
-                const int pj = prev[i];
-                if (pj >= 0) {
-                    double qx, qy, qz;
-                    tgt_xyz(pj, qx, qy, qz);
-                    const double d = sqdist(px, py, pz, qx, qy, qz);
-                    if (d < bd) { bd = d; bo = tgt_orig(pj); bp = pj; }
+            if (i < end) s_cls[i - base] = (unsigned char)cls;
+#pragma unroll
+            for (int c = 0; c < kClasses; ++c) {
+                const unsigned long long m = __ballot(cls == c);
+                if (m && lane == 0) atomicAdd(&s_cnt[c], __popcll(m));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int c = 0; c < kClasses; ++c) { s_cur[c] = run; run += s_cnt[c]; }
+            s_nq = run;
+        }
+        __syncthreads();
+        for (int i0 = base; i0 < end; i0 += kSearchWG) {
+            const int i = i0 + tid;
+            const int cls = i < end ? (int)s_cls[i - base] : kClasses;
+#pragma unroll
+            for (int c = 0; c < kClasses; ++c) {
+                const unsigned long long m = __ballot(cls == c);
+                if (m) {                                      // one LDS atomic per wave and class reserves the slots
+                    int qb = 0;
+                    if (lane == 0) qb = atomicAdd(&s_cur[c], __popcll(m));
+                    qb = __shfl(qb, 0, 64);
+                    if (cls == c) s_q[qb + __popcll(m & ((1ull << lane) - 1ull))] = i;
                 }
-                if (nt > 0 && px == px && py == py && pz == pz) {
-                    // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the cells overlapping it suffice
-                    const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
-                    const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
-                    const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
-                    const int za = grid_coord(pz - rad, minz, inv, gz), zb = grid_coord(pz + rad, minz, inv, gz);
-                    for (int y = ya; y <= yb; ++y)
-                        for (int x = xa; x <= xb; ++x) {
+            }
+        }
+        __syncthreads();
+        const int nq = s_nq;
+        for (int q = tid; q < nq; q += kSearchWG) {
+            const int i = s_q[q];
+            const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+            const int pj = prev[i];
+            // a point without correspondence searches 1.5 x max_dist once: the distance it finds (or the search
+            // radius) minus its later motion is the lower bound that keeps it out of the queue (A1)
+            const double bound2 = pj >= 0 ? r2 : far2;
+            double bd = bound2;
+            int bo = -1, bp = -1;
+            if (pj >= 0) {
+                double qx, qy, qz;
+                tgt_xyz(pj, qx, qy, qz);
+                const double d = sqdist(px, py, pz, qx, qy, qz);
+                if (d < bd) { bd = d; bo = tgt_orig(pj); bp = pj; }
+            }
+            if (nt > 0 && px == px && py == py && pz == pz) {
+                // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the cells overlapping it suffice
+                const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
+                const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
+                const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
+                const int za = grid_coord(pz - rad, minz, inv, gz), zb = grid_coord(pz + rad, minz, inv, gz);
+                const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
+                int x = xa, y = ya;
+                for (int r0 = 0; r0 < ncol; r0 += 4) {
+                    int ca4[4], cb4[4];                           // four columns per trip: their bounds load independently
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ca4[u] = 0; cb4[u] = 0;
+                        if (r0 + u < ncol) {
                             const int c = (y * gx + x) * gz;
-                            const int a = cell_at(c + za), b = cell_at(c + zb + 1);
-                            for (int j = a; j < b; ++j) {
+                            ca4[u] = cell_at(c + za); cb4[u] = cell_at(c + zb + 1);
+                            if (++x > xb) { x = xa; ++y; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int a = ca4[u], b = cb4[u];
+                        // four candidates per trip (independent LDS reads in flight); indices past the run are
+                        // clamped to its last point, which only re-tests a candidate
+                        for (int j0 = a; j0 < b; j0 += 4) {
+                            double d4[4];
+                            int j4[4];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                j4[v] = j0 + v < b ? j0 + v : b - 1;
                                 double qx, qy, qz;
-                                tgt_xyz(j, qx, qy, qz);
-                                const double d = sqdist(px, py, pz, qx, qy, qz);
+                                tgt_xyz(j4[v], qx, qy, qz);
+                                d4[v] = sqdist(px, py, pz, qx, qy, qz);
+                            }
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int j = j4[v];
+                                const double d = d4[v];
                                 if (d < bd) { bd = d; bo = tgt_orig(j); bp = j; }
                                 else if (d == bd && bp >= 0 && bp != j) { const int o = tgt_orig(j); if (o < bo) { bo = o; bp = j; } }
                             }
                         }
+                    }
                 }
-                prev[i] = bp;
             }
-            __syncthreads();
-            clk[4] += (long long)__builtin_amdgcn_s_memtime() - ca;
-            if (tid == 0) s_nq = 0;
+            if (bp >= 0 && !(bd < r2)) bp = -1;              // seen, but not a correspondence (d^2 < max_dist^2 required)
+            prev[i] = bp;
+            if (bp < 0) lb[i] = sqrt(bd);                     // every target closer than sqrt(bound2) was visited
         }
         __syncthreads();
-        const long long cb = (long long)__builtin_amdgcn_s_memtime();
-        // --- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences ---
-        double acc[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-        for (int i = tid; i < ns; i += kLoopWG) {
-            const int bp = prev[i];
-            if (bp < 0) continue;
-            const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
-            double qx, qy, qz;
-            tgt_xyz(bp, qx, qy, qz);
-            const double bd = sqdist(px, py, pz, qx, qy, qz);
-            const double nx = N[3 * (size_t)bp], ny = N[3 * (size_t)bp + 1], nz = N[3 * (size_t)bp + 2];
-            const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
-            const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-            acc[27] += bd;
-            acc[28] += 1.0;
-        }
-        long long c1 = (long long)__builtin_amdgcn_s_memtime();
-        clk[0] += c1 - c0;
-        clk[5] += c1 - cb;
-        {
-            const double v = wave_reduce32(acc, lane);
-            if ((lane & 1) == 0) s_part[wave][lane >> 1] = v;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            double v = 0;
-            for (int w = 0; w < kLoopWG / 64; ++w) v += s_part[w][tid];
-            s_sum[tid] = v;
-        }
-        __syncthreads();
-        long long c2 = (long long)__builtin_amdgcn_s_memtime();
-        clk[1] += c2 - c1;
-        if (tid == 0) {
-            const int ncorr = (int)s_sum[28];
-            const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
-            const double rmse = ncorr ? sqrt(s_sum[27] / (double)ncorr) : 0.0;
-            if (it > 0 && fabs(s_fit - fit) < rel_tol && fabs(s_rmse - rmse) < rel_tol) s_stop = 1;
-            s_fit = fit; s_rmse = rmse; s_ncorr = ncorr;
-            if (it == max_iter) s_stop = 1;
-            if (!s_stop) {
-                // TransformationEstimationPointToPlane::ComputeTransformation
-                double (*A)[6] = s_A;
-                double *b = s_b, *x = s_x;
-                int k = 0;
-                for (int a = 0; a < 6; ++a)
-                    for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
-                for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
-                double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-                if (ncorr >= 6 && solve6(A, b, x)) {
-                    double sx, cx, sy, cy, sz, cz;
-                    sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
-                    // Rz(x2) * Ry(x1) * Rx(x0)
-                    U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
-                    U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
-                    U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
-                }
-                for (int a = 0; a < 12; ++a) s_upd[a] = U[a];
-                // transformation = update * transformation
-                double Tn[12];
-                for (int r = 0; r < 3; ++r)
-                    for (int c = 0; c < 4; ++c)
-                        Tn[4 * r + c] = U[4 * r] * s_T[c] + U[4 * r + 1] * s_T[4 + c] + U[4 * r + 2] * s_T[8 + c] + (c == 3 ? U[4 * r + 3] : 0.0);
-                for (int a = 0; a < 12; ++a) s_T[a] = Tn[a];
-                s_iters = it + 1;
-            }
-        }
-        __syncthreads();
-        long long c3 = (long long)__builtin_amdgcn_s_memtime();
-        clk[2] += c3 - c2;
-        if (s_stop) break;
-        // pcd.Transform(update)
-        for (int i = tid; i < ns; i += kLoopWG) {
-            const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
-            P[3 * (size_t)i] = s_upd[0] * x + s_upd[1] * y + s_upd[2] * z + s_upd[3];
-            P[3 * (size_t)i + 1] = s_upd[4] * x + s_upd[5] * y + s_upd[6] * z + s_upd[7];
-            P[3 * (size_t)i + 2] = s_upd[8] * x + s_upd[9] * y + s_upd[10] * z + s_upd[11];
-        }
-        __syncthreads();
-        clk[3] += (long long)__builtin_amdgcn_s_memtime() - c3;
     }
-    if (tid == 0) {
-        for (int a = 0; a < 8; ++a) S.clk[a] = clk[a];
-        for (int a = 0; a < 16; ++a) S.T[a] = s_T[a];
-        S.fitness = s_fit; S.rmse = s_rmse; S.iterations = s_iters; S.n_corr = s_ncorr;
+    // --- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences of the slice ---
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
+        const int bp = prev[i];
+        if (bp < 0) continue;
+        const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
+        double qx, qy, qz;
+        tgt_xyz(bp, qx, qy, qz);
+        const double bd = sqdist(px, py, pz, qx, qy, qz);
+        const double nx = N[3 * (size_t)bp], ny = N[3 * (size_t)bp + 1], nz = N[3 * (size_t)bp + 2];
+        const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+        const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+        acc[27] += bd;
+        acc[28] += 1.0;
+    }
+    {
+        const double v = wave_reduce32(acc, lane);
+        if ((lane & 1) == 0) s_part[wave][lane >> 1] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double v = 0;
+        for (int w = 0; w < kSearchWG / 64; ++w) v += s_part[w][tid];
+        B.partial[((size_t)h * kIcpMaxSplit + g) * 32 + tid] = v;
     }
 }
 
-__global__ void __launch_bounds__(kLoopWG)
-k_icp_loop(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
+__global__ void __launch_bounds__(kSearchWG)
+k_icp_search(IcpBuffers B, int it, double max_dist) {
     __shared__ TgtRec s_tgt[kLoopLdsPts];
     __shared__ unsigned short s_cs[kIcpCells];
     __shared__ int s_q[kLoopQueue];
-    const int h = blockIdx.x;
+    __shared__ unsigned char s_cls[kLoopQueue];
+    const int h = blockIdx.y;
     IcpState& S = B.st[h];
-    if (S.status != 0) return;
-    if (S.n_tgt <= kLoopLdsPts) icp_loop_body<true>(B, S, h, s_tgt, s_cs, s_q, max_dist, max_iter, rel_tol);
-    else icp_loop_body<false>(B, S, h, s_tgt, s_cs, s_q, max_dist, max_iter, rel_tol);
+    if (S.status != 0 || S.stop != 0) return;
+    if (S.n_tgt <= kLoopLdsPts) icp_search_body<true>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist);
+    else icp_search_body<false>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist);
+}
+
+// RegistrationICP's loop body after the correspondence step (one wave per hypothesis): fitness / rmse,
+// the relative-change convergence test, TransformationEstimationPointToPlane::ComputeTransformation
+// (6x6 LU with partial pivoting), transformation = update * transformation.
+__global__ void __launch_bounds__(64)
+k_icp_solve(IcpBuffers B, int it, int splits, int max_iter, double rel_tol) {
+    __shared__ double s_sum[32];
+    __shared__ double s_A[6][6], s_b[6], s_x[6];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    IcpState& S = B.st[h];
+    if (S.status != 0 || S.stop != 0) return;
+    if (tid < 32) {
+        double v = 0;
+        for (int g = 0; g < splits; ++g) v += B.partial[((size_t)h * kIcpMaxSplit + g) * 32 + tid];
+        s_sum[tid] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const int ns = S.n_src;
+    const int ncorr = (int)s_sum[28];
+    const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
+    const double rmse = ncorr ? sqrt(s_sum[27] / (double)ncorr) : 0.0;
+    bool stop = false;
+    if (it == 0) {
+        for (int a = 0; a < 16; ++a) S.T[a] = (a % 5 == 0) ? 1.0 : 0.0;
+        S.T[3] = S.init[0]; S.T[7] = S.init[1]; S.T[11] = S.init[2];
+        S.iterations = 0;
+    } else if (fabs(S.fitness - fit) < rel_tol && fabs(S.rmse - rmse) < rel_tol) {
+        stop = true;
+    }
+    S.fitness = fit; S.rmse = rmse; S.n_corr = ncorr;
+    if (it == max_iter) stop = true;
+    if (stop) { S.stop = 1; return; }
+    double (*A)[6] = s_A;
+    double *b = s_b, *x = s_x;
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
+    for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
+    double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if (ncorr >= 6 && solve6(A, b, x)) {
+        double sx, cx, sy, cy, sz, cz;
+        sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
+        // Rz(x2) * Ry(x1) * Rx(x0)
+        U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
+        U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
+        U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
+    }
+    // transformation = update * transformation
+    double Tn[12];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            Tn[4 * r + c] = U[4 * r] * S.T[c] + U[4 * r + 1] * S.T[4 + c] + U[4 * r + 2] * S.T[8 + c] + (c == 3 ? U[4 * r + 3] : 0.0);
+    for (int a = 0; a < 12; ++a) { S.T[a] = Tn[a]; S.upd[a] = U[a]; }
+    S.iterations = it + 1;
 }
 
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
@@ -1066,7 +1138,14 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_knn, dim3(32, count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
-    hipLaunchKernelGGL(k_icp_loop, dim3(count), dim3(kLoopWG), 0, s, B, max_dist, max_iter, rel_tol);
+    // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
+    int splits = 512 / count;
+    if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
+    if (splits < 1) splits = 1;
+    for (int it = 0; it <= max_iter; ++it) {
+        hipLaunchKernelGGL(k_icp_search, dim3(splits, count), dim3(kSearchWG), 0, s, B, it, max_dist);
+        hipLaunchKernelGGL(k_icp_solve, dim3(count), dim3(64), 0, s, B, it, splits, max_iter, rel_tol);
+    }
 }
 
 }  // namespace lm

@@ -12,6 +12,7 @@ namespace lm {
 
 constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 cells per axis ...
 constexpr int kIcpCells = 16384 + 1;              // ... and at most 16384 cells (+1 end marker)
+constexpr int kIcpMaxSplit = 16;                  // workgroups (source slices) per hypothesis in k_icp_search
 constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
 
 struct IcpIn {               // one pose hypothesis (uploaded)
@@ -32,6 +33,9 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     double gminx, gminy, gminz, cell, inv_cell;
     double T[16];            // final transformation_ (row-major)
     double fitness, rmse;    // fitness_, inlier_rmse_
+    int stop;                // RegistrationICP finished (converged or max_iteration)
+    int pad2;
+    double upd[12];          // pending update (3x4), applied to the source cloud by the next k_icp_search
     long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };
 
@@ -54,6 +58,8 @@ struct IcpBuffers {
     double* normals;         // [count][cap][3]  per sorted position
     double* work;            // [count][cap][3]  transformed source cloud
     int* prev_nn;            // [count][cap]     previous correspondence (sorted position) of every source point
+    double* nn_lb;           // [count][cap]     lower bound on the distance to the nearest target of a point without correspondence
+    double* partial;         // [count][kIcpMaxSplit][32] partial sums of one ICP evaluation
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
 };
 
