@@ -11,7 +11,7 @@
 //   k_icp_knn      one wave per target point: ring search over the columns, the k nearest in
 //                  (distance, index) order, cumulants accumulated in that order;
 //   k_icp_normals  covariance + Jacobi eigenvector, one thread per point
-//   k_icp_search / k_icp_solve, once per ICP evaluation (<= 31): exact nearest neighbours through the
+//   k_icp_eval     once per ICP evaluation (<= 31 + 1): exact nearest neighbours through the
 //                  grid (search radius = distance to the previous correspondence), 29 double sums by a
 //                  halving wave reduction, then 6x6 LU, Rz*Ry*Rx update and the convergence test.
 // All arithmetic is double like Open3D's (f64 VALU; nothing here is a dense contraction, so no MFMA).
@@ -358,12 +358,11 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
 
 // ---------------------------------------------------------------------------------------------
 // k_icp_grid: the target cloud binned into a dense 3-D grid (cell edge >= 5 mm, grown until the grid
-// has <= 64 cells per axis and <= 16384 cells), points reordered by (y, x, z cell, original index):
+// has <= 64 cells per axis and <= 16384 cells), points reordered by (x, y, z cell, original index):
 // the cells of one (x, y) column are contiguous, so a search visits one run per column and only the
-// z range it needs.  cell_start[c] = first sorted position of cell c.
+// z range it needs, and an x slab of the grid is one contiguous range of cells and of points (what a
+// source slice stages in LDS).  cell_start[c] = first sorted position of cell c.
 // ---------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int pad; };   // LDS copy of a target point
-
 __global__ void __launch_bounds__(kWG)
 k_icp_grid(IcpBuffers B, int flags) {
     __shared__ unsigned long long s_keys[kSortLds];
@@ -413,7 +412,7 @@ k_icp_grid(IcpBuffers B, int flags) {
         if (i < nt) {
             const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy),
                       cz = grid_coord(T[3 * (size_t)i + 2], minz, inv, gz);
-            key = ((unsigned long long)((cy * gx + cx) * gz + cz) << kIdxBits) | (unsigned long long)i;
+            key = ((unsigned long long)((cx * gy + cy) * gz + cz) << kIdxBits) | (unsigned long long)i;
         }
         if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
@@ -421,11 +420,16 @@ k_icp_grid(IcpBuffers B, int flags) {
     if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort(gk, npad);
     double* Ts = B.tgt_sorted + (size_t)h * B.cap * 3;
     int* orig = B.tgt_orig + (size_t)h * B.cap;
+    TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
+    unsigned short* cs16 = B.cell_start16 + (size_t)h * kIcpCells16;
     for (int p = tid; p < nt; p += kWG) {
         const unsigned long long k = in_lds ? s_keys[p] : gk[p];
         const size_t i = (size_t)(k & ((1ull << kIdxBits) - 1ull));
         Ts[3 * (size_t)p] = T[3 * i]; Ts[3 * (size_t)p + 1] = T[3 * i + 1]; Ts[3 * (size_t)p + 2] = T[3 * i + 2];
         orig[p] = (int)i;
+        TgtRec r;
+        r.x = T[3 * i]; r.y = T[3 * i + 1]; r.z = T[3 * i + 2]; r.orig = (int)i; r.pad = 0;
+        rec[p] = r;
     }
     const int ncell = gx * gy * gz;
     for (int c = tid; c <= ncell; c += kWG) {                       // lower_bound of (c << kIdxBits)
@@ -437,6 +441,7 @@ k_icp_grid(IcpBuffers B, int flags) {
             if (k < want) lo = mid + 1; else hi = mid;
         }
         cs[c] = lo;
+        cs16[c] = (unsigned short)lo;
     }
     if (tid == 0) {
         S.gx = gx; S.gy = gy; S.gz = gz; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
@@ -481,12 +486,10 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * (kKnnWG / 64);
     const int k = knn < nt ? knn : nt;
-    if (kLds) {
-        for (int j = threadIdx.x; j < nt; j += kKnnWG) {
-            TgtRec r;
-            r.x = T[3 * (size_t)j]; r.y = T[3 * (size_t)j + 1]; r.z = T[3 * (size_t)j + 2]; r.orig = orig[j]; r.pad = 0;
-            s_tgt[j] = r;
-        }
+    if (kLds) {                                                  // 16-byte copies of the prepared records
+        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap);
+        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
+        for (int j = threadIdx.x; j < nt * 2; j += kKnnWG) dst[j] = src[j];
         __syncthreads();
     }
     auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
@@ -517,7 +520,7 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
                 int a = 0, len = 0;
                 if (r < nruns) {
                     const int y = ya + r / nx, x = xa + r % nx;
-                    const int c = (y * gx + x) * gz;
+                    const int c = (x * gy + y) * gz;
                     a = cs[c + za];
                     len = cs[c + zb + 1] - a;
                 }
@@ -553,7 +556,7 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
             } else {
                 for (int y = ya; y <= yb; ++y)
                     for (int x = xa; x <= xb; ++x) {
-                        const int c = (y * gx + x) * gz;
+                        const int c = (x * gy + y) * gz;
                         const int a = cs[c + za], b = cs[c + zb + 1];
                         for (int j0 = a; j0 < b; j0 += 64) {
                             const int j = j0 + lane;
@@ -649,7 +652,7 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
                 int bo = INT_MAX, bp = -1;
                 for (int y = ya; y <= yb; ++y)
                     for (int x = xa; x <= xb; ++x) {
-                        const int c = (y * gx + x) * gz;
+                        const int c = (x * gy + y) * gz;
                         const int a = cs[c + za], b = cs[c + zb + 1];
                         for (int j = a + lane; j < b; j += 64) {
                             double qx, qy, qz;
@@ -757,19 +760,16 @@ k_icp_normals(IcpBuffers B) {
 }
 
 // ---- RegistrationICP ------------------------------------------------------------------------------
-// One ICP evaluation = two launches:
-//   k_icp_search  grid (G, hypotheses): workgroup g owns a slice of the source points.  It applies the
-//                 pending update to its slice (pcd.Transform), finds the correspondences (below) and
-//                 writes its 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded);
-//   k_icp_solve   one wave per hypothesis: adds the G partials in fixed order, applies Open3D's
-//                 convergence test, solves the 6x6 system and publishes the update.
-// Splitting a hypothesis over G workgroups is what fills the chip at the batch sizes of the pipeline
-// (16 hypotheses x 16 slices = 256 workgroups = one per CU); the stream order of the launches is the
-// only synchronisation, converged hypotheses return at once.
+// One launch (k_icp_eval) per ICP evaluation, grid (G, hypotheses): workgroup g owns a slice of the
+// source points.  Splitting a hypothesis over G workgroups is what fills the chip at the batch sizes of
+// the pipeline (16 hypotheses x 16 slices = 256 workgroups = one per CU); the stream order of the
+// launches is the only synchronisation, converged hypotheses return at once.
 constexpr int kSearchWG = 256;      // workgroup of k_icp_search
 constexpr double kFarMargin = 1.5;  // search radius (x max_dist) of a source point that has no correspondence
 constexpr int kClasses = 8;         // search-cost classes of the queue (by overlapped grid columns)
-constexpr int kLoopQueue = 4096;    // source points per round whose correspondence needs a grid search
+constexpr int kLoopQueue = 1024;    // source points per round whose correspondence needs a grid search
+constexpr int kSlabPts = 1024;      // target points of a slice's x slab staged in LDS (32-byte records)
+constexpr int kSlabCells = 4096;    // cells of that slab (16-bit starts)
 
 // Gaussian elimination with partial pivoting, A x = b (6x6), on LDS arrays (one thread; keeps the
 // dynamically indexed rows out of scratch).  Returns false if singular / non-finite.
@@ -822,24 +822,111 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
     return v[0] + shfl_xor_d(v[0], 1);
 }
 
-// Correspondences of one slice (GetRegistrationResultAndCorrespondences):
+// One ICP evaluation of one source slice.  Prologue (evaluations >= 1, every workgroup of the hypothesis
+// redundantly, so that no second launch or inter-workgroup barrier is needed): add the G partials of
+// the previous evaluation in fixed order, Open3D's relative-change convergence test,
+// TransformationEstimationPointToPlane::ComputeTransformation (6x6 LU with partial pivoting),
+// transformation = update * transformation (workgroup 0 records it).  Then pcd.Transform on the slice and
+// the correspondences (GetRegistrationResultAndCorrespondences):
 //   A1  every source point first re-measures its previous correspondence j: with d = |p - t_j|^2 and
 //       sep2(j) = squared distance from t_j to its nearest other target (from k_icp_knn), 4 d < sep2(j)
 //       proves by the triangle inequality that t_j is still the unique nearest neighbour — no search.
 //       A point without correspondence carries a lower bound on its nearest-target distance (what its
 //       last search saw, minus its motion since); while that exceeds max_dist it needs no search either.
 //       The other points are queued in LDS, ordered by the number of grid columns their search cube
-//       overlaps, so that the 64 searches a wave runs in lock-step cost about the same;
+//       overlaps, so that the searches a wave runs in lock-step cost about the same;
 //   A2  queued points search the cells overlapping the cube of half-width sqrt(min(d_prev, r^2)):
-//       exact lexicographic minimum of (d, original index).
-template <bool kLds>
-static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
-                                                       unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist) {
+//       exact lexicographic minimum of (d, original index); 1, 2 or 4 lanes share a point's columns
+//       when the slice has fewer points than the workgroup has lanes;
+// and the slice's 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded) for the next prologue.
+static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
+                                                     unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist,
+                                                     const int max_iter, const double rel_tol) {
     __shared__ double s_part[kSearchWG / 64][32];
-    __shared__ int s_nq;
+    __shared__ double s_sum[32];
+    __shared__ double s_U[12];
+    __shared__ double s_A[6][6], s_b[6], s_x[6];
+    __shared__ int s_nq, s_stop;
     __shared__ int s_cnt[kClasses], s_cur[kClasses];
+    __shared__ double s_xmm[kSearchWG / 64][2];
+    __shared__ double s_red8[8][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x, g = blockIdx.x;
+    const int ns = S.n_src, nt = S.n_tgt;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+
+    // ---- prologue: finish evaluation it - 1 ----
+    if (it > 0) {
+        const double* part = B.partial + (((size_t)((it - 1) & 1) * B.count + h) * kIcpMaxSplit) * 32;
+        {   // fixed association: 8 interleaved groups of <= 8 slices each, loads issued together
+            const int k = tid & 31, grp = tid >> 5;
+            double a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int gg = grp + 8 * u; a8[u] = gg < G ? part[(size_t)gg * 32 + k] : 0.0; }
+            double v = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += a8[u];
+            s_red8[grp][k] = v;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s_red8[w][tid];
+            s_sum[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int ncorr = (int)s_sum[28];
+            const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
+            const double rmse = ncorr ? sqrt(s_sum[27] / (double)ncorr) : 0.0;
+            bool stop = false;
+            if (it > 1 && fabs(S.fit_hist[it & 1] - fit) < rel_tol && fabs(S.rmse_hist[it & 1] - rmse) < rel_tol) stop = true;
+            if (it - 1 == max_iter) stop = true;
+            if (g == 0) {
+                S.fit_hist[(it - 1) & 1] = fit; S.rmse_hist[(it - 1) & 1] = rmse;
+                S.fitness = fit; S.rmse = rmse; S.n_corr = ncorr;
+                if (stop) S.stop = 1;
+            }
+            s_stop = stop ? 1 : 0;
+            if (!stop) {
+                double (*A)[6] = s_A;
+                double *b = s_b, *x = s_x;
+                int k = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
+                for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
+                double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                if (ncorr >= 6 && solve6(A, b, x)) {
+                    double sx, cx, sy, cy, sz, cz;
+                    sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
+                    // Rz(x2) * Ry(x1) * Rx(x0)
+                    U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
+                    U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
+                    U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
+                }
+                for (int a = 0; a < 12; ++a) s_U[a] = U[a];
+                if (g == 0) {                               // transformation = update * transformation
+                    double Tn[12];
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 4; ++c)
+                            Tn[4 * r + c] = U[4 * r] * S.T[c] + U[4 * r + 1] * S.T[4 + c] + U[4 * r + 2] * S.T[8 + c] + (c == 3 ? U[4 * r + 3] : 0.0);
+                    for (int a = 0; a < 12; ++a) S.T[a] = Tn[a];
+                    S.iterations = it;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_stop) return;
+    } else if (g == 0 && tid == 0) {
+        for (int a = 0; a < 16; ++a) S.T[a] = (a % 5 == 0) ? 1.0 : 0.0;
+        S.T[3] = S.init[0]; S.T[7] = S.init[1]; S.T[11] = S.init[2];
+        S.iterations = 0;
+    }
+    if (it > max_iter) return;                              // the last launch only finishes evaluation max_iter
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+
     const double* Src = B.src + (size_t)h * B.cap * 3;
     const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
     const double* N = B.normals + (size_t)h * B.cap * 3;
@@ -849,37 +936,33 @@ static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpS
     double* P = B.work + (size_t)h * B.cap * 3;
     int* prev = B.prev_nn + (size_t)h * B.cap;
     double* lb = B.nn_lb + (size_t)h * B.cap;
-    const int ns = S.n_src, nt = S.n_tgt;
     const int gx = S.gx, gy = S.gy, gz = S.gz;
     const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell;
     const double r2 = max_dist * max_dist;
     const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
-    const int G = gridDim.x, g = blockIdx.x;
     const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
+    // lanes per queued point: spread the columns of a search over idle lanes
+    const int lpp_shift = (i_hi - i_lo) * 4 <= kSearchWG ? 2 : (i_hi - i_lo) * 2 <= kSearchWG ? 1 : 0;
+    const int lpp = 1 << lpp_shift, sub = tid & (lpp - 1);
 
-    if (kLds) {
-        for (int j = tid; j < nt; j += kSearchWG) {
-            TgtRec r;
-            r.x = T[3 * (size_t)j]; r.y = T[3 * (size_t)j + 1]; r.z = T[3 * (size_t)j + 2]; r.orig = orig[j]; r.pad = 0;
-            s_tgt[j] = r;
-        }
-        for (int c = tid; c <= gx * gy * gz; c += kSearchWG) s_cs[c] = (unsigned short)cs[c];
-    }
-    // pcd.Transform: the initial guess at evaluation 0, the pending update afterwards
+    // pcd.Transform: the initial guess at evaluation 0, the update afterwards
+    double xmn = 1e300, xmx = -1e300;
     if (it == 0) {
         const double t0 = S.init[0], t1 = S.init[1], t2 = S.init[2];
         for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
             const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
-            P[3 * (size_t)i] = 1.0 * x + 0.0 * y + 0.0 * z + t0;
+            const double nx = 1.0 * x + 0.0 * y + 0.0 * z + t0;
+            P[3 * (size_t)i] = nx;
             P[3 * (size_t)i + 1] = 0.0 * x + 1.0 * y + 0.0 * z + t1;
             P[3 * (size_t)i + 2] = 0.0 * x + 0.0 * y + 1.0 * z + t2;
             prev[i] = -1;
             lb[i] = 0.0;
+            xmn = fmin(xmn, nx); xmx = fmax(xmx, nx);
         }
     } else {
         double U[12];
 #pragma unroll
-        for (int a = 0; a < 12; ++a) U[a] = S.upd[a];
+        for (int a = 0; a < 12; ++a) U[a] = s_U[a];
         for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
             const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
             const double nx = U[0] * x + U[1] * y + U[2] * z + U[3];
@@ -887,16 +970,42 @@ static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpS
             const double nz = U[8] * x + U[9] * y + U[10] * z + U[11];
             P[3 * (size_t)i] = nx; P[3 * (size_t)i + 1] = ny; P[3 * (size_t)i + 2] = nz;
             if (prev[i] < 0) lb[i] -= sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12;
+            xmn = fmin(xmn, nx); xmx = fmax(xmx, nx);
         }
     }
+    // the x slab of the grid this slice can reach (every search radius is <= 1.5 max_dist): a contiguous range of
+    // cells [c0, c1] and of sorted target points [p0, p1), staged in LDS when it fits
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { xmn = fmin(xmn, shfl_xor_d(xmn, o)); xmx = fmax(xmx, shfl_xor_d(xmx, o)); }
+    if (lane == 0) { s_xmm[wave][0] = xmn; s_xmm[wave][1] = xmx; }
     __syncthreads();
+    for (int w = 0; w < kSearchWG / 64; ++w) { xmn = fmin(xmn, s_xmm[w][0]); xmx = fmax(xmx, s_xmm[w][1]); }
+    const int xlo = grid_coord(xmn - far * 1.001, minx, inv, gx), xhi = grid_coord(xmx + far * 1.001, minx, inv, gx);
+    const int c0 = xlo * gy * gz, c1 = (xhi + 1) * gy * gz;
+    const int c0a = c0 & ~7;                                  // 16-byte aligned start of the table copy
+    const int p0 = cs[c0], p1 = cs[c1];
+    const int np = p1 - p0;
+    const bool kLds = np <= kSlabPts && c1 - c0a + 1 <= kSlabCells && nt < 65536;
+    if (kLds) {                                              // 16-byte copies of the prepared records / 16-bit cell table
+        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap + p0);
+        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
+        for (int j = tid; j < np * 2; j += kSearchWG) dst[j] = src[j];
+        const uint4* csrc = reinterpret_cast<const uint4*>(B.cell_start16 + (size_t)h * kIcpCells16 + c0a);
+        uint4* cdst = reinterpret_cast<uint4*>(s_cs);
+        for (int j = tid; j < (c1 - c0a + 8) / 8; j += kSearchWG) cdst[j] = csrc[j];
+    }
+    __syncthreads();
+    const long long t2 = (long long)__builtin_amdgcn_s_memtime();
+    long long t_a2 = 0;
 
+    // target point j (sorted position): from the staged slab when it is inside (always, for the candidates of a search;
+    // a previous correspondence may have been left behind by a large update)
     auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
-        if (kLds) { const TgtRec& r = s_tgt[j]; x = r.x; y = r.y; z = r.z; }
+        if (kLds && (unsigned)(j - p0) < (unsigned)np) { const TgtRec& r = s_tgt[j - p0]; x = r.x; y = r.y; z = r.z; }
         else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
     };
-    auto tgt_orig = [&](int j) { return kLds ? s_tgt[j].orig : orig[j]; };
-    auto cell_at = [&](int c) { return kLds ? (int)s_cs[c] : cs[c]; };
+    auto tgt_orig = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].orig : orig[j]; };
+    auto cell_at = [&](int c) { return kLds ? (int)s_cs[c - c0a] : cs[c]; };
 
     for (int base = i_lo; base < i_hi; base += kLoopQueue) {
         const int end = base + kLoopQueue < i_hi ? base + kLoopQueue : i_hi;
@@ -957,38 +1066,42 @@ static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpS
         }
         __syncthreads();
         const int nq = s_nq;
-        for (int q = tid; q < nq; q += kSearchWG) {
-            const int i = s_q[q];
+        const long long ta = (long long)__builtin_amdgcn_s_memtime();
+        for (int q0 = 0; q0 < nq; q0 += kSearchWG >> lpp_shift) {
+            const int q = q0 + (tid >> lpp_shift);
+            const bool active = q < nq;
+            const int i = active ? s_q[q] : i_lo;
             const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
             const int pj = prev[i];
             // a point without correspondence searches 1.5 x max_dist once: the distance it finds (or the search
             // radius) minus its later motion is the lower bound that keeps it out of the queue (A1)
             const double bound2 = pj >= 0 ? r2 : far2;
             double bd = bound2;
-            int bo = -1, bp = -1;
+            int bo = INT_MAX, bp = -1;
             if (pj >= 0) {
                 double qx, qy, qz;
                 tgt_xyz(pj, qx, qy, qz);
                 const double d = sqdist(px, py, pz, qx, qy, qz);
                 if (d < bd) { bd = d; bo = tgt_orig(pj); bp = pj; }
             }
-            if (nt > 0 && px == px && py == py && pz == pz) {
+            if (active && nt > 0 && px == px && py == py && pz == pz) {
                 // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the cells overlapping it suffice
                 const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
                 const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
                 const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
                 const int za = grid_coord(pz - rad, minz, inv, gz), zb = grid_coord(pz + rad, minz, inv, gz);
                 const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
-                int x = xa, y = ya;
-                for (int r0 = 0; r0 < ncol; r0 += 4) {
+                const float inv_nxc = 1.0f / (float)nxc;
+                for (int r0 = sub * 4; r0 < ncol; r0 += 4 * lpp) {
                     int ca4[4], cb4[4];                           // four columns per trip: their bounds load independently
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         ca4[u] = 0; cb4[u] = 0;
-                        if (r0 + u < ncol) {
-                            const int c = (y * gx + x) * gz;
+                        const int r = r0 + u;
+                        if (r < ncol) {
+                            const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
+                            const int c = ((xa + (r - yy * nxc)) * gy + ya + yy) * gz;
                             ca4[u] = cell_at(c + za); cb4[u] = cell_at(c + zb + 1);
-                            if (++x > xb) { x = xa; ++y; }
                         }
                     }
 #pragma unroll
@@ -1017,12 +1130,21 @@ static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpS
                     }
                 }
             }
-            if (bp >= 0 && !(bd < r2)) bp = -1;              // seen, but not a correspondence (d^2 < max_dist^2 required)
-            prev[i] = bp;
-            if (bp < 0) lb[i] = sqrt(bd);                     // every target closer than sqrt(bound2) was visited
+            for (int off = 1; off < lpp; off <<= 1) {         // combine the lanes that shared the point
+                const double od = shfl_xor_d(bd, off);
+                const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
+                if (op >= 0 && (od < bd || (od == bd && oo < bo))) { bd = od; bo = oo; bp = op; }
+            }
+            if (active && sub == 0) {
+                if (bp >= 0 && !(bd < r2)) bp = -1;          // seen, but not a correspondence (d^2 < max_dist^2 required)
+                prev[i] = bp;
+                if (bp < 0) lb[i] = sqrt(bd);                 // every target closer than sqrt(bound2) was visited
+            }
         }
         __syncthreads();
+        t_a2 += (long long)__builtin_amdgcn_s_memtime() - ta;
     }
+    const long long t3 = (long long)__builtin_amdgcn_s_memtime();
     // --- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences of the slice ---
     double acc[32];
 #pragma unroll
@@ -1055,77 +1177,24 @@ static __device__ __forceinline__ void icp_search_body(const IcpBuffers& B, IcpS
     if (tid < 32) {
         double v = 0;
         for (int w = 0; w < kSearchWG / 64; ++w) v += s_part[w][tid];
-        B.partial[((size_t)h * kIcpMaxSplit + g) * 32 + tid] = v;
+        B.partial[((((size_t)(it & 1) * B.count + h) * kIcpMaxSplit) + g) * 32 + tid] = v;
+    }
+    if (g == 0 && tid == 0) {      // shader-cycle split of workgroup 0 (diagnostics): prologue, staging+transform, queue, search, sums
+        const long long t4 = (long long)__builtin_amdgcn_s_memtime();
+        S.clk[0] += t1 - t0; S.clk[1] += t2 - t1; S.clk[2] += (t3 - t2) - t_a2; S.clk[3] += t_a2; S.clk[4] += t4 - t3; S.clk[5] += 1;
     }
 }
 
 __global__ void __launch_bounds__(kSearchWG)
-k_icp_search(IcpBuffers B, int it, double max_dist) {
-    __shared__ TgtRec s_tgt[kLoopLdsPts];
-    __shared__ unsigned short s_cs[kIcpCells];
+k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) {
+    __shared__ TgtRec s_tgt[kSlabPts];
+    __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
     __shared__ int s_q[kLoopQueue];
     __shared__ unsigned char s_cls[kLoopQueue];
     const int h = blockIdx.y;
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
-    if (S.n_tgt <= kLoopLdsPts) icp_search_body<true>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist);
-    else icp_search_body<false>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist);
-}
-
-// RegistrationICP's loop body after the correspondence step (one wave per hypothesis): fitness / rmse,
-// the relative-change convergence test, TransformationEstimationPointToPlane::ComputeTransformation
-// (6x6 LU with partial pivoting), transformation = update * transformation.
-__global__ void __launch_bounds__(64)
-k_icp_solve(IcpBuffers B, int it, int splits, int max_iter, double rel_tol) {
-    __shared__ double s_sum[32];
-    __shared__ double s_A[6][6], s_b[6], s_x[6];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    IcpState& S = B.st[h];
-    if (S.status != 0 || S.stop != 0) return;
-    if (tid < 32) {
-        double v = 0;
-        for (int g = 0; g < splits; ++g) v += B.partial[((size_t)h * kIcpMaxSplit + g) * 32 + tid];
-        s_sum[tid] = v;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    const int ns = S.n_src;
-    const int ncorr = (int)s_sum[28];
-    const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
-    const double rmse = ncorr ? sqrt(s_sum[27] / (double)ncorr) : 0.0;
-    bool stop = false;
-    if (it == 0) {
-        for (int a = 0; a < 16; ++a) S.T[a] = (a % 5 == 0) ? 1.0 : 0.0;
-        S.T[3] = S.init[0]; S.T[7] = S.init[1]; S.T[11] = S.init[2];
-        S.iterations = 0;
-    } else if (fabs(S.fitness - fit) < rel_tol && fabs(S.rmse - rmse) < rel_tol) {
-        stop = true;
-    }
-    S.fitness = fit; S.rmse = rmse; S.n_corr = ncorr;
-    if (it == max_iter) stop = true;
-    if (stop) { S.stop = 1; return; }
-    double (*A)[6] = s_A;
-    double *b = s_b, *x = s_x;
-    int k = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
-    for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
-    double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    if (ncorr >= 6 && solve6(A, b, x)) {
-        double sx, cx, sy, cy, sz, cz;
-        sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
-        // Rz(x2) * Ry(x1) * Rx(x0)
-        U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
-        U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
-        U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
-    }
-    // transformation = update * transformation
-    double Tn[12];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 4; ++c)
-            Tn[4 * r + c] = U[4 * r] * S.T[c] + U[4 * r + 1] * S.T[4 + c] + U[4 * r + 2] * S.T[8 + c] + (c == 3 ? U[4 * r + 3] : 0.0);
-    for (int a = 0; a < 12; ++a) { S.T[a] = Tn[a]; S.upd[a] = U[a]; }
-    S.iterations = it + 1;
+    icp_eval_body(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol);
 }
 
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
@@ -1139,13 +1208,12 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_knn, dim3(32, count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
-    int splits = 512 / count;
+    int splits = 768 / count;
     if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
     if (splits < 1) splits = 1;
-    for (int it = 0; it <= max_iter; ++it) {
-        hipLaunchKernelGGL(k_icp_search, dim3(splits, count), dim3(kSearchWG), 0, s, B, it, max_dist);
-        hipLaunchKernelGGL(k_icp_solve, dim3(count), dim3(64), 0, s, B, it, splits, max_iter, rel_tol);
-    }
+    // evaluation `it` is finished (convergence test, solve, update) by the prologue of launch it + 1
+    for (int it = 0; it <= max_iter + 1; ++it)
+        hipLaunchKernelGGL(k_icp_eval, dim3(splits, count), dim3(kSearchWG), 0, s, B, it, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

@@ -12,8 +12,11 @@ namespace lm {
 
 constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 cells per axis ...
 constexpr int kIcpCells = 16384 + 1;              // ... and at most 16384 cells (+1 end marker)
-constexpr int kIcpMaxSplit = 16;                  // workgroups (source slices) per hypothesis in k_icp_search
+constexpr int kIcpCells16 = 16392;                // kIcpCells rounded up to a multiple of 8 (16-byte copies of the u16 table)
+constexpr int kIcpMaxSplit = 64;                  // workgroups (source slices) per hypothesis in k_icp_search
 constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
+
+struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int pad; };   // target point as staged in LDS (32 B)
 
 struct IcpIn {               // one pose hypothesis (uploaded)
     float mK[9];             // model camera matrix (row-major 3x3, float like the reference's cv::Mat_<float>)
@@ -35,7 +38,7 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     double fitness, rmse;    // fitness_, inlier_rmse_
     int stop;                // RegistrationICP finished (converged or max_iteration)
     int pad2;
-    double upd[12];          // pending update (3x4), applied to the source cloud by the next k_icp_search
+    double fit_hist[2], rmse_hist[2];   // fitness / rmse of the last two evaluations, slot = evaluation parity
     long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };
 
@@ -45,6 +48,7 @@ struct IcpBuffers {
     const IcpIn* in;         // [count]
     IcpState* st;            // [count]
     float sK[9];             // scene camera matrix
+    int count;               // hypotheses of this run
     size_t cap;              // points per hypothesis and cloud (= W*H)
     size_t cap2;             // cap rounded up to a power of two (sort scratch)
     double* model_pts;       // [count][cap][3]
@@ -53,13 +57,15 @@ struct IcpBuffers {
     double* tgt;             // [count][cap][3]  VoxelDownSample(scene) (scene-from-scene mode only)
     double* tgt_sorted;      // [count][cap][3]  target points in grid-cell order
     int* tgt_orig;           // [count][cap]     original index of the point at a sorted position
+    TgtRec* tgt_rec;         // [count][cap]     the same points as 32-byte records (xyz + original index): LDS staging source
     int* cell_start;         // [count][kIcpCells]
+    unsigned short* cell_start16;  // [count][kIcpCells16] the same table in 16 bits (valid when n_tgt < 65536)
     double* cov;             // [count][cap][kIcpCovStride] cumulants of the k nearest neighbours (sorted positions)
     double* normals;         // [count][cap][3]  per sorted position
     double* work;            // [count][cap][3]  transformed source cloud
     int* prev_nn;            // [count][cap]     previous correspondence (sorted position) of every source point
     double* nn_lb;           // [count][cap]     lower bound on the distance to the nearest target of a point without correspondence
-    double* partial;         // [count][kIcpMaxSplit][32] partial sums of one ICP evaluation
+    double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
 };
 

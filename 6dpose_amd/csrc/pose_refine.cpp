@@ -67,7 +67,7 @@ namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.keys, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
@@ -107,7 +107,9 @@ int ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.tgt_orig, (size_t)n * cap * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.prev_nn, (size_t)n * cap * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.nn_lb, (size_t)n * cap * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&B.partial, (size_t)n * kIcpMaxSplit * 32 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.partial, (size_t)2 * n * kIcpMaxSplit * 32 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.tgt_rec, (size_t)n * cap * sizeof(TgtRec)));
+    HIP_TRY(hipMalloc((void**)&B.cell_start16, (size_t)n * kIcpCells16 * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.keys, (size_t)n * 2 * cap2 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&c->d_in, (size_t)n * sizeof(IcpIn)));
@@ -242,6 +244,7 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     }
     IcpBuffers B = c->B;
     B.scene = c->d_scene; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
+    B.count = count;
     memcpy(B.sK, c->sK, sizeof(B.sK));
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
     HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));

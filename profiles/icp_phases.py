@@ -21,7 +21,6 @@ print("device_ms", ms)
 for h in range(n):
     d = ctx.read_debug(h, 3)
     it, clk = d[24], d[25:33]
-    n = max(it, 1) + 1
-    print("   columns/eval %.0f candidates/eval %.0f max columns %d max candidates %d" % (clk[7] / n, clk[1] / n, clk[2], clk[3]))
-    print("hyp %2d iters %2d  cycles/eval: corr+acc %8.0f (search %8.0f, accumulate %7.0f) reduce %6.0f solve %6.0f transform %6.0f  queued/eval %6.0f"
-          % (h, it, clk[0] / n, clk[4] / n, clk[5] / n, clk[1] / n, clk[2] / n, clk[3] / n, clk[6] / n))
+    ev = max(clk[5], 1)
+    print("hyp %2d iters %2d evals %2d  cycles/eval of workgroup 0: prologue %6.0f staging+transform %6.0f queue %6.0f search %6.0f sums %6.0f"
+          % (h, it, clk[5], clk[0] / ev, clk[1] / ev, clk[2] / ev, clk[3] / ev, clk[4] / ev))
