@@ -18,6 +18,7 @@
 // The grid only prunes: candidate distances are the same expression the oracle evaluates and ties go
 // to the lower original index, so correspondences equal a brute-force search.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "icp_kernels.h"
 
@@ -1185,7 +1186,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
     }
 }
 
-__global__ void __launch_bounds__(kSearchWG)
+__global__ void __launch_bounds__(kSearchWG, 3)
 k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) {
     __shared__ TgtRec s_tgt[kSlabPts];
     __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
@@ -1209,6 +1210,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
     int splits = 768 / count;
+    if (const char* e = getenv("LM_ICP_SPLITS")) splits = atoi(e);      // tuning knob (profiles/)
     if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
     if (splits < 1) splits = 1;
     // evaluation `it` is finished (convergence test, solve, update) by the prologue of launch it + 1
