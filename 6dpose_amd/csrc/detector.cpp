@@ -14,11 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/amd_linemod.h"
-#include "host_templates.h"
-#include "lm_kernels.h"
-
-using namespace lm;
+#include "detector_internal.h"
 
 // ---- errors -----------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -31,13 +27,6 @@ int lm_set_error(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                                         \
-    do {                                                                                                      \
-        hipError_t _e = (expr);                                                                               \
-        if (_e != hipSuccess) return lm_set_error(LM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                                                  __FILE__, __LINE__);                                        \
-    } while (0)
-
 extern "C" const char* lm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
 extern "C" int lm_device_count(void) {
@@ -46,114 +35,6 @@ extern "C" int lm_device_count(void) {
     return n;
 }
 extern "C" void lm_free(void* p) { free(p); }
-
-// ---- device buffer helper ---------------------------------------------------------------------
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;   // elements
-    int ensure(size_t n) {
-        if (n <= cap) return LM_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
-        cap = n;
-        return LM_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct LevelBufs {
-    int W = 0, H = 0;
-    DevBuf<uint8_t> rgb;      // level>0 only (level 0 aliases the frame)
-    DevBuf<float> mag;
-    DevBuf<uint8_t> ang;      // one-hot quantised orientation (unmasked)
-    DevBuf<uint8_t> nrm;      // one-hot quantised normal (unmasked)
-    DevBuf<uint8_t> mask[2];  // per modality, optional
-};
-
-struct lm_detector {
-    // parameters (LL.cpp:1663-1692 + modality defaults :645-650, :968-974)
-    int num_features = 63;
-    std::vector<int> T_at_level{5, 8};
-    int pyramid_levels = 2;
-    float weak_threshold = 10.0f, strong_threshold = 55.0f;
-    int distance_threshold = 2000, difference_threshold = 50, extract_threshold = 2;
-    TemplatesMap class_templates;
-
-    // device
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    int shard_rank = 0, shard_world = 1;
-
-    // frame
-    int fW = 0, fH = 0;
-    bool frame_valid = false, have_mask[2] = {false, false};
-    DevBuf<uint8_t> frame_rgb;
-    DevBuf<uint16_t> frame_depth;
-    DevBuf<uint16_t> tmp16;
-    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
-
-    LevelBufs lvl[kMaxLevels];
-    FrameGeom geom{};
-    size_t lm_block_bytes[kMaxLevels] = {};
-    std::vector<DevBuf<uint8_t>> slot_rgb;      // frames parked in HBM (lm_detector_store_frame)
-    std::vector<DevBuf<uint16_t>> slot_depth;
-    std::vector<int> slot_w, slot_h;
-    void* pinned = nullptr;          // staging for H2D frame and D2H results
-    size_t pinned_bytes = 0;
-    float last_h2d_ms = 0.f;
-
-    // bank on device
-    bool bank_dirty = true;
-    int bank_geom_W = -1, bank_geom_H = -1;
-    std::vector<std::string> bank_classes;          // sorted
-    std::vector<int> bank_class_base;               // first flat pyramid index per class
-    std::vector<int> bank_class_count;
-    std::vector<TemplEntry> h_entries;
-    DevBuf<TemplEntry> d_entries;
-    DevBuf<int32_t> d_feat_off;
-    DevBuf<uint32_t> d_feat_xy;
-    DevBuf<FeatStrip> d_feat_strip;
-    // work list
-    std::vector<int32_t> work_pyr;
-    std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;   // shared with in-flight result slots
-    DevBuf<int32_t> d_work;
-    std::vector<std::string> work_key;              // class_ids the cached work list was built for
-    int work_key_rank = -1, work_key_world = -1;
-    bool work_valid = false;
-    int64_t work_coarse_bytes = 0;
-    DevBuf<Candidate> d_cands;
-    DevBuf<unsigned long long> d_counters;
-    uint32_t cand_cap = 1u << 18;
-    // Two result slots: the refinement kernel of frame k+1 writes into one pinned buffer while the host
-    // collects frame k from the other (lm_detector_submit / lm_detector_collect).
-    struct Slot {
-        Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
-        uint32_t match_cap = 0;
-        unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [8..] 2 words of statistics per refinement block
-        hipGraph_t graph = nullptr;                 // the whole per-frame device pipeline, captured once
-        hipGraphExec_t exec = nullptr;
-        uint64_t key[8] = {};
-        hipEvent_t ev[5] = {};                      // stage timing (recorded inside the graph)
-        hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
-        bool pending = false;
-        float threshold = 0.f, h2d_ms = 0.f;
-        int num_work = 0;
-        int64_t coarse_bytes = 0;
-        std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
-        std::chrono::steady_clock::time_point t0, t1;
-    } slot[2];
-    uint64_t n_submitted = 0, n_collected = 0;
-    int local_blocks = 0;
-    int num_cus = 256;
-
-    bool use_graph = true;
-    bool graph_events_ok = true;
-
-    lm_timings timings{};
-};
 
 static int ensure_pinned(lm_detector* d, size_t bytes) {
     if (bytes <= d->pinned_bytes) return LM_OK;
@@ -229,7 +110,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
@@ -872,8 +753,13 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     }
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
     if (rc) return rc;
-    if (!d->work_pyr.empty())
+    if ((rc = d->d_work_cls.ensure(std::max<size_t>(1, d->work_pyr.size())))) return rc;
+    if ((rc = d->d_work_tid.ensure(std::max<size_t>(1, d->work_pyr.size())))) return rc;
+    if (!d->work_pyr.empty()) {
         HIP_TRY(hipMemcpy(d->d_work.p, d->work_pyr.data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_work_cls.p, d->work_cls->data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_work_tid.p, d->work_tid->data(), d->work_pyr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     // algorithmic bytes of the coarse pass over this work list: sum_m nfeat_m * template_positions
     {
         const int L = d->pyramid_levels;
@@ -906,7 +792,7 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
 }
 
 // Enqueue the whole device pipeline of the current frame into a free result slot (asynchronous).
-static int submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
+int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame / select_frame first");
     if (d->n_submitted - d->n_collected >= 2)
         return lm_set_error(LM_ERR_INVALID, "two frames already in flight: call lm_detector_collect first");
@@ -921,6 +807,7 @@ static int submit_frame(lm_detector* d, float threshold, const char* const* clas
     const int num_work = (int)d->work_pyr.size();
     if ((rc = d->d_counters.ensure(8))) return rc;
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+    if ((rc = d->d_matches_dev.ensure(d->cand_cap))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream;
     sl.t0 = std::chrono::steady_clock::now();
@@ -944,7 +831,8 @@ static int submit_frame(lm_detector* d, float threshold, const char* const* clas
         // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
         // the per-block statistics and the results, stored straight into this slot's pinned host memory
         launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, sl.match_cap, d->d_counters.p, d_hcounters,
+                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->d_matches_dev.p, std::min<uint32_t>(sl.match_cap, d->cand_cap),
+                     d->d_counters.p, d_hcounters,
                      d->local_blocks, s);
         HIP_TRY(hipEventRecord(sl.ev[3], s));
         HIP_TRY(hipEventRecord(sl.ev[4], s));
@@ -956,7 +844,8 @@ static int submit_frame(lm_detector* d, float threshold, const char* const* clas
         memcpy(&thr_bits, &threshold, 4);
         const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
-                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p};
+                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
+                                     ((uint64_t)(uintptr_t)d->d_matches_dev.p << 2)};
         if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
             if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
             if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
@@ -988,7 +877,7 @@ static int submit_frame(lm_detector* d, float threshold, const char* const* clas
 
 // Wait for the oldest frame in flight and turn its records into lm_match.  Returns 1 when a buffer
 // overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
-static int collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
+int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
     if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
     lm_detector::Slot& sl = d->slot[d->n_collected & 1];
     HIP_TRY(hipSetDevice(d->device));
@@ -1025,6 +914,12 @@ static int collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t
         }
         tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;
     }
+    if (sort_unique < 0) {                            // pipeline mode: the records stay on the device
+        d->timings = tm;
+        if (out) *out = nullptr;
+        if (n_out) *n_out = 0;
+        return LM_OK;
+    }
     lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
     const std::vector<int32_t>& wcls = *sl.work_cls;
@@ -1056,13 +951,13 @@ static int collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t
 
 extern "C" int lm_detector_submit(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
-    return submit_frame(d, threshold, class_ids, num_class_ids);
+    return lm_submit_frame(d, threshold, class_ids, num_class_ids);
 }
 
 extern "C" int lm_detector_collect(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
     if (!d || !out || !n_out) return lm_set_error(LM_ERR_INVALID, "null argument");
     *out = nullptr; *n_out = 0;
-    int rc = collect_frame(d, sort_unique, out, n_out);
+    int rc = lm_collect_frame(d, sort_unique, out, n_out);
     if (rc == 1)
         return lm_set_error(LM_ERR_OVERFLOW, "candidate buffer overflow: capacity raised to %u, submit the frame again "
                             "(lm_detector_match_resident does this by itself)", d->cand_cap);
@@ -1075,9 +970,9 @@ extern "C" int lm_detector_match_resident(lm_detector* d, float threshold, const
     *out = nullptr; *n_out = 0;
     if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them first");
     for (;;) {   // one pass normally; grow-and-rerun when a buffer overflowed
-        int rc = submit_frame(d, threshold, class_ids, num_class_ids);
+        int rc = lm_submit_frame(d, threshold, class_ids, num_class_ids);
         if (rc) return rc;
-        rc = collect_frame(d, sort_unique, out, n_out);
+        rc = lm_collect_frame(d, sort_unique, out, n_out);
         if (rc != 1) return rc;
     }
 }

@@ -1,0 +1,138 @@
+// Private view of the detector shared by detector.cpp and pipeline.cpp (not part of the C ABI).
+#pragma once
+#include <chrono>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/amd_linemod.h"
+#include "host_templates.h"
+#include "lm_kernels.h"
+
+int lm_set_error(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return lm_set_error(LM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                                  __FILE__, __LINE__);                                        \
+    } while (0)
+
+
+namespace lm {}
+using namespace lm;
+
+// ---- device buffer helper ---------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return LM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return LM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct LevelBufs {
+    int W = 0, H = 0;
+    DevBuf<uint8_t> rgb;      // level>0 only (level 0 aliases the frame)
+    DevBuf<float> mag;
+    DevBuf<uint8_t> ang;      // one-hot quantised orientation (unmasked)
+    DevBuf<uint8_t> nrm;      // one-hot quantised normal (unmasked)
+    DevBuf<uint8_t> mask[2];  // per modality, optional
+};
+
+struct lm_detector {
+    // parameters (LL.cpp:1663-1692 + modality defaults :645-650, :968-974)
+    int num_features = 63;
+    std::vector<int> T_at_level{5, 8};
+    int pyramid_levels = 2;
+    float weak_threshold = 10.0f, strong_threshold = 55.0f;
+    int distance_threshold = 2000, difference_threshold = 50, extract_threshold = 2;
+    TemplatesMap class_templates;
+
+    // device
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int shard_rank = 0, shard_world = 1;
+
+    // frame
+    int fW = 0, fH = 0;
+    bool frame_valid = false, have_mask[2] = {false, false};
+    DevBuf<uint8_t> frame_rgb;
+    DevBuf<uint16_t> frame_depth;
+    DevBuf<uint16_t> tmp16;
+    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
+
+    LevelBufs lvl[kMaxLevels];
+    FrameGeom geom{};
+    size_t lm_block_bytes[kMaxLevels] = {};
+    std::vector<DevBuf<uint8_t>> slot_rgb;      // frames parked in HBM (lm_detector_store_frame)
+    std::vector<DevBuf<uint16_t>> slot_depth;
+    std::vector<int> slot_w, slot_h;
+    void* pinned = nullptr;          // staging for H2D frame and D2H results
+    size_t pinned_bytes = 0;
+    float last_h2d_ms = 0.f;
+
+    // bank on device
+    bool bank_dirty = true;
+    int bank_geom_W = -1, bank_geom_H = -1;
+    std::vector<std::string> bank_classes;          // sorted
+    std::vector<int> bank_class_base;               // first flat pyramid index per class
+    std::vector<int> bank_class_count;
+    std::vector<TemplEntry> h_entries;
+    DevBuf<TemplEntry> d_entries;
+    DevBuf<int32_t> d_feat_off;
+    DevBuf<uint32_t> d_feat_xy;
+    DevBuf<FeatStrip> d_feat_strip;
+    // work list
+    std::vector<int32_t> work_pyr;
+    std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;   // shared with in-flight result slots
+    DevBuf<int32_t> d_work;
+    std::vector<std::string> work_key;              // class_ids the cached work list was built for
+    int work_key_rank = -1, work_key_world = -1;
+    bool work_valid = false;
+    int64_t work_coarse_bytes = 0;
+    DevBuf<Candidate> d_cands;
+    DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K)
+    DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
+    DevBuf<unsigned long long> d_counters;
+    uint32_t cand_cap = 1u << 18;
+    // Two result slots: the refinement kernel of frame k+1 writes into one pinned buffer while the host
+    // collects frame k from the other (lm_detector_submit / lm_detector_collect).
+    struct Slot {
+        Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
+        uint32_t match_cap = 0;
+        unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [8..] 2 words of statistics per refinement block
+        hipGraph_t graph = nullptr;                 // the whole per-frame device pipeline, captured once
+        hipGraphExec_t exec = nullptr;
+        uint64_t key[8] = {};
+        hipEvent_t ev[5] = {};                      // stage timing (recorded inside the graph)
+        hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
+        bool pending = false;
+        float threshold = 0.f, h2d_ms = 0.f;
+        int num_work = 0;
+        int64_t coarse_bytes = 0;
+        std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
+        std::chrono::steady_clock::time_point t0, t1;
+    } slot[2];
+    uint64_t n_submitted = 0, n_collected = 0;
+    int local_blocks = 0;
+    int num_cus = 256;
+
+    bool use_graph = true;
+    bool graph_events_ok = true;
+
+    lm_timings timings{};
+};
+
+
+// detector.cpp
+int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids);
+int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out);   // sort_unique < 0: discard the records

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "icp_kernels.h"
+#include "lm_kernels.h"
 
 namespace lm {
 
@@ -110,6 +111,63 @@ static __device__ __forceinline__ void bitonic_sort(P A, int npad) {
     }
 }
 
+// The same for lists longer than the LDS buffer (npad > kSortLds keys in HBM): chunks of kSortLds keys are
+// sorted / merged in LDS, only the compare-exchange steps whose partner lies in another chunk touch HBM —
+// log2(npad / kSortLds) * (log2(npad / kSortLds) + 1) / 2 passes instead of ~log2(npad)^2 / 2.
+static __device__ __forceinline__ void bitonic_sort_hybrid(unsigned long long* g, int npad, unsigned long long* s) {
+    const int C = kSortLds;
+    auto chunk_steps = [&](int c0, int k, int jmax) {            // steps j = jmax .. 1 of merge size k on the chunk at c0
+        for (int i = threadIdx.x; i < C; i += blockDim.x) s[i] = g[c0 + i];
+        __syncthreads();
+        for (int j = jmax; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (C >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = s[i], b = s[l];
+                const bool up = ((c0 + i) & k) == 0;
+                if ((a > b) == up) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < C; i += blockDim.x) g[c0 + i] = s[i];
+        __syncthreads();
+    };
+    for (int c0 = 0; c0 < npad; c0 += C)
+        for (int k = 2; k <= C; k <<= 1) {
+            if (k == 2) {                                          // load once, run every k <= C in LDS, store once
+                for (int i = threadIdx.x; i < C; i += blockDim.x) s[i] = g[c0 + i];
+                __syncthreads();
+            }
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < (C >> 1); t += blockDim.x) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const unsigned long long a = s[i], b = s[l];
+                    const bool up = ((c0 + i) & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[l] = a; }
+                }
+                __syncthreads();
+            }
+            if (k == C) {
+                for (int i = threadIdx.x; i < C; i += blockDim.x) g[c0 + i] = s[i];
+                __syncthreads();
+            }
+        }
+    for (int k = 2 * C; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) {                    // partner in another chunk: HBM pass
+            for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = g[i], b = g[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { g[i] = b; g[l] = a; }
+            }
+            __syncthreads();
+        }
+        for (int c0 = 0; c0 < npad; c0 += C) chunk_steps(c0, k, C >> 1);
+    }
+}
+
 static __device__ __forceinline__ int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -131,6 +189,7 @@ static __device__ __forceinline__ int grid_coord(double v, double mn, double inv
 __global__ void __launch_bounds__(256)
 k_icp_bbox(IcpBuffers B, int W, int H) {
     const int h = blockIdx.y;
+    if (B.st[h].status != 0) return;                              // slot without a detection (pipeline)
     const uint16_t* img = B.models + (size_t)B.in[h].model_slot * W * H;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
     const bool vec = (W & 7) == 0;
@@ -169,40 +228,87 @@ k_icp_bbox(IcpBuffers B, int W, int H) {
 // k_icp_points (LL.cpp:52-104): raster scan of the dilated bounding box; model point where
 // modelDepth > 0, scene point where the dilated mask is set and sceneDepth (window shifted by
 // detect - 4, clamped at 0) > 0; compaction keeps raster order; centroid difference = init_guess.
+// The box is cut into kIcpStrips row strips, one workgroup each: pass 0 counts the points of every
+// strip, pass 1 starts each strip at the sum of the counts before it and writes points + centroid sums
+// (k_icp_grid adds the strips' sums in order -> init_guess).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWG)
+constexpr int kPtsWG = 256;
+
+template <bool kWrite>
+__global__ void __launch_bounds__(kPtsWG)
 k_icp_points(IcpBuffers B, int W, int H, int flags) {
-    __shared__ int s_wave[32];
-    __shared__ double s_red[16][7];
-    const int h = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_wave[8];
+    __shared__ double s_red[kPtsWG / 64][7];
+    __shared__ int s_tot[2];
+    const int h = blockIdx.y, strip = blockIdx.x, tid = threadIdx.x;
     IcpState& S = B.st[h];
+    if (S.status != 0) return;
     const IcpIn I = B.in[h];
     const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
-    if (x1 < 0) {
-        if (tid == 0) { S.status = 2; S.n_model = 0; S.n_scene = 0; }
+    if (x1 < 0) {                                                  // pass 1 never gets here: pass 0 set the status
+        if (strip == 0 && tid == 0) { S.status = 2; S.n_model = 0; S.n_scene = 0; }
         return;
     }
     const int bx0 = max(x0 - kDilate, 0), by0 = max(y0 - kDilate, 0);
     const int bx1 = min(x1 + kDilate, W - 1), by1 = min(y1 + kDilate, H - 1);
     const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
     if (I.dx + bw >= W || I.dy + bh >= H) {                       // LL.cpp:52-55
-        if (tid == 0) { S.status = 1; S.n_model = 0; S.n_scene = 0; }
+        if (strip == 0 && tid == 0) { S.status = 1; S.n_model = 0; S.n_scene = 0; }
         return;
     }
     const uint16_t* model = B.models + (size_t)I.model_slot * W * H;
     const uint16_t* scene = B.scene;
+    int* cnt = B.strip_cnt + ((size_t)h * kIcpStrips) * 2;
+    const int r_lo = (int)((long long)bh * strip / kIcpStrips), r_hi = (int)((long long)bh * (strip + 1) / kIcpStrips);
+    const int p_lo = r_lo * bw, p_hi = r_hi * bw;
+    const bool keep_scene = (flags & 1) != 0;
+
+    if (!kWrite) {
+        int cm = 0, cs = 0;
+        for (int p = p_lo + tid; p < p_hi; p += kPtsWG) {
+            const int r = p / bw, c = p - r * bw;
+            const int mr = r + by0, mc = c + bx0;
+            const int sr = max(r + I.dy - kDilate, 0), sc = max(c + I.dx - kDilate, 0);
+            const uint16_t md = model[(size_t)mr * W + mc];
+            const uint16_t sd = scene[(size_t)sr * W + sc];
+            cm += md > 0;
+            if (sd > 0 && keep_scene) {
+                bool in_mask = md > 0;
+                if (!in_mask) {                                   // dilate(modelDepth > 0, 9x9) at (mr, mc)
+                    const int ya = max(mr - kDilate, 0), yb = min(mr + kDilate, H - 1);
+                    const int xa = max(mc - kDilate, 0), xb = min(mc + kDilate, W - 1);
+                    for (int yy = ya; yy <= yb && !in_mask; ++yy)
+                        for (int xx = xa; xx <= xb; ++xx)
+                            if (model[(size_t)yy * W + xx]) { in_mask = true; break; }
+                }
+                cs += in_mask;
+            }
+        }
+        if (tid < 2) s_tot[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cm += __shfl_xor(cm, o, 64); cs += __shfl_xor(cs, o, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&s_tot[0], cm); atomicAdd(&s_tot[1], cs); }
+        __syncthreads();
+        if (tid < 2) cnt[strip * 2 + tid] = s_tot[tid];
+        return;
+    }
+
     const double anchor = model[(size_t)(H / 2) * W + W / 2] / 1000.0;   // LL.cpp:62
     double* mp = B.model_pts + (size_t)h * B.cap * 3;
     double* sp = B.scene_pts + (size_t)h * B.cap * 3;
-    const bool keep_scene = (flags & 1) != 0;
-    int nm = 0, nsn = 0;
+    int nm = 0, nsn = 0, tot_m = 0, tot_s = 0;
+    for (int k = 0; k < kIcpStrips; ++k) {
+        const int a = cnt[k * 2], b2 = cnt[k * 2 + 1];
+        if (k < strip) { nm += a; nsn += b2; }
+        tot_m += a; tot_s += b2;
+    }
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};     // model xyz, scene-near-anchor xyz, its count
-    const int area = bw * bh;
-    for (int base = 0; base < area; base += kWG) {
+    for (int base = p_lo; base < p_hi; base += kPtsWG) {
         const int p = base + tid;
         bool is_m = false, is_s = false;
         double mx = 0, my = 0, mz = 0, sx = 0, sy = 0, sz = 0;
-        if (p < area) {
+        if (p < p_hi) {
             const int r = p / bw, c = p - r * bw;
             const int mr = r + by0, mc = c + bx0;
             const int sr = max(r + I.dy - kDilate, 0), sc = max(c + I.dx - kDilate, 0);
@@ -250,19 +356,12 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
         if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        double t[7];
-        for (int k = 0; k < 7; ++k) {
-            double v = 0;
-            for (int w = 0; w < (kWG >> 6); ++w) v += s_red[w][k];
-            t[k] = v;
-        }
-        const double n = (double)nm;
-        S.init[0] = t[3] / t[6] - t[0] / n;      // NaN when no scene point is near the anchor, as the reference
-        S.init[1] = t[4] / t[6] - t[1] / n;
-        S.init[2] = t[5] / t[6] - t[2] / n;
-        S.n_model = nm; S.n_scene = nsn;
+    if (tid < 7) {
+        double v = 0;
+        for (int w = 0; w < kPtsWG / 64; ++w) v += s_red[w][tid];
+        B.strip_sum[((size_t)h * kIcpStrips + strip) * 8 + tid] = v;
     }
+    if (strip == 0 && tid == 0) { S.n_model = tot_m; S.n_scene = keep_scene ? tot_s : 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,7 +420,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort(gk, npad);
+    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort_hybrid(gk, npad, s_keys);
     const unsigned long long imask = (1ull << bi) - 1ull;
     int nout = 0;
     for (int base = 0; base < n; base += kWG) {
@@ -358,12 +457,20 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_icp_grid: the target cloud binned into a dense 3-D grid (cell edge >= 5 mm, grown until the grid
-// has <= 64 cells per axis and <= 16384 cells), points reordered by (x, y, z cell, original index):
-// the cells of one (x, y) column are contiguous, so a search visits one run per column and only the
-// z range it needs, and an x slab of the grid is one contiguous range of cells and of points (what a
-// source slice stages in LDS).  cell_start[c] = first sorted position of cell c.
+// k_icp_grid: the target cloud binned into xy columns (cell edge >= 5 mm, <= 64 x 64 columns) and, inside
+// a column, ordered by quantised depth (>= 0.1 mm steps): points sorted by (x column, y column, z step,
+// original index).  A search visits one run per column and finds the depth range it needs by bisection,
+// so the table stays a few thousand entries however deep the cloud is (a scene cloud carries background
+// far behind the object); an x slab of columns is one contiguous range of cells and of points (what a
+// source slice stages in LDS).  cell_start[c] = first sorted position of column c.
 // ---------------------------------------------------------------------------------------------
+constexpr int kZBits = 20;         // quantised-depth bits of the grid sort key
+
+static __device__ __forceinline__ int zq_of(double z, double minz, double inv_z, int zq_max) {
+    const double f = floor((z - minz) * inv_z);
+    return f >= 0.0 ? (f < (double)zq_max ? (int)f : zq_max) : 0;      // NaN -> 0
+}
+
 __global__ void __launch_bounds__(kWG)
 k_icp_grid(IcpBuffers B, int flags) {
     __shared__ unsigned long long s_keys[kSortLds];
@@ -371,12 +478,21 @@ k_icp_grid(IcpBuffers B, int flags) {
     __shared__ double s_mm[6];
     const int h = blockIdx.x, tid = threadIdx.x;
     IcpState& S = B.st[h];
+    if (tid == 0 && S.status == 0) {                               // init_guess: centroid difference (LL.cpp:91-104), strips added in order
+        double t[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < kIcpStrips; ++k)
+            for (int q = 0; q < 7; ++q) t[q] += B.strip_sum[((size_t)h * kIcpStrips + k) * 8 + q];
+        const double n = (double)S.n_model;
+        S.init[0] = t[3] / t[6] - t[0] / n;      // NaN when no scene point is near the anchor, as the reference
+        S.init[1] = t[4] / t[6] - t[1] / n;
+        S.init[2] = t[5] / t[6] - t[2] / n;
+    }
     int* cs = B.cell_start + (size_t)h * kIcpCells;
     const int nt = S.status == 0 ? S.n_tgt : 0;
     if (nt == 0 || nt >= (1 << kIdxBits)) {
         if (tid == 0) {
             if (nt > 0) { S.status = 3; S.n_tgt = 0; }
-            S.gx = 1; S.gy = 1; S.gz = 1; S.gminx = 0; S.gminy = 0; S.gminz = 0; S.cell = kCellMin; S.inv_cell = 1.0 / kCellMin;
+            S.gx = 1; S.gy = 1; S.zq_max = 0; S.gminx = 0; S.gminy = 0; S.gminz = 0; S.cell = kCellMin; S.inv_cell = 1.0 / kCellMin; S.inv_z = 1e4;
             cs[0] = 0; cs[1] = 0;
         }
         return;
@@ -389,36 +505,32 @@ k_icp_grid(IcpBuffers B, int flags) {
     }
     block_minmax<3>(mn, mx, s_part, s_mm);
     const double minx = s_mm[0], miny = s_mm[1], minz = s_mm[2];
-    double cell = kCellMin, inv = 1.0 / kCellMin;
-    int gx = 1, gy = 1, gz = 1;
-    bool ok = false;
-    for (int tries = 0; tries < 400; ++tries) {                      // uniform: every thread computes the same grid
-        inv = 1.0 / cell;
-        const double fx = (s_mm[3] - minx) * inv, fy = (s_mm[4] - miny) * inv, fz = (s_mm[5] - minz) * inv;
-        if (fx < (double)kIcpGrid && fy < (double)kIcpGrid && fz < (double)kIcpGrid) {
-            gx = (int)fx + 1; gy = (int)fy + 1; gz = (int)fz + 1;
-            if (gx * gy * gz < kIcpCells) { ok = true; break; }
-        }
-        cell *= 1.25;
-    }
-    if (!ok) {                                                         // non-finite coordinates
-        if (tid == 0) { S.status = 3; S.n_tgt = 0; S.gx = 1; S.gy = 1; S.gz = 1; cs[0] = 0; cs[1] = 0; }
+    const double ext = fmax(s_mm[3] - minx, s_mm[4] - miny), extz = s_mm[5] - minz;
+    double cell = ext / (double)kIcpGrid;
+    if (!(cell > kCellMin)) cell = kCellMin;                       // also catches NaN
+    double zres = extz / (double)((1 << kZBits) - 1);
+    if (!(zres > 1e-4)) zres = 1e-4;
+    const double inv = 1.0 / cell, inv_z = 1.0 / zres;
+    if (!(ext < 1e30) || !(extz < 1e30)) {                         // non-finite coordinates
+        if (tid == 0) { S.status = 3; S.n_tgt = 0; S.gx = 1; S.gy = 1; S.zq_max = 0; cs[0] = 0; cs[1] = 0; }
         return;
     }
+    const int gx = grid_coord(s_mm[3], minx, inv, kIcpGrid) + 1, gy = grid_coord(s_mm[4], miny, inv, kIcpGrid) + 1;
+    const int zq_max = zq_of(s_mm[5], minz, inv_z, (1 << kZBits) - 1);
     const int npad = next_pow2(nt < 2 ? 2 : nt);
     const bool in_lds = npad <= kSortLds;
     unsigned long long* gk = B.keys + (size_t)h * 2 * B.cap2;
     for (int i = tid; i < npad; i += kWG) {
         unsigned long long key = ~0ull;
         if (i < nt) {
-            const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy),
-                      cz = grid_coord(T[3 * (size_t)i + 2], minz, inv, gz);
-            key = ((unsigned long long)((cx * gy + cy) * gz + cz) << kIdxBits) | (unsigned long long)i;
+            const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy);
+            const int zq = zq_of(T[3 * (size_t)i + 2], minz, inv_z, zq_max);
+            key = ((((unsigned long long)(cx * gy + cy) << kZBits) | (unsigned long long)zq) << kIdxBits) | (unsigned long long)i;
         }
         if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort(gk, npad);
+    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort_hybrid(gk, npad, s_keys);
     double* Ts = B.tgt_sorted + (size_t)h * B.cap * 3;
     int* orig = B.tgt_orig + (size_t)h * B.cap;
     TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
@@ -429,12 +541,13 @@ k_icp_grid(IcpBuffers B, int flags) {
         Ts[3 * (size_t)p] = T[3 * i]; Ts[3 * (size_t)p + 1] = T[3 * i + 1]; Ts[3 * (size_t)p + 2] = T[3 * i + 2];
         orig[p] = (int)i;
         TgtRec r;
-        r.x = T[3 * i]; r.y = T[3 * i + 1]; r.z = T[3 * i + 2]; r.orig = (int)i; r.pad = 0;
+        r.x = T[3 * i]; r.y = T[3 * i + 1]; r.z = T[3 * i + 2]; r.orig = (int)i;
+        r.zq = (int)((k >> kIdxBits) & ((1ull << kZBits) - 1ull));
         rec[p] = r;
     }
-    const int ncell = gx * gy * gz;
-    for (int c = tid; c <= ncell; c += kWG) {                       // lower_bound of (c << kIdxBits)
-        const unsigned long long want = (unsigned long long)c << kIdxBits;
+    const int ncell = gx * gy;
+    for (int c = tid; c <= ncell; c += kWG) {                       // lower_bound of the column's smallest key
+        const unsigned long long want = (unsigned long long)c << (kZBits + kIdxBits);
         int lo = 0, hi = nt;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -445,14 +558,15 @@ k_icp_grid(IcpBuffers B, int flags) {
         cs16[c] = (unsigned short)lo;
     }
     if (tid == 0) {
-        S.gx = gx; S.gy = gy; S.gz = gz; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
+        S.gx = gx; S.gy = gy; S.zq_max = zq_max; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
+        S.inv_z = inv_z;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_icp_knn: open3d EstimateNormals(KDTreeSearchParamKNN(30)), neighbour search part.  One wave per
-// target point.  The cube of cells within ring R of the point's cell holds every point closer than
-// R*cell, so once >= k candidates are closer than that, the k nearest of the cube are the k nearest
+// target point.  The columns within ring R of the point's column, cut to depths pz -+ R*cell, hold every point
+// closer than R*cell, so once >= k candidates are closer than that, the k nearest of them are the k nearest
 // of the cloud.  Candidates sit one per lane-slot in registers; the k-th smallest squared distance is
 // found by bisection on its bit pattern (a ballot + popcount per step, no sorting), ties at the
 // threshold go to the lower original index, and the cumulants of the selected points are wave-reduced.
@@ -474,7 +588,6 @@ static __device__ __forceinline__ void reduce_halve16(double (&v)[16], int lane)
     }
 }
 
-template <bool kLds>
 static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpState& S, const int h, const int knn, TgtRec* s_tgt,
                                                 int* s_list) {
     const int nt = S.n_tgt;
@@ -482,48 +595,64 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
     const int* orig = B.tgt_orig + (size_t)h * B.cap;
     const int* cs = B.cell_start + (size_t)h * kIcpCells;
     double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-    const int gx = S.gx, gy = S.gy, gz = S.gz;
-    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, cell = S.cell;
+    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max;
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, cell = S.cell, inv_z = S.inv_z;
+    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * (kKnnWG / 64);
     const int k = knn < nt ? knn : nt;
+    int R0 = (int)ceil(0.009 / cell);
+    if (R0 < 1) R0 = 1;
+    // this workgroup's points: a contiguous range of sorted positions = an x slab of the grid; the cells within
+    // R0 + 1 rings of it are staged in LDS (larger rings, rare, read HBM)
+    const int q0 = (int)((long long)nt * blockIdx.x / gridDim.x), q1 = (int)((long long)nt * (blockIdx.x + 1) / gridDim.x);
+    if (q0 >= q1) return;
+    const int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
+    const int xhi = min(grid_coord(T[3 * (size_t)(q1 - 1)], minx, inv, gx) + (R0 + 1), gx - 1);
+    const int p0 = cs[xlo * gy], p1 = cs[(xhi + 1) * gy];
+    const int np = p1 - p0;
+    const bool kLds = np <= kLoopLdsPts;
     if (kLds) {                                                  // 16-byte copies of the prepared records
-        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap);
+        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap + p0);
         uint4* dst = reinterpret_cast<uint4*>(s_tgt);
-        for (int j = threadIdx.x; j < nt * 2; j += kKnnWG) dst[j] = src[j];
+        for (int j = threadIdx.x; j < np * 2; j += kKnnWG) dst[j] = src[j];
         __syncthreads();
     }
     auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
-        if (kLds) { const TgtRec& r = s_tgt[j]; x = r.x; y = r.y; z = r.z; }
+        if (kLds && (unsigned)(j - p0) < (unsigned)np) { const TgtRec& r = s_tgt[j - p0]; x = r.x; y = r.y; z = r.z; }
         else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
     };
-    auto tgt_orig = [&](int j) { return kLds ? s_tgt[j].orig : orig[j]; };
+    auto tgt_orig = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].orig : orig[j]; };
+    auto tgt_zq = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].zq : rec[j].zq; };
     int* list = s_list + wave * kKnnCache;
-    int R0 = (int)ceil(0.009 / cell);
-    if (R0 < 1) R0 = 1;
 
-    for (int pos = blockIdx.x * (kKnnWG / 64) + wave; pos < nt; pos += nwaves) {
+    for (int pos = q0 + wave; pos < q1; pos += kKnnWG / 64) {
         double px, py, pz;
         tgt_xyz(pos, px, py, pz);
-        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy), cz = grid_coord(pz, minz, inv, gz);
-        int R = R0, M = 0, xa = 0, xb = 0, ya = 0, yb = 0, za = 0, zb = 0;
+        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
+        int R = R0, M = 0, xa = 0, xb = 0, ya = 0, yb = 0;
         double dreg[kKnnSlots];
         int preg[kKnnSlots];
         for (;;) {
             xa = max(cx - R, 0); xb = min(cx + R, gx - 1); ya = max(cy - R, 0); yb = min(cy + R, gy - 1);
-            za = max(cz - R, 0); zb = min(cz + R, gz - 1);
-            const bool all = xa == 0 && ya == 0 && za == 0 && xb == gx - 1 && yb == gy - 1 && zb == gz - 1;
+            const double gw = (double)R * cell * (1.0 + 1e-9) + 1e-12;      // every point closer than R*cell has its depth in pz -+ gw
+            const int zlo = zq_of(pz - gw, minz, inv_z, zq_max), zhi = zq_of(pz + gw, minz, inv_z, zq_max);
+            const bool all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1 && zlo == 0 && zhi == zq_max;
             const double g = (double)R * cell * (1.0 - 1e-9), g2 = g * g;   // margin >> the rounding of grid_coord
             const int nx = xb - xa + 1, nruns = nx * (yb - ya + 1);
             M = 0;
-            for (int r0 = 0; r0 < nruns; r0 += 64) {                // one (x, y) column per lane: its z run
+            for (int r0 = 0; r0 < nruns; r0 += 64) {                // one (x, y) column per lane: its depth range by bisection
                 const int r = r0 + lane;
                 int a = 0, len = 0;
                 if (r < nruns) {
                     const int y = ya + r / nx, x = xa + r % nx;
-                    const int c = (x * gy + y) * gz;
-                    a = cs[c + za];
-                    len = cs[c + zb + 1] - a;
+                    const int c = x * gy + y;
+                    const int ca = cs[c], cb = cs[c + 1];
+                    int lo = ca, hi = cb;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tgt_zq(mid) < zlo) lo = mid + 1; else hi = mid; }
+                    a = lo;
+                    hi = cb;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tgt_zq(mid) <= zhi) lo = mid + 1; else hi = mid; }
+                    len = lo - a;
                 }
                 int incl = len;
 #pragma unroll
@@ -555,34 +684,44 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
                     }
                 }
             } else {
-                for (int y = ya; y <= yb; ++y)
-                    for (int x = xa; x <= xb; ++x) {
-                        const int c = (x * gy + y) * gz;
-                        const int a = cs[c + za], b = cs[c + zb + 1];
-                        for (int j0 = a; j0 < b; j0 += 64) {
-                            const int j = j0 + lane;
-                            bool in = false;
-                            if (j < b) {
-                                double qx, qy, qz;
-                                tgt_xyz(j, qx, qy, qz);
-                                in = sqdist(px, py, pz, qx, qy, qz) < g2;
+                // too many candidates for the registers: one coalesced scan (columns (x, ya..yb) are one contiguous run, a
+                // superset of the ring) in which every lane keeps the kKnnSlots smallest distances it has seen, sorted
+#pragma unroll
+                for (int s = 0; s < kKnnSlots; ++s) { dreg[s] = __longlong_as_double(0x7FF0000000000000ll); preg[s] = -1; }
+                for (int x = xa; x <= xb; ++x) {
+                    const int a = cs[x * gy + ya], b = cs[x * gy + yb + 1];
+                    for (int j0 = a; j0 < b; j0 += 64) {
+                        const int j = j0 + lane;
+                        bool in = false;
+                        if (j < b) {
+                            double qx, qy, qz;
+                            tgt_xyz(j, qx, qy, qz);
+                            double d = sqdist(px, py, pz, qx, qy, qz);
+                            in = d < g2;
+                            if (d < dreg[kKnnSlots - 1]) {
+                                int jj = j;
+#pragma unroll
+                                for (int s = 0; s < kKnnSlots; ++s)
+                                    if (d < dreg[s]) { const double td = dreg[s]; const int tj = preg[s]; dreg[s] = d; preg[s] = jj; d = td; jj = tj; }
                             }
-                            inside += __popcll(__ballot(in));
                         }
+                        inside += __popcll(__ballot(in));
                     }
+                }
             }
             if (inside >= k || all) break;
-            ++R;
+            R += R > 1 ? R >> 1 : 1;                               // isolated points: grow geometrically, not ring by ring
         }
         double sum[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) sum[q] = 0.0;
         double sep2 = 1e300;
         int taken = 0;
-        if (M <= kKnnCache) {
-            const int nslots = (M + 63) >> 6;
+        const int nslots = M <= kKnnCache ? (M + 63) >> 6 : kKnnSlots;
+        bool exact = true;
+        unsigned long long v = 0;
+        {
             // k-th smallest squared distance by bisection on the (non-negative) bit pattern
-            unsigned long long v = 0;
             for (int bit = 62; bit >= 0; --bit) {
                 const unsigned long long t = v | (1ull << bit);
                 int c = 0;
@@ -591,6 +730,11 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
                     if (s < nslots) c += __popcll(__ballot((unsigned long long)__double_as_longlong(dreg[s]) < t));
                 if (c < k) v = t;
             }
+            // lanes that kept only their smallest: a lane whose largest kept distance does not exceed the k-th smallest may
+            // have dropped a neighbour -> the per-lane lists are not proof enough, take the pass-by-pass path
+            if (M > kKnnCache && __ballot(!((unsigned long long)__double_as_longlong(dreg[kKnnSlots - 1]) > v))) exact = false;
+        }
+        if (exact) {
             const double dk = __longlong_as_double((long long)v);
             int less = 0, eq = 0;
 #pragma unroll
@@ -651,19 +795,17 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
             for (int pass = 0; pass < k; ++pass) {
                 double bd = 1e300;
                 int bo = INT_MAX, bp = -1;
-                for (int y = ya; y <= yb; ++y)
-                    for (int x = xa; x <= xb; ++x) {
-                        const int c = (x * gy + y) * gz;
-                        const int a = cs[c + za], b = cs[c + zb + 1];
-                        for (int j = a + lane; j < b; j += 64) {
-                            double qx, qy, qz;
-                            tgt_xyz(j, qx, qy, qz);
-                            const double d = sqdist(px, py, pz, qx, qy, qz);
-                            const int o = tgt_orig(j);
-                            const bool after = d > prev_d || (d == prev_d && o > prev_o);
-                            if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
-                        }
+                for (int x = xa; x <= xb; ++x) {
+                    const int a = cs[x * gy + ya], b = cs[x * gy + yb + 1];
+                    for (int j = a + lane; j < b; j += 64) {
+                        double qx, qy, qz;
+                        tgt_xyz(j, qx, qy, qz);
+                        const double d = sqdist(px, py, pz, qx, qy, qz);
+                        const int o = tgt_orig(j);
+                        const bool after = d > prev_d || (d == prev_d && o > prev_o);
+                        if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
                     }
+                }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     const double od = shfl_xor_d(bd, off);
@@ -696,8 +838,7 @@ k_icp_knn(IcpBuffers B, int knn) {
     const int h = blockIdx.y;
     const IcpState& S = B.st[h];
     if (S.status != 0 || S.n_tgt == 0) return;
-    if (S.n_tgt <= kLoopLdsPts) knn_body<true>(B, S, h, knn, s_tgt, s_list);
-    else knn_body<false>(B, S, h, knn, s_tgt, s_list);
+    knn_body(B, S, h, knn, s_tgt, s_list);
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----
@@ -937,8 +1078,9 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
     double* P = B.work + (size_t)h * B.cap * 3;
     int* prev = B.prev_nn + (size_t)h * B.cap;
     double* lb = B.nn_lb + (size_t)h * B.cap;
-    const int gx = S.gx, gy = S.gy, gz = S.gz;
-    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell;
+    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max;
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
+    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
     const double r2 = max_dist * max_dist;
     const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
     const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
@@ -982,7 +1124,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
     __syncthreads();
     for (int w = 0; w < kSearchWG / 64; ++w) { xmn = fmin(xmn, s_xmm[w][0]); xmx = fmax(xmx, s_xmm[w][1]); }
     const int xlo = grid_coord(xmn - far * 1.001, minx, inv, gx), xhi = grid_coord(xmx + far * 1.001, minx, inv, gx);
-    const int c0 = xlo * gy * gz, c1 = (xhi + 1) * gy * gz;
+    const int c0 = xlo * gy, c1 = (xhi + 1) * gy;
     const int c0a = c0 & ~7;                                  // 16-byte aligned start of the table copy
     const int p0 = cs[c0], p1 = cs[c1];
     const int np = p1 - p0;
@@ -1006,6 +1148,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
         else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
     };
     auto tgt_orig = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].orig : orig[j]; };
+    auto tgt_zq = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].zq : rec[j].zq; };
     auto cell_at = [&](int c) { return kLds ? (int)s_cs[c - c0a] : cs[c]; };
 
     for (int base = i_lo; base < i_hi; base += kLoopQueue) {
@@ -1086,11 +1229,12 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
                 if (d < bd) { bd = d; bo = tgt_orig(pj); bp = pj; }
             }
             if (active && nt > 0 && px == px && py == py && pz == pz) {
-                // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the cells overlapping it suffice
+                // every target with d <= bd lies in the cube of half-width sqrt(bd) around p: the columns overlapping it,
+                // cut to its depth range, suffice
                 const double rad = sqrt(bd) * (1.0 + 1e-9) + 1e-12;
                 const int xa = grid_coord(px - rad, minx, inv, gx), xb = grid_coord(px + rad, minx, inv, gx);
                 const int ya = grid_coord(py - rad, miny, inv, gy), yb = grid_coord(py + rad, miny, inv, gy);
-                const int za = grid_coord(pz - rad, minz, inv, gz), zb = grid_coord(pz + rad, minz, inv, gz);
+                const int zlo = zq_of(pz - rad, minz, inv_z, zq_max), zhi = zq_of(pz + rad, minz, inv_z, zq_max);
                 const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
                 const float inv_nxc = 1.0f / (float)nxc;
                 for (int r0 = sub * 4; r0 < ncol; r0 += 4 * lpp) {
@@ -1101,24 +1245,31 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
                         const int r = r0 + u;
                         if (r < ncol) {
                             const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
-                            const int c = ((xa + (r - yy * nxc)) * gy + ya + yy) * gz;
-                            ca4[u] = cell_at(c + za); cb4[u] = cell_at(c + zb + 1);
+                            const int c = (xa + (r - yy * nxc)) * gy + ya + yy;
+                            ca4[u] = cell_at(c); cb4[u] = cell_at(c + 1);
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int a = ca4[u], b = cb4[u];
+                        int a = ca4[u];
+                        const int b = cb4[u];
+                        {                                         // first point of the column at depth step >= zlo (the run is depth-ordered)
+                            int hi = b;
+                            while (a < hi) { const int mid = (a + hi) >> 1; if (tgt_zq(mid) < zlo) a = mid + 1; else hi = mid; }
+                        }
                         // four candidates per trip (independent LDS reads in flight); indices past the run are
-                        // clamped to its last point, which only re-tests a candidate
+                        // clamped to its last point, which only re-tests a candidate; past depth step zhi the run is done
                         for (int j0 = a; j0 < b; j0 += 4) {
                             double d4[4];
                             int j4[4];
+                            bool more = true;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 j4[v] = j0 + v < b ? j0 + v : b - 1;
                                 double qx, qy, qz;
                                 tgt_xyz(j4[v], qx, qy, qz);
                                 d4[v] = sqdist(px, py, pz, qx, qy, qz);
+                                if (tgt_zq(j4[v]) > zhi) more = false;
                             }
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
@@ -1127,6 +1278,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
                                 if (d < bd) { bd = d; bo = tgt_orig(j); bp = j; }
                                 else if (d == bd && bp >= 0 && bp != j) { const int o = tgt_orig(j); if (o < bo) { bo = o; bp = j; } }
                             }
+                            if (!more) break;
                         }
                     }
                 }
@@ -1198,12 +1350,49 @@ k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) 
     icp_eval_body(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol);
 }
 
+// Pipeline glue (pipeline.cpp): turns the detections kept by the on-device NMS into ICP hypotheses without a
+// host round trip.  One thread per hypothesis slot: the view (rendered depth slot + camera matrix) of the
+// matched template, detect = match position (linemod_and_levelup_test.py:354-367).
+__global__ void k_icp_bind(const TopkSel* __restrict__ sel, const int32_t* __restrict__ nsel_status, const int32_t* __restrict__ class_base,
+                           const float* __restrict__ view_K, const int32_t* __restrict__ view_valid, int num_views, IcpIn* __restrict__ in,
+                           IcpState* __restrict__ st, int top_k) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= top_k) return;
+    IcpIn I;
+    for (int k = 0; k < 9; ++k) I.mK[k] = 0.f;
+    I.dx = 0; I.dy = 0; I.model_slot = 0; I.pad = 0;
+    int status = 4;                                              // no detection for this slot
+    if (nsel_status[1] == 0 && h < nsel_status[0]) {
+        const TopkSel s = sel[h];
+        const int base = class_base[s.class_index];
+        const int v = base + s.template_id;
+        status = 5;                                              // the matched template has no rendered view
+        if (base >= 0 && v >= 0 && v < num_views && view_valid[v]) {
+            status = 0;
+            for (int k = 0; k < 9; ++k) I.mK[k] = view_K[(size_t)v * 9 + k];
+            I.dx = s.x; I.dy = s.y; I.model_slot = v;
+        }
+    }
+    in[h] = I;
+    IcpState& S = st[h];                                         // zeroed by the caller (hipMemsetAsync)
+    S.bbox[0] = INT_MAX; S.bbox[1] = INT_MAX; S.bbox[2] = -1; S.bbox[3] = -1;
+    S.status = status;
+}
+
+void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32_t* class_base, const float* view_K,
+                     const int32_t* view_valid, int num_views, IcpIn* in, IcpState* st, int top_k, hipStream_t s) {
+    if (top_k <= 0) return;
+    hipLaunchKernelGGL(k_icp_bind, dim3((top_k + 63) / 64), dim3(64), 0, s, sel, nsel_status, class_base, view_K, view_valid, num_views, in, st,
+                       top_k);
+}
+
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, hipStream_t s) {
     if (count <= 0) return;
     const int scene_mode = flags & 1;
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
-    hipLaunchKernelGGL(k_icp_points, dim3(count), dim3(kWG), 0, s, B, W, H, flags);
+    hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+    hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_knn, dim3(32, count), dim3(kKnnWG), 0, s, B, knn);

@@ -1,0 +1,38 @@
+// Private view of the ICP context shared by pose_refine.cpp and pipeline.cpp (not part of the C ABI).
+#pragma once
+#include "../../include/amd_linemod.h"
+#include "icp_kernels.h"
+
+using lm::IcpBuffers;
+using lm::IcpIn;
+using lm::IcpState;
+
+struct lm_icp {
+    int device = 0;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int W = 0, H = 0;
+    bool have_scene = false;
+    float sK[9] = {0};
+    int slots = 0;                 // resident model depth images
+    int max_count = 0;             // hypotheses the arenas hold
+    int last_count = 0, last_flags = 0;
+    uint16_t* d_scene = nullptr;
+    uint16_t* d_models = nullptr;
+    IcpIn* d_in = nullptr;
+    IcpState* d_st = nullptr;
+    IcpBuffers B{};
+    void* pinned = nullptr;        // staging for images
+    size_t pinned_bytes = 0;
+    IcpIn* h_in = nullptr;         // pinned
+    IcpState* h_st = nullptr;      // pinned
+    int h_cap = 0;
+};
+
+
+// pose_refine.cpp
+int lm_icp_set_geometry(lm_icp* c, int W, int H);      // (re)allocates for a frame size; drops the slots when it changes
+int lm_icp_ensure_arenas(lm_icp* c, int count);        // arenas for `count` hypotheses
+int lm_icp_ensure_slots(lm_icp* c, int slots);         // resident model depth images
+// [R|t] of LL.cpp:34-41 and LL.cpp:146-154 from the device state of one hypothesis
+void lm_icp_compose_result(const lm::IcpState& st, const float* model_R, const float* model_t, lm_pose_result* o);

@@ -10,13 +10,14 @@
 
 namespace lm {
 
-constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 cells per axis ...
-constexpr int kIcpCells = 16384 + 1;              // ... and at most 16384 cells (+1 end marker)
-constexpr int kIcpCells16 = 16392;                // kIcpCells rounded up to a multiple of 8 (16-byte copies of the u16 table)
+constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 x 64 ...
+constexpr int kIcpCells = kIcpGrid * kIcpGrid + 1; // ... columns in x and y (+1 end marker)
+constexpr int kIcpCells16 = 4104;                 // kIcpCells rounded up to a multiple of 8 (16-byte copies of the u16 table)
+constexpr int kIcpStrips = 16;                    // row strips of the bounding box in k_icp_points
 constexpr int kIcpMaxSplit = 64;                  // workgroups (source slices) per hypothesis in k_icp_search
 constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
 
-struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int pad; };   // target point as staged in LDS (32 B)
+struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int zq; };    // target point as staged in LDS (32 B): xyz, original index, quantised depth
 
 struct IcpIn {               // one pose hypothesis (uploaded)
     float mK[9];             // model camera matrix (row-major 3x3, float like the reference's cv::Mat_<float>)
@@ -30,10 +31,10 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys
     int n_model, n_scene;    // back-projected points
     int n_src, n_tgt;        // after voxel down-sampling
-    int gx, gy, gz;          // search grid dimensions
+    int gx, gy, zq_max;      // search grid: columns in x and y, largest quantised depth
     int iterations, n_corr;
     double init[3];          // init_guess translation (LL.cpp:101-104)
-    double gminx, gminy, gminz, cell, inv_cell;
+    double gminx, gminy, gminz, cell, inv_cell, inv_z;
     double T[16];            // final transformation_ (row-major)
     double fitness, rmse;    // fitness_, inlier_rmse_
     int stop;                // RegistrationICP finished (converged or max_iteration)
@@ -65,10 +66,15 @@ struct IcpBuffers {
     double* work;            // [count][cap][3]  transformed source cloud
     int* prev_nn;            // [count][cap]     previous correspondence (sorted position) of every source point
     double* nn_lb;           // [count][cap]     lower bound on the distance to the nearest target of a point without correspondence
+    int* strip_cnt;          // [count][kIcpStrips][2] model / scene points per strip
+    double* strip_sum;       // [count][kIcpStrips][8] centroid sums per strip
     double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
 };
 
+struct TopkSel;
+void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32_t* class_base, const float* view_K,
+                     const int32_t* view_valid, int num_views, IcpIn* in, IcpState* st, int top_k, hipStream_t s);
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, hipStream_t s);
 

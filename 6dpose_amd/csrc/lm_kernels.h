@@ -60,7 +60,24 @@ struct FeatStrip {        // per feature of a level below the top: strip-plane b
 };
 void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, uint32_t cap, const unsigned long long* counters,
+                  float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
                   unsigned long long* block_stats, int grid_blocks, hipStream_t s);
+
+// ---- on-device NMS + top-K (nms.hip): the caller-side loop of linemod_and_levelup_test.py:331-352 ----
+struct TopkSel {          // one kept detection
+    int32_t x, y;
+    float similarity;
+    int32_t work;         // work-list index
+    int32_t class_index, template_id;
+    int32_t width, height;   // level-0 template size (the NMS box)
+};
+// Greedy NMS (numpy `nms` of the driver, IoU with the +1 pixel convention, suppress when IoU > thresh) over
+// the canonical match list of the frame (sorted + adjacent-unique as Detector::match returns it), stopped
+// after top_k kept boxes.  matches_dev / counters as written by launch_local; scratch: topk_nms_scratch_bytes(cap).
+// sel[0..*nsel) in keep order; status: 0 ok, 1 field overflow (template id >= 2^24, class >= 128, |x|,|y| >= 2^15).
+void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* counters, uint32_t cap, const int32_t* work_pyramids,
+                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels, int top_k,
+                     double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s);
+size_t topk_nms_scratch_bytes(uint32_t cap);
 
 }  // namespace lm

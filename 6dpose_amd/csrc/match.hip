@@ -222,8 +222,8 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
         const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
-        float threshold, Candidate* __restrict__ matches, uint32_t cap, const unsigned long long* __restrict__ counters,
-        unsigned long long* __restrict__ block_stats) {
+        float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
+        const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats) {
     __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -377,6 +377,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             Candidate m;
             m.x = mx; m.y = my; m.score = sim; m.work = alive ? work : -1;
             matches[ci] = m;
+            matches_dev[ci] = m;                 // HBM copy for the on-device NMS / top-K (pipeline.cpp)
         }
     }
     // per-block statistics (16x16 evaluations, their algorithmic bytes): plain stores, summed on the host
@@ -393,11 +394,11 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
 void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
                   const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, uint32_t cap, const unsigned long long* counters,
+                  float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
                   unsigned long long* block_stats, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
-                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, cap, counters, block_stats);
+                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats);
 }
 
 }  // namespace lm

@@ -1,0 +1,226 @@
+// On-device NMS + top-K over the matches of one frame: the caller-side loop of the
+// reference driver (linemod_and_levelup_test.py:331-352 — boxes x..x+width, y..y+height of the matched
+// template, numpy `nms` :34-61 with IoU > 0.5 suppressing, then the first few kept detections go to
+// poseRefine) without the device-to-host copy of thousands of matches and the Python greedy loop.
+//
+// Semantics = lm_nms_boxes(canonical match list) stopped after top_k kept boxes, exactly:
+//   * candidates are the entries of the list Detector::match returns (canonical sort + adjacent-unique,
+//     SURVEY A12).  Nothing is sorted here: an entry R is removed by std::unique iff its immediate
+//     predecessor in the canonical order has the same (x, y, similarity, class) — found with one
+//     arg-max pass over the records, and only for the few entries that are about to be kept;
+//   * visiting order of the greedy loop: similarity descending, ties by HIGHER canonical index first
+//     (scores.argsort()[::-1], the rule lm_nms_boxes documents);
+//   * IoU in double with the +1 pixel convention, suppressed iff !(IoU <= thresh).
+// One 1024-thread workgroup.  Records identical in every field (several coarse candidates of a template refined
+// to one position) are dropped first with a hash; the distinct ones (a few thousand) live in LDS.  A round =
+// arg-max of the live records, predecessor test, suppression: three passes over LDS.
+#include "lm_kernels.h"
+
+namespace lm {
+
+constexpr int kNmsWG = 1024;
+
+// packed record: .x = x | y << 16 (int16 each), .y = w | h << 16, .z = similarity bits (valid: >= 0 float), .w = tid | cls << 24 | dead << 31
+struct NmsKey {           // canonical order key of a record (ascending = earlier in the list) + its slot
+    uint32_t sim;         // similarity bits (non-negative floats order like unsigned)
+    int32_t tid, cls, y, x, slot;
+};
+
+static __device__ __forceinline__ NmsKey key_of(const int4 r, int slot) {
+    NmsKey k;
+    k.sim = (uint32_t)r.z;
+    k.tid = r.w & 0xFFFFFF; k.cls = (r.w >> 24) & 0x7F;
+    k.x = (int)(int16_t)(r.x & 0xFFFF); k.y = (int)(int16_t)((uint32_t)r.x >> 16);
+    k.slot = slot;
+    return k;
+}
+// a before b in the canonical order (similarity desc, template_id, class, y, x asc; slot separates identical records)
+static __device__ __forceinline__ bool canon_before(const NmsKey& a, const NmsKey& b) {
+    if (a.sim != b.sim) return a.sim > b.sim;
+    if (a.tid != b.tid) return a.tid < b.tid;
+    if (a.cls != b.cls) return a.cls < b.cls;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.x != b.x) return a.x < b.x;
+    return a.slot < b.slot;
+}
+// a is visited before b by the greedy loop: higher similarity, then the LATER canonical entry
+static __device__ __forceinline__ bool visit_before(const NmsKey& a, const NmsKey& b) {
+    if (a.sim != b.sim) return a.sim > b.sim;
+    return canon_before(b, a);
+}
+static __device__ __forceinline__ NmsKey shfl_key(const NmsKey& k, int off) {
+    NmsKey o;
+    o.sim = (uint32_t)__shfl_xor((int)k.sim, off, 64); o.tid = __shfl_xor(k.tid, off, 64); o.cls = __shfl_xor(k.cls, off, 64);
+    o.y = __shfl_xor(k.y, off, 64); o.x = __shfl_xor(k.x, off, 64); o.slot = __shfl_xor(k.slot, off, 64);
+    return o;
+}
+
+// Workgroup-wide selection of the key that `better` prefers; slot < 0 = none.  Result broadcast to every thread.
+template <typename Better>
+static __device__ __forceinline__ NmsKey block_select(NmsKey k, NmsKey* s_keys, Better better) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const NmsKey o = shfl_key(k, off);
+        if (o.slot >= 0 && (k.slot < 0 || better(o, k))) k = o;
+    }
+    __syncthreads();
+    if (lane == 0) s_keys[wave] = k;
+    __syncthreads();
+    NmsKey best = s_keys[0];
+    for (int w = 1; w < kNmsWG / 64; ++w) {
+        const NmsKey o = s_keys[w];
+        if (o.slot >= 0 && (best.slot < 0 || better(o, best))) best = o;
+    }
+    return best;
+}
+
+constexpr int kNmsLds = 8192;      // distinct records held in LDS (128 KiB); more than that stay in the HBM scratch
+
+// Greedy loop over m distinct records (rec in LDS or HBM).
+template <typename RecPtr>
+static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const int top_k, const double thresh, NmsKey* s_keys,
+                                                 TopkSel* __restrict__ sel) {
+    const int tid = threadIdx.x;
+    int kept = 0;
+    while (kept < top_k) {
+        // (1) next entry the greedy loop visits
+        NmsKey mine; mine.slot = -1; mine.sim = 0; mine.tid = mine.cls = mine.x = mine.y = 0;
+        for (int i = tid; i < m; i += kNmsWG) {
+            const int4 r = rec[i];
+            if (r.w < 0) continue;                                              // suppressed / removed
+            const NmsKey k = key_of(r, i);
+            if (mine.slot < 0 || visit_before(k, mine)) mine = k;
+        }
+        const NmsKey R = block_select(mine, s_keys, [](const NmsKey& a, const NmsKey& b) { return visit_before(a, b); });
+        if (R.slot < 0) break;
+        // (2) std::unique: R disappears iff its canonical predecessor (over ALL entries of the frame) equals it in (x, y, similarity, class)
+        NmsKey pm; pm.slot = -1; pm.sim = 0; pm.tid = pm.cls = pm.x = pm.y = 0;
+        for (int i = tid; i < m; i += kNmsWG) {
+            const NmsKey k = key_of(rec[i], i);
+            if (canon_before(k, R) && (pm.slot < 0 || canon_before(pm, k))) pm = k;
+        }
+        const NmsKey P = block_select(pm, s_keys, [](const NmsKey& a, const NmsKey& b) { return canon_before(b, a); });
+        const bool dup = P.slot >= 0 && P.sim == R.sim && P.cls == R.cls && P.x == R.x && P.y == R.y;
+        const int4 rr = rec[R.slot];
+        __syncthreads();
+        if (dup) {
+            if (tid == 0) rec[R.slot].w = rr.w | (int)0x80000000;
+            __syncthreads();
+            continue;
+        }
+        // (3) keep R, suppress what overlaps it (R itself has IoU 1)
+        const double x1 = (double)R.x, y1 = (double)R.y;
+        const double x2 = x1 + (double)(rr.y & 0xFFFF), y2 = y1 + (double)((uint32_t)rr.y >> 16);
+        const double ai = (x2 - x1 + 1) * (y2 - y1 + 1);
+        for (int i = tid; i < m; i += kNmsWG) {
+            const int4 r = rec[i];
+            if (r.w < 0) continue;
+            const double bx1 = (double)(int16_t)(r.x & 0xFFFF), by1 = (double)(int16_t)((uint32_t)r.x >> 16);
+            const double bx2 = bx1 + (double)(r.y & 0xFFFF), by2 = by1 + (double)((uint32_t)r.y >> 16);
+            const double xx1 = fmax(x1, bx1), yy1 = fmax(y1, by1), xx2 = fmin(x2, bx2), yy2 = fmin(y2, by2);
+            const double w = fmax(0.0, xx2 - xx1 + 1), h = fmax(0.0, yy2 - yy1 + 1);
+            const double inter = w * h;
+            const double aj = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+            const double ovr = __ddiv_rn(inter, ai + aj - inter);
+            if (!(ovr <= thresh)) rec[i].w = r.w | (int)0x80000000;
+        }
+        if (tid == 0) {
+            TopkSel o;
+            o.x = R.x; o.y = R.y; o.similarity = __int_as_float((int)R.sim); o.work = -1;
+            o.class_index = R.cls; o.template_id = R.tid;
+            o.width = rr.y & 0xFFFF; o.height = (int)((uint32_t)rr.y >> 16);
+            sel[kept] = o;
+        }
+        ++kept;
+        __syncthreads();
+    }
+    return kept;
+}
+
+// Pack + exact-duplicate removal + greedy loop.  Several coarse candidates of one template often refine to the
+// same position: those records are identical in every output field, std::unique removes all but one, so they are
+// dropped up front with an open-addressing hash on (x, y, template, class) (`table`: 64-bit slots preset to ~0).
+__global__ void __launch_bounds__(kNmsWG)
+k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __restrict__ counters, uint32_t cap,
+           const int32_t* __restrict__ work_pyramids, const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid,
+           const TemplEntry* __restrict__ entries, int levels, int top_k, double thresh, int4* __restrict__ rec,
+           unsigned long long* __restrict__ table, uint32_t table_mask, TopkSel* __restrict__ sel, int32_t* __restrict__ nsel_status) {
+    __shared__ int4 s_rec[kNmsLds];
+    __shared__ NmsKey s_keys[kNmsWG / 64];
+    __shared__ int s_bad, s_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long nc = counters[0];
+    const int n = (int)(nc < cap ? nc : cap);
+    if (tid == 0) { s_bad = 0; s_m = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kNmsWG) {
+        const int i = i0 + tid;
+        bool keep = false;
+        int4 r = make_int4(0, 0, 0, 0);
+        if (i < n) {
+            const Candidate c = matches[i];
+            if (c.work >= 0) {
+                const TemplEntry e = entries[(size_t)work_pyramids[c.work] * levels];  // level 0: the template's size
+                const int t = work_tid[c.work], cl = work_cls[c.work];
+                if (t < 0 || t >= (1 << 24) || cl < 0 || cl >= 128 || c.x < -32768 || c.x > 32767 || c.y < -32768 || c.y > 32767 ||
+                    e.width < 0 || e.width > 65535 || e.height < 0 || e.height > 65535 || c.score < 0.f || !(c.score == c.score)) {
+                    s_bad = 1;
+                } else {
+                    r.x = (c.x & 0xFFFF) | (c.y << 16);
+                    r.y = (e.width & 0xFFFF) | (e.height << 16);
+                    r.z = __float_as_int(c.score);
+                    r.w = t | (cl << 24);
+                    const unsigned long long key = ((unsigned long long)(uint32_t)r.x << 32) | (uint32_t)r.w;
+                    unsigned long long hsh = key * 0x9E3779B97F4A7C15ull;
+                    uint32_t slot = (uint32_t)(hsh >> 40) & table_mask;
+                    for (;;) {                                                     // linear probing; the table is never full (>= 2 x cap slots)
+                        const unsigned long long prev = atomicCAS(&table[slot], ~0ull, key);
+                        if (prev == ~0ull) { keep = true; break; }
+                        if (prev == key) break;                                    // an identical record is already in
+                        slot = (slot + 1) & table_mask;
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(keep);                            // one LDS atomic per wave reserves the slots
+        if (mask) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_m, __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < kNmsLds) s_rec[pos] = r;
+                rec[pos] = r;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) { nsel_status[0] = 0; nsel_status[1] = 1; }
+        return;
+    }
+    const int m = s_m;
+    const int kept = m <= kNmsLds ? nms_rounds(s_rec, m, top_k, thresh, s_keys, sel) : nms_rounds(rec, m, top_k, thresh, s_keys, sel);
+    if (tid == 0) { nsel_status[0] = kept; nsel_status[1] = 0; }
+}
+
+void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* counters, uint32_t cap, const int32_t* work_pyramids,
+                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels, int top_k,
+                     double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s) {
+    // scratch: cap int4 records, then the hash table (power of two >= 2 * cap 64-bit slots)
+    size_t tsz = 1;
+    while (tsz < 2 * (size_t)cap) tsz <<= 1;
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + (size_t)cap * 16);
+    (void)hipMemsetAsync(table, 0xFF, tsz * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_topk_nms, dim3(1), dim3(kNmsWG), 0, s, matches_dev, counters, cap, work_pyramids, work_cls, work_tid, entries,
+                       levels, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), sel, nsel_status);
+}
+
+size_t topk_nms_scratch_bytes(uint32_t cap) {
+    size_t tsz = 1;
+    while (tsz < 2 * (size_t)cap) tsz <<= 1;
+    return (size_t)cap * 16 + tsz * sizeof(unsigned long long);
+}
+
+}  // namespace lm

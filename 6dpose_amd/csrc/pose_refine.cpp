@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "../../include/amd_linemod.h"
-#include "icp_kernels.h"
+#include "icp_internal.h"
 
 using namespace lm;
 
@@ -41,33 +41,11 @@ size_t pow2_at_least(size_t n) {
 }
 }  // namespace
 
-struct lm_icp {
-    int device = 0;
-    hipStream_t s = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int W = 0, H = 0;
-    bool have_scene = false;
-    float sK[9] = {0};
-    int slots = 0;                 // resident model depth images
-    int max_count = 0;             // hypotheses the arenas hold
-    int last_count = 0, last_flags = 0;
-    uint16_t* d_scene = nullptr;
-    uint16_t* d_models = nullptr;
-    IcpIn* d_in = nullptr;
-    IcpState* d_st = nullptr;
-    IcpBuffers B{};
-    void* pinned = nullptr;        // staging for images
-    size_t pinned_bytes = 0;
-    IcpIn* h_in = nullptr;         // pinned
-    IcpState* h_st = nullptr;      // pinned
-    int h_cap = 0;
-};
-
 namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
@@ -87,7 +65,8 @@ int ensure_pinned(lm_icp* c, size_t bytes) {
     return LM_OK;
 }
 
-int ensure_arenas(lm_icp* c, int count) {
+}  // namespace
+int lm_icp_ensure_arenas(lm_icp* c, int count) {
     if (count <= c->max_count) return LM_OK;
     HIP_TRY(hipStreamSynchronize(c->s));
     free_arenas(c);
@@ -108,6 +87,8 @@ int ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.prev_nn, (size_t)n * cap * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.nn_lb, (size_t)n * cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.partial, (size_t)2 * n * kIcpMaxSplit * 32 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.strip_cnt, (size_t)n * kIcpStrips * 2 * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&B.strip_sum, (size_t)n * kIcpStrips * 8 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.tgt_rec, (size_t)n * cap * sizeof(TgtRec)));
     HIP_TRY(hipMalloc((void**)&B.cell_start16, (size_t)n * kIcpCells16 * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
@@ -121,7 +102,7 @@ int ensure_arenas(lm_icp* c, int count) {
     return LM_OK;
 }
 
-int set_geometry(lm_icp* c, int W, int H) {
+int lm_icp_set_geometry(lm_icp* c, int W, int H) {
     if (W == c->W && H == c->H) return LM_OK;
     HIP_TRY(hipStreamSynchronize(c->s));
     free_arenas(c);
@@ -133,7 +114,7 @@ int set_geometry(lm_icp* c, int W, int H) {
     return LM_OK;
 }
 
-int ensure_slots(lm_icp* c, int slots) {
+int lm_icp_ensure_slots(lm_icp* c, int slots) {
     if (slots <= c->slots) return LM_OK;
     const size_t img = (size_t)c->W * c->H * sizeof(uint16_t);
     const int n = std::max(slots, std::max(16, c->slots * 2));
@@ -149,7 +130,36 @@ int ensure_slots(lm_icp* c, int slots) {
     return LM_OK;
 }
 
-}  // namespace
+
+void lm_icp_compose_result(const IcpState& st, const float* model_R, const float* model_t, lm_pose_result* op) {
+    lm_pose_result& o = *op;
+    // init_base (float): [R|t], only t.z / 1000 (LL.cpp:34-39)
+    float base[16];
+    for (int k = 0; k < 16; ++k) base[k] = 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 3; ++q) base[4 * r + q] = model_R[3 * r + q];
+        base[4 * r + 3] = model_t[r];
+    }
+    base[11] = base[11] / 1000.0f;
+    base[15] = 1.f;
+    // result = transformation_ * init_base.cast<double>() (LL.cpp:146); t * 1000 (LL.cpp:154)
+    double M[16];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            double v = 0;
+            for (int k = 0; k < 4; ++k) v += st.T[4 * a + k] * (double)base[4 * k + b];
+            M[4 * a + b] = v;
+        }
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) o.R[3 * a + b] = M[4 * a + b];
+        o.t[a] = M[4 * a + 3] * 1000.0;
+    }
+    o.residual = (float)st.fitness;       // residual = fitness_ (LL.cpp:148)
+    o.inlier_rmse = (float)st.rmse;
+    o.iterations = st.iterations;
+    o.n_source = st.n_src;
+    o.n_target = st.n_tgt;
+}
 
 extern "C" int lm_icp_create(int device, lm_icp** out) {
     if (!out) return lm_set_error(LM_ERR_INVALID, "null argument");
@@ -187,7 +197,7 @@ extern "C" void lm_icp_destroy(lm_icp* c) {
 extern "C" int lm_icp_set_scene(lm_icp* c, const uint16_t* scene_depth, int width, int height, const float* scene_K) {
     if (!c || !scene_depth || !scene_K || width <= 0 || height <= 0) return lm_set_error(LM_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = set_geometry(c, width, height);
+    int rc = lm_icp_set_geometry(c, width, height);
     if (rc) return rc;
     const size_t img = (size_t)width * height * sizeof(uint16_t);
     HIP_TRY(hipStreamSynchronize(c->s));                            // the staging buffer may still be in flight
@@ -206,7 +216,7 @@ extern "C" int lm_icp_set_models(lm_icp* c, int first_slot, int count, const uin
     for (int i = 0; i < count; ++i)
         if (!model_depths[i]) return lm_set_error(LM_ERR_INVALID, "model depth %d is null", i);
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_slots(c, first_slot + count);
+    int rc = lm_icp_ensure_slots(c, first_slot + count);
     if (rc) return rc;
     const size_t img = (size_t)c->W * c->H * sizeof(uint16_t);
     HIP_TRY(hipStreamSynchronize(c->s));
@@ -230,7 +240,7 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
         if (slot < 0 || slot >= c->slots) return lm_set_error(LM_ERR_INVALID, "model slot %d of hypothesis %d is not resident", slot, i);
     }
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_arenas(c, count);
+    int rc = lm_icp_ensure_arenas(c, count);
     if (rc) return rc;
     for (int i = 0; i < count; ++i) {
         IcpIn& in = c->h_in[i];
@@ -267,32 +277,7 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
         lm_pose_result& o = results[i];
         memset(&o, 0, sizeof(o));
         if (st.status == 1) { o.residual = -1.f; continue; }        // LL.cpp:52-55
-        // init_base (float): [R|t], only t.z / 1000 (LL.cpp:34-39)
-        float base[16];
-        for (int k = 0; k < 16; ++k) base[k] = 0.f;
-        for (int r = 0; r < 3; ++r) {
-            for (int q = 0; q < 3; ++q) base[4 * r + q] = model_Rs[9 * i + 3 * r + q];
-            base[4 * r + 3] = model_ts[3 * i + r];
-        }
-        base[11] = base[11] / 1000.0f;
-        base[15] = 1.f;
-        // result = transformation_ * init_base.cast<double>() (LL.cpp:146); t * 1000 (LL.cpp:154)
-        double M[16];
-        for (int a = 0; a < 4; ++a)
-            for (int b = 0; b < 4; ++b) {
-                double v = 0;
-                for (int k = 0; k < 4; ++k) v += st.T[4 * a + k] * (double)base[4 * k + b];
-                M[4 * a + b] = v;
-            }
-        for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b) o.R[3 * a + b] = M[4 * a + b];
-            o.t[a] = M[4 * a + 3] * 1000.0;
-        }
-        o.residual = (float)st.fitness;       // residual = fitness_ (LL.cpp:148)
-        o.inlier_rmse = (float)st.rmse;
-        o.iterations = st.iterations;
-        o.n_source = st.n_src;
-        o.n_target = st.n_tgt;
+        lm_icp_compose_result(st, model_Rs + 9 * i, model_ts + 3 * i, &o);
     }
     return LM_OK;
 }

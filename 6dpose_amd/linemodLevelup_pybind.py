@@ -36,7 +36,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["Detector", "Match", "poseRefine", "IcpContext", "Template", "library_path", "load_library", "nms"]
+__all__ = ["Detector", "Match", "poseRefine", "IcpContext", "Pipeline", "Template", "library_path", "load_library", "nms"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libamdlinemod.so"
@@ -66,6 +66,21 @@ class _CPoseResult(ctypes.Structure):
     _fields_ = [("R", ctypes.c_double * 9), ("t", ctypes.c_double * 3), ("residual", ctypes.c_float),
                 ("inlier_rmse", ctypes.c_float), ("iterations", ctypes.c_int32), ("n_source", ctypes.c_int32),
                 ("n_target", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class _CDetection(ctypes.Structure):
+    _fields_ = [("match", _CMatch), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("pose", _CPoseResult)]
+
+
+class PipelineTimings(ctypes.Structure):
+    """lm_pipeline_timings (include/amd_linemod.h)."""
+    _fields_ = [("match_ms", ctypes.c_float), ("nms_ms", ctypes.c_float), ("icp_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("coarse_candidates", ctypes.c_int64), ("matches_pre_unique", ctypes.c_int64), ("icp_iterations", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 MATCH_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("similarity", np.float32),
@@ -135,6 +150,12 @@ def load_library():
     lib.lm_icp_run.argtypes = [P, I, P, P, P, P, P, I, ctypes.POINTER(_CPoseResult), ctypes.POINTER(F)]
     lib.lm_icp_read_debug.argtypes = [P, I, I, P, ctypes.c_int64]
     lib.lm_icp_read_debug.restype = ctypes.c_int64
+    lib.lm_pipeline_create.argtypes = [P, I, I, ctypes.POINTER(P)]
+    lib.lm_pipeline_destroy.argtypes = [P]
+    lib.lm_pipeline_destroy.restype = None
+    lib.lm_pipeline_set_views.argtypes = [P, S, I, I, ctypes.POINTER(P), P, P, P]
+    lib.lm_pipeline_run.argtypes = [P, F, ctypes.POINTER(S), I, P, I, ctypes.c_double, I, ctypes.POINTER(_CDetection), ctypes.POINTER(I),
+                                    ctypes.POINTER(PipelineTimings)]
     _lib = lib
     return lib
 
@@ -552,3 +573,58 @@ class IcpContext:
         if n:
             self._lib.lm_icp_read_debug(self._h, int(hypothesis), int(kind), _ptr(out), int(n))
         return out if kind == 3 else out.reshape(-1, 3)
+
+
+class Pipeline:
+    """lm_pipeline (include/amd_linemod.h): the per-frame loop of linemod_and_levelup_test.py:324-372 — match, boxes,
+    nms, poseRefine on the first top_k kept matches — as one stream of device work on the detector's resident frame.
+    set_views(class_id, depth_rens, Ks, Rs, ts) uploads what the driver renders per matched template; run(...) returns
+    (list of dict(x, y, similarity, class_index, template_id, width, height, status, R, t, residual, iterations...),
+    timings dict)."""
+
+    def __init__(self, detector: "Detector", width: int, height: int, scene_from_scene: bool = False):
+        self._lib = load_library()
+        self._det = detector
+        self._h = ctypes.c_void_p()
+        _check(self._lib.lm_pipeline_create(detector._h, int(width), int(height), ctypes.byref(self._h)))
+        self.flags = LM_ICP_SCENE_FROM_SCENE if scene_from_scene else 0
+        self.shape = (int(height), int(width))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lm_pipeline_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def set_views(self, class_id: str, depth_rens, Ks, Rs, ts, first_template: int = 0):
+        mds = [_as_depth(m, "depth_ren") for m in depth_rens]
+        for m in mds:
+            if m.shape != self.shape:
+                raise RuntimeError("depth rendering size differs from the pipeline's frame size")
+        n = len(mds)
+        ptrs = (ctypes.c_void_p * n)(*[m.ctypes.data for m in mds])
+        Ks = np.ascontiguousarray(np.asarray(Ks, np.float32).reshape(n, 9))
+        Rs = np.ascontiguousarray(np.asarray(Rs, np.float32).reshape(n, 9))
+        ts = np.ascontiguousarray(np.asarray(ts, np.float32).reshape(n, 3))
+        _check(self._lib.lm_pipeline_set_views(self._h, class_id.encode(), int(first_template), n, ptrs, _ptr(Ks), _ptr(Rs), _ptr(ts)))
+
+    def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5):
+        ids = [c.encode() for c in class_ids]
+        arr = (ctypes.c_char_p * len(ids))(*ids) if ids else None
+        sK = np.ascontiguousarray(np.asarray(scene_K, np.float32).reshape(9))
+        out = (_CDetection * int(top_k))()
+        n = ctypes.c_int()
+        tm = PipelineTimings()
+        _check(self._lib.lm_pipeline_run(self._h, float(threshold), arr, len(ids), _ptr(sK), int(top_k), float(nms_iou), self.flags, out,
+                                         ctypes.byref(n), ctypes.byref(tm)))
+        res = []
+        for i in range(n.value):
+            o = out[i]
+            res.append({"x": int(o.match.x), "y": int(o.match.y), "similarity": float(o.match.similarity),
+                        "class_index": int(o.match.class_index), "template_id": int(o.match.template_id),
+                        "width": int(o.width), "height": int(o.height), "status": int(o.status),
+                        "R": np.array(o.pose.R).reshape(3, 3), "t": np.array(o.pose.t), "residual": float(o.pose.residual),
+                        "rmse": float(o.pose.inlier_rmse), "iterations": int(o.pose.iterations),
+                        "n_source": int(o.pose.n_source), "n_target": int(o.pose.n_target)})
+        return res, tm.as_dict()

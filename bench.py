@@ -196,7 +196,8 @@ def main():
         if world == 1:
             out["extras"] = {"synchronous_call": sync_latency(det, classes, args.templates),
                              "pcie_inclusive": pcie_inclusive(det, frames, classes, args.templates),
-                             "icp": icp_bench(local_rank)}
+                             "icp": icp_bench(local_rank),
+                             "pipeline": pipeline_bench(det, frames, banks[classes[0]], classes)}
         traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
         if os.path.exists(traffic):
             try:
@@ -294,6 +295,56 @@ def icp_bench(device, hypotheses=16, reps=5):
             pcie = cur
     best["pcie_inclusive"] = {"wall_ms": pcie["wall_ms"], "icp_iters_per_sec_wall": pcie["icp_iters_per_sec_wall"]}
     return best
+
+
+def pipeline_bench(det, frames, bank, classes, top_k=16, steps=20):
+    """BASELINE configs[2] end to end: match (2k templates) -> boxes -> NMS -> top-16 -> poseRefine on every kept match,
+    one stream of device work per frame (lm_pipeline_run), everything resident in HBM.  The depth rendering of a
+    template view (what the reference driver gets from its OpenGL renderer) is synthetic: the scene depth under the
+    template's best match on frame 0, pushed back 3 mm and shifted 2 px, so that ICP has real work to do."""
+    import linemodLevelup_pybind as lm
+    K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
+    rgb, dep = frames[0]
+    feat, offs, wh = bank
+    E = 2 * len(T_LEVELS)
+    n = (len(offs) - 1) // E
+    m = det.matchArray([rgb, dep], THRESHOLD, classes)
+    best = {}
+    for r in m:                                                  # canonical order: the first entry of a template is its best
+        best.setdefault(int(r["template_id"]), (int(r["x"]), int(r["y"])))
+    pipe = lm.Pipeline(det, W, H, scene_from_scene=True)
+    R = np.eye(3, dtype=np.float32)
+    chunk = 100
+    for t0 in range(0, n, chunk):
+        rens, Ks, Rs, ts = [], [], [], []
+        for t in range(t0, min(n, t0 + chunk)):
+            w, h = int(wh[t * E][0]), int(wh[t * E][1])
+            x, y = best.get(t, (W // 2 - w // 2, H // 2 - h // 2))
+            ren = np.zeros((H, W), np.uint16)
+            patch = dep[y:y + h, x:x + w]
+            yy, xx = min(H - h, y + 1), min(W - w, x + 2)
+            ren[yy:yy + h, xx:xx + w] = np.where(patch > 0, patch + 3, 0)
+            ren[H // 2, W // 2] = ren[H // 2, W // 2] or int(np.median(patch[patch > 0])) if (patch > 0).any() else 1000   # LL.cpp:62 anchor pixel
+            rens.append(ren); Ks.append(K); Rs.append(R); ts.append(np.array([0, 0, 1000], np.float32))
+        pipe.set_views(classes[0], rens, Ks, Rs, ts, first_template=t0)
+    det.setFrame([rgb, dep])
+    for _ in range(3):
+        res, tm = pipe.run(THRESHOLD, classes, K, top_k=top_k, nms_iou=0.5)
+    acc = {"match_ms": 0.0, "nms_ms": 0.0, "icp_ms": 0.0, "total_ms": 0.0, "icp_iterations": 0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, tm = pipe.run(THRESHOLD, classes, K, top_k=top_k, nms_iou=0.5)
+        for q in acc:
+            acc[q] += tm[q]
+    wall = (time.perf_counter() - t0) / steps
+    pipe.close()
+    out = {q: acc[q] / steps for q in acc}
+    out.update({"wall_ms_per_frame": wall * 1e3, "frames_per_sec": 1.0 / wall, "top_k": top_k, "detections": len(res),
+                "refined": int(sum(1 for r in res if r["status"] == 0)),
+                "mean_fitness": float(np.mean([r["residual"] for r in res if r["status"] == 0])) if res else 0.0,
+                "icp_iters_per_sec_device": (acc["icp_iterations"] / steps) / (out["icp_ms"] * 1e-3) if out["icp_ms"] > 0 else 0.0,
+                "templates": n})
+    return out
 
 
 def cpu_baseline(frames, bank, n_templates):

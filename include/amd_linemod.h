@@ -221,6 +221,37 @@ int lm_icp_run(lm_icp *c, int count, const int32_t *model_slots, const float *mo
  * n_model, n_scene, grid_x, grid_y, cell, iterations, 4 phase cycle counts of the iteration kernel}.  Copies min(capacity, size) doubles, returns the size. */
 int64_t lm_icp_read_debug(lm_icp *c, int hypothesis, int kind, double *dst, int64_t capacity);
 
+/* ---- per-frame pipeline --------------------------------------------------------
+ * The loop of the reference driver, linemod_and_levelup_test.py:324-372, as one stream of device work:
+ * Detector::match -> dets (x, y, x+width, y+height, similarity) of the matched templates (:331-339) ->
+ * numpy nms(dets, 0.5) (:340, :34-61) -> for the first top_k kept matches poseRefine.process against
+ * the depth rendering of the matched template view (:349-367).  The renderings (what the driver gets
+ * from pysixd's renderer with aTemplateInfo[template_id]'s cam_K / cam_R_w2c / cam_t_w2c) are uploaded
+ * once per template and stay in HBM; NMS, top-K, hypothesis set-up and ICP run on the device with no
+ * host round trip.  Result = lm_detector_match + lm_nms_boxes + lm_pose_refine_batch on the same frame. */
+typedef struct lm_pipeline lm_pipeline;
+typedef struct lm_detection {
+    lm_match match;          /* the kept match */
+    int32_t width, height;   /* its NMS box: the template's size */
+    int32_t status;          /* 0 refined; 1 detection window leaves the frame (residual -1, LL.cpp:52-55); 5 no view for this template */
+    int32_t reserved;
+    lm_pose_result pose;     /* refined pose (status 0) */
+} lm_detection;
+typedef struct lm_pipeline_timings {
+    float match_ms, nms_ms, icp_ms, total_ms;   /* HIP events on the detector's stream */
+    int64_t coarse_candidates, matches_pre_unique;
+    int32_t icp_iterations, reserved;
+} lm_pipeline_timings;
+int lm_pipeline_create(lm_detector *det, int width, int height, lm_pipeline **out);
+void lm_pipeline_destroy(lm_pipeline *p);
+/* Views of templates [first_template, first_template + count) of a class: depth rendering (uint16 [height][width],
+ * mm), cam_K, cam_R_w2c (float32 3x3 row-major), cam_t_w2c (float32 3, mm). */
+int lm_pipeline_set_views(lm_pipeline *p, const char *class_id, int first_template, int count,
+                          const uint16_t *const *depth_ren, const float *Ks, const float *Rs, const float *ts);
+/* Runs on the detector's resident frame (lm_detector_set_frame / select_frame).  out: top_k entries; *n_out kept. */
+int lm_pipeline_run(lm_pipeline *p, float threshold, const char *const *class_ids, int num_class_ids, const float *scene_K,
+                    int top_k, double nms_iou, int flags, lm_detection *out, int *n_out, lm_pipeline_timings *tm);
+
 #ifdef __cplusplus
 }
 #endif

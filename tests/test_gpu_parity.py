@@ -523,6 +523,74 @@ def test_icp_context_slots_shared_by_hypotheses(lm):
 
 
 # ---------------------------------------------------------------------------------------------
+# per-frame pipeline: match -> boxes -> nms -> top-k -> poseRefine, all on the device
+# ---------------------------------------------------------------------------------------------
+def _pipeline_reference(mod, det, rgb, dep, wh, E, views, thr, top_k, iou):
+    """The driver loop (linemod_and_levelup_test.py:324-372) with the product's reference-shaped calls."""
+    m = det.matchArray([rgb, dep], thr, ["obj"])
+    dets = np.zeros((len(m), 5))
+    for i, r in enumerate(m):
+        w, h = wh[int(r["template_id"]) * E]
+        dets[i] = (r["x"], r["y"], r["x"] + w, r["y"] + h, r["similarity"])
+    keep = mod.nms(dets, iou)[:top_k]
+    sel = [m[i] for i in keep]
+    mds = [views[int(r["template_id"])][0] for r in sel]
+    Ks = np.stack([views[int(r["template_id"])][1] for r in sel]); Rs = np.stack([views[int(r["template_id"])][2] for r in sel])
+    ts = np.stack([views[int(r["template_id"])][3] for r in sel])
+    xy = [(int(r["x"]), int(r["y"])) for r in sel]
+    poses, _ = mod.pose_refine_batch(dep, K_CAM, mds, Ks, Rs, ts, xy, device=0, scene_from_scene=True)
+    return sel, poses, len(m)
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_pipeline_equals_match_nms_pose_refine(lm, dup):
+    """lm_pipeline_run on the device = Detector.match + nms + poseRefine of the reference driver, detection by
+    detection.  dup=True appends copies of templates under new ids: equal (x, y, similarity) across template ids
+    exercises the adjacent-unique rule of Detector::match inside the on-device NMS."""
+    W, H, T, nfeat, n = 640, 480, [4, 8], (64, 32), 60
+    rgb, dep = synth.make_frame(11, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    feat, offs, wh = synth.make_planted_bank(77, n, [(p[0], p[1]) for p in pyr], T, nfeat)
+    E = 2 * len(T)
+    if dup:                                                     # templates 0..19 again as ids n..n+19
+        extra_f = feat[:offs[20 * E]]
+        extra_o = offs[1:20 * E + 1] + offs[-1]
+        feat = np.concatenate([feat, extra_f]); offs = np.concatenate([offs, extra_o]).astype(np.int32); wh = np.concatenate([wh, wh[:20 * E]])
+        n += 20
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("obj", feat, offs, wh)
+    rng = np.random.default_rng(5)
+    shapes = [synth.synth_model_depth(200 + k, W, H) for k in range(4)]
+    views = []
+    for t in range(n):
+        R = np.eye(3, dtype=np.float32)
+        tt = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), 1000 + rng.uniform(-20, 20)], np.float32)
+        views.append((shapes[t % 4], K_CAM.copy(), R, tt))
+    pipe = lm.Pipeline(det, W, H, scene_from_scene=True)
+    pipe.set_views("obj", [v[0] for v in views], [v[1] for v in views], [v[2] for v in views], [v[3] for v in views])
+    for thr, top_k in ((70.0, 8), (85.0, 5)):
+        sel, poses, n_matches = _pipeline_reference(lm, det, rgb, dep, wh, E, views, thr, top_k, 0.5)
+        det.setFrame([rgb, dep])
+        got, tm = pipe.run(thr, ["obj"], K_CAM, top_k=top_k, nms_iou=0.5)
+        assert len(got) == len(sel) and len(got) > 0
+        for g, r, p in zip(got, sel, poses):
+            assert (g["x"], g["y"], g["template_id"]) == (int(r["x"]), int(r["y"]), int(r["template_id"]))
+            assert g["similarity"] == float(r["similarity"])
+            assert (g["width"], g["height"]) == tuple(int(v) for v in wh[int(r["template_id"]) * E])
+            if p["residual"] == -1.0:
+                assert g["status"] == 1 and g["residual"] == -1.0
+                continue
+            assert g["status"] == 0 and g["iterations"] == p["iterations"] and abs(g["residual"] - p["residual"]) < 1e-6
+            if len(got) == top_k:                                # same hypothesis count = same slicing: identical sums
+                assert np.allclose(g["R"], p["R"], atol=1e-9, equal_nan=True) and np.allclose(g["t"], p["t"], atol=1e-6, equal_nan=True)
+            else:
+                assert np.allclose(g["R"], p["R"], atol=1e-6, equal_nan=True) and np.allclose(g["t"], p["t"], atol=1e-3, equal_nan=True)
+        assert tm["total_ms"] > 0 and tm["coarse_candidates"] > 0
+    pipe.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # multi-process sharding on the one visible GPU
 # ---------------------------------------------------------------------------------------------
 _SHARD_WORKER = r'''
