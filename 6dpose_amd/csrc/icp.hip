@@ -1253,7 +1253,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
                     for (int u = 0; u < 4; ++u) {
                         int a = ca4[u];
                         const int b = cb4[u];
-                        {                                         // first point of the column at depth step >= zlo (the run is depth-ordered)
+                        if (b - a > 8) {                          // long run: first point at depth step >= zlo by bisection (the run is depth-ordered)
                             int hi = b;
                             while (a < hi) { const int mid = (a + hi) >> 1; if (tgt_zq(mid) < zlo) a = mid + 1; else hi = mid; }
                         }

@@ -301,7 +301,8 @@ def pipeline_bench(det, frames, bank, classes, top_k=16, steps=20):
     """BASELINE configs[2] end to end: match (2k templates) -> boxes -> NMS -> top-16 -> poseRefine on every kept match,
     one stream of device work per frame (lm_pipeline_run), everything resident in HBM.  The depth rendering of a
     template view (what the reference driver gets from its OpenGL renderer) is synthetic: the scene depth under the
-    template's best match on frame 0, pushed back 3 mm and shifted 2 px, so that ICP has real work to do."""
+    template's best match on frame 0, moved to the image centre, pushed back 3 mm and shifted 2 px, so that ICP has
+    real work to do."""
     import linemodLevelup_pybind as lm
     K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
     rgb, dep = frames[0]
@@ -320,11 +321,13 @@ def pipeline_bench(det, frames, bank, classes, top_k=16, steps=20):
         for t in range(t0, min(n, t0 + chunk)):
             w, h = int(wh[t * E][0]), int(wh[t * E][1])
             x, y = best.get(t, (W // 2 - w // 2, H // 2 - h // 2))
+            # the renderer puts the object at the image centre (the reference reads its depth there, LL.cpp:62)
             ren = np.zeros((H, W), np.uint16)
-            patch = dep[y:y + h, x:x + w]
-            yy, xx = min(H - h, y + 1), min(W - w, x + 2)
-            ren[yy:yy + h, xx:xx + w] = np.where(patch > 0, patch + 3, 0)
-            ren[H // 2, W // 2] = ren[H // 2, W // 2] or int(np.median(patch[patch > 0])) if (patch > 0).any() else 1000   # LL.cpp:62 anchor pixel
+            patch = np.roll(dep[y:y + h, x:x + w], 2, axis=1)
+            oy, ox = H // 2 - h // 2, W // 2 - w // 2
+            ren[oy:oy + h, ox:ox + w] = np.where(patch > 0, patch + 3, 0)
+            if ren[H // 2, W // 2] == 0:
+                ren[H // 2, W // 2] = int(np.median(patch[patch > 0])) + 3 if (patch > 0).any() else 1000
             rens.append(ren); Ks.append(K); Rs.append(R); ts.append(np.array([0, 0, 1000], np.float32))
         pipe.set_views(classes[0], rens, Ks, Rs, ts, first_template=t0)
     det.setFrame([rgb, dep])
