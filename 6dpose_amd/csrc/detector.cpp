@@ -77,7 +77,8 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     }
     d->pyramid_levels = (int)d->T_at_level.size();
     d->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&d->mstream, hipStreamNonBlocking) != hipSuccess) {
         delete d;
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
@@ -85,6 +86,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     for (auto& sl : d->slot) {
         for (auto& e : sl.ev) (void)hipEventCreate(&e);
         (void)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&sl.fe_done, hipEventDisableTiming);
     }
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
@@ -104,8 +106,10 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
+    if (d->mstream) (void)hipStreamSynchronize(d->mstream);
     d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
-    d->q16.release(); d->nrm_raw.release(); d->rowor.release(); d->lm_arena.release(); d->sm_arena.release();
+    d->q16.release(); d->nrm_raw.release(); d->rowor.release();
+    for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
@@ -116,12 +120,16 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.graph) (void)hipGraphDestroy(sl.graph);
+        if (sl.mexec) (void)hipGraphExecDestroy(sl.mexec);
+        if (sl.mgraph) (void)hipGraphDestroy(sl.mgraph);
+        if (sl.fe_done) (void)hipEventDestroy(sl.fe_done);
         for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (d->pinned) (void)hipHostFree(d->pinned);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->mstream) (void)hipStreamDestroy(d->mstream);
     delete d;
 }
 
@@ -183,13 +191,15 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     if ((rc = d->nrm_raw.ensure(n0))) return rc;
     if ((rc = d->rowor.ensure(n0))) return rc;
 
-    bool realloc_arena = arena > d->lm_arena.cap;
-    if ((rc = d->lm_arena.ensure(arena))) return rc;
-    if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
-        HIP_TRY(hipMemsetAsync(d->lm_arena.p, 0, d->lm_arena.cap, d->stream));
-    bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena.cap;
-    if ((rc = d->sm_arena.ensure(std::max<size_t>(sarena, 256)))) return rc;
-    if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena.p, 0, d->sm_arena.cap, d->stream));
+    for (int a = 0; a < lm_detector::kSlots; ++a) {
+        const bool realloc_arena = arena > d->lm_arena[a].cap;
+        if ((rc = d->lm_arena[a].ensure(arena))) return rc;
+        if (realloc_arena || d->fW != W || d->fH != H)   // zero tails (and everything else) once
+            HIP_TRY(hipMemsetAsync(d->lm_arena[a].p, 0, d->lm_arena[a].cap, d->stream));
+        const bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena[a].cap;
+        if ((rc = d->sm_arena[a].ensure(std::max<size_t>(sarena, 256)))) return rc;
+        if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena[a].p, 0, d->sm_arena[a].cap, d->stream));
+    }
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
         b.W = g.lv[l].W; b.H = g.lv[l].H;
@@ -245,7 +255,7 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
 }
 
 // quantise every level; build_lm=false for addTemplate (only the quantised maps are needed)
-static int run_frontend(lm_detector* d, bool build_lm) {
+static int run_frontend(lm_detector* d, bool build_lm, int arena = 0) {
     // One stream: measured on MI355X, forking the colour / pyramid / depth chains onto three streams
     // (events, also inside the hipGraph) cost more in cross-stream synchronisation (+26 us) than the
     // ~3 us kernels could overlap.
@@ -260,21 +270,21 @@ static int run_frontend(lm_detector* d, bool build_lm) {
             launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
             launch_nn_down2(a.nrm.p, b.nrm.p, a.W, a.H, s);                                   // LL.cpp:857-880
         } else {
-            launch_normals(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
-                           d->difference_threshold, s);                                       // LL.cpp:729-819
+            launch_normals_fused(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+                                 d->difference_threshold, s);                                 // LL.cpp:729-819
         }
-        launch_blur7(src, d->tmp16.p, d->smoothed.p, b.W, b.H, s);                            // LL.cpp:367
-        launch_sobel_quant(d->smoothed.p, b.mag.p, d->q16.p, b.W, b.H, s);                    // LL.cpp:368-455
-        launch_hysteresis(d->q16.p, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                   // LL.cpp:457-504
+        launch_color_quant(src, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                       // LL.cpp:367-504
         if (build_lm) {
             const LevelGeom& lv = d->geom.lv[l];
             const bool strips = l < L - 1;
-            launch_build_lm(b.ang.p, d->have_mask[0] ? b.mask[0].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[0],
-                            strips ? d->sm_arena.p + lv.sm_off[0] : nullptr, b.W, b.H, lv.T, s);
-            launch_build_lm(b.nrm.p, d->have_mask[1] ? b.mask[1].p : nullptr, d->rowor.p, d->lm_arena.p + lv.lm_off[1],
-                            strips ? d->sm_arena.p + lv.sm_off[1] : nullptr, b.W, b.H, lv.T, s);
+            const uint8_t* quant[2] = {b.ang.p, b.nrm.p};
+            const uint8_t* mask[2] = {d->have_mask[0] ? b.mask[0].p : nullptr, d->have_mask[1] ? b.mask[1].p : nullptr};
+            uint8_t* lmp[2] = {d->lm_arena[arena].p + lv.lm_off[0], d->lm_arena[arena].p + lv.lm_off[1]};
+            uint8_t* smp[2] = {strips ? d->sm_arena[arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[arena].p + lv.sm_off[1] : nullptr};
+            launch_build_lm(quant, mask, lmp, smp, b.W, b.H, lv.T, s);
         }
     }
+    if (build_lm) d->last_arena = arena;
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
@@ -701,7 +711,7 @@ extern "C" int lm_detector_select_frame(lm_detector* d, int slot) {
     HIP_TRY(hipSetDevice(d->device));
     d->frame_valid = false;
     const int W = d->slot_w[slot], H = d->slot_h[slot];
-    if (W != d->fW || H != d->fH || d->lm_arena.cap == 0) {
+    if (W != d->fW || H != d->fH || d->lm_arena[0].cap == 0) {
         int rc = setup_geometry(d, W, H, true);
         if (rc) return rc;
     }
@@ -794,10 +804,10 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
 // Enqueue the whole device pipeline of the current frame into a free result slot (asynchronous).
 int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame / select_frame first");
-    if (d->n_submitted - d->n_collected >= 2)
-        return lm_set_error(LM_ERR_INVALID, "two frames already in flight: call lm_detector_collect first");
+    if (d->n_submitted - d->n_collected >= (uint64_t)lm_detector::kSlots)
+        return lm_set_error(LM_ERR_INVALID, "%d frames already in flight: call lm_detector_collect first", lm_detector::kSlots);
     HIP_TRY(hipSetDevice(d->device));
-    lm_detector::Slot& sl = d->slot[d->n_submitted & 1];
+    lm_detector::Slot& sl = d->slot[d->n_submitted % lm_detector::kSlots];
     int rc;
     if (d->bank_dirty || d->bank_geom_W != d->fW || d->bank_geom_H != d->fH) {
         if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "bank or frame geometry changed with a frame in flight");
@@ -809,7 +819,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
     if ((rc = d->d_matches_dev.ensure(d->cand_cap))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
-    hipStream_t s = d->stream;
+    hipStream_t s = d->stream, ms = d->mstream;
+    const int arena = (int)(d->n_submitted % lm_detector::kSlots);
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
@@ -818,57 +829,76 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     unsigned long long* d_hcounters = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, sl.h_counters, 0));
     HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, sl.h_matches, 0));
-    // front end + coarse + refinement, all on the detector's stream
-    auto enqueue = [&]() -> int {
+    // Two streams: the front end of this frame (on `stream`, into this slot's linear-memory arenas) overlaps the
+    // matching kernels of the previous frame (on `mstream`, reading the other slot's arenas).  The arenas of this
+    // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
+    auto enqueue_fe = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[0], s));
-        int r = run_frontend(d, true);
+        int r = run_frontend(d, true, arena);
         if (r) return r;
         HIP_TRY(hipEventRecord(sl.ev[1], s));
-        HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), s));
-        launch_coarse(d->lm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
-                      d->cand_cap, d->d_counters.p, s);
-        HIP_TRY(hipEventRecord(sl.ev[2], s));
-        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
-        // the per-block statistics and the results, stored straight into this slot's pinned host memory
-        launch_local(d->lm_arena.p, d->sm_arena.p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->d_cands.p,
-                     num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->d_matches_dev.p, std::min<uint32_t>(sl.match_cap, d->cand_cap),
-                     d->d_counters.p, d_hcounters,
-                     d->local_blocks, s);
-        HIP_TRY(hipEventRecord(sl.ev[3], s));
-        HIP_TRY(hipEventRecord(sl.ev[4], s));
         return LM_OK;
     };
-    bool launched = false;
+    auto enqueue_match = [&]() -> int {
+        HIP_TRY(hipEventRecord(sl.ev[2], ms));
+        HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), ms));
+        launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
+                      d->cand_cap, d->d_counters.p, ms);
+        HIP_TRY(hipEventRecord(sl.ev[3], ms));
+        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
+        // the per-block statistics and the results, stored straight into this slot's pinned host memory
+        launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
+                     d->d_work.p, d->d_cands.p, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->d_matches_dev.p,
+                     std::min<uint32_t>(sl.match_cap, d->cand_cap), d->d_counters.p, d_hcounters, d->local_blocks, ms);
+        HIP_TRY(hipEventRecord(sl.ev[4], ms));
+        return LM_OK;
+    };
+    auto capture = [&](hipStream_t st, hipGraph_t& g, hipGraphExec_t& ex, auto&& fn) -> bool {
+        if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
+        if (g) { (void)hipGraphDestroy(g); g = nullptr; }
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            int r = fn();
+            hipError_t ee = hipStreamEndCapture(st, &g);
+            ok = (r == LM_OK) && ee == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
+            if (g) { (void)hipGraphDestroy(g); g = nullptr; }
+        }
+        return ok;
+    };
     if (d->use_graph) {
         uint32_t thr_bits;
         memcpy(&thr_bits, &threshold, 4);
         const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
-                                     ((uint64_t)(uintptr_t)d->d_matches_dev.p << 2)};
-        if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
-            if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
-            if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
-            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                int r = enqueue();
-                hipError_t ee = hipStreamEndCapture(s, &sl.graph);
-                ok = (r == LM_OK) && ee == hipSuccess && sl.graph && hipGraphInstantiate(&sl.exec, sl.graph, nullptr, nullptr, 0) == hipSuccess;
-            }
+                                     ((uint64_t)(uintptr_t)d->d_matches_dev.p << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3)};
+        if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
+            const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
             if (ok) memcpy(sl.key, key, sizeof(key));
             else {   // capture unavailable: fall back to plain launches for good
-                (void)hipGetLastError();
                 if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
                 if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
+                if (sl.mexec) { (void)hipGraphExecDestroy(sl.mexec); sl.mexec = nullptr; }
+                if (sl.mgraph) { (void)hipGraphDestroy(sl.mgraph); sl.mgraph = nullptr; }
                 d->use_graph = false;
             }
         }
-        if (sl.exec) { HIP_TRY(hipGraphLaunch(sl.exec, s)); launched = true; }
     }
-    if (!launched && (rc = enqueue())) return rc;
-    // An event recorded by a graph node keeps its previous (completed) state until that node runs, so waiting
-    // on sl.ev[4] could return before the frame is done: the host waits on an eagerly recorded event instead.
-    HIP_TRY(hipEventRecord(sl.done, s));
+    if (d->use_graph && sl.exec && sl.mexec) {
+        HIP_TRY(hipGraphLaunch(sl.exec, s));
+        d->last_arena = arena;
+    } else if ((rc = enqueue_fe())) return rc;
+    // events recorded by graph nodes keep their previous state until the node runs: cross-stream ordering and the
+    // host wait use eagerly recorded events
+    HIP_TRY(hipEventRecord(sl.fe_done, s));
+    HIP_TRY(hipStreamWaitEvent(ms, sl.fe_done, 0));
+    if (d->use_graph && sl.exec && sl.mexec) HIP_TRY(hipGraphLaunch(sl.mexec, ms));
+    else if ((rc = enqueue_match())) return rc;
+    HIP_TRY(hipEventRecord(sl.done, ms));
     sl.t1 = std::chrono::steady_clock::now();
     sl.pending = true;
     ++d->n_submitted;
@@ -879,7 +909,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
 // overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
     if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
-    lm_detector::Slot& sl = d->slot[d->n_collected & 1];
+    lm_detector::Slot& sl = d->slot[d->n_collected % lm_detector::kSlots];
     HIP_TRY(hipSetDevice(d->device));
     HIP_TRY(hipEventSynchronize(sl.done));
     const auto t2 = std::chrono::steady_clock::now();
@@ -902,10 +932,10 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;
+    tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
     if (hipEventElapsedTime(&tm.frontend_ms, sl.ev[0], sl.ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&tm.coarse_ms, sl.ev[1], sl.ev[2]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, sl.ev[2], sl.ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.d2h_ms, sl.ev[3], sl.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, sl.ev[2], sl.ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, sl.ev[3], sl.ev[4]) != hipSuccess ||
         hipEventElapsedTime(&tm.total_ms, sl.ev[0], sl.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
         if (d->use_graph && d->graph_events_ok) {   // event nodes of a graph are not timeable here: time with plain launches
@@ -1001,12 +1031,13 @@ extern "C" int64_t lm_detector_read_stage(lm_detector* d, int level, int kind, u
     switch (kind) {
         case 0: src = b.ang.p; size = (int64_t)b.W * b.H; break;
         case 1: src = b.nrm.p; size = (int64_t)b.W * b.H; break;
-        case 2: src = d->lm_arena.p + lv.lm_off[0]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
-        default: src = d->lm_arena.p + lv.lm_off[1]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+        case 2: src = d->lm_arena[d->last_arena].p + lv.lm_off[0]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+        default: src = d->lm_arena[d->last_arena].p + lv.lm_off[1]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
     }
     if (dst && capacity > 0) {
         if (hipSetDevice(d->device) != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipSetDevice failed");
         (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamSynchronize(d->mstream);
         hipError_t e = hipMemcpy(dst, src, (size_t)std::min(size, capacity), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
     }

@@ -58,7 +58,8 @@ struct lm_detector {
 
     // device
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // frame upload / select + front end (and addTemplate)
+    hipStream_t mstream = nullptr;      // coarse + refinement (+ the pipeline's NMS / ICP): runs frame k while `stream` prepares frame k+1
     hipEvent_t ev[8] = {};
     int shard_rank = 0, shard_world = 1;
 
@@ -68,7 +69,11 @@ struct lm_detector {
     DevBuf<uint8_t> frame_rgb;
     DevBuf<uint16_t> frame_depth;
     DevBuf<uint16_t> tmp16;
-    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor, lm_arena, sm_arena;
+    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor;
+    static constexpr int kSlots = 3;            // frames in flight (lm_detector_submit / collect)
+    DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
+                                                // while the matching kernels of frame k read the other
+    int last_arena = 0;                         // set written by the most recent front end (lm_detector_read_stage)
 
     LevelBufs lvl[kMaxLevels];
     FrameGeom geom{};
@@ -104,24 +109,25 @@ struct lm_detector {
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;
     uint32_t cand_cap = 1u << 18;
-    // Two result slots: the refinement kernel of frame k+1 writes into one pinned buffer while the host
-    // collects frame k from the other (lm_detector_submit / lm_detector_collect).
+    // Result slots: the refinement kernel of a later frame writes into one pinned buffer while the host
+    // collects an earlier frame from another (lm_detector_submit / lm_detector_collect).
     struct Slot {
         Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
         uint32_t match_cap = 0;
         unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [8..] 2 words of statistics per refinement block
-        hipGraph_t graph = nullptr;                 // the whole per-frame device pipeline, captured once
-        hipGraphExec_t exec = nullptr;
+        hipGraph_t graph = nullptr, mgraph = nullptr;       // front end (on `stream`) / matching (on `mstream`), captured once each
+        hipGraphExec_t exec = nullptr, mexec = nullptr;
         uint64_t key[8] = {};
         hipEvent_t ev[5] = {};                      // stage timing (recorded inside the graph)
         hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
+        hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
         bool pending = false;
         float threshold = 0.f, h2d_ms = 0.f;
         int num_work = 0;
         int64_t coarse_bytes = 0;
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
-    } slot[2];
+    } slot[kSlots];
     uint64_t n_submitted = 0, n_collected = 0;
     int local_blocks = 0;
     int num_cus = 256;

@@ -145,6 +145,113 @@ void launch_hysteresis(const uint8_t* q16, const float* mag, uint8_t* onehot, in
     hipLaunchKernelGGL(k_hysteresis, dim3((W + 255) / 256, H), dim3(256), 0, s, q16, mag, onehot, W, H, thr_sq);
 }
 
+// ---- the colour chain in one launch: GaussianBlur 7x7 -> Sobel -> strongest channel -> phase -> 16-bin
+// quantisation -> 3x3 majority vote (LL.cpp:367-504), one 32x16 output tile per workgroup, every intermediate
+// in LDS.  Each stage keeps its own border rule by evaluating a stage at the CLAMPED position of the pixel the
+// next stage asks for (blur and Sobel replicate the border: smoothed(clamp(p)), not a blur centred outside the
+// image), so the result is bit-identical to the four separate kernels above (kept for addTemplate-free testing).
+constexpr int kCTX = 32, kCTY = 16;           // output tile
+__global__ void __launch_bounds__(256)
+k_color_quant(const uint8_t* __restrict__ rgb, float* __restrict__ mag, uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
+    // virtual coordinates: tile origin (x0, y0); halos: rgb 5, blurred 2, quantised 1
+    __shared__ uint8_t s_rgb[kCTY + 10][kCTX + 10][3];
+    __shared__ uint16_t s_tmp[kCTY + 10][kCTX + 4][3];     // horizontal pass at columns clamp(x0-2 .. x0+TX+1), all halo rows
+    __shared__ uint8_t s_sm[kCTY + 4][kCTX + 4][3];         // smoothed at clamp(y0-2 ..), clamp(x0-2 ..)
+    __shared__ uint8_t s_q[kCTY + 2][kCTX + 2];             // 16-bin code & 7 at y0-1 .., x0-1 .. (0 outside the interior)
+    __shared__ float s_mag[kCTY][kCTX];
+    const int x0 = blockIdx.x * kCTX, y0 = blockIdx.y * kCTY, tid = threadIdx.x;
+    const int w7[7] = {8, 28, 56, 72, 56, 28, 8};
+    for (int i = tid; i < (kCTY + 10) * (kCTX + 10); i += 256) {
+        const int ty = i / (kCTX + 10), tx = i - ty * (kCTX + 10);
+        const uint8_t* p = rgb + ((size_t)clampi(y0 - 5 + ty, 0, H - 1) * W + clampi(x0 - 5 + tx, 0, W - 1)) * 3;
+        s_rgb[ty][tx][0] = p[0]; s_rgb[ty][tx][1] = p[1]; s_rgb[ty][tx][2] = p[2];
+    }
+    __syncthreads();
+    // horizontal pass: rows = all halo rows (virtual y0-5+ty, already clamped by the load), columns cx = clamp(x0-2+tx)
+    for (int i = tid; i < (kCTY + 10) * (kCTX + 4); i += 256) {
+        const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
+        const int cx = clampi(x0 - 2 + tx, 0, W - 1) - (x0 - 5);           // tile column of the clamped centre
+        int a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { a0 += w7[k] * s_rgb[ty][cx + k - 3][0]; a1 += w7[k] * s_rgb[ty][cx + k - 3][1]; a2 += w7[k] * s_rgb[ty][cx + k - 3][2]; }
+        s_tmp[ty][tx][0] = (uint16_t)a0; s_tmp[ty][tx][1] = (uint16_t)a1; s_tmp[ty][tx][2] = (uint16_t)a2;
+    }
+    __syncthreads();
+    // vertical pass at rows cy = clamp(y0-2+ty)
+    for (int i = tid; i < (kCTY + 4) * (kCTX + 4); i += 256) {
+        const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
+        const int cy = clampi(y0 - 2 + ty, 0, H - 1) - (y0 - 5);           // tile row of the clamped centre
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int a = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a += w7[k] * s_tmp[cy + k - 3][tx][c];
+            s_sm[ty][tx][c] = (uint8_t)((a + 32768) >> 16);
+        }
+    }
+    __syncthreads();
+    // Sobel + strongest channel + quantisation at (y0-1+ty, x0-1+tx); s_sm index of virtual (vy, vx) = (vy - y0 + 2, vx - x0 + 2)
+    for (int i = tid; i < (kCTY + 2) * (kCTX + 2); i += 256) {
+        const int ty = i / (kCTX + 2), tx = i - ty * (kCTX + 2);
+        const int y = y0 - 1 + ty, x = x0 - 1 + tx;
+        uint8_t q = 0;
+        if (x >= 0 && y >= 0 && x < W && y < H) {
+            const int sy = ty + 1, sx = tx + 1;                             // this pixel in s_sm; its neighbours are the clamped ones by construction
+            int dxs[3], dys[3], mags[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int a00 = s_sm[sy - 1][sx - 1][c], a01 = s_sm[sy - 1][sx][c], a02 = s_sm[sy - 1][sx + 1][c];
+                const int a10 = s_sm[sy][sx - 1][c], a12 = s_sm[sy][sx + 1][c];
+                const int a20 = s_sm[sy + 1][sx - 1][c], a21 = s_sm[sy + 1][sx][c], a22 = s_sm[sy + 1][sx + 1][c];
+                dxs[c] = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+                dys[c] = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+                mags[c] = dxs[c] * dxs[c] + dys[c] * dys[c];
+            }
+            int bdx, bdy, bmag;
+            if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
+            else if (mags[1] >= mags[0] && mags[1] >= mags[2]) { bdx = dxs[1]; bdy = dys[1]; bmag = mags[1]; }
+            else { bdx = dxs[2]; bdy = dys[2]; bmag = mags[2]; }
+            if (ty >= 1 && ty <= kCTY && tx >= 1 && tx <= kCTX) s_mag[ty - 1][tx - 1] = (float)bmag;
+            if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
+                const float ang = fast_atan2_deg((float)bdy, (float)bdx);
+                const float v = rintf(__fmul_rn(ang, (float)(16.0 / 360.0)));   // cvRound: half to even
+                const int iv = v < 0.f ? 0 : (v > 255.f ? 255 : (int)v);
+                q = (uint8_t)(iv & 7);
+            }
+        }
+        s_q[ty][tx] = q;
+    }
+    __syncthreads();
+    for (int i = tid; i < kCTY * kCTX; i += 256) {
+        const int ty = i / kCTX, tx = i - ty * kCTX;
+        const int y = y0 + ty, x = x0 + tx;
+        if (x >= W || y >= H) continue;
+        const float m = s_mag[ty][tx];
+        uint8_t res = 0;
+        if (x > 0 && y > 0 && x < W - 1 && y < H - 1 && m > thr_sq) {
+            uint32_t hist = 0;   // eight 4-bit counters (max 9 votes)
+#pragma unroll
+            for (int dy = 0; dy <= 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx <= 2; ++dx) hist += 1u << (4 * s_q[ty + dy][tx + dx]);
+            int best = -1, votes = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = (hist >> (4 * k)) & 15;
+                if (votes < v) { votes = v; best = k; }   // first strict maximum (LL.cpp:491)
+            }
+            if (votes >= 5) res = (uint8_t)(1u << best);
+        }
+        const size_t o = (size_t)y * W + x;
+        mag[o] = m;
+        onehot[o] = res;
+    }
+}
+
+void launch_color_quant(const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq, hipStream_t s) {
+    hipLaunchKernelGGL(k_color_quant, dim3((W + kCTX - 1) / kCTX, (H + kCTY - 1) / kCTY), dim3(256), 0, s, rgb, mag, onehot, W, H, thr_sq);
+}
+
 // ---- cv::pyrDown 8UC3 (LL.cpp:566; Appendix A.6): 5x5 [1 4 6 4 1], REFLECT_101, (sum+128)>>8 ----
 static __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
@@ -251,6 +358,89 @@ void launch_normals(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, in
     hipLaunchKernelGGL(k_median5, dim3((W + 255) / 256, H), dim3(256), 0, s, raw, med, W, H);
 }
 
+// quantizedNormals + medianBlur(5) in one launch: the raw normals of a 32x16 tile (+2 halo, evaluated at the
+// clamped positions medianBlur's replicate border asks for) live in LDS.
+static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__ depth, int x, int y, int W, int H, int dist_thr, int diff_thr) {
+    const int r = 5;
+    uint8_t res = 0;
+    if (x >= r && y >= r && x < W - r - 1 && y < H - r - 1) {
+        const uint16_t* p = depth + (size_t)y * W + x;
+        long long d = p[0];
+        if (d < dist_thr) {
+            long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+            const int oi[8] = {-r, 0, r, -r, r, -r, 0, r};
+            const int oj[8] = {-r, -r, -r, 0, 0, r, r, r};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                long long delta = (long long)p[oj[k] * W + oi[k]] - d;
+                long long ad = delta < 0 ? -delta : delta;
+                long long f = ad < diff_thr ? 1 : 0;
+                long long fi = f * oi[k], fj = f * oj[k];
+                A0 += fi * oi[k]; A1 += fi * oj[k]; A3 += fj * oj[k];
+                b0 += fi * delta; b1 += fj * delta;
+            }
+            long long det = A0 * A3 - A1 * A1;
+            long long ddx = A3 * b0 - A1 * b1;
+            long long ddy = -A1 * b0 + A0 * b1;
+            float nx = (float)(1150 * ddx), ny = (float)(1150 * ddy), nz = (float)(-det * d);
+            float ss = __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz));
+            float sq = __fsqrt_rn(ss);
+            if (sq > 0.f) {
+                float inv = __fdiv_rn(1.0f, sq);
+                nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+                int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+                int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+                int flat = (v2 * 20 + v1) % 400;
+                if (flat < 0) flat += 400;
+                res = c_normal_lut[flat];
+            }
+        }
+    }
+    return res;
+}
+
+__global__ void __launch_bounds__(256)
+k_normals_median(const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw, uint8_t* __restrict__ med, int W, int H, int dist_thr,
+                 int diff_thr) {
+    __shared__ uint8_t s_raw[kCTY + 4][kCTX + 4];
+    const int x0 = blockIdx.x * kCTX, y0 = blockIdx.y * kCTY, tid = threadIdx.x;
+    for (int i = tid; i < (kCTY + 4) * (kCTX + 4); i += 256) {
+        const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
+        const int y = clampi(y0 - 2 + ty, 0, H - 1), x = clampi(x0 - 2 + tx, 0, W - 1);
+        const uint8_t v = normal_at(depth, x, y, W, H, dist_thr, diff_thr);
+        s_raw[ty][tx] = v;
+        if (ty >= 2 && ty < kCTY + 2 && tx >= 2 && tx < kCTX + 2 && y0 - 2 + ty < H && x0 - 2 + tx < W) raw[(size_t)y * W + x] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kCTY * kCTX; i += 256) {
+        const int ty = i / kCTX, tx = i - ty * kCTX;
+        const int y = y0 + ty, x = x0 + tx;
+        if (x >= W || y >= H) continue;
+        unsigned long long cnt = 0;
+#pragma unroll
+        for (int dy = 0; dy <= 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx <= 4; ++dx) {
+                const uint32_t v = s_raw[ty + dy][tx + dx];
+                const int rank = v ? (32 - __clz(v)) : 0;     // 0 -> 0, 1<<k -> k+1
+                cnt += 1ull << (5 * rank);
+            }
+        int cum = 0, rank = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int c = (int)((cnt >> (5 * k)) & 31);
+            if (cum < 13 && cum + c >= 13) rank = k;
+            cum += c;
+        }
+        med[(size_t)y * W + x] = rank ? (uint8_t)(1u << (rank - 1)) : 0;
+    }
+}
+
+void launch_normals_fused(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr, hipStream_t s) {
+    hipLaunchKernelGGL(k_normals_median, dim3((W + kCTX - 1) / kCTX, (H + kCTY - 1) / kCTY), dim3(256), 0, s, depth, raw, med, W, H, dist_thr,
+                       diff_thr);
+}
+
 // cv::resize(INTER_NEAREST) to (cols/2, rows/2) (LL.cpp:576, 867, 877) = pixel (2y, 2x)
 __global__ void k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int Wo) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -263,28 +453,19 @@ void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t
     hipLaunchKernelGGL(k_nn_down2, dim3((Wo + 255) / 256, Ho), dim3(256), 0, s, src, dst, W, Wo);
 }
 
-// ---- spread (LL.cpp:1094-1109) as separable OR, fused with computeResponseMaps (LL.cpp:1134-1203,
-// active SIMILARITY_LUT :1121 in closed form) and linearize (LL.cpp:1215-1243) ----------------------
-// pass 1: rowor(y,x) = OR_{c<T} q(y, x+c)   (zero beyond the right edge; mask applied as quantize() does)
-__global__ void k_spread_rows(const uint8_t* __restrict__ q, const uint8_t* __restrict__ mask, uint8_t* __restrict__ rowor,
-                              int W, int H, int T) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const uint8_t* row = q + (size_t)y * W;
-    const uint8_t* mrow = mask ? mask + (size_t)y * W : nullptr;
-    uint32_t v = 0;
-    int xe = x + T < W ? x + T : W;
-    for (int c = x; c < xe; ++c) v |= (mrow && !mrow[c]) ? 0u : row[c];
-    rowor[(size_t)y * W + x] = (uint8_t)v;
-}
+// ---- spread (LL.cpp:1094-1109) fused with computeResponseMaps (LL.cpp:1134-1203, active SIMILARITY_LUT
+// :1121 in closed form) and linearize (LL.cpp:1215-1243), both modalities of a level in ONE launch ------
+// One thread per linear-memory position (phase, decimated index) and modality (blockIdx.z): OR the T x T
+// quantised pixels below / right of it (zero beyond the edges; mask applied as quantize() does), derive the
+// 8 responses (4 / 1 / 0), store to LM[label][phase][idx] — consecutive lanes write consecutive bytes of
+// each label's plane.  Levels below the top also get the "strip" copy the refinement kernel gathers from:
+// every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so that a 16x16 window
+// touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.  (The frame is a few hundred
+// KB: the T*T byte reads per thread hit L1/L2; what counts here is one launch instead of four.)
+struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
 
-// pass 2: one thread per linear-memory position (phase, decimated index): OR the T rows, derive the
-// 8 responses (4 / 1 / 0), store to LM[label][phase][idx] — consecutive lanes write consecutive
-// bytes of each label's plane.  Levels below the top also get the "strip" copy the refinement kernel
-// gathers from: every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so
-// that a 16x16 window touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.
-__global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restrict__ lm, uint8_t* __restrict__ strips,
-                           int W, int H, int T, int Wd, int Hd, int NS) {
+__global__ void k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS) {
+    const LmJob J = blockIdx.z ? j1 : j0;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;   // decimated raster index
     int phase = blockIdx.y;                              // r_start*T + c_start
     int npos = Wd * Hd;
@@ -293,13 +474,21 @@ __global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restric
     int rs = phase / T, cs = phase - rs * T;
     int y = ry * T + rs, x = rx * T + cs;
     uint32_t v = 0;
-    int ye = y + T < H ? y + T : H;
-    for (int r = y; r < ye; ++r) v |= rowor[(size_t)r * W + x];
+    const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
+    for (int r = y; r < ye; ++r) {
+        const uint8_t* row = J.quant + (size_t)r * W;
+        if (J.mask) {
+            const uint8_t* mrow = J.mask + (size_t)r * W;
+            for (int c = x; c < xe; ++c) v |= mrow[c] ? (uint32_t)row[c] : 0u;
+        } else {
+            for (int c = x; c < xe; ++c) v |= row[c];
+        }
+    }
     uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
     size_t plane = (size_t)T * T * npos;
-    uint8_t* o = lm + (size_t)phase * npos + idx;
+    uint8_t* o = J.lm + (size_t)phase * npos + idx;
     const size_t splane1 = (size_t)NS * Hd * 16;             // one (label, phase) plane in strip form
-    uint8_t* so = strips ? strips + (size_t)phase * splane1 + ((size_t)(rx >> 4) * Hd + ry) * 16 + (rx & 15) : nullptr;
+    uint8_t* so = J.strips ? J.strips + (size_t)phase * splane1 + ((size_t)(rx >> 4) * Hd + ry) * 16 + (rx & 15) : nullptr;
 #pragma unroll
     for (int ori = 0; ori < 8; ++ori) {
         uint8_t r = ((v >> ori) & 1u) ? 4 : (((adj >> ori) & 1u) ? 1 : 0);
@@ -308,11 +497,11 @@ __global__ void k_build_lm(const uint8_t* __restrict__ rowor, uint8_t* __restric
     }
 }
 
-void launch_build_lm(const uint8_t* quant, const uint8_t* mask, uint8_t* rowor, uint8_t* lm, uint8_t* strips, int W, int H,
-                     int T, hipStream_t s) {
+void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
+                     int W, int H, int T, hipStream_t s) {
     int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
-    hipLaunchKernelGGL(k_spread_rows, dim3((W + 255) / 256, H), dim3(256), 0, s, quant, mask, rowor, W, H, T);
-    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T), dim3(256), 0, s, rowor, lm, strips, W, H, T, Wd, Hd, NS);
+    LmJob j0{quant[0], mask[0], lm[0], strips[0]}, j1{quant[1], mask[1], lm[1], strips[1]};
+    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS);
 }
 
 }  // namespace lm

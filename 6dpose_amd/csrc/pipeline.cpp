@@ -67,6 +67,7 @@ extern "C" void lm_pipeline_destroy(lm_pipeline* p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
     (void)hipStreamSynchronize(p->det->stream);
+    (void)hipStreamSynchronize(p->det->mstream);
     void* dev[] = {p->d_view_K, p->d_view_valid, p->d_class_base, p->d_sel, p->d_nsel, p->d_scratch};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* pin[] = {p->h_sel, p->h_nsel, p->h_class_base};
@@ -99,6 +100,7 @@ extern "C" int lm_pipeline_set_views(lm_pipeline* p, const char* class_id, int f
     if (count == 0) return LM_OK;
     HIP_TRY(hipSetDevice(p->det->device));
     HIP_TRY(hipStreamSynchronize(p->det->stream));                 // the slot array may be reallocated: no frame may be in flight
+    HIP_TRY(hipStreamSynchronize(p->det->mstream));
     const int slot0 = it->second.base + first_template;
     int rc = lm_icp_set_models(p->icp, slot0, count, depth_ren);
     if (rc) return rc;
@@ -167,12 +169,12 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
     if (!d->frame_valid || d->fW != p->W || d->fH != p->H)
         return lm_set_error(LM_ERR_INVALID, "the detector's resident frame is not %dx%d", p->W, p->H);
     HIP_TRY(hipSetDevice(d->device));
-    hipStream_t s = d->stream;
+    hipStream_t s = d->mstream;                                   // after the matching kernels of the frame
     lm_icp* c = p->icp;
     int rc;
     if ((rc = lm_icp_ensure_arenas(c, top_k))) return rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        HIP_TRY(hipEventRecord(p->e0, s));
+        HIP_TRY(hipEventRecord(p->e0, d->stream));
         if ((rc = lm_submit_frame(d, threshold, class_ids, num_class_ids))) return rc;
         // class position (caller's class_ids order, or sorted order) -> first view slot
         std::vector<std::string> order;

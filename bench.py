@@ -39,6 +39,7 @@ NFEAT = (150, 75)
 N_TEMPLATES = 2000
 THRESHOLD = 75.0
 N_FRAMES = 4
+PIPELINE_DEPTH = 3         # frames in flight: front end of k+2 | matching of k+1 | host collects k
 HBM_PEAK_GBS = 8000.0
 
 
@@ -107,7 +108,7 @@ def main():
     acc = {k: 0.0 for k in keys}
     last = {"n": 0}
 
-    # Pipelined stream (depth 2): the GPU runs frame k+1 while the host collects / sorts / gathers frame k.
+    # Pipelined stream (depth 3): the GPU prepares frame k+2 and matches frame k+1 while the host collects / sorts / gathers frame k.
     def submit(k):
         t0 = time.perf_counter()
         det.selectFrame(k % N_FRAMES)            # device-to-device copy of a frame parked in HBM
@@ -133,12 +134,16 @@ def main():
         last["n"] = len(out)
 
     def run(nsteps):
+        inflight = 0
         for k in range(nsteps):
             submit(k)
-            if k > 0:
+            inflight += 1
+            if inflight == PIPELINE_DEPTH:
                 finish()
-        if nsteps > 0:
+                inflight -= 1
+        while inflight:
             finish()
+            inflight -= 1
 
     def fence():
         if world > 1:
@@ -181,7 +186,7 @@ def main():
                                    % args.templates,
                        "templates_total": total_templates, "objects": n_obj, "frames_in_stream": N_FRAMES,
                        "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world,
-                       "pipeline_depth": 2,
+                       "pipeline_depth": PIPELINE_DEPTH,
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
             "stages_ms": {k: mean[k] for k in ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},

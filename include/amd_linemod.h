@@ -143,8 +143,9 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
                                int sort_unique, lm_match **out, size_t *n);
 /* Pipelined stream mode: lm_detector_submit enqueues front end + matching of the current
  * frame and returns; lm_detector_collect waits for the OLDEST submitted frame and returns its matches.
- * Up to two frames may be in flight (the GPU works on frame k+1 while the host sorts frame k):
- *   select_frame(k+1); submit(); collect() -> frame k; ...
+ * Up to three frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
+ * streams while the host sorts frame k:
+ *   select_frame(k+2); submit(); collect() -> frame k; ...
  * lm_detector_match_resident == submit + collect. */
 int lm_detector_submit(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids);
 int lm_detector_collect(lm_detector *d, int sort_unique, lm_match **out, size_t *n);

@@ -251,10 +251,11 @@ def test_sharded_equals_unsharded_on_one_device(lm):
 
 
 def test_pipelined_submit_collect_equals_synchronous(lm):
-    """Stream mode: two frames in flight (submit k+1 before collecting k) returns exactly what the
-    synchronous calls return, frame by frame; a third submit without a collect is refused."""
+    """Stream mode: three frames in flight (front end of k+2 and matching of k+1 on two streams while the host
+    collects k) returns exactly what the synchronous calls return, frame by frame, also when the stream wraps around
+    the result slots; a fourth submit without a collect is refused."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
-    frames = [synth.make_frame(50 + i, W, H) for i in range(3)]
+    frames = [synth.make_frame(50 + i, W, H) for i in range(4)]
     od = lo.OracleDetector(nfeat[0], T)
     pyr = od.quantize_pyramid(*frames[0])
     bank = synth.make_planted_bank(61, 150, [(p[0], p[1]) for p in pyr], T, nfeat)
@@ -268,16 +269,21 @@ def test_pipelined_submit_collect_equals_synchronous(lm):
     got = []
     det.selectFrame(0); det.submit(70.0, ["o"])
     det.selectFrame(1); det.submit(70.0, ["o"])
+    det.selectFrame(2); det.submit(70.0, ["o"])
     with pytest.raises(RuntimeError, match="in flight"):
         det.submit(70.0, ["o"])
     got.append(det.collect())
-    det.selectFrame(2); det.submit(70.0, ["o"])
+    order = [0, 1, 2]
+    for k in range(3, 11):                                   # keep three in flight for a while
+        det.selectFrame(k % 4); det.submit(70.0, ["o"]); order.append(k % 4)
+        got.append(det.collect())
     got.append(det.collect())
     got.append(det.collect())
     with pytest.raises(RuntimeError, match="no frame in flight"):
         det.collect()
-    for g, w in zip(got, want):
-        assert g.tobytes() == w.tobytes()
+    assert len(got) == len(order)
+    for g, fi in zip(got, order):
+        assert g.tobytes() == want[fi].tobytes()
 
 
 def test_config1_size_2k_templates_bit_exact(lm):
