@@ -575,7 +575,7 @@ k_icp_grid(IcpBuffers B, int flags) {
 constexpr int kKnnWG = 512;        // 8 waves: 8 target points in flight per workgroup
 constexpr int kKnnCache = 384;     // candidates per point held in registers (6 per lane)
 constexpr int kKnnSlots = kKnnCache / 64;
-constexpr int kLoopLdsPts = 3072;  // target points staged in LDS by k_icp_knn and k_icp_loop (32-byte records, 96 KiB)
+constexpr int kLoopLdsPts = 1536;  // target points of a workgroup's x slab staged in LDS by k_icp_knn (32-byte records, 48 KiB: two workgroups per CU)
 
 template <int N, int OFF>
 static __device__ __forceinline__ void reduce_halve16(double (&v)[16], int lane) {
@@ -1395,7 +1395,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
-    hipLaunchKernelGGL(k_icp_knn, dim3(32, count), dim3(kKnnWG), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn, dim3(count <= 32 ? 64 : 32, count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
     int splits = 768 / count;
