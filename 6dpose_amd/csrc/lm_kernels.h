@@ -80,7 +80,9 @@ struct TopkSel {          // one kept detection
 // after top_k kept boxes.  matches_dev / counters as written by launch_local; scratch: topk_nms_scratch_bytes(cap).
 // sel[0..*nsel) in keep order; status: 0 ok, 1 field overflow (template id >= 2^24, class >= 128, |x|,|y| >= 2^15).
 void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* counters, uint32_t cap, const int32_t* work_pyramids,
-                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels, int top_k,
+                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels,
+                     const int32_t* class_base /*class position -> first view slot, may be null*/,
+                     const int32_t* view_wh /*[views][2] box override, -1 = template size, may be null*/, int num_views, int top_k,
                      double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s);
 size_t topk_nms_scratch_bytes(uint32_t cap);
 

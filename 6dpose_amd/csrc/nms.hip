@@ -144,7 +144,8 @@ static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const 
 __global__ void __launch_bounds__(kNmsWG)
 k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __restrict__ counters, uint32_t cap,
            const int32_t* __restrict__ work_pyramids, const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid,
-           const TemplEntry* __restrict__ entries, int levels, int top_k, double thresh, int4* __restrict__ rec,
+           const TemplEntry* __restrict__ entries, int levels, const int32_t* __restrict__ class_base, const int32_t* __restrict__ view_wh,
+           int num_views, int top_k, double thresh, int4* __restrict__ rec,
            unsigned long long* __restrict__ table, uint32_t table_mask, TopkSel* __restrict__ sel, int32_t* __restrict__ nsel_status) {
     __shared__ int4 s_rec[kNmsLds];
     __shared__ NmsKey s_keys[kNmsWG / 64];
@@ -163,12 +164,18 @@ k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __re
             if (c.work >= 0) {
                 const TemplEntry e = entries[(size_t)work_pyramids[c.work] * levels];  // level 0: the template's size
                 const int t = work_tid[c.work], cl = work_cls[c.work];
+                int bw = e.width, bh = e.height;                                      // NMS box: the template's size, or the
+                if (class_base && view_wh && cl >= 0 && cl < 128) {                   // caller's aTemplateInfo width / height
+                    const int base = class_base[cl];
+                    const int v = base + t;
+                    if (base >= 0 && v >= 0 && v < num_views && view_wh[2 * v] >= 0) { bw = view_wh[2 * v]; bh = view_wh[2 * v + 1]; }
+                }
                 if (t < 0 || t >= (1 << 24) || cl < 0 || cl >= 128 || c.x < -32768 || c.x > 32767 || c.y < -32768 || c.y > 32767 ||
-                    e.width < 0 || e.width > 65535 || e.height < 0 || e.height > 65535 || c.score < 0.f || !(c.score == c.score)) {
+                    bw < 0 || bw > 65535 || bh < 0 || bh > 65535 || c.score < 0.f || !(c.score == c.score)) {
                     s_bad = 1;
                 } else {
                     r.x = (c.x & 0xFFFF) | (c.y << 16);
-                    r.y = (e.width & 0xFFFF) | (e.height << 16);
+                    r.y = (bw & 0xFFFF) | (bh << 16);
                     r.z = __float_as_int(c.score);
                     r.w = t | (cl << 24);
                     const unsigned long long key = ((unsigned long long)(uint32_t)r.x << 32) | (uint32_t)r.w;
@@ -206,7 +213,8 @@ k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __re
 }
 
 void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* counters, uint32_t cap, const int32_t* work_pyramids,
-                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels, int top_k,
+                     const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels,
+                     const int32_t* class_base, const int32_t* view_wh, int num_views, int top_k,
                      double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s) {
     // scratch: cap int4 records, then the hash table (power of two >= 2 * cap 64-bit slots)
     size_t tsz = 1;
@@ -214,7 +222,7 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
     unsigned long long* table = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + (size_t)cap * 16);
     (void)hipMemsetAsync(table, 0xFF, tsz * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_topk_nms, dim3(1), dim3(kNmsWG), 0, s, matches_dev, counters, cap, work_pyramids, work_cls, work_tid, entries,
-                       levels, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), sel, nsel_status);
+                       levels, class_base, view_wh, num_views, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), sel, nsel_status);
 }
 
 size_t topk_nms_scratch_bytes(uint32_t cap) {

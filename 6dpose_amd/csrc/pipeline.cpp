@@ -28,6 +28,8 @@ struct lm_pipeline {
     int num_views = 0;                            // slots handed out
     std::vector<float> view_K, view_R, view_t;    // per slot: 9, 9, 3
     std::vector<int32_t> view_valid;
+    std::vector<int32_t> view_wh;                 // per slot: NMS box width, height (-1: the template's size)
+    int32_t* d_view_wh = nullptr;
     bool views_dirty = true;
     float* d_view_K = nullptr;
     int32_t* d_view_valid = nullptr;
@@ -68,7 +70,7 @@ extern "C" void lm_pipeline_destroy(lm_pipeline* p) {
     (void)hipSetDevice(p->det->device);
     (void)hipStreamSynchronize(p->det->stream);
     (void)hipStreamSynchronize(p->det->mstream);
-    void* dev[] = {p->d_view_K, p->d_view_valid, p->d_class_base, p->d_sel, p->d_nsel, p->d_scratch};
+    void* dev[] = {p->d_view_K, p->d_view_valid, p->d_view_wh, p->d_class_base, p->d_sel, p->d_nsel, p->d_scratch};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* pin[] = {p->h_sel, p->h_nsel, p->h_class_base};
     for (void* q : pin) if (q) (void)hipHostFree(q);
@@ -80,7 +82,7 @@ extern "C" void lm_pipeline_destroy(lm_pipeline* p) {
 }
 
 extern "C" int lm_pipeline_set_views(lm_pipeline* p, const char* class_id, int first_template, int count, const uint16_t* const* depth_ren,
-                                     const float* Ks, const float* Rs, const float* ts) {
+                                     const float* Ks, const float* Rs, const float* ts, const int32_t* box_wh) {
     if (!p || !class_id || first_template < 0 || count < 0 || (count && (!depth_ren || !Ks || !Rs || !ts)))
         return lm_set_error(LM_ERR_INVALID, "null argument");
     const int nt = lm_detector_num_templates(p->det, class_id);
@@ -93,6 +95,7 @@ extern "C" int lm_pipeline_set_views(lm_pipeline* p, const char* class_id, int f
         p->num_views += nt;
         p->view_K.resize((size_t)p->num_views * 9, 0.f); p->view_R.resize((size_t)p->num_views * 9, 0.f);
         p->view_t.resize((size_t)p->num_views * 3, 0.f); p->view_valid.resize((size_t)p->num_views, 0);
+        p->view_wh.resize((size_t)p->num_views * 2, -1);
         it = p->views.emplace(class_id, cv).first;
     } else if (it->second.count != nt) {
         return lm_set_error(LM_ERR_INVALID, "class '%s' changed its template count after views were set", class_id);
@@ -108,7 +111,11 @@ extern "C" int lm_pipeline_set_views(lm_pipeline* p, const char* class_id, int f
     memcpy(&p->view_K[(size_t)slot0 * 9], Ks, (size_t)count * 9 * sizeof(float));
     memcpy(&p->view_R[(size_t)slot0 * 9], Rs, (size_t)count * 9 * sizeof(float));
     memcpy(&p->view_t[(size_t)slot0 * 3], ts, (size_t)count * 3 * sizeof(float));
-    for (int i = 0; i < count; ++i) p->view_valid[(size_t)slot0 + i] = 1;
+    for (int i = 0; i < count; ++i) {
+        p->view_valid[(size_t)slot0 + i] = 1;
+        p->view_wh[2 * ((size_t)slot0 + i)] = box_wh ? box_wh[2 * i] : -1;
+        p->view_wh[2 * ((size_t)slot0 + i) + 1] = box_wh ? box_wh[2 * i + 1] : -1;
+    }
     p->views_dirty = true;
     return LM_OK;
 }
@@ -119,14 +126,17 @@ static int ensure_run_buffers(lm_pipeline* p, int top_k, int num_classes) {
         if (p->view_cap < p->num_views) {
             if (p->d_view_K) (void)hipFree(p->d_view_K);
             if (p->d_view_valid) (void)hipFree(p->d_view_valid);
-            p->d_view_K = nullptr; p->d_view_valid = nullptr;
+            if (p->d_view_wh) (void)hipFree(p->d_view_wh);
+            p->d_view_K = nullptr; p->d_view_valid = nullptr; p->d_view_wh = nullptr;
             p->view_cap = std::max(p->num_views, 1);
             HIP_TRY(hipMalloc((void**)&p->d_view_K, (size_t)p->view_cap * 9 * sizeof(float)));
             HIP_TRY(hipMalloc((void**)&p->d_view_valid, (size_t)p->view_cap * sizeof(int32_t)));
+            HIP_TRY(hipMalloc((void**)&p->d_view_wh, (size_t)p->view_cap * 2 * sizeof(int32_t)));
         }
         if (p->num_views) {
             HIP_TRY(hipMemcpy(p->d_view_K, p->view_K.data(), (size_t)p->num_views * 9 * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(p->d_view_valid, p->view_valid.data(), (size_t)p->num_views * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_view_wh, p->view_wh.data(), (size_t)p->num_views * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         p->views_dirty = false;
     }
@@ -189,7 +199,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
             HIP_TRY(hipMemcpyAsync(p->d_class_base, p->h_class_base, order.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(p->e1, s));
         launch_topk_nms(d->d_matches_dev.p, d->d_counters.p, d->cand_cap, d->d_work.p, d->d_work_cls.p, d->d_work_tid.p, d->d_entries.p,
-                        d->pyramid_levels, top_k, nms_iou, p->d_scratch, p->d_sel, p->d_nsel, s);
+                        d->pyramid_levels, p->d_class_base, p->d_view_wh, p->num_views, top_k, nms_iou, p->d_scratch, p->d_sel, p->d_nsel, s);
         HIP_TRY(hipMemsetAsync(c->d_st, 0, (size_t)top_k * sizeof(IcpState), s));
         launch_icp_bind(p->d_sel, p->d_nsel, p->d_class_base, p->d_view_K, p->d_view_valid, p->num_views, c->d_in, c->d_st, top_k, s);
         HIP_TRY(hipEventRecord(p->e2, s));

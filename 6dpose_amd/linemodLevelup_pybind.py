@@ -153,7 +153,7 @@ def load_library():
     lib.lm_pipeline_create.argtypes = [P, I, I, ctypes.POINTER(P)]
     lib.lm_pipeline_destroy.argtypes = [P]
     lib.lm_pipeline_destroy.restype = None
-    lib.lm_pipeline_set_views.argtypes = [P, S, I, I, ctypes.POINTER(P), P, P, P]
+    lib.lm_pipeline_set_views.argtypes = [P, S, I, I, ctypes.POINTER(P), P, P, P, P]
     lib.lm_pipeline_run.argtypes = [P, F, ctypes.POINTER(S), I, P, I, ctypes.c_double, I, ctypes.POINTER(_CDetection), ctypes.POINTER(I),
                                     ctypes.POINTER(PipelineTimings)]
     _lib = lib
@@ -597,7 +597,7 @@ class Pipeline:
 
     __del__ = close
 
-    def set_views(self, class_id: str, depth_rens, Ks, Rs, ts, first_template: int = 0):
+    def set_views(self, class_id: str, depth_rens, Ks, Rs, ts, first_template: int = 0, box_wh=None):
         mds = [_as_depth(m, "depth_ren") for m in depth_rens]
         for m in mds:
             if m.shape != self.shape:
@@ -607,7 +607,9 @@ class Pipeline:
         Ks = np.ascontiguousarray(np.asarray(Ks, np.float32).reshape(n, 9))
         Rs = np.ascontiguousarray(np.asarray(Rs, np.float32).reshape(n, 9))
         ts = np.ascontiguousarray(np.asarray(ts, np.float32).reshape(n, 3))
-        _check(self._lib.lm_pipeline_set_views(self._h, class_id.encode(), int(first_template), n, ptrs, _ptr(Ks), _ptr(Rs), _ptr(ts)))
+        wh = None if box_wh is None else np.ascontiguousarray(np.asarray(box_wh, np.int32).reshape(n, 2))
+        _check(self._lib.lm_pipeline_set_views(self._h, class_id.encode(), int(first_template), n, ptrs, _ptr(Ks), _ptr(Rs), _ptr(ts),
+                                               None if wh is None else _ptr(wh)))
 
     def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5):
         ids = [c.encode() for c in class_ids]

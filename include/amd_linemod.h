@@ -246,9 +246,11 @@ typedef struct lm_pipeline_timings {
 int lm_pipeline_create(lm_detector *det, int width, int height, lm_pipeline **out);
 void lm_pipeline_destroy(lm_pipeline *p);
 /* Views of templates [first_template, first_template + count) of a class: depth rendering (uint16 [height][width],
- * mm), cam_K, cam_R_w2c (float32 3x3 row-major), cam_t_w2c (float32 3, mm). */
+ * mm), cam_K, cam_R_w2c (float32 3x3 row-major), cam_t_w2c (float32 3, mm); box_wh: NULL, or [count][2] int32
+ * aTemplateInfo 'width','height' (the NMS box of the driver, :335-338); NULL / negative = the template's own size. */
 int lm_pipeline_set_views(lm_pipeline *p, const char *class_id, int first_template, int count,
-                          const uint16_t *const *depth_ren, const float *Ks, const float *Rs, const float *ts);
+                          const uint16_t *const *depth_ren, const float *Ks, const float *Rs, const float *ts,
+                          const int32_t *box_wh);
 /* Runs on the detector's resident frame (lm_detector_set_frame / select_frame).  out: top_k entries; *n_out kept. */
 int lm_pipeline_run(lm_pipeline *p, float threshold, const char *const *class_ids, int num_class_ids, const float *scene_K,
                     int top_k, double nms_iou, int flags, lm_detection *out, int *n_out, lm_pipeline_timings *tm);

@@ -531,12 +531,12 @@ def test_icp_context_slots_shared_by_hypotheses(lm):
 # ---------------------------------------------------------------------------------------------
 # per-frame pipeline: match -> boxes -> nms -> top-k -> poseRefine, all on the device
 # ---------------------------------------------------------------------------------------------
-def _pipeline_reference(mod, det, rgb, dep, wh, E, views, thr, top_k, iou):
+def _pipeline_reference(mod, det, rgb, dep, wh, E, views, thr, top_k, iou, box=None):
     """The driver loop (linemod_and_levelup_test.py:324-372) with the product's reference-shaped calls."""
     m = det.matchArray([rgb, dep], thr, ["obj"])
     dets = np.zeros((len(m), 5))
     for i, r in enumerate(m):
-        w, h = wh[int(r["template_id"]) * E]
+        w, h = wh[int(r["template_id"]) * E] if box is None else box[int(r["template_id"])]
         dets[i] = (r["x"], r["y"], r["x"] + w, r["y"] + h, r["similarity"])
     keep = mod.nms(dets, iou)[:top_k]
     sel = [m[i] for i in keep]
@@ -574,16 +574,18 @@ def test_pipeline_equals_match_nms_pose_refine(lm, dup):
         tt = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), 1000 + rng.uniform(-20, 20)], np.float32)
         views.append((shapes[t % 4], K_CAM.copy(), R, tt))
     pipe = lm.Pipeline(det, W, H, scene_from_scene=True)
-    pipe.set_views("obj", [v[0] for v in views], [v[1] for v in views], [v[2] for v in views], [v[3] for v in views])
+    # dup=True also overrides the NMS boxes with the driver's aTemplateInfo width / height (the rendered depth's extent)
+    box = None if not dup else [(int(wh[t * E][0]) + 7 - t % 5, int(wh[t * E][1]) - 4 + t % 3) for t in range(n)]
+    pipe.set_views("obj", [v[0] for v in views], [v[1] for v in views], [v[2] for v in views], [v[3] for v in views], box_wh=box)
     for thr, top_k in ((70.0, 8), (85.0, 5)):
-        sel, poses, n_matches = _pipeline_reference(lm, det, rgb, dep, wh, E, views, thr, top_k, 0.5)
+        sel, poses, n_matches = _pipeline_reference(lm, det, rgb, dep, wh, E, views, thr, top_k, 0.5, box)
         det.setFrame([rgb, dep])
         got, tm = pipe.run(thr, ["obj"], K_CAM, top_k=top_k, nms_iou=0.5)
         assert len(got) == len(sel) and len(got) > 0
         for g, r, p in zip(got, sel, poses):
             assert (g["x"], g["y"], g["template_id"]) == (int(r["x"]), int(r["y"]), int(r["template_id"]))
             assert g["similarity"] == float(r["similarity"])
-            assert (g["width"], g["height"]) == tuple(int(v) for v in wh[int(r["template_id"]) * E])
+            assert (g["width"], g["height"]) == (tuple(int(v) for v in wh[int(r["template_id"]) * E]) if box is None else box[int(r["template_id"])])
             if p["residual"] == -1.0:
                 assert g["status"] == 1 and g["residual"] == -1.0
                 continue
