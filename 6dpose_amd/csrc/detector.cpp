@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "detector_internal.h"
+#include "render_internal.h"
 
 // ---- errors -----------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -305,13 +306,11 @@ static int validate_pyramid(const lm_detector* d, const TemplatePyramid& tp) {
     return LM_OK;
 }
 
-extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, const uint8_t* mask,
-                                        int width, int height, const char* class_id) {
-    if (!d || !class_id) return lm_set_error(LM_ERR_INVALID, "null argument");
+// Detector::addTemplate on the frame resident in frame_rgb / frame_depth (LL.cpp:1943-1975).
+static int add_template_resident(lm_detector* d, const uint8_t* mask, int width, int height, const char* class_id) {
     // quantise() in addTemplate passes object_mask to every modality (LL.cpp:1957), but the masked
     // quantised image is not used by extractTemplate; only the unmasked maps + the mask are.
-    int rc = upload_frame(d, rgb, depth, width, height, nullptr, false);
-    if (rc) return rc;
+    int rc;
     if ((rc = run_frontend(d, false))) return rc;
     d->frame_valid = false;   // LM arena not built for this frame
     const int L = d->pyramid_levels;
@@ -352,6 +351,68 @@ extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, cons
     if ((rc = validate_pyramid(d, tp))) return rc;
     tps.push_back(std::move(tp));
     return (int)tps.size() - 1;
+}
+
+extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, const uint8_t* mask,
+                                        int width, int height, const char* class_id) {
+    if (!d || !class_id) return lm_set_error(LM_ERR_INVALID, "null argument");
+    int rc = upload_frame(d, rgb, depth, width, height, nullptr, false);
+    if (rc) return rc;
+    return add_template_resident(d, mask, width, height, class_id);
+}
+
+// render_train (linemod_and_levelup_test.py:170-252) on the device: the rendered colour / depth images go from the
+// rasteriser's buffers into the detector's frame buffers without touching the host; only the depth comes back (the
+// object mask depth > 0 and the extent of the rendering) together with the maps the greedy feature selection reads.
+extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, const char* class_id, int count, int width, int height,
+                                                  const float* Ks, const float* Rs, const float* ts, float clip_near, float clip_far,
+                                                  float ambient, int ssaa, int32_t* template_ids, int32_t* box_wh) {
+    if (!d || !m || !class_id || count < 0 || (count && (!Ks || !Rs || !ts || !template_ids)))
+        return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (m->device != d->device) return lm_set_error(LM_ERR_INVALID, "mesh and detector live on different devices");
+    if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "a frame is in flight: collect it first");
+    if (width < 16 || height < 16) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", width, height);
+    HIP_TRY(hipSetDevice(d->device));
+    const size_t npx = (size_t)width * height;
+    const size_t per_view = npx * (size_t)ssaa * ssaa * sizeof(unsigned long long);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)2 << 30) / std::max<size_t>(per_view, 1)));
+    std::vector<uint16_t> hdepth(npx);
+    std::vector<uint8_t> hmask(npx);
+    int rc;
+    for (int c0 = 0; c0 < count; c0 += chunk) {
+        const int n = std::min(chunk, count - c0);
+        if ((rc = lm_mesh_render_device(m, n, width, height, Ks + 9 * (size_t)c0, Rs + 9 * (size_t)c0, ts + 3 * (size_t)c0, clip_near, clip_far,
+                                        ambient, ssaa, true, true)))
+            return rc;
+        HIP_TRY(hipStreamSynchronize(m->s));
+        for (int i = 0; i < n; ++i) {
+            d->frame_valid = false;
+            if ((rc = setup_geometry(d, width, height, false))) return rc;
+            d->have_mask[0] = d->have_mask[1] = false;
+            HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, d->stream));
+            HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, d->stream));
+            HIP_TRY(hipMemcpyAsync(hdepth.data(), m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToHost, d->stream));
+            HIP_TRY(hipStreamSynchronize(d->stream));
+            int x0 = width, y0 = height, x1 = -1, y1 = -1;
+            for (int y = 0; y < height; ++y)
+                for (int x = 0; x < width; ++x) {
+                    const bool on = hdepth[(size_t)y * width + x] > 0;
+                    hmask[(size_t)y * width + x] = on ? 255 : 0;                       // mask = (depth > 0) * 255 (:238)
+                    if (on) { x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y); }
+                }
+            if (box_wh) {                                                              // xmax - xmin, ymax - ymin (:235-236)
+                box_wh[2 * ((size_t)c0 + i)] = x1 >= 0 ? x1 - x0 : 0;
+                box_wh[2 * ((size_t)c0 + i) + 1] = y1 >= 0 ? y1 - y0 : 0;
+            }
+            int id = -1;
+            if (x1 >= 0) {
+                id = add_template_resident(d, hmask.data(), width, height, class_id);
+                if (id < -1) return id;
+            }
+            template_ids[(size_t)c0 + i] = id;
+        }
+    }
+    return LM_OK;
 }
 
 extern "C" int lm_detector_read_class(lm_detector* d, const char* path, const char* class_id_override) {

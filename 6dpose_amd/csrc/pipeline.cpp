@@ -13,6 +13,7 @@
 
 #include "detector_internal.h"
 #include "icp_internal.h"
+#include "render_internal.h"
 
 namespace {
 constexpr double kVoxel = 0.0025, kMaxDist = 0.01, kRelTol = 1e-6;   // as pose_refine.cpp (LL.cpp:106, :31; Open3D defaults)
@@ -108,6 +109,59 @@ extern "C" int lm_pipeline_set_views(lm_pipeline* p, const char* class_id, int f
     int rc = lm_icp_set_models(p->icp, slot0, count, depth_ren);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->icp->s));
+    memcpy(&p->view_K[(size_t)slot0 * 9], Ks, (size_t)count * 9 * sizeof(float));
+    memcpy(&p->view_R[(size_t)slot0 * 9], Rs, (size_t)count * 9 * sizeof(float));
+    memcpy(&p->view_t[(size_t)slot0 * 3], ts, (size_t)count * 3 * sizeof(float));
+    for (int i = 0; i < count; ++i) {
+        p->view_valid[(size_t)slot0 + i] = 1;
+        p->view_wh[2 * ((size_t)slot0 + i)] = box_wh ? box_wh[2 * i] : -1;
+        p->view_wh[2 * ((size_t)slot0 + i) + 1] = box_wh ? box_wh[2 * i + 1] : -1;
+    }
+    p->views_dirty = true;
+    return LM_OK;
+}
+
+// Views rendered on the device: the depth of template first_template + i goes from the rasteriser straight into the
+// ICP context's model slot — what the driver does per match at linemod_and_levelup_test.py:352, once per template.
+extern "C" int lm_pipeline_set_views_rendered(lm_pipeline* p, lm_mesh* m, const char* class_id, int first_template, int count,
+                                              const float* Ks, const float* Rs, const float* ts, float clip_near, float clip_far,
+                                              const int32_t* box_wh) {
+    if (!p || !m || !class_id || first_template < 0 || count < 0 || (count && (!Ks || !Rs || !ts)))
+        return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (m->device != p->det->device) return lm_set_error(LM_ERR_INVALID, "mesh and detector live on different devices");
+    const int nt = lm_detector_num_templates(p->det, class_id);
+    if (nt <= 0) return lm_set_error(LM_ERR_NOT_FOUND, "class '%s' has no templates in the detector", class_id);
+    if (first_template + count > nt) return lm_set_error(LM_ERR_INVALID, "views [%d, %d) exceed the %d templates of class '%s'", first_template, first_template + count, nt, class_id);
+    auto it = p->views.find(class_id);
+    if (it == p->views.end()) {
+        lm_pipeline::ClassViews cv;
+        cv.base = p->num_views; cv.count = nt;
+        p->num_views += nt;
+        p->view_K.resize((size_t)p->num_views * 9, 0.f); p->view_R.resize((size_t)p->num_views * 9, 0.f);
+        p->view_t.resize((size_t)p->num_views * 3, 0.f); p->view_valid.resize((size_t)p->num_views, 0);
+        p->view_wh.resize((size_t)p->num_views * 2, -1);
+        it = p->views.emplace(class_id, cv).first;
+    } else if (it->second.count != nt) {
+        return lm_set_error(LM_ERR_INVALID, "class '%s' changed its template count after views were set", class_id);
+    }
+    if (count == 0) return LM_OK;
+    HIP_TRY(hipSetDevice(p->det->device));
+    HIP_TRY(hipStreamSynchronize(p->det->stream));
+    HIP_TRY(hipStreamSynchronize(p->det->mstream));
+    const int slot0 = it->second.base + first_template;
+    int rc = lm_icp_ensure_slots(p->icp, slot0 + count);
+    if (rc) return rc;
+    const size_t npx = (size_t)p->W * p->H;
+    const int chunk = 256;
+    for (int c0 = 0; c0 < count; c0 += chunk) {
+        const int n = std::min(chunk, count - c0);
+        if ((rc = lm_mesh_render_device(m, n, p->W, p->H, Ks + 9 * (size_t)c0, Rs + 9 * (size_t)c0, ts + 3 * (size_t)c0, clip_near, clip_far, 0.f,
+                                        1, true, false)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(p->icp->d_models + ((size_t)slot0 + c0) * npx, m->d_depth, (size_t)n * npx * sizeof(uint16_t),
+                               hipMemcpyDeviceToDevice, m->s));
+        HIP_TRY(hipStreamSynchronize(m->s));
+    }
     memcpy(&p->view_K[(size_t)slot0 * 9], Ks, (size_t)count * 9 * sizeof(float));
     memcpy(&p->view_R[(size_t)slot0 * 9], Rs, (size_t)count * 9 * sizeof(float));
     memcpy(&p->view_t[(size_t)slot0 * 3], ts, (size_t)count * 3 * sizeof(float));

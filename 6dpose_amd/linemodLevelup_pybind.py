@@ -36,7 +36,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["Detector", "Match", "poseRefine", "IcpContext", "Pipeline", "Template", "library_path", "load_library", "nms"]
+__all__ = ["Detector", "Match", "poseRefine", "IcpContext", "Pipeline", "Mesh", "Template", "library_path", "load_library", "nms"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libamdlinemod.so"
@@ -150,6 +150,14 @@ def load_library():
     lib.lm_icp_run.argtypes = [P, I, P, P, P, P, P, I, ctypes.POINTER(_CPoseResult), ctypes.POINTER(F)]
     lib.lm_icp_read_debug.argtypes = [P, I, I, P, ctypes.c_int64]
     lib.lm_icp_read_debug.restype = ctypes.c_int64
+    lib.lm_mesh_create.argtypes = [I, P, P, P, I, P, I, ctypes.POINTER(P)]
+    lib.lm_mesh_load_ply.argtypes = [I, S, ctypes.POINTER(P)]
+    lib.lm_mesh_destroy.argtypes = [P]
+    lib.lm_mesh_destroy.restype = None
+    lib.lm_mesh_counts.argtypes = [P, ctypes.POINTER(I), ctypes.POINTER(I)]
+    lib.lm_mesh_render.argtypes = [P, I, I, I, P, P, P, F, F, F, I, P, P]
+    lib.lm_detector_add_templates_rendered.argtypes = [P, P, S, I, I, I, P, P, P, F, F, F, I, P, P]
+    lib.lm_pipeline_set_views_rendered.argtypes = [P, P, S, I, I, P, P, P, F, F, P]
     lib.lm_pipeline_create.argtypes = [P, I, I, ctypes.POINTER(P)]
     lib.lm_pipeline_destroy.argtypes = [P]
     lib.lm_pipeline_destroy.restype = None
@@ -611,6 +619,13 @@ class Pipeline:
         _check(self._lib.lm_pipeline_set_views(self._h, class_id.encode(), int(first_template), n, ptrs, _ptr(Ks), _ptr(Rs), _ptr(ts),
                                                None if wh is None else _ptr(wh)))
 
+    def set_views_rendered(self, class_id: str, mesh: "Mesh", Ks, Rs, ts, first_template: int = 0, clip_near=10.0, clip_far=10000.0, box_wh=None):
+        """depth_ren of every template view rendered on the device straight into the resident slots."""
+        n, Ks, Rs, ts = Mesh._views(Ks, Rs, ts)
+        wh = None if box_wh is None else np.ascontiguousarray(np.asarray(box_wh, np.int32).reshape(n, 2))
+        _check(self._lib.lm_pipeline_set_views_rendered(self._h, mesh._h, class_id.encode(), int(first_template), n, _ptr(Ks), _ptr(Rs), _ptr(ts),
+                                                        float(clip_near), float(clip_far), None if wh is None else _ptr(wh)))
+
     def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5):
         ids = [c.encode() for c in class_ids]
         arr = (ctypes.c_char_p * len(ids))(*ids) if ids else None
@@ -630,3 +645,69 @@ class Pipeline:
                         "rmse": float(o.pose.inlier_rmse), "iterations": int(o.pose.iterations),
                         "n_source": int(o.pose.n_source), "n_target": int(o.pose.n_target)})
         return res, tm.as_dict()
+
+
+class Mesh:
+    """lm_mesh (include/amd_linemod.h): a triangle mesh resident in HBM and its rasteriser — what the reference driver
+    gets from pysixd (inout.load_ply + renderer.render).  Mesh(path) loads a PLY; Mesh(pts, faces, normals=, colors=)
+    takes arrays (model dict keys of pysixd: 'pts', 'faces', 'normals', 'colors')."""
+
+    def __init__(self, pts_or_path, faces=None, normals=None, colors=None, device: int = 0):
+        lib = load_library()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        if isinstance(pts_or_path, (str, bytes, os.PathLike)):
+            _check(lib.lm_mesh_load_ply(int(device), os.fspath(pts_or_path).encode(), ctypes.byref(self._h)))
+        else:
+            V = np.ascontiguousarray(np.asarray(pts_or_path, np.float32).reshape(-1, 3))
+            Fc = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
+            Nn = None if normals is None else np.ascontiguousarray(np.asarray(normals, np.float32).reshape(-1, 3))
+            Cc = None if colors is None else np.ascontiguousarray(np.asarray(colors, np.uint8).reshape(-1, 3))
+            _check(lib.lm_mesh_create(int(device), _ptr(V), None if Nn is None else _ptr(Nn), None if Cc is None else _ptr(Cc), len(V),
+                                      _ptr(Fc), len(Fc), ctypes.byref(self._h)))
+        nv, nf = ctypes.c_int(), ctypes.c_int()
+        _check(lib.lm_mesh_counts(self._h, ctypes.byref(nv), ctypes.byref(nf)))
+        self.num_vertices, self.num_faces = nv.value, nf.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.lm_mesh_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def _views(Ks, Rs, ts):
+        Rs = np.ascontiguousarray(np.asarray(Rs, np.float32).reshape(-1, 9))
+        n = len(Rs)
+        Ks = np.asarray(Ks, np.float32)
+        Ks = np.ascontiguousarray(np.tile(Ks.reshape(1, 9), (n, 1)) if Ks.size == 9 else Ks.reshape(n, 9))
+        ts = np.ascontiguousarray(np.asarray(ts, np.float32).reshape(n, 3))
+        return n, Ks, Rs, ts
+
+    def render(self, im_size, Ks, Rs, ts, clip_near=10.0, clip_far=10000.0, ambient_weight=0.8, ssaa=4, mode="rgb+depth"):
+        """renderer.render for a batch of views; im_size = (width, height).  Returns depth uint16 (n,H,W) and / or rgb uint8 (n,H,W,3)."""
+        W, H = int(im_size[0]), int(im_size[1])
+        n, Ks, Rs, ts = self._views(Ks, Rs, ts)
+        depth = np.zeros((n, H, W), np.uint16) if "depth" in mode else None
+        rgb = np.zeros((n, H, W, 3), np.uint8) if "rgb" in mode else None
+        _check(self._lib.lm_mesh_render(self._h, n, W, H, _ptr(Ks), _ptr(Rs), _ptr(ts), float(clip_near), float(clip_far), float(ambient_weight),
+                                        int(ssaa), None if depth is None else _ptr(depth), None if rgb is None else _ptr(rgb)))
+        if mode == "depth":
+            return depth
+        if mode == "rgb":
+            return rgb
+        return rgb, depth
+
+
+def add_templates_rendered(detector: "Detector", mesh: Mesh, class_id: str, im_size, Ks, Rs, ts, clip_near=10.0, clip_far=10000.0,
+                           ambient_weight=0.8, ssaa=4):
+    """The render_train loop of the driver (linemod_and_levelup_test.py:170-252) on the device.  Returns (template ids (n,),
+    -1 where addTemplate failed; box_wh (n,2) = aTemplateInfo 'width','height')."""
+    n, Ks, Rs, ts = Mesh._views(Ks, Rs, ts)
+    ids = np.zeros(n, np.int32)
+    wh = np.zeros((n, 2), np.int32)
+    _check(load_library().lm_detector_add_templates_rendered(detector._h, mesh._h, class_id.encode(), n, int(im_size[0]), int(im_size[1]), _ptr(Ks),
+                                                             _ptr(Rs), _ptr(ts), float(clip_near), float(clip_far), float(ambient_weight), int(ssaa),
+                                                             _ptr(ids), _ptr(wh)))
+    return ids, wh

@@ -255,6 +255,34 @@ int lm_pipeline_set_views(lm_pipeline *p, const char *class_id, int first_templa
 int lm_pipeline_run(lm_pipeline *p, float threshold, const char *const *class_ids, int num_class_ids, const float *scene_K,
                     int top_k, double nms_iou, int flags, lm_detection *out, int *n_out, lm_pipeline_timings *tm);
 
+/* ---- meshes and rendering --------------------------------------------------------
+ * What the reference driver gets from pysixd: inout.load_ply (inout.py) and renderer.render
+ * (renderer.py:306-420; linemod_and_levelup_test.py:206-215 for the training views, :352 for the depth_ren
+ * poseRefine registers against).  The mesh lives in HBM; a batch of views is rasterised on the device
+ * (depth at the native resolution; colour with per-fragment phong shading, light at the eye, at ssaa x the
+ * resolution and box-averaged).  OpenCV camera convention: p_cam = R v + t, pixel (i, j) sampled at (i, j). */
+typedef struct lm_mesh lm_mesh;
+int lm_mesh_create(int device, const float *vertices /*[nv][3] mm*/, const float *normals /*[nv][3] or NULL*/,
+                   const uint8_t *colors /*[nv][3] or NULL*/, int nv, const int32_t *faces /*[nf][3]*/, int nf, lm_mesh **out);
+int lm_mesh_load_ply(int device, const char *path, lm_mesh **out);   /* ascii / binary_little_endian, triangles */
+void lm_mesh_destroy(lm_mesh *m);
+int lm_mesh_counts(const lm_mesh *m, int *nv, int *nf);
+/* render(model, (width, height), K, R, t, clip_near, clip_far, ambient_weight, shading='phong') for `count` views.
+ * Ks/Rs [count][9] float32 row-major, ts [count][3] (mm).  depth_out: uint16 [count][height][width] (mm, truncated
+ * like depth.astype(np.uint16)) or NULL; rgb_out: uint8 [count][height][width][3] or NULL. */
+int lm_mesh_render(lm_mesh *m, int count, int width, int height, const float *Ks, const float *Rs, const float *ts,
+                   float clip_near, float clip_far, float ambient, int ssaa, uint16_t *depth_out, uint8_t *rgb_out);
+/* The render_train loop of the driver (:170-252) without the round trip through host images: renders every view
+ * (depth + colour), runs Detector::addTemplate on it (mask = depth > 0) and reports the template id per view (-1 where
+ * no template could be extracted) plus the extent of the rendered depth (aTemplateInfo 'width','height', :229-236). */
+int lm_detector_add_templates_rendered(lm_detector *d, lm_mesh *m, const char *class_id, int count, int width, int height,
+                                       const float *Ks, const float *Rs, const float *ts, float clip_near, float clip_far,
+                                       float ambient, int ssaa, int32_t *template_ids /*[count]*/, int32_t *box_wh /*[count][2] or NULL*/);
+/* Views of a pipeline rendered on the device: depth_ren of template first_template + i = the mesh at (Rs[i], ts[i]). */
+int lm_pipeline_set_views_rendered(lm_pipeline *p, lm_mesh *m, const char *class_id, int first_template, int count,
+                                   const float *Ks, const float *Rs, const float *ts, float clip_near, float clip_far,
+                                   const int32_t *box_wh);
+
 #ifdef __cplusplus
 }
 #endif

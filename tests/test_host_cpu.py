@@ -140,3 +140,22 @@ def test_gather_over_gloo_world_size_2(lib, tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_view_sampler_reproduces_the_reference_golden():
+    """6dpose_amd/views.py vs tests/golden/views_golden.npz (pysixd/view_sampler.py imported by make_views_golden.py)."""
+    import math
+    import views
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "views_golden.npz"))
+    vs, lv = views.sample_views(100, 1000, (0, 2 * math.pi), (0, 0.5 * math.pi), tilt_range=(0, 2 * math.pi), tilt_step=0.5 * math.pi)
+    assert len(vs) == len(g["a_R"]) and lv == g["a_levels"].tolist()
+    assert np.abs(np.stack([v["R"] for v in vs]) - g["a_R"]).max() < 1e-12 and np.abs(np.stack([v["t"] for v in vs]) - g["a_t"]).max() < 1e-9
+    vs, _ = views.sample_views(100, 1000, (0, 2 * math.pi), (0, 0.5 * math.pi), tilt_range=(0, 2 * math.pi), tilt_step=0.1 * math.pi)   # the driver's call
+    assert len(vs) == int(g["b_count"][0])
+    assert abs(sum(v["R"].sum() for v in vs) - g["b_sum"][0]) < 1e-9 and abs(sum(v["t"].sum() for v in vs) - g["b_sum"][1]) < 1e-6
+    for k, i in enumerate((0, 1, 777, len(vs) - 1)):
+        assert np.abs(np.concatenate([vs[i]["R"].ravel(), vs[i]["t"].ravel()]) - g["b_first_last"][k]).max() < 1e-9
+    pts, lv = views.hinter_sampling(300, radius=2.5)
+    assert np.abs(pts - g["c_pts"]).max() < 1e-12 and lv == g["c_levels"].tolist()
+    vs, _ = views.sample_views(42, 600.0, tilt_step=0.25 * math.pi)
+    assert np.abs(np.stack([v["R"] for v in vs]) - g["d_R"]).max() < 1e-12 and np.abs(np.stack([v["t"] for v in vs]) - g["d_t"]).max() < 1e-9
