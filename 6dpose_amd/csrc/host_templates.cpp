@@ -105,8 +105,8 @@ struct ScoreDesc {
 
 }  // namespace
 
-bool extract_color_template(const float* mag, const uint8_t* angle, const uint8_t* mask, int W, int H,
-                            size_t num_features, float strong_threshold, int level, Template& out) {
+static bool extract_color_full(const float* mag, const uint8_t* angle, const uint8_t* mask, int W, int H,
+                               size_t num_features, float strong_threshold, int level, Template& out) {
     std::vector<uint8_t> local;
     if (mask) {
         std::vector<uint8_t> m(mask, mask + (size_t)W * H);
@@ -136,8 +136,8 @@ bool extract_color_template(const float* mag, const uint8_t* angle, const uint8_
     return true;
 }
 
-bool extract_normal_template(const uint8_t* normal, const uint8_t* mask, int W, int H, size_t num_features,
-                             int extract_threshold, int level, Template& out) {
+static bool extract_normal_full(const uint8_t* normal, const uint8_t* mask, int W, int H, size_t num_features,
+                                int extract_threshold, int level, Template& out) {
     const size_t N = (size_t)W * H;
     std::vector<uint8_t> local;
     if (mask) {
@@ -177,6 +177,58 @@ bool extract_normal_template(const uint8_t* normal, const uint8_t* mask, int W, 
     select_scattered(cands, out.features, num_features, distance);      // return value ignored, LL.cpp:958
     out.width = out.height = -1;
     out.pyramid_level = level;
+    return true;
+}
+
+// With an object mask every candidate lies inside it, and erosion / the chessboard distance transform at a masked pixel
+// only depend on pixels up to the first zero around it.  The mask's bounding box grown by one pixel (all zeros, or the
+// image border itself, where the full-image code clamps in the same way) therefore gives exactly the same templates
+// as the whole frame, at the cost of the object's pixels instead of the image's (render_train: ~30x less host work).
+namespace {
+struct Roi { int x0, y0, w, h; bool any; };
+Roi mask_roi(const uint8_t* mask, int W, int H) {
+    int x0 = W, y0 = H, x1 = -1, y1 = -1;
+    for (int y = 0; y < H; ++y) {
+        const uint8_t* row = mask + (size_t)y * W;
+        int first = -1, last = -1;
+        for (int x = 0; x < W; ++x)
+            if (row[x]) { if (first < 0) first = x; last = x; }
+        if (first >= 0) { x0 = std::min(x0, first); x1 = std::max(x1, last); y0 = std::min(y0, y); y1 = y; }
+    }
+    Roi r{0, 0, 0, 0, x1 >= 0};
+    if (!r.any) return r;
+    x0 = std::max(x0 - 1, 0); y0 = std::max(y0 - 1, 0); x1 = std::min(x1 + 1, W - 1); y1 = std::min(y1 + 1, H - 1);
+    r.x0 = x0; r.y0 = y0; r.w = x1 - x0 + 1; r.h = y1 - y0 + 1;
+    return r;
+}
+template <typename T>
+std::vector<T> crop(const T* src, int W, const Roi& r) {
+    std::vector<T> out((size_t)r.w * r.h);
+    for (int y = 0; y < r.h; ++y) memcpy(&out[(size_t)y * r.w], src + (size_t)(r.y0 + y) * W + r.x0, (size_t)r.w * sizeof(T));
+    return out;
+}
+}  // namespace
+
+bool extract_color_template(const float* mag, const uint8_t* angle, const uint8_t* mask, int W, int H,
+                            size_t num_features, float strong_threshold, int level, Template& out) {
+    if (!mask) return extract_color_full(mag, angle, nullptr, W, H, num_features, strong_threshold, level, out);
+    const Roi r = mask_roi(mask, W, H);
+    if (!r.any) return false;                                            // no candidates at all (LL.cpp:626)
+    const std::vector<float> m = crop(mag, W, r);
+    const std::vector<uint8_t> a = crop(angle, W, r), k = crop(mask, W, r);
+    if (!extract_color_full(m.data(), a.data(), k.data(), r.w, r.h, num_features, strong_threshold, level, out)) return false;
+    for (Feature& f : out.features) { f.x += r.x0; f.y += r.y0; }
+    return true;
+}
+
+bool extract_normal_template(const uint8_t* normal, const uint8_t* mask, int W, int H, size_t num_features,
+                             int extract_threshold, int level, Template& out) {
+    if (!mask) return extract_normal_full(normal, nullptr, W, H, num_features, extract_threshold, level, out);
+    const Roi r = mask_roi(mask, W, H);
+    if (!r.any) return false;                                            // no candidates at all (LL.cpp:943)
+    const std::vector<uint8_t> n = crop(normal, W, r), k = crop(mask, W, r);
+    if (!extract_normal_full(n.data(), k.data(), r.w, r.h, num_features, extract_threshold, level, out)) return false;
+    for (Feature& f : out.features) { f.x += r.x0; f.y += r.y0; }
     return true;
 }
 
