@@ -108,8 +108,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
-    d->frame_rgb.release(); d->frame_depth.release(); d->tmp16.release(); d->smoothed.release();
-    d->q16.release(); d->nrm_raw.release(); d->rowor.release();
+    d->frame_rgb.release(); d->frame_depth.release(); d->nrm_raw.release();
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
@@ -186,11 +185,7 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
     int rc;
     if ((rc = d->frame_rgb.ensure(n0 * 3))) return rc;
     if ((rc = d->frame_depth.ensure(n0))) return rc;
-    if ((rc = d->tmp16.ensure(n0 * 3))) return rc;
-    if ((rc = d->smoothed.ensure(n0 * 3))) return rc;
-    if ((rc = d->q16.ensure(n0))) return rc;
     if ((rc = d->nrm_raw.ensure(n0))) return rc;
-    if ((rc = d->rowor.ensure(n0))) return rc;
 
     for (int a = 0; a < lm_detector::kSlots; ++a) {
         const bool realloc_arena = arena > d->lm_arena[a].cap;

@@ -68,8 +68,7 @@ struct lm_detector {
     bool frame_valid = false, have_mask[2] = {false, false};
     DevBuf<uint8_t> frame_rgb;
     DevBuf<uint16_t> frame_depth;
-    DevBuf<uint16_t> tmp16;
-    DevBuf<uint8_t> smoothed, q16, nrm_raw, rowor;
+    DevBuf<uint8_t> nrm_raw;                    // normals before the median (level 0)
     static constexpr int kSlots = 3;            // frames in flight (lm_detector_submit / collect)
     DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
                                                 // while the matching kernels of frame k read the other

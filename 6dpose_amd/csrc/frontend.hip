@@ -19,38 +19,6 @@ void upload_normal_lut(const uint8_t lut400[400]) {
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// ---- cv::GaussianBlur(8UC3, 7x7, sigma 0, BORDER_REPLICATE) (LL.cpp:367; Appendix A.1) ----------
-// separable fixed point: weights [8,28,56,72,56,28,8]; out = (sum_ij + 32768) >> 16
-__global__ void k_blur_h(const uint8_t* __restrict__ src, uint16_t* __restrict__ tmp, int W, int H) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const int w[7] = {8, 28, 56, 72, 56, 28, 8};
-    const uint8_t* row = src + (size_t)y * W * 3;
-    int s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        int xx = clampi(x + k - 3, 0, W - 1) * 3;
-        s0 += w[k] * row[xx]; s1 += w[k] * row[xx + 1]; s2 += w[k] * row[xx + 2];
-    }
-    uint16_t* o = tmp + ((size_t)y * W + x) * 3;
-    o[0] = (uint16_t)s0; o[1] = (uint16_t)s1; o[2] = (uint16_t)s2;
-}
-
-__global__ void k_blur_v(const uint16_t* __restrict__ tmp, uint8_t* __restrict__ dst, int W, int H) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;   // i over W*3 interleaved samples
-    if (i >= W * 3) return;
-    const int w[7] = {8, 28, 56, 72, 56, 28, 8};
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += w[k] * tmp[(size_t)clampi(y + k - 3, 0, H - 1) * W * 3 + i];
-    dst[(size_t)y * W * 3 + i] = (uint8_t)((s + 32768) >> 16);
-}
-
-void launch_blur7(const uint8_t* rgb, uint16_t* tmp, uint8_t* smoothed, int W, int H, hipStream_t s) {
-    hipLaunchKernelGGL(k_blur_h, dim3((W + 255) / 256, H), dim3(256), 0, s, rgb, tmp, W, H);
-    hipLaunchKernelGGL(k_blur_v, dim3((W * 3 + 255) / 256, H), dim3(256), 0, s, tmp, smoothed, W, H);
-}
-
 // ---- cv::phase(dx, dy, angle, true): OpenCV fastAtan2 polynomial (LL.cpp:423; Appendix A.3) -----
 static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -75,81 +43,15 @@ static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// ---- Sobel 3x3 (replicate) per channel, strongest channel, phase, 16-bin quantisation -----------
-// (LL.cpp:368-425, 434-455): q16 = interior ? (saturate_u8(rint(angle*16/360)) & 7) : 0
-__global__ void k_sobel_quant(const uint8_t* __restrict__ sm, float* __restrict__ mag, uint8_t* __restrict__ q16,
-                              int W, int H) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    int xm = clampi(x - 1, 0, W - 1) * 3, xc = x * 3, xp = clampi(x + 1, 0, W - 1) * 3;
-    const uint8_t* r0 = sm + (size_t)clampi(y - 1, 0, H - 1) * W * 3;
-    const uint8_t* r1 = sm + (size_t)y * W * 3;
-    const uint8_t* r2 = sm + (size_t)clampi(y + 1, 0, H - 1) * W * 3;
-    int bdx = 0, bdy = 0, bmag = -1;
-    int dxs[3], dys[3], mags[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int a00 = r0[xm + c], a01 = r0[xc + c], a02 = r0[xp + c];
-        int a10 = r1[xm + c], a12 = r1[xp + c];
-        int a20 = r2[xm + c], a21 = r2[xc + c], a22 = r2[xp + c];
-        dxs[c] = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
-        dys[c] = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-        mags[c] = dxs[c] * dxs[c] + dys[c] * dys[c];
-    }
-    // LL.cpp:395-412: first channel that is >= the other two (ties: lowest index)
-    if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
-    else if (mags[1] >= mags[0] && mags[1] >= mags[2]) { bdx = dxs[1]; bdy = dys[1]; bmag = mags[1]; }
-    else { bdx = dxs[2]; bdy = dys[2]; bmag = mags[2]; }
-    size_t o = (size_t)y * W + x;
-    mag[o] = (float)bmag;
-    uint8_t q = 0;
-    if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
-        float ang = fast_atan2_deg((float)bdy, (float)bdx);
-        float v = rintf(__fmul_rn(ang, (float)(16.0 / 360.0)));   // cvRound: half to even
-        int iv = v < 0.f ? 0 : (v > 255.f ? 255 : (int)v);
-        q = (uint8_t)(iv & 7);
-    }
-    q16[o] = q;
-}
-
-void launch_sobel_quant(const uint8_t* smoothed, float* mag, uint8_t* q16, int W, int H, hipStream_t s) {
-    hipLaunchKernelGGL(k_sobel_quant, dim3((W + 255) / 256, H), dim3(256), 0, s, smoothed, mag, q16, W, H);
-}
-
-// ---- hysteresisGradient second half (LL.cpp:457-504): 3x3 majority vote ----------------------
-__global__ void k_hysteresis(const uint8_t* __restrict__ q, const float* __restrict__ mag, uint8_t* __restrict__ out,
-                             int W, int H, float thr_sq) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    size_t o = (size_t)y * W + x;
-    uint8_t res = 0;
-    if (x > 0 && y > 0 && x < W - 1 && y < H - 1 && mag[o] > thr_sq) {
-        uint32_t hist = 0;   // eight 4-bit counters (max 9 votes)
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) hist += 1u << (4 * q[o + dy * W + dx]);
-        int best = -1, votes = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int v = (hist >> (4 * i)) & 15;
-            if (votes < v) { votes = v; best = i; }   // first strict maximum (LL.cpp:491)
-        }
-        if (votes >= 5) res = (uint8_t)(1u << best);
-    }
-    out[o] = res;
-}
-
-void launch_hysteresis(const uint8_t* q16, const float* mag, uint8_t* onehot, int W, int H, float thr_sq,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(k_hysteresis, dim3((W + 255) / 256, H), dim3(256), 0, s, q16, mag, onehot, W, H, thr_sq);
-}
-
-// ---- the colour chain in one launch: GaussianBlur 7x7 -> Sobel -> strongest channel -> phase -> 16-bin
-// quantisation -> 3x3 majority vote (LL.cpp:367-504), one 32x16 output tile per workgroup, every intermediate
-// in LDS.  Each stage keeps its own border rule by evaluating a stage at the CLAMPED position of the pixel the
-// next stage asks for (blur and Sobel replicate the border: smoothed(clamp(p)), not a blur centred outside the
-// image), so the result is bit-identical to the four separate kernels above (kept for addTemplate-free testing).
+// ---- the colour chain in one launch (LL.cpp:367-504), one 32x16 output tile per workgroup, every intermediate in LDS:
+//   cv::GaussianBlur(8UC3, 7x7, sigma 0, BORDER_REPLICATE) (LL.cpp:367; Appendix A.1): separable fixed point, weights
+//     [8,28,56,72,56,28,8], out = (sum_ij + 32768) >> 16;
+//   Sobel 3x3 (replicate) per channel, strongest channel (first that is >= the other two, LL.cpp:395-412), cv::phase,
+//     q16 = interior ? (saturate_u8(rint(angle*16/360)) & 7) : 0 (LL.cpp:368-455);
+//   hysteresisGradient's 3x3 majority vote (LL.cpp:457-504).
+// Each stage keeps its own border rule by evaluating a stage at the CLAMPED position of the pixel the next stage asks
+// for (blur and Sobel replicate the border: smoothed(clamp(p)), not a blur centred outside the image), which makes the
+// fused kernel bit-identical to running the stages as separate whole-image passes (the oracle does exactly that).
 constexpr int kCTX = 32, kCTY = 16;           // output tile
 __global__ void __launch_bounds__(256)
 k_color_quant(const uint8_t* __restrict__ rgb, float* __restrict__ mag, uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
@@ -281,11 +183,11 @@ void launch_pyrdown_rgb(const uint8_t* src, uint8_t* dst, int W, int H, hipStrea
     hipLaunchKernelGGL(k_pyrdown_rgb, dim3((Wo * 3 + 255) / 256, Ho), dim3(256), 0, s, src, dst, W, H, Wo, Ho);
 }
 
-// ---- quantizedNormals (LL.cpp:729-817; Appendix A.7) ------------------------------------------
-__global__ void k_normals(const uint16_t* __restrict__ depth, uint8_t* __restrict__ out, int W, int H, int dist_thr,
-                          int diff_thr) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+// ---- quantizedNormals (LL.cpp:729-817; Appendix A.7) + cv::medianBlur(5) (LL.cpp:818), replicate border ----------
+// One launch: the raw normals of a 32x16 tile (+2 halo, evaluated at the clamped positions medianBlur's replicate
+// border asks for) live in LDS.  Values are 0 or one-hot -> 9 ranks; the median is the 13th smallest of 25, found with
+// packed 5-bit counters in a 64-bit word.
+static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__ depth, int x, int y, int W, int H, int dist_thr, int diff_thr) {
     const int r = 5;
     uint8_t res = 0;
     if (x >= r && y >= r && x < W - r - 1 && y < H - r - 1) {
@@ -317,79 +219,6 @@ __global__ void k_normals(const uint16_t* __restrict__ depth, uint8_t* __restric
                 int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
                 // v3 = (int)(nz*20+20) only selects the (z-independent) table plane; an index of 20 in
                 // x or y continues into the next row exactly as the reference's flat memory read does.
-                int flat = (v2 * 20 + v1) % 400;
-                if (flat < 0) flat += 400;
-                res = c_normal_lut[flat];
-            }
-        }
-    }
-    out[(size_t)y * W + x] = res;
-}
-
-// cv::medianBlur(5) (LL.cpp:818), replicate border.  Values are 0 or one-hot -> 9 ranks; packed
-// 5-bit counters (25 samples max) in a 64-bit word, 13th smallest wins.
-__global__ void k_median5(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    unsigned long long cnt = 0;
-#pragma unroll
-    for (int dy = -2; dy <= 2; ++dy) {
-        const uint8_t* row = src + (size_t)clampi(y + dy, 0, H - 1) * W;
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
-            uint32_t v = row[clampi(x + dx, 0, W - 1)];
-            int rank = v ? (32 - __clz(v)) : 0;     // 0 -> 0, 1<<k -> k+1
-            cnt += 1ull << (5 * rank);
-        }
-    }
-    int cum = 0, rank = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        int c = (int)((cnt >> (5 * i)) & 31);
-        if (cum < 13 && cum + c >= 13) rank = i;
-        cum += c;
-    }
-    dst[(size_t)y * W + x] = rank ? (uint8_t)(1u << (rank - 1)) : 0;
-}
-
-void launch_normals(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(k_normals, dim3((W + 255) / 256, H), dim3(256), 0, s, depth, raw, W, H, dist_thr, diff_thr);
-    hipLaunchKernelGGL(k_median5, dim3((W + 255) / 256, H), dim3(256), 0, s, raw, med, W, H);
-}
-
-// quantizedNormals + medianBlur(5) in one launch: the raw normals of a 32x16 tile (+2 halo, evaluated at the
-// clamped positions medianBlur's replicate border asks for) live in LDS.
-static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__ depth, int x, int y, int W, int H, int dist_thr, int diff_thr) {
-    const int r = 5;
-    uint8_t res = 0;
-    if (x >= r && y >= r && x < W - r - 1 && y < H - r - 1) {
-        const uint16_t* p = depth + (size_t)y * W + x;
-        long long d = p[0];
-        if (d < dist_thr) {
-            long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
-            const int oi[8] = {-r, 0, r, -r, r, -r, 0, r};
-            const int oj[8] = {-r, -r, -r, 0, 0, r, r, r};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                long long delta = (long long)p[oj[k] * W + oi[k]] - d;
-                long long ad = delta < 0 ? -delta : delta;
-                long long f = ad < diff_thr ? 1 : 0;
-                long long fi = f * oi[k], fj = f * oj[k];
-                A0 += fi * oi[k]; A1 += fi * oj[k]; A3 += fj * oj[k];
-                b0 += fi * delta; b1 += fj * delta;
-            }
-            long long det = A0 * A3 - A1 * A1;
-            long long ddx = A3 * b0 - A1 * b1;
-            long long ddy = -A1 * b0 + A0 * b1;
-            float nx = (float)(1150 * ddx), ny = (float)(1150 * ddy), nz = (float)(-det * d);
-            float ss = __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz));
-            float sq = __fsqrt_rn(ss);
-            if (sq > 0.f) {
-                float inv = __fdiv_rn(1.0f, sq);
-                nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
-                int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
-                int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
                 int flat = (v2 * 20 + v1) % 400;
                 if (flat < 0) flat += 400;
                 res = c_normal_lut[flat];

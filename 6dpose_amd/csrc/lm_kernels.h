@@ -8,16 +8,10 @@ namespace lm {
 
 // ---- front end (frontend.hip): reference A1-A7, LL.cpp:350-505, 557-581, 729-880, 1026-1243 ----
 void upload_normal_lut(const uint8_t lut400[400]);
-void launch_blur7(const uint8_t* rgb, uint16_t* tmp, uint8_t* smoothed, int W, int H, hipStream_t s);
-void launch_sobel_quant(const uint8_t* smoothed, float* mag, uint8_t* q16, int W, int H, hipStream_t s);
-void launch_hysteresis(const uint8_t* q16, const float* mag, uint8_t* onehot, int W, int H, float thr_sq,
-                       hipStream_t s);
 // the colour chain (blur7 + sobel_quant + hysteresis) and the normal chain (normals + median5) as single tiled launches
 void launch_color_quant(const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq, hipStream_t s);
 void launch_normals_fused(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr, hipStream_t s);
 void launch_pyrdown_rgb(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s);  // dst (W/2,H/2)
-void launch_normals(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr,
-                    hipStream_t s);
 void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s);     // dst (W/2,H/2)
 // spread (T x T OR) -> 8 response maps -> linearised layout LM[8][T*T][(W/T)*(H/T)] for both modalities of a level in one
 // launch ([0] colour, [1] normals); mask[m] may be null; `strips[m]` (may be null) receives the strip-major copy used by

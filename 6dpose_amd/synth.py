@@ -172,3 +172,32 @@ def synth_model_depth(seed: int, W: int = 640, H: int = 480, z0: float = 1000.0)
     bump = np.sqrt(np.clip(1 - r2, 0, None))
     depth = z0 - 60.0 * bump + 8.0 * np.sin(u / 5.0) * np.cos(v / 7.0) * (r2 < 1)
     return np.where(r2 < 1, depth, 0).astype(np.uint16)
+
+
+def icosphere(level: int = 2, radius: float = 60.0, seed: int = 0):
+    """A bumpy blob for the rasteriser tests / training benchmark: refined icosahedron (20 * 4**level triangles) with
+    vertex normals and random vertex colours.  Returns (vertices f32 (n,3) mm, faces i32 (m,3), normals f32, colours u8)."""
+    a, b, c = 0.0, 1.0, (1.0 + np.sqrt(5.0)) / 2.0
+    V = [(-b, c, a), (b, c, a), (-b, -c, a), (b, -c, a), (a, -b, c), (a, b, c), (a, -b, -c), (a, b, -c), (c, a, -b), (c, a, b), (-c, a, -b), (-c, a, b)]
+    F = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    V = [np.array(v, np.float64) for v in V]
+    for _ in range(level):
+        mid, Fn = {}, []
+        for f in F:
+            ids = list(f)
+            for i in range(3):
+                e = tuple(sorted((f[i], f[(i + 1) % 3])))
+                if e not in mid:
+                    mid[e] = len(V)
+                    V.append(0.5 * (V[e[0]] + V[e[1]]))
+                ids.append(mid[e])
+            Fn += [(ids[0], ids[3], ids[5]), (ids[3], ids[1], ids[4]), (ids[3], ids[4], ids[5]), (ids[5], ids[4], ids[2])]
+        F = Fn
+    V = np.array(V)
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    N = V.copy()
+    rng = np.random.default_rng(seed)
+    V = V * radius * (1.0 + 0.15 * np.sin(3 * V[:, :1]) * np.cos(2 * V[:, 1:2]))        # a bumpy blob, not a perfect sphere
+    C = rng.integers(40, 256, (len(V), 3)).astype(np.uint8)
+    return V.astype(np.float32), np.array(F, np.int32), N.astype(np.float32), C

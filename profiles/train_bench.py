@@ -4,9 +4,9 @@ into templates on the device."""
 import json, math, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "6dpose_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]   # oracle only because the test module that holds the mesh generator imports it
+sys.path[:0] = [os.path.join(ROOT, "6dpose_amd")]
 import linemodLevelup_pybind as lm, views
-from test_gpu_render import icosphere
+from synth import icosphere
 K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
 V, F, N, C = icosphere(5, radius=70.0, seed=1)          # 20480 triangles
 C[:] = (C // 64) * 64 + 30

@@ -322,6 +322,26 @@ def test_config1_size_2k_templates_bit_exact(lm):
     assert as_multiset(back, ["x", "y", "similarity", "template_id"]) == as_multiset(want, ["x", "y", "sim", "tid"])
 
 
+def test_config4_shard_size(lm):
+    """One GPU's share of BASELINE configs[4]: 1280x960, 11250 template pyramids — compared record by record with the
+    oracle (its C loops on 32 host threads take a fraction of a second)."""
+    W, H, T, nfeat, n = 1280, 960, [4, 8], (150, 75), 11250
+    rgb, dep = synth.make_frame(0, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    bank = synth.make_planted_bank(99, n, [(p[0], p[1]) for p in pyr], T, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("obj", *bank)
+    feat, offs, wh = bank
+    lms, sizes = od.linear_memories(rgb, dep)
+    raw, st = lo.match_bank_c(lo.PackedBank(n, 2, feat, offs, wh), lms, sizes, T, 75.0, nthreads=32)
+    raw["cls"] = 0
+    got = det.matchArray([rgb, dep], 75.0, ["obj"])
+    same_records(got, lo.canonical_sort_unique(raw))
+    tm = det.lastTimings()
+    assert tm["coarse_candidates"] == st["coarse_candidates"] > 50000 and tm["local_evals"] == st["local_evals"]
+
+
 # ---------------------------------------------------------------------------------------------
 # addTemplate / YAML through the product
 # ---------------------------------------------------------------------------------------------

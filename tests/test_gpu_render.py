@@ -24,29 +24,7 @@ def lm():
     return mod
 
 
-def icosphere(level=2, radius=60.0, seed=0):
-    a, b, c = 0.0, 1.0, (1.0 + np.sqrt(5.0)) / 2.0
-    V = [(-b, c, a), (b, c, a), (-b, -c, a), (b, -c, a), (a, -b, c), (a, b, c), (a, -b, -c), (a, b, -c), (c, a, -b), (c, a, b), (-c, a, -b), (-c, a, b)]
-    F = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
-         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
-    V = [np.array(v, np.float64) for v in V]
-    for _ in range(level):
-        mid, Fn = {}, []
-        for f in F:
-            ids = list(f)
-            for i in range(3):
-                e = tuple(sorted((f[i], f[(i + 1) % 3])))
-                if e not in mid:
-                    mid[e] = len(V); V.append(0.5 * (V[e[0]] + V[e[1]]))
-                ids.append(mid[e])
-            Fn += [(ids[0], ids[3], ids[5]), (ids[3], ids[1], ids[4]), (ids[3], ids[4], ids[5]), (ids[5], ids[4], ids[2])]
-        F = Fn
-    V = np.array(V); V /= np.linalg.norm(V, axis=1, keepdims=True)
-    N = V.copy()
-    rng = np.random.default_rng(seed)
-    V = V * radius * (1.0 + 0.15 * np.sin(3 * V[:, :1]) * np.cos(2 * V[:, 1:2]))        # a bumpy blob, not a perfect sphere
-    C = rng.integers(40, 256, (len(V), 3)).astype(np.uint8)
-    return V.astype(np.float32), np.array(F, np.int32), N.astype(np.float32), C
+from synth import icosphere  # noqa: E402
 
 
 def look_at_views(n, dist=600.0, seed=1):

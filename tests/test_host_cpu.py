@@ -159,3 +159,20 @@ def test_view_sampler_reproduces_the_reference_golden():
     assert np.abs(pts - g["c_pts"]).max() < 1e-12 and lv == g["c_levels"].tolist()
     vs, _ = views.sample_views(42, 600.0, tilt_step=0.25 * math.pi)
     assert np.abs(np.stack([v["R"] for v in vs]) - g["d_R"]).max() < 1e-12 and np.abs(np.stack([v["t"] for v in vs]) - g["d_t"]).max() < 1e-9
+
+
+def test_new_entry_points_fail_loudly_without_a_gpu():
+    """lm_icp / lm_mesh / lm_pipeline: no CPU fallback — creation reports LM_ERR_NO_DEVICE (or rejects bad arguments first)."""
+    import linemodLevelup_pybind as mod
+    lib = mod.load_library()
+    if lib.lm_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        mod.IcpContext(device=0)
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        mod.Mesh(V, np.array([[0, 1, 2]], np.int32))
+    with pytest.raises(RuntimeError, match="out of range"):
+        mod.Mesh(V, np.array([[0, 1, 3]], np.int32))            # face index checked before any device use
+    with pytest.raises(RuntimeError):
+        mod.Mesh("/nonexistent/model.ply")
