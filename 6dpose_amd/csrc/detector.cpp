@@ -443,6 +443,74 @@ extern "C" int lm_detector_write_class(lm_detector* d, const char* class_id, con
     return LM_OK;
 }
 
+// Detector::write / Detector::read (LL.cpp:2013-2041) with the modality parameters of ColorGradient::write (:686-692) and
+// DepthNormal::write (:1012-1020), OpenCV FileStorage YAML 1.0 layout.  read() clears the classes like the reference.
+extern "C" int lm_detector_write_params(const lm_detector* d, const char* path) {
+    if (!d || !path) return lm_set_error(LM_ERR_INVALID, "null argument");
+    FILE* f = fopen(path, "w");
+    if (!f) return lm_set_error(LM_ERR_IO, "cannot open for writing: %s", path);
+    auto real = [](float v) {                                   // cv::FileStorage prints 10.f as "10."
+        char b[64];
+        snprintf(b, sizeof(b), "%.8g", (double)v);
+        std::string s(b);
+        if (s.find_first_of(".eEn") == std::string::npos) s += ".";
+        return s;
+    };
+    fprintf(f, "%%YAML:1.0\n---\npyramid_levels: %d\nT: [", d->pyramid_levels);
+    for (size_t i = 0; i < d->T_at_level.size(); ++i) fprintf(f, "%s %d", i ? "," : "", d->T_at_level[i]);
+    fprintf(f, " ]\nmodalities:\n");
+    fprintf(f, "   -\n      type: ColorGradient\n      weak_threshold: %s\n      num_features: %d\n      strong_threshold: %s\n",
+            real(d->weak_threshold).c_str(), d->num_features, real(d->strong_threshold).c_str());
+    fprintf(f, "   -\n      type: DepthNormal\n      distance_threshold: %d\n      difference_threshold: %d\n      num_features: %d\n"
+               "      extract_threshold: %d\n",
+            d->distance_threshold, d->difference_threshold, d->num_features, d->extract_threshold);
+    if (fclose(f) != 0) return lm_set_error(LM_ERR_IO, "write failed: %s", path);
+    return LM_OK;
+}
+
+extern "C" int lm_detector_read_params(lm_detector* d, const char* path) {
+    if (!d || !path) return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "a frame is in flight: collect it first");
+    FILE* f = fopen(path, "r");
+    if (!f) return lm_set_error(LM_ERR_IO, "cannot open: %s", path);
+    int levels = -1, nf[2] = {-1, -1}, dist = d->distance_threshold, diff = d->difference_threshold, ext = d->extract_threshold;
+    float weak = d->weak_threshold, strong = d->strong_threshold;
+    std::vector<int> T;
+    std::vector<std::string> types;
+    char line[1024];
+    while (fgets(line, sizeof(line), f)) {
+        char* p = line;
+        while (*p == ' ' || *p == '\t' || *p == '-') ++p;
+        char key[64];
+        if (sscanf(p, "%63[A-Za-z_]:", key) != 1) continue;
+        const char* v = strchr(p, ':') + 1;
+        const std::string k(key);
+        const std::string cur = types.empty() ? "" : types.back();
+        if (k == "pyramid_levels") levels = atoi(v);
+        else if (k == "T") { for (const char* q = v; *q; ++q) if (*q >= '0' && *q <= '9') { T.push_back(atoi(q)); while (*q >= '0' && *q <= '9') ++q; --q; } }
+        else if (k == "type") { char t[64] = {0}; sscanf(v, " %63s", t); types.push_back(t); }
+        else if (k == "weak_threshold") weak = (float)atof(v);
+        else if (k == "strong_threshold") strong = (float)atof(v);
+        else if (k == "num_features") { if (cur == "ColorGradient") nf[0] = atoi(v); else if (cur == "DepthNormal") nf[1] = atoi(v); }
+        else if (k == "distance_threshold") dist = atoi(v);
+        else if (k == "difference_threshold") diff = atoi(v);
+        else if (k == "extract_threshold") ext = atoi(v);
+    }
+    fclose(f);
+    if (levels < 1 || levels > kMaxLevels || (int)T.size() != levels) return lm_set_error(LM_ERR_IO, "%s: pyramid_levels / T missing or inconsistent", path);
+    if (types.size() != 2 || types[0] != "ColorGradient" || types[1] != "DepthNormal")   // Modality::create (LL.cpp:320-328) knows these two
+        return lm_set_error(LM_ERR_INVALID, "%s: modalities must be [ColorGradient, DepthNormal]", path);
+    if (nf[0] <= 0 || nf[0] != nf[1]) return lm_set_error(LM_ERR_INVALID, "%s: the modalities must agree on num_features (one bank layout)", path);
+    for (int t : T) if (t < 1) return lm_set_error(LM_ERR_INVALID, "T must be >= 1");
+    d->class_templates.clear();                                   // LL.cpp:2015
+    d->bank_dirty = true; d->work_valid = false; d->frame_valid = false;
+    d->pyramid_levels = levels; d->T_at_level = T;
+    d->num_features = nf[0]; d->weak_threshold = weak; d->strong_threshold = strong;
+    d->distance_threshold = dist; d->difference_threshold = diff; d->extract_threshold = ext;
+    d->fW = d->fH = 0;                                            // geometry depends on T: rebuilt by the next frame
+    return LM_OK;
+}
+
 extern "C" int lm_detector_add_class_packed(lm_detector* d, const char* class_id, int num_pyramids, const int32_t* features,
                                             const int32_t* tmpl_offsets, const int32_t* tmpl_wh) {
     if (!d || !class_id || num_pyramids < 0 || (num_pyramids && (!features || !tmpl_offsets || !tmpl_wh)))

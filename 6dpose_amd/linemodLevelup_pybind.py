@@ -113,6 +113,8 @@ def load_library():
     lib.lm_detector_add_template.argtypes = [P, P, P, P, I, I, S]
     lib.lm_detector_read_class.argtypes = [P, S, S]
     lib.lm_detector_write_class.argtypes = [P, S, S]
+    lib.lm_detector_write_params.argtypes = [P, S]
+    lib.lm_detector_read_params.argtypes = [P, S]
     lib.lm_detector_add_class_packed.argtypes = [P, S, I, P, P, P]
     lib.lm_detector_num_classes.argtypes = [P]
     lib.lm_detector_class_id.argtypes = [P, I]
@@ -311,6 +313,14 @@ class Detector:
 
     def getT(self, level: int) -> int:
         return self._lib.lm_detector_get_T(self._h, level)
+
+    def write(self, path: str) -> None:
+        """Detector::write (LL.cpp:2029-2041, C++-only in the reference): pyramid levels, T and modality parameters as YAML."""
+        _check(self._lib.lm_detector_write_params(self._h, os.fspath(path).encode()))
+
+    def read(self, path: str) -> None:
+        """Detector::read (LL.cpp:2013-2027): replaces the parameters and clears the classes."""
+        _check(self._lib.lm_detector_read_params(self._h, os.fspath(path).encode()))
 
     def getTemplates(self, class_id: str, template_id: int) -> List[Template]:
         out = []

@@ -94,6 +94,12 @@ int lm_detector_add_template(lm_detector *d, const uint8_t *rgb, const uint16_t 
 int lm_detector_read_class(lm_detector *d, const char *path, const char *class_id_override);
 int lm_detector_write_class(lm_detector *d, const char *class_id, const char *path);
 
+/* Detector::write / Detector::read (LL.cpp:2013-2041; C++-only in the reference): pyramid_levels, T and the parameters of
+ * the two modalities (ColorGradient::write :686-692, DepthNormal::write :1012-1020) as OpenCV FileStorage YAML.  read clears
+ * the classes (LL.cpp:2015). */
+int lm_detector_write_params(const lm_detector *d, const char *path);
+int lm_detector_read_params(lm_detector *d, const char *path);
+
 /* Bulk import of a packed class (binary bank for >=16k templates).
  * features: [total][3] int32 (x,y,label); tmpl_offsets: [num_pyramids*levels*2+1] prefix offsets in
  * reference TemplatePyramid order (level-major, modality-minor; LL.h:336-337); tmpl_wh:

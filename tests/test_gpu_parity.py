@@ -378,6 +378,29 @@ def test_add_template_reproduces_reference_golden(lm, tmp_path):
         lm.Detector([5, 8, 8], device=0).readClasses(["s"], str(tmp_path / "%s.yaml"))   # pyramid_levels, LL.cpp:2052
 
 
+def test_detector_params_write_read_round_trip(lm, tmp_path):
+    """Detector::write / read (LL.cpp:2013-2041): parameters survive the YAML, read() clears the classes, and a detector
+    configured from the file matches like the one that wrote it."""
+    rgb, dep, mask = load_bgr("train_rgb.png"), load_u16("train_dep.png"), load_gray("train_mask.png")
+    a = lm.Detector(127, [4, 8], device=0)
+    assert a.addTemplate([rgb, dep], "c", mask) == 0
+    path = str(tmp_path / "detector.yaml")
+    a.write(path)
+    text = open(path).read()
+    assert "pyramid_levels: 2" in text and "T: [ 4, 8 ]" in text and "type: ColorGradient" in text and "weak_threshold: 10." in text
+    assert "num_features: 127" in text and "type: DepthNormal" in text and "distance_threshold: 2000" in text
+    b = lm.Detector(device=0)                                    # Detector(): 63 features, T = {5, 8}
+    assert b.addTemplate([rgb, dep], "c", mask) == 0
+    b.read(path)
+    assert b.numClasses() == 0 and b.getT(0) == 4 and b.pyramidLevels() == 2
+    assert b.addTemplate([rgb, dep], "c", mask) == 0
+    for x, y in zip(a.getTemplates("c", 0), b.getTemplates("c", 0)):
+        assert (x.width, x.height) == (y.width, y.height) and np.array_equal(x.features, y.features)
+    assert len(x.features) > 0
+    with pytest.raises(RuntimeError):
+        b.read(str(tmp_path / "missing.yaml"))
+
+
 # ---------------------------------------------------------------------------------------------
 # poseRefine / ICP  (parity unpinned by the reference: GPU vs the oracle's Open3D restatement)
 # ---------------------------------------------------------------------------------------------
