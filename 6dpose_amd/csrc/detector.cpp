@@ -114,9 +114,10 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
+        if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.graph) (void)hipGraphDestroy(sl.graph);
@@ -920,6 +921,9 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         sl.h_matches = nullptr; sl.match_cap = 0;
         HIP_TRY(hipHostMalloc((void**)&sl.h_matches, (size_t)match_cap * sizeof(Candidate), hipHostMallocDefault));
+        if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
+        sl.h_distinct = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&sl.h_distinct, (size_t)match_cap * sizeof(Candidate), hipHostMallocDefault));
         sl.match_cap = match_cap;
     }
     return LM_OK;
@@ -939,12 +943,20 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     }
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
-    if ((rc = d->d_counters.ensure(8))) return rc;
+    if (d->d_cands.cap < d->cand_cap || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
+        // buffers are about to be replaced (first use, or the candidate capacity was raised): frames still in flight keep
+        // using the old ones until they are done
+        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
+    }
+    if ((rc = d->d_counters.ensure(8 * lm_detector::kSlots))) return rc;          // per result slot
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
-    if ((rc = d->d_matches_dev.ensure(d->cand_cap))) return rc;
+    if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
+    if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap)))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream, ms = d->mstream;
     const int arena = (int)(d->n_submitted % lm_detector::kSlots);
+    unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
+    Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
@@ -953,6 +965,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     unsigned long long* d_hcounters = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, sl.h_counters, 0));
     HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, sl.h_matches, 0));
+    Candidate* d_distinct = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_distinct, sl.h_distinct, 0));
     // Two streams: the front end of this frame (on `stream`, into this slot's linear-memory arenas) overlaps the
     // matching kernels of the previous frame (on `mstream`, reading the other slot's arenas).  The arenas of this
     // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
@@ -965,16 +979,21 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     };
     auto enqueue_match = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[2], ms));
-        HIP_TRY(hipMemsetAsync(d->d_counters.p, 0, 8 * sizeof(unsigned long long), ms));
+        HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned long long), ms));
         launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
-                      d->cand_cap, d->d_counters.p, ms);
+                      d->cand_cap, counters, ms);
         HIP_TRY(hipEventRecord(sl.ev[3], ms));
         // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
         // the per-block statistics and the results, stored straight into this slot's pinned host memory
         launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
-                     d->d_work.p, d->d_cands.p, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, d->d_matches_dev.p,
-                     std::min<uint32_t>(sl.match_cap, d->cand_cap), d->d_counters.p, d_hcounters, d->local_blocks, ms);
+                     d->d_work.p, d->d_cands.p, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
+                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, d->local_blocks, ms);
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
+        // exact duplicates out (they never survive std::unique), distinct records + counts to this slot's pinned memory
+        if (num_work > 0) {
+            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->num_cus * 2, ms);
+            HIP_TRY(hipMemcpyAsync(sl.h_counters + 1, counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
+        }
         return LM_OK;
     };
     auto capture = [&](hipStream_t st, hipGraph_t& g, hipGraphExec_t& ex, auto&& fn) -> bool {
@@ -999,7 +1018,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
-                                     ((uint64_t)(uintptr_t)d->d_matches_dev.p << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3)};
+                                     ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
+                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5)};
         if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
             if (ok) memcpy(sl.key, key, sizeof(key));
@@ -1074,22 +1094,32 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         if (n_out) *n_out = 0;
         return LM_OK;
     }
-    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nm) * sizeof(lm_match));
+    // sort_unique = 0: every record alive (the raw pre-unique multiset); 1 / 2: the records without exact duplicates
+    // (k_dedupe) — what std::unique would leave of them anyway — canonically sorted + uniqued (1) or as they are (2)
+    const bool use_distinct = sort_unique != 0 && sl.num_work > 0;
+    const uint64_t nd = use_distinct ? sl.h_counters[1] : 0;
+    if (use_distinct && (nd > ncand || sl.h_counters[2] != nm))
+        return lm_set_error(LM_ERR_HIP, "duplicate removal out of step with the refinement (%llu distinct of %llu, %llu alive vs %llu)",
+                            (unsigned long long)nd, (unsigned long long)ncand, (unsigned long long)sl.h_counters[2], (unsigned long long)nm);
+    const size_t nrec = use_distinct ? (size_t)nd : (size_t)nm;
+    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, nrec) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
     const std::vector<int32_t>& wcls = *sl.work_cls;
     const std::vector<int32_t>& wtid = *sl.work_tid;
     size_t w = 0;
-    for (uint64_t i = 0; i < ncand; ++i) {
-        const Candidate& c = hm[i];
+    const Candidate* src = use_distinct ? sl.h_distinct : hm;
+    const uint64_t nsrc = use_distinct ? nd : ncand;
+    for (uint64_t i = 0; i < nsrc; ++i) {
+        const Candidate& c = src[i];
         if (c.work < 0) continue;                     // dropped below the threshold during refinement
         res[w].x = c.x; res[w].y = c.y; res[w].similarity = c.score;
         res[w].class_index = wcls[c.work];
         res[w].template_id = wtid[c.work];
         ++w;
     }
-    size_t n = (size_t)nm;
+    size_t n = w;
     const auto t3 = std::chrono::steady_clock::now();
-    if (sort_unique) n = lm_merge_matches(res, (size_t)nm);
+    if (sort_unique == 1) n = lm_merge_matches(res, w);
     const auto t4 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<float, std::milli>(b - a).count();

@@ -104,7 +104,8 @@ struct lm_detector {
     bool work_valid = false;
     int64_t work_coarse_bytes = 0;
     DevBuf<Candidate> d_cands;
-    DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K)
+    DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K, duplicate removal)
+    DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;
     uint32_t cand_cap = 1u << 18;
@@ -112,8 +113,9 @@ struct lm_detector {
     // collects an earlier frame from another (lm_detector_submit / lm_detector_collect).
     struct Slot {
         Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
+        Candidate* h_distinct = nullptr;            // pinned: the same without exact duplicates (k_dedupe), unordered
         uint32_t match_cap = 0;
-        unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [8..] 2 words of statistics per refinement block
+        unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [1] distinct records, [2] records alive, [8..] 2 words of statistics per refinement block
         hipGraph_t graph = nullptr, mgraph = nullptr;       // front end (on `stream`) / matching (on `mstream`), captured once each
         hipGraphExec_t exec = nullptr, mexec = nullptr;
         uint64_t key[8] = {};

@@ -79,5 +79,10 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
                      const int32_t* view_wh /*[views][2] box override, -1 = template size, may be null*/, int num_views, int top_k,
                      double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s);
 size_t topk_nms_scratch_bytes(uint32_t cap);
+// Exact-duplicate removal of the refined records of a frame (nms.hip): counters[0] = candidate slots (from launch_coarse),
+// counters[1] / [2] receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.
+void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
+                   Candidate* distinct, int blocks, hipStream_t s);
+size_t dedupe_table_slots(uint32_t cap);
 
 }  // namespace lm

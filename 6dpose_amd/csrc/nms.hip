@@ -225,6 +225,65 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
                        levels, class_base, view_wh, num_views, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), sel, nsel_status);
 }
 
+// Records identical in every field — several coarse candidates of one template refined to the same position — are
+// adjacent in the canonical order and std::unique removes all but one (LL.cpp:1772-1774), so dropping them on the device
+// changes nothing and shrinks what the host converts / sorts and what the multi-GPU all-gather carries (typically 5x).
+// Persistent grid over the candidate slots; open-addressing hash on (x, y, work item); one atomic per wave appends the
+// survivors to `distinct` (pinned host memory).  counters[1] = distinct records, counters[2] = records alive before.
+__global__ void __launch_bounds__(256)
+k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__ counters, uint32_t cap,
+         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct) {
+    const unsigned long long nc = counters[0];
+    const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool alive = false, keep = false;
+        Candidate c{0, 0, 0.f, -1};
+        if (i < n) {
+            c = matches[i];
+            alive = c.work >= 0;
+            if (alive) {
+                const unsigned long long key = ((unsigned long long)(uint32_t)c.work << 32) | ((uint32_t)(c.x & 0xFFFF) << 16) | (uint32_t)(c.y & 0xFFFF);
+                const bool packable = c.x >= -32768 && c.x <= 32767 && c.y >= -32768 && c.y <= 32767;
+                keep = !packable;                                                    // cannot be keyed: keep it (std::unique decides on the host)
+                if (packable) {
+                    unsigned long long hsh = key * 0x9E3779B97F4A7C15ull;
+                    uint32_t slot = (uint32_t)(hsh >> 40) & table_mask;
+                    for (;;) {                                                         // the table has >= 2 x cap slots: never full
+                        const unsigned long long prev = atomicCAS(&table[slot], ~0ull, key);
+                        if (prev == ~0ull) { keep = true; break; }
+                        if (prev == key) break;
+                        slot = (slot + 1) & table_mask;
+                    }
+                }
+            }
+        }
+        const unsigned long long mk = __ballot(keep), ma = __ballot(alive);
+        if (ma) {
+            unsigned long long base = 0;
+            if (lane == 0) {
+                if (mk) base = atomicAdd(&counters[1], (unsigned long long)__popcll(mk));
+                atomicAdd(&counters[2], (unsigned long long)__popcll(ma));
+            }
+            base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+            if (keep) distinct[base + __popcll(mk & ((1ull << lane) - 1ull))] = c;
+        }
+    }
+}
+
+void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
+                   Candidate* distinct, int blocks, hipStream_t s) {
+    (void)hipMemsetAsync(table, 0xFF, table_slots * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct);
+}
+
+size_t dedupe_table_slots(uint32_t cap) {
+    size_t t = 1;
+    while (t < 2 * (size_t)cap) t <<= 1;
+    return t;
+}
+
 size_t topk_nms_scratch_bytes(uint32_t cap) {
     size_t tsz = 1;
     while (tsz < 2 * (size_t)cap) tsz <<= 1;

@@ -371,11 +371,11 @@ class Detector:
         """Makes a parked frame current with a device-to-device copy (lm_detector_select_frame)."""
         _check(self._lib.lm_detector_select_frame(self._h, slot))
 
-    def matchResident(self, threshold: float, class_ids: Sequence[str] = (), sort_unique: bool = True) -> np.ndarray:
+    def matchResident(self, threshold: float, class_ids: Sequence[str] = (), sort_unique: bool = True, distinct: bool = False) -> np.ndarray:
         """Front end + matching on the frame uploaded by setFrame(); returns MATCH_DTYPE records."""
         carr, n, _names = self._class_args(class_ids)
         out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
-        _check(self._lib.lm_detector_match_resident(self._h, float(threshold), carr, n, 1 if sort_unique else 0,
+        _check(self._lib.lm_detector_match_resident(self._h, float(threshold), carr, n, 1 if sort_unique else (2 if distinct else 0),
                                                     ctypes.byref(out), ctypes.byref(cnt)))
         return self._take(out, cnt.value)
 
@@ -384,10 +384,10 @@ class Detector:
         carr, n, _names = self._class_args(class_ids)
         _check(self._lib.lm_detector_submit(self._h, float(threshold), carr, n))
 
-    def collect(self, sort_unique: bool = True) -> np.ndarray:
+    def collect(self, sort_unique: bool = True, distinct: bool = False) -> np.ndarray:
         """Pipelined mode: matches of the oldest submitted frame (lm_detector_collect)."""
         out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
-        _check(self._lib.lm_detector_collect(self._h, 1 if sort_unique else 0, ctypes.byref(out), ctypes.byref(cnt)))
+        _check(self._lib.lm_detector_collect(self._h, 1 if sort_unique else (2 if distinct else 0), ctypes.byref(out), ctypes.byref(cnt)))
         return self._take(out, cnt.value)
 
     def _take(self, out, n) -> np.ndarray:

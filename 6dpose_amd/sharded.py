@@ -57,6 +57,7 @@ def match_sharded(detector: "lm.Detector", sources, threshold: float, class_ids:
     detector.setShard(rank, world)
     if not resident:
         detector.setFrame(sources, masks)
-    local = detector.matchResident(threshold, class_ids, sort_unique=False)
+    # records without exact duplicates (dropped on the device: std::unique removes them on every rank's merge anyway)
+    local = detector.matchResident(threshold, class_ids, sort_unique=False, distinct=True)
     allrec = gather_records(local, device=device, group=group)
     return lm.merge_matches(allrec)

@@ -121,7 +121,7 @@ def main():
             out = det.collect(sort_unique=True)
             t1 = t2 = t3 = time.perf_counter()
         else:                 # pre-unique records of this rank's shard -> all-gather -> merge on every rank
-            local = det.collect(sort_unique=False)
+            local = det.collect(sort_unique=False, distinct=True)
             t1 = time.perf_counter()
             allrec = sharded.gather_records(local, device=dev)
             t2 = time.perf_counter()

@@ -138,7 +138,9 @@ int lm_detector_match(lm_detector *d, const uint8_t *rgb, const uint16_t *depth,
 
 /* The same in two steps, so that a benchmark can time the device path with the frame already
  * resident in HBM: lm_detector_set_frame uploads (and keeps) the frame; lm_detector_match_resident
- * runs front end + matching on it.  `sort_unique`=0 returns the raw pre-unique list (unordered). */
+ * runs front end + matching on it.  `sort_unique`: 1 = canonical sort + unique (Detector::match); 0 = the raw pre-unique
+ * records, unordered; 2 = the records without exact duplicates (same x, y, template: several coarse candidates refined to
+ * one position; removed on the device, std::unique drops them in any merge), unordered — what the multi-GPU gather ships. */
 int lm_detector_set_frame(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
                           const uint8_t *const *masks);
 /* Stream support: park frames in HBM slots once, then make one current with a

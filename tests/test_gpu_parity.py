@@ -242,12 +242,18 @@ def test_sharded_equals_unsharded_on_one_device(lm):
     for world in (2, 3, 8):
         parts = []
         det.setFrame([rgb, dep])
-        for r in range(world):
-            det.setShard(r, world)
-            parts.append(det.matchResident(75.0, ["b", "a"], sort_unique=False))
-        det.setShard(0, 1)
-        merged = lm.merge_matches(np.concatenate(parts))
-        assert merged.tobytes() == whole.tobytes()
+        for distinct in (False, True):                          # raw pre-unique records / without exact duplicates (what the gather ships)
+            parts = []
+            for r in range(world):
+                det.setShard(r, world)
+                parts.append(det.matchResident(75.0, ["b", "a"], sort_unique=False, distinct=distinct))
+            det.setShard(0, 1)
+            merged = lm.merge_matches(np.concatenate(parts))
+            assert merged.tobytes() == whole.tobytes()
+        raw = det.matchResident(75.0, ["b", "a"], sort_unique=False)
+        dis = det.matchResident(75.0, ["b", "a"], sort_unique=False, distinct=True)
+        key = lambda r: set(zip(r["x"].tolist(), r["y"].tolist(), r["similarity"].tolist(), r["class_index"].tolist(), r["template_id"].tolist()))
+        assert key(raw) == key(dis) and len(dis) == len(key(dis)) <= len(raw)
 
 
 def test_pipelined_submit_collect_equals_synchronous(lm):
