@@ -116,6 +116,10 @@ def load_library():
     lib.lm_detector_write_params.argtypes = [P, S]
     lib.lm_detector_read_params.argtypes = [P, S]
     lib.lm_detector_add_class_packed.argtypes = [P, S, I, P, P, P]
+    lib.lm_detector_write_bank.argtypes = [P, S, ctypes.POINTER(S), I]
+    lib.lm_detector_read_bank.argtypes = [P, S, ctypes.POINTER(S), I]
+    lib.lm_bank_file_info.argtypes = [S, P, P, P, P]
+    lib.lm_bank_file_class_id.argtypes = [S, I, P, I]
     lib.lm_detector_num_classes.argtypes = [P]
     lib.lm_detector_class_id.argtypes = [P, I]
     lib.lm_detector_class_id.restype = S
@@ -299,6 +303,17 @@ class Detector:
                                                       _ptr(features), _ptr(tmpl_offsets), _ptr(tmpl_wh)))
 
     # ---- queries --------------------------------------------------------------------------------
+    def writeBank(self, path, class_ids: Sequence[str] = ()) -> None:
+        """All classes (or the named ones) into ONE packed binary file (lm_detector_write_bank): 4 bytes per feature
+        against ~45 text bytes in the YAML files of writeClasses (LL.cpp:2124-2146)."""
+        arr, n, _ = self._class_args(class_ids)
+        _check(self._lib.lm_detector_write_bank(self._h, os.fspath(path).encode(), arr, n))
+
+    def readBank(self, path, class_ids: Sequence[str] = ()) -> None:
+        """Adds the classes of a packed bank file (all, or the named ones), mmap'ed (lm_detector_read_bank)."""
+        arr, n, _ = self._class_args(class_ids)
+        _check(self._lib.lm_detector_read_bank(self._h, os.fspath(path).encode(), arr, n))
+
     def classIds(self) -> List[str]:
         return [self._lib.lm_detector_class_id(self._h, i).decode() for i in range(self._lib.lm_detector_num_classes(self._h))]
 
@@ -433,6 +448,20 @@ class Detector:
         buf = np.zeros(n, np.uint8)
         _check(self._lib.lm_detector_read_stage(self._h, level, kind, _ptr(buf), n))
         return buf
+
+
+def bank_file_info(path) -> dict:
+    """Header of a packed bank file (no detector, no GPU): pyramid levels, class ids, template pyramid and feature counts."""
+    lib = load_library()
+    lv, nc = ctypes.c_int32(), ctypes.c_int32()
+    npyr, nf = ctypes.c_int64(), ctypes.c_int64()
+    _check(lib.lm_bank_file_info(os.fspath(path).encode(), ctypes.byref(lv), ctypes.byref(nc), ctypes.byref(npyr), ctypes.byref(nf)))
+    ids = []
+    buf = ctypes.create_string_buffer(4096)
+    for i in range(nc.value):
+        _check(lib.lm_bank_file_class_id(os.fspath(path).encode(), i, buf, len(buf)))
+        ids.append(buf.value.decode())
+    return {"pyramid_levels": lv.value, "class_ids": ids, "num_pyramids": npyr.value, "num_features": nf.value}
 
 
 def merge_matches(records: np.ndarray) -> np.ndarray:

@@ -107,6 +107,18 @@ int lm_detector_read_params(lm_detector *d, const char *path);
 int lm_detector_add_class_packed(lm_detector *d, const char *class_id, int num_pyramids,
                                  const int32_t *features, const int32_t *tmpl_offsets, const int32_t *tmpl_wh);
 
+/* Packed binary bank file next to the reference's one-YAML-per-class files (LL.cpp:2124-2146): the same
+ * information — class id, per template width/height/pyramid level, per feature x, y, label (LL.cpp:2072-2122) — as flat
+ * arrays, 4 bytes per feature (x int16, y int13, label 3 bits), read through mmap.  write: the named classes, or all of
+ * them when num_class_ids == 0; LM_ERR_INVALID when a feature does not fit the packing (the YAML path has no such
+ * limit).  read: adds the named classes of the file (all when num_class_ids == 0), so a rank that serves some of the
+ * objects touches only their part of the file; pyramid_levels must match (LL.cpp:2052), a class already present is an
+ * error (LL.cpp:2059) and then nothing is added.  lm_bank_file_info / _class_id inspect a file without a detector. */
+int lm_detector_write_bank(const lm_detector *d, const char *path, const char *const *class_ids, int num_class_ids);
+int lm_detector_read_bank(lm_detector *d, const char *path, const char *const *class_ids, int num_class_ids);
+int lm_bank_file_info(const char *path, int32_t *pyramid_levels, int32_t *num_classes, int64_t *num_pyramids, int64_t *num_features);
+int lm_bank_file_class_id(const char *path, int index, char *out, int capacity);
+
 /* Detector::numClasses / classIds / numTemplates (LL.h:343, LL.cpp:1984-2011). */
 int lm_detector_num_classes(const lm_detector *d);
 const char *lm_detector_class_id(const lm_detector *d, int index);   /* sorted (std::map) order */

@@ -407,6 +407,83 @@ def test_detector_params_write_read_round_trip(lm, tmp_path):
         b.read(str(tmp_path / "missing.yaml"))
 
 
+def test_packed_bank_file_round_trip(lm, tmp_path):
+    """the packed binary bank holds what the per-class YAML files hold (LL.cpp:2043-2146) — every template
+    of every class comes back identical, a detector loaded from it matches bit-exactly, and a file written by the test
+    itself (layout of csrc/bank_file.cpp) is read the same way."""
+    from test_host_cpu import _bank_file_bytes
+    rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
+    a = lm.Detector(127, [5, 8], device=0)
+    a.readClasses(["06_template"], os.path.join(GOLDEN, "bank127_%s.yaml.gz"))
+    rng = np.random.default_rng(11)
+    P, E = 7, 4                                         # a second class: random pyramids, one empty template, negative coordinates
+    counts = rng.integers(0, 130, P * E); counts[5] = 0
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    feats = np.stack([rng.integers(-3, 200, offs[-1]), rng.integers(-3, 150, offs[-1]), rng.integers(0, 8, offs[-1])], 1).astype(np.int32)
+    wh = np.repeat(rng.integers(30, 200, (P * 2, 2)), 2, axis=0).astype(np.int32)   # both modalities of a level share the size
+    a.addClassPacked("zz random", feats, offs, wh)
+    path = tmp_path / "all.lmb"
+    a.writeBank(path)
+    info = lm.bank_file_info(path)
+    assert info["class_ids"] == ["06_template", "zz random"] and info["num_pyramids"] == 89 + len(wh) // 4
+    yaml_bytes = 0
+    a.writeClasses(str(tmp_path / "%s.yaml"))
+    for c in a.classIds():
+        yaml_bytes += os.path.getsize(tmp_path / (c + ".yaml"))
+    assert os.path.getsize(path) * 6 < yaml_bytes                       # 4 B per feature against ~45 text bytes
+
+    b = lm.Detector(127, [5, 8], device=0)
+    b.readBank(path)
+    assert b.classIds() == a.classIds()
+    for cid in a.classIds():
+        assert a.numTemplates(cid) == b.numTemplates(cid)
+        for tid in range(a.numTemplates(cid)):
+            for x, y in zip(a.getTemplates(cid, tid), b.getTemplates(cid, tid)):
+                assert (x.width, x.height, x.pyramid_level) == (y.width, y.height, y.pyramid_level)
+                assert np.array_equal(x.features, y.features)
+    for ids in ([], ["06_template"]):
+        assert np.array_equal(b.matchArray([rgb, dep], 75.0, ids), a.matchArray([rgb, dep], 75.0, ids))
+    assert len(a.matchArray([rgb, dep], 75.0, ["06_template"])) > 0
+
+    # class filter (a rank that serves one object), double load, level mismatch, selective write
+    c = lm.Detector(127, [5, 8], device=0)
+    c.readBank(path, ["zz random"])
+    assert c.classIds() == ["zz random"]
+    with pytest.raises(RuntimeError, match="already present"):
+        c.readBank(path)
+    assert c.classIds() == ["zz random"]                                # nothing was added by the failed call
+    with pytest.raises(RuntimeError, match="not in"):
+        c.readBank(path, ["nope"])
+    with pytest.raises(RuntimeError, match="pyramid levels"):
+        lm.Detector([4, 4, 8], device=0).readBank(path)
+    a.writeBank(tmp_path / "one.lmb", ["06_template"])
+    assert lm.bank_file_info(tmp_path / "one.lmb")["class_ids"] == ["06_template"]
+    with pytest.raises(RuntimeError):
+        a.writeBank(tmp_path / "x.lmb", ["nope"])
+
+    # a file produced outside the library
+    P, E = 3, 4
+    counts = rng.integers(1, 60, P * E)
+    f2 = np.stack([rng.integers(0, 100, counts.sum()), rng.integers(0, 100, counts.sum()), rng.integers(0, 8, counts.sum())], 1)
+    wh2 = np.repeat(rng.integers(30, 120, (P * 2, 2)), 2, axis=0)
+    (tmp_path / "hand.lmb").write_bytes(_bank_file_bytes(2, [("hand", wh2, counts, f2)]))
+    d = lm.Detector(127, [5, 8], device=0)
+    d.readBank(tmp_path / "hand.lmb")
+    k = 0
+    for tid in range(P):
+        for e, t in enumerate(d.getTemplates("hand", tid)):
+            n = counts[tid * E + e]
+            assert np.array_equal(t.features, f2[k:k + n]) and (t.width, t.height) == tuple(wh2[tid * E + e])
+            k += n
+    # y outside the 13-bit field: the packed format refuses, the YAML path does not
+    e2 = lm.Detector(127, [5, 8], device=0)
+    big = f2.astype(np.int32).copy(); big[0, 1] = 5000
+    e2.addClassPacked("tall", big, np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), wh2.astype(np.int32))
+    with pytest.raises(RuntimeError, match="packed format"):
+        e2.writeBank(tmp_path / "tall.lmb")
+    assert not os.path.exists(tmp_path / "tall.lmb")
+
+
 # ---------------------------------------------------------------------------------------------
 # poseRefine / ICP  (parity unpinned by the reference: GPU vs the oracle's Open3D restatement)
 # ---------------------------------------------------------------------------------------------

@@ -176,3 +176,51 @@ def test_new_entry_points_fail_loudly_without_a_gpu():
         mod.Mesh(V, np.array([[0, 1, 3]], np.int32))            # face index checked before any device use
     with pytest.raises(RuntimeError):
         mod.Mesh("/nonexistent/model.ply")
+
+
+def _bank_file_bytes(levels, classes):
+    """The packed bank layout of csrc/bank_file.cpp written from numpy: classes = [(name, wh [P*E][2], counts [P*E], feats [n][3])]."""
+    import struct
+    body = bytearray(40)
+    dirs = []
+    for name, wh, counts, feats in classes:
+        begins = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        recs = np.zeros(len(begins), dtype=[("w", "<i4"), ("h", "<i4"), ("b", "<u8")])
+        recs["w"][:-1], recs["h"][:-1], recs["b"] = wh[:, 0], wh[:, 1], begins
+        packed = ((feats[:, 0].astype(np.int64) & 0xFFFF) | ((feats[:, 1].astype(np.int64) & 0x1FFF) << 16) | (feats[:, 2].astype(np.int64) << 29)).astype("<u4")
+        body += b"\0" * (-len(body) % 8); toff = len(body); body += recs.tobytes()
+        body += b"\0" * (-len(body) % 8); foff = len(body); body += packed.tobytes()
+        dirs.append((name.encode(), len(counts) // (2 * levels), toff, foff, len(feats)))
+    body += b"\0" * (-len(body) % 8)
+    dir_off = len(body)
+    names_off = dir_off + 40 * len(dirs)
+    for nm, P, toff, foff, nf in dirs:
+        body += struct.pack("<QIIQQQ", names_off, len(nm), P, toff, foff, nf)
+        names_off += len(nm)
+    for nm, *_ in dirs:
+        body += nm
+    body[0:40] = b"LMBANK01" + struct.pack("<IIIIQQ", 1, levels, len(dirs), 0, dir_off, len(body))
+    return bytes(body)
+
+
+def test_packed_bank_file_header_and_rejections(lib, tmp_path):
+    """lm_bank_file_info needs no GPU: a file laid out by hand is understood, damaged ones are refused."""
+    import linemodLevelup_pybind as lm
+    rng = np.random.default_rng(3)
+    classes = []
+    for name, P in (("obj_01", 3), ("a much longer class id / with spaces", 2)):
+        counts = rng.integers(0, 40, P * 4)
+        feats = np.stack([rng.integers(-5, 600, counts.sum()), rng.integers(-5, 400, counts.sum()), rng.integers(0, 8, counts.sum())], 1)
+        classes.append((name, rng.integers(20, 200, (P * 4, 2)), counts, feats))
+    blob = _bank_file_bytes(2, classes)
+    good = tmp_path / "bank.lmb"
+    good.write_bytes(blob)
+    info = lm.bank_file_info(good)
+    assert info == {"pyramid_levels": 2, "class_ids": [c[0] for c in classes], "num_pyramids": 5,
+                    "num_features": int(sum(c[2].sum() for c in classes))}
+    for bad in (blob[:-3], b"LMBANK02" + blob[8:], blob[:24] + (2 ** 40).to_bytes(8, "little") + blob[32:], b"short"):
+        (tmp_path / "bad.lmb").write_bytes(bad)
+        with pytest.raises(RuntimeError):
+            lm.bank_file_info(tmp_path / "bad.lmb")
+    with pytest.raises(RuntimeError, match="cannot open"):
+        lm.bank_file_info(tmp_path / "missing.lmb")
