@@ -114,7 +114,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_dev.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
@@ -127,6 +127,13 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (d->xchg.stream) (void)hipStreamSynchronize(d->xchg.stream);
+    for (int a = 0; a < lm_detector::kSlots; ++a) {
+        d->xchg.d_merged[a].release();
+        if (d->xchg.h_merged[a]) (void)hipHostFree(d->xchg.h_merged[a]);
+        if (d->xchg.done[a]) (void)hipEventDestroy(d->xchg.done[a]);
+    }
+    if (d->xchg.stream) (void)hipStreamDestroy(d->xchg.stream);
     if (d->pinned) (void)hipHostFree(d->pinned);
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -886,6 +893,11 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
         *d->work_cls = std::vector<int32_t>(d->work_cls->begin() + a, d->work_cls->begin() + b);
         *d->work_tid = std::vector<int32_t>(d->work_tid->begin() + a, d->work_tid->begin() + b);
     }
+    // frames in flight still read the device-resident work list: let them finish before it is replaced
+    if (d->n_submitted != d->n_collected) {
+        HIP_TRY(hipStreamSynchronize(d->mstream));
+        if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
+    }
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
     if (rc) return rc;
     if ((rc = d->d_work_cls.ensure(std::max<size_t>(1, d->work_pyr.size())))) return rc;
@@ -943,20 +955,24 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     }
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
-    if (d->d_cands.cap < d->cand_cap || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
+    if (d->d_cands.cap < d->cand_cap || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots ||
+        d->d_distinct_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
         // buffers are about to be replaced (first use, or the candidate capacity was raised): frames still in flight keep
         // using the old ones until they are done
         HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
+        if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     }
     if ((rc = d->d_counters.ensure(8 * lm_detector::kSlots))) return rc;          // per result slot
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
     if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap)))) return rc;
+    if ((rc = d->d_distinct_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream, ms = d->mstream;
     const int arena = (int)(d->n_submitted % lm_detector::kSlots);
     unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
     Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
+    Candidate* distinct_dev = d->d_distinct_dev.p + (size_t)d->cand_cap * arena;
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
@@ -991,7 +1007,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
         // exact duplicates out (they never survive std::unique), distinct records + counts to this slot's pinned memory
         if (num_work > 0) {
-            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->num_cus * 2, ms);
+            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, distinct_dev, d->num_cus * 2, ms);
             HIP_TRY(hipMemcpyAsync(sl.h_counters + 1, counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
         }
         return LM_OK;
@@ -1019,7 +1035,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5)};
+                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_dev << 6)};
         if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
             if (ok) memcpy(sl.key, key, sizeof(key));
@@ -1058,6 +1074,13 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     HIP_TRY(hipEventSynchronize(sl.done));
     const auto t2 = std::chrono::steady_clock::now();
     sl.pending = false;
+    {
+        const int slot_index = (int)(d->n_collected % lm_detector::kSlots);
+        if (d->xchg.state[slot_index] != 0) {          // exchange work of this frame may still read the slot's buffers
+            HIP_TRY(hipStreamSynchronize(d->xchg.stream));
+            d->xchg.state[slot_index] = 0;
+        }
+    }
     ++d->n_collected;
     HIP_TRY(hipGetLastError());
     const uint64_t ncand = sl.h_counters[0];

@@ -106,6 +106,7 @@ struct lm_detector {
     DevBuf<Candidate> d_cands;
     DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K, duplicate removal)
     DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
+    DevBuf<Candidate> d_distinct_dev;               // HBM copy of the distinct records per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;
     uint32_t cand_cap = 1u << 18;
@@ -130,6 +131,18 @@ struct lm_detector {
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
     uint64_t n_submitted = 0, n_collected = 0;
+
+    // multi-GPU exchange on the device (exchange.cpp): its own stream, so that the sort of frame k's records, the caller's
+    // RCCL all-gather and the merge run beside the matching kernels of frame k+1
+    struct Exchange {
+        hipStream_t stream = nullptr;
+        DevBuf<int32_t> d_merged[kSlots];
+        int32_t* h_merged[kSlots] = {};             // pinned
+        size_t h_words[kSlots] = {};
+        hipEvent_t done[kSlots] = {};
+        int state[kSlots] = {};                     // 0 idle, 1 packed, 2 merged (result on its way to h_merged)
+        int cap[kSlots] = {}, world[kSlots] = {};
+    } xchg;
     int local_blocks = 0;
     int num_cus = 256;
 

@@ -82,7 +82,18 @@ size_t topk_nms_scratch_bytes(uint32_t cap);
 // Exact-duplicate removal of the refined records of a frame (nms.hip): counters[0] = candidate slots (from launch_coarse),
 // counters[1] / [2] receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, int blocks, hipStream_t s);
+                   Candidate* distinct, Candidate* distinct_dev /*HBM copy, may be null*/, int blocks, hipStream_t s);
 size_t dedupe_table_slots(uint32_t cap);
+
+// ---- multi-GPU exchange of match records (exchange.hip) ----
+// Block a rank contributes to the all-gather: 4 header words {count, flags, capacity, 0} + capacity 128-bit keys (a sorted run).
+constexpr uint32_t kXchgRunOverflow = 1;      // more distinct records than the block holds (count says how many)
+constexpr uint32_t kXchgCandOverflow = 2;     // the candidate buffer of the matching kernels overflowed: the frame has to be rerun
+constexpr uint32_t kXchgFieldOverflow = 4;    // |x|,|y| >= 32768: not representable in the key
+constexpr int kXchgHeaderWords = 256;         // result: {records, flags, world, capacity, -, -, -, -, count per rank...}, then 5-word records
+constexpr uint32_t kXchgMaxCapacity = 8192;   // keys one workgroup sorts in LDS (128 KB)
+int launch_exchange_pack(const Candidate* distinct, const unsigned long long* counters, uint32_t cand_cap, const int32_t* work_cls,
+                         const int32_t* work_tid, uint32_t cap, uint32_t* block, hipStream_t s);
+void launch_exchange_merge(const uint32_t* blocks, int world, uint32_t cap, int32_t* merged, hipStream_t s);
 
 }  // namespace lm

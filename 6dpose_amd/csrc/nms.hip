@@ -232,7 +232,7 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
 // survivors to `distinct` (pinned host memory).  counters[1] = distinct records, counters[2] = records alive before.
 __global__ void __launch_bounds__(256)
 k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__ counters, uint32_t cap,
-         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct) {
+         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct, Candidate* __restrict__ distinct_dev) {
     const unsigned long long nc = counters[0];
     const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
     const int lane = threadIdx.x & 63;
@@ -267,15 +267,19 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
                 atomicAdd(&counters[2], (unsigned long long)__popcll(ma));
             }
             base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
-            if (keep) distinct[base + __popcll(mk & ((1ull << lane) - 1ull))] = c;
+            if (keep) {
+                const unsigned long long at = base + __popcll(mk & ((1ull << lane) - 1ull));
+                distinct[at] = c;
+                if (distinct_dev) distinct_dev[at] = c;
+            }
         }
     }
 }
 
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, int blocks, hipStream_t s) {
+                   Candidate* distinct, Candidate* distinct_dev, int blocks, hipStream_t s) {
     (void)hipMemsetAsync(table, 0xFF, table_slots * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct);
+    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, distinct_dev);
 }
 
 size_t dedupe_table_slots(uint32_t cap) {

@@ -30,6 +30,7 @@ from __future__ import annotations
 import ctypes
 import gzip
 import os
+import sys
 import shutil
 import tempfile
 from typing import List, Optional, Sequence
@@ -92,6 +93,25 @@ def library_path() -> str:
     return os.environ.get("AMD_LINEMOD_LIB", os.path.join(_HERE, _LIB_NAME))
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so; if this library were bound to /opt/rocm's
+    copy first, a later `import torch` would bring up a second runtime that finds no GPU ("No HIP GPUs are available"),
+    and stream handles could not be shared (sharded.DeviceExchange hands the exchange stream to torch.distributed).
+    So when torch is installed, its runtime is loaded first (without importing torch) and libamdlinemod.so binds to it."""
+    if "torch" in sys.modules:
+        return                                   # already loaded: the dynamic linker reuses it
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:                            # torch absent or not a ROCm build: /opt/rocm's runtime is used
+        pass
+
+
 def load_library():
     """Loads libamdlinemod.so and declares the C ABI.  Raises RuntimeError when it is missing."""
     global _lib
@@ -101,6 +121,7 @@ def load_library():
     if not os.path.exists(path):
         raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     S = ctypes.c_char_p
@@ -136,6 +157,13 @@ def load_library():
     lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
                                                ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_submit.argtypes = [P, F, ctypes.POINTER(S), I]
+    lib.lm_detector_exchange_stream.argtypes = [P]
+    lib.lm_detector_exchange_stream.restype = P
+    lib.lm_exchange_block_bytes.argtypes = [I]
+    lib.lm_exchange_block_bytes.restype = ctypes.c_size_t
+    lib.lm_detector_exchange_pack.argtypes = [P, P, I]
+    lib.lm_detector_exchange_merge.argtypes = [P, P, I, I]
+    lib.lm_detector_exchange_collect.argtypes = [P, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I)]
     lib.lm_detector_collect.argtypes = [P, I, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_last_timings.argtypes = [P, ctypes.POINTER(Timings)]
     lib.lm_detector_read_stage.argtypes = [P, I, I, P, ctypes.c_int64]
@@ -404,6 +432,30 @@ class Detector:
         out, cnt = ctypes.POINTER(_CMatch)(), ctypes.c_size_t()
         _check(self._lib.lm_detector_collect(self._h, 1 if sort_unique else (2 if distinct else 0), ctypes.byref(out), ctypes.byref(cnt)))
         return self._take(out, cnt.value)
+
+    # ---- multi-GPU exchange on the device (sharded.DeviceExchange drives these) ------------------
+    def exchangeStream(self) -> int:
+        """hipStream_t (as an integer) the exchange kernels run on; collectives go on the same stream."""
+        h = self._lib.lm_detector_exchange_stream(self._h)
+        if not h:
+            raise RuntimeError(self._lib.lm_last_error().decode("utf-8", "replace"))
+        return int(h)
+
+    def exchangePack(self, send_ptr: int, capacity: int) -> None:
+        _check(self._lib.lm_detector_exchange_pack(self._h, ctypes.c_void_p(send_ptr), capacity))
+
+    def exchangeMerge(self, recv_ptr: int, world: int, capacity: int) -> None:
+        _check(self._lib.lm_detector_exchange_merge(self._h, ctypes.c_void_p(recv_ptr), world, capacity))
+
+    def exchangeCollect(self):
+        """(records, 0) — the frame's Detector.match result, identical on every rank — or (None, failed != 0)."""
+        out = ctypes.POINTER(_CMatch)()
+        n = ctypes.c_size_t(0)
+        failed = ctypes.c_int(0)
+        _check(self._lib.lm_detector_exchange_collect(self._h, ctypes.byref(out), ctypes.byref(n), ctypes.byref(failed)))
+        if failed.value:
+            return None, failed.value
+        return self._take(out, n.value), 0
 
     def _take(self, out, n) -> np.ndarray:
         try:

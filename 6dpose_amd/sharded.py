@@ -8,6 +8,14 @@ The records gathered are the PRE-unique lists: Match::operator== ignores templat
 key contains it (LL.h:234-246), so unique-ing per shard first could drop entries that are not
 adjacent in the global order.  Messages are tiny (20 B per match), i.e. latency-bound; counts are
 gathered first, then records padded to the maximum.
+
+Two ways to do the exchange:
+  * gather_records + lm.merge_matches: records through host memory, sort on every rank's host.  Simple, used by the CPU
+    (gloo) tests and as the fall-back; its cost grows with the number of ranks (every host sorts every rank's records).
+  * DeviceExchange: the exchange as device work — each rank sorts its records in LDS, one all_gather_into_tensor of
+    fixed-size blocks on the detector's exchange stream (RCCL reads and writes HBM directly), a ranking merge kernel, and
+    the host only copies the result out.  No host synchronisation between submit and collect, so with frames in flight it
+    overlaps the matching kernels of the following frames.
 """
 from __future__ import annotations
 
@@ -46,8 +54,85 @@ def gather_records(local: np.ndarray, device=None, group=None, force: bool = Fal
     return np.concatenate(out)
 
 
+class DeviceExchange:
+    """Sharded Detector.match with the exchange on the device (lm_detector_exchange_*; kernels in csrc/exchange.hip).
+
+        ex = DeviceExchange(detector, device)            # after init_process_group; detector.setShard is done here
+        ex.submit(threshold, class_ids)                  # up to three frames in flight
+        records = ex.collect()                           # oldest frame: canonical list, identical on every rank
+
+    collect() returns None when a rank had more distinct records than `capacity` or overflowed its candidate buffer —
+    on every rank alike, so all of them can rerun that frame through match_sharded (host path); the capacity is doubled
+    for the following frames when that helps.  With a backend that cannot gather device tensors (gloo in the tests)
+    the blocks are staged through the host; the kernels are the same."""
+
+    def __init__(self, detector: "lm.Detector", device, group=None, capacity: int = 4096, force: bool = False):
+        import torch
+        import torch.distributed as dist
+        self.det, self.group = detector, group
+        self.dev = torch.device(device)
+        self.world, self.rank = 1, 0
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        if self.dist is not None:
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.collective = self.dist is not None and (self.world > 1 or force)
+        self.device_collective = self.collective and dist.get_backend(group) == "nccl"
+        detector.setShard(self.rank, self.world)
+        self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
+        self.slots = 3
+        self.next = 0
+        self._alloc(capacity)
+
+    def _alloc(self, capacity: int):
+        import torch
+        self.capacity = capacity
+        nbytes = lm.load_library().lm_exchange_block_bytes(capacity)
+        if nbytes == 0:
+            raise ValueError("capacity must be a power of two in [256, 8192]")
+        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
+        self.recv = [torch.zeros(nbytes * self.world, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
+        self.cap_of = [capacity] * self.slots
+
+    def submit(self, threshold: float, class_ids: Sequence[str] = ()) -> None:
+        import torch
+        k = self.next
+        self.next = (k + 1) % self.slots
+        self.det.submit(threshold, class_ids)
+        send, recv, cap = self.send[k], self.recv[k], self.cap_of[k]
+        self.det.exchangePack(send.data_ptr(), cap)
+        if not self.collective:
+            recv = send
+        elif self.device_collective:
+            with torch.cuda.stream(self.stream):                 # RCCL orders itself after the pack kernel / before the merge
+                self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:                                                    # backend without device collectives: stage through the host
+            with torch.cuda.stream(self.stream):
+                mine = send.cpu()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine, group=self.group)
+                recv.copy_(torch.cat(parts), non_blocking=False)
+        self.det.exchangeMerge(recv.data_ptr(), self.world, cap)
+
+    def collect(self) -> Optional[np.ndarray]:
+        out, failed = self.det.exchangeCollect()
+        if failed > self.capacity and failed <= 8192 // 2:       # a run did not fit: larger blocks from the next submit on
+            cap = self.capacity
+            while cap < failed:
+                cap *= 2
+            self._pending_capacity = cap
+        return out
+
+    def grow_if_needed(self) -> None:
+        """Call with no frame in flight after collect() returned None: applies the larger capacity (same on every rank)."""
+        cap = getattr(self, "_pending_capacity", None)
+        if cap:
+            self._pending_capacity = None
+            self._alloc(cap)
+            self.next = 0
+
+
 def match_sharded(detector: "lm.Detector", sources, threshold: float, class_ids: Sequence[str] = (), masks=(),
-                  device=None, group=None, resident: bool = False) -> np.ndarray:
+                  device=None, group=None, resident: bool = False, exchange: Optional[DeviceExchange] = None) -> np.ndarray:
     """Detector.match across all ranks of the process group: identical, canonically ordered result on
     every rank.  The detector must hold the full bank on every rank (template ids stay global)."""
     import torch.distributed as dist
@@ -57,6 +142,12 @@ def match_sharded(detector: "lm.Detector", sources, threshold: float, class_ids:
     detector.setShard(rank, world)
     if not resident:
         detector.setFrame(sources, masks)
+    if exchange is not None:                                     # sort / gather / merge on the device
+        exchange.submit(threshold, class_ids)
+        out = exchange.collect()
+        if out is not None:
+            return out
+        exchange.grow_if_needed()                                # every rank takes the host path for this frame
     # records without exact duplicates (dropped on the device: std::unique removes them on every rank's merge anyway)
     local = detector.matchResident(threshold, class_ids, sort_unique=False, distinct=True)
     allrec = gather_records(local, device=device, group=group)

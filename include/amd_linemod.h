@@ -138,6 +138,26 @@ int lm_detector_get_template(const lm_detector *d, const char *class_id, int tem
  * stay global.  Default (0,1). */
 int lm_detector_set_shard(lm_detector *d, int rank, int world);
 
+/* Multi-GPU exchange on the device.  Detector::match sorts and adjacent-uniques the records of ALL templates
+ * (LL.cpp:1771-1776); with the bank sharded over W ranks that is a distributed merge sort, done without the host:
+ *   lm_detector_submit(...)                         this rank's shard of the frame
+ *   lm_detector_exchange_pack(d, send, capacity)    sorts the rank's distinct records into `send` (device memory,
+ *                                                   lm_exchange_block_bytes(capacity) bytes: header + a sorted run of keys)
+ *   all-gather of the W blocks into `recv`          the caller's collective (RCCL), enqueued on lm_detector_exchange_stream(d)
+ *   lm_detector_exchange_merge(d, recv, W, capacity) merges the W runs, marks what std::unique drops, copies to pinned memory
+ *   lm_detector_exchange_collect(d, &out, &n, &failed) waits for the oldest frame in flight: the same list on every rank,
+ *                                                   identical to an unsharded lm_detector_match (lm_free(out))
+ * pack / merge apply to the most recently submitted frame and only enqueue work on the exchange stream (hipStream_t
+ * returned as void*); up to three frames can be in flight.  capacity: power of two in [256, 8192], the same on every rank.
+ * *failed != 0 (on every rank alike, *out == NULL): > 0 some rank had that many distinct records (> capacity), < 0 a
+ * candidate buffer overflowed or a field did not fit the key — rerun the frame through lm_detector_match_resident +
+ * lm_merge_matches (sharded.py does). */
+void *lm_detector_exchange_stream(lm_detector *d);
+size_t lm_exchange_block_bytes(int capacity);
+int lm_detector_exchange_pack(lm_detector *d, void *send_block, int capacity);
+int lm_detector_exchange_merge(lm_detector *d, const void *recv_blocks, int world, int capacity);
+int lm_detector_exchange_collect(lm_detector *d, lm_match **out, size_t *n, int *failed);
+
 /* Detector::match (pybind11.cpp:32-33, LL.cpp:1702-1777).  class_ids may be NULL/0 = all classes.
  * masks: NULL, or two pointers (colour, depth modality), each NULL or a [height][width] uint8 mask.
  * On success *out is a malloc'd array of *n matches in the canonical order of SURVEY §8a A12

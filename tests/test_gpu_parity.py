@@ -256,6 +256,77 @@ def test_sharded_equals_unsharded_on_one_device(lm):
         assert key(raw) == key(dis) and len(dis) == len(key(dis)) <= len(raw)
 
 
+def test_device_exchange_merges_shards_like_the_host(lm):
+    """SURVEY §8e on the device: W detectors stand in for W ranks of one job (same frame, shard r of W each); their
+    packed blocks are concatenated the way an all-gather lays them out and every "rank" merges them with the ranking
+    kernel.  The result must be the unsharded Detector.match list — order, adjacent-unique and all — on every rank."""
+    import torch
+    W_, H_, T, nfeat = 640, 480, [4, 8], (150, 75)
+    rgb, dep = synth.make_frame(13, W_, H_)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    banks = [synth.make_planted_bank(31 + i, n, [(p[0], p[1]) for p in pyr], T, nfeat) for i, n in enumerate((130, 77))]
+    ids = ["b", "a"]
+
+    def make():
+        d = lm.Detector(nfeat[0], T, device=0)
+        for c, b in zip("ab", banks):
+            d.addClassPacked(c, *b)
+        d.setFrame([rgb, dep])
+        return d
+    ref = make()
+    lib = lm.load_library()
+    for thr, cap in ((75.0, 4096), (75.0, 8192), (60.0, 8192), (99.5, 256)):
+        whole = ref.matchResident(thr, ids)
+        assert len(whole) > 0 or thr > 99
+        for world in (1, 2, 3, 8):
+            dets = [make() for _ in range(world)]
+            nb = lib.lm_exchange_block_bytes(cap)
+            send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
+            for r, d in enumerate(dets):
+                d.setShard(r, world)
+                d.submit(thr, ids)
+                d.exchangePack(send[r].data_ptr(), cap)
+            streams = [torch.cuda.ExternalStream(d.exchangeStream(), device="cuda:0") for d in dets]
+            for st in streams:
+                st.synchronize()
+            recv = torch.cat(send)
+            counts = [int(b[:4].cpu().numpy().view(np.uint32)[0]) for b in send]
+            pre = ref.matchResident(thr, ids, sort_unique=False, distinct=True)
+            assert sum(counts) == len(pre), (counts, len(pre))
+            for d in dets:
+                d.exchangeMerge(recv.data_ptr(), world, cap)
+                got, failed = d.exchangeCollect()
+                assert failed == 0 and got.tobytes() == whole.tobytes(), (thr, cap, world, len(got), len(whole))
+    # blocks too small for the records: every rank reports the same need, nothing is returned
+    dets = [make() for _ in range(2)]
+    nb = lib.lm_exchange_block_bytes(256)
+    send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    for r, d in enumerate(dets):
+        d.setShard(r, 2); d.submit(60.0, ids); d.exchangePack(send[r].data_ptr(), 256)
+        torch.cuda.ExternalStream(d.exchangeStream(), device="cuda:0").synchronize()
+    recv = torch.cat(send)
+    needs = []
+    for d in dets:
+        d.exchangeMerge(recv.data_ptr(), 2, 256)
+        got, failed = d.exchangeCollect()
+        assert got is None and failed > 256
+        needs.append(failed)
+    assert needs[0] == needs[1]
+    # protocol errors are loud
+    d = make()
+    with pytest.raises(RuntimeError, match="no frame in flight"):
+        d.exchangePack(send[0].data_ptr(), 256)
+    d.submit(75.0, ids)
+    with pytest.raises(RuntimeError, match="power of two"):
+        d.exchangePack(send[0].data_ptr(), 300)
+    with pytest.raises(RuntimeError, match="precede"):
+        d.exchangeMerge(recv.data_ptr(), 2, 256)
+    with pytest.raises(RuntimeError, match="not exchanged"):
+        d.exchangeCollect()
+    assert len(d.collect()) == len(ref.matchResident(75.0, ids))
+
+
 def test_pipelined_submit_collect_equals_synchronous(lm):
     """Stream mode: three frames in flight (front end of k+2 and matching of k+1 on two streams while the host
     collects k) returns exactly what the synchronous calls return, frame by frame, also when the stream wraps around
@@ -749,6 +820,30 @@ if backend == "nccl":   # single rank: also push the records through the RCCL al
     pre = det.matchResident(75.0, ["c", "a", "b"], sort_unique=False)
     again = lm.merge_matches(sharded.gather_records(pre, device=dev, force=True))
     assert again.tobytes() == got.tobytes()
+# the same exchange as device work: sort per rank, all-gather of the blocks (RCCL / staged for gloo), ranking merge
+ex = sharded.DeviceExchange(det, "cuda:0", force=True)
+dev_got = sharded.match_sharded(det, [rgb, dep], 75.0, ["c", "a", "b"], device=dev, exchange=ex)
+assert dev_got.tobytes() == got.tobytes(), (rank, len(dev_got), len(got))
+frames = [synth.make_frame(13 + k, W, H) for k in range(4)]
+for k, f in enumerate(frames):
+    det.storeFrame(k, f)
+want = []
+for k in range(4):
+    det.selectFrame(k)
+    want.append(sharded.match_sharded(det, None, 75.0, ["c", "a", "b"], device=dev, resident=True))
+outs = []
+for k in range(6):                                          # three frames in flight
+    det.selectFrame(k % 4); ex.submit(75.0, ["c", "a", "b"])
+    if k >= 2:
+        outs.append(ex.collect())
+outs += [ex.collect(), ex.collect()]
+for k, o in enumerate(outs):
+    assert o is not None and o.tobytes() == want[k % 4].tobytes(), (rank, k)
+small = sharded.DeviceExchange(det, "cuda:0", capacity=256, force=True)      # a block too small: every rank falls back together
+det.selectFrame(0)
+fb = sharded.match_sharded(det, None, 60.0, ["c", "a", "b"], device=dev, resident=True, exchange=small)
+assert fb.tobytes() == sharded.match_sharded(det, None, 60.0, ["c", "a", "b"], device=dev, resident=True).tobytes()
+assert small.capacity > 256 or world > 1
 det.setShard(0, 1)
 whole = det.matchArray([rgb, dep], 75.0, ["c", "a", "b"])
 assert len(whole) > 0 and got.tobytes() == whole.tobytes(), (rank, len(got), len(whole))
