@@ -114,7 +114,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_dev.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
@@ -130,6 +130,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (d->xchg.stream) (void)hipStreamSynchronize(d->xchg.stream);
     for (int a = 0; a < lm_detector::kSlots; ++a) {
         d->xchg.d_merged[a].release();
+        d->xchg.d_runs.release();
         if (d->xchg.h_merged[a]) (void)hipHostFree(d->xchg.h_merged[a]);
         if (d->xchg.done[a]) (void)hipEventDestroy(d->xchg.done[a]);
     }
@@ -956,7 +957,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
     if (d->d_cands.cap < d->cand_cap || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots ||
-        d->d_distinct_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
+        d->d_distinct_keys.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
         // buffers are about to be replaced (first use, or the candidate capacity was raised): frames still in flight keep
         // using the old ones until they are done
         HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
@@ -966,13 +967,13 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
     if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap)))) return rc;
-    if ((rc = d->d_distinct_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
+    if ((rc = d->d_distinct_keys.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream, ms = d->mstream;
     const int arena = (int)(d->n_submitted % lm_detector::kSlots);
     unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
     Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
-    Candidate* distinct_dev = d->d_distinct_dev.p + (size_t)d->cand_cap * arena;
+    ulonglong2* distinct_keys = d->d_distinct_keys.p + (size_t)d->cand_cap * arena;
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
@@ -1007,7 +1008,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
         // exact duplicates out (they never survive std::unique), distinct records + counts to this slot's pinned memory
         if (num_work > 0) {
-            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, distinct_dev, d->num_cus * 2, ms);
+            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p, distinct_keys, d->num_cus * 2, ms);
             HIP_TRY(hipMemcpyAsync(sl.h_counters + 1, counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
         }
         return LM_OK;
@@ -1035,7 +1036,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_dev << 6)};
+                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8)};
         if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
             if (ok) memcpy(sl.key, key, sizeof(key));
@@ -1094,7 +1095,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     uint64_t evals = 0, lbytes = 0, nm = 0;
     for (int b = 0; b < d->local_blocks; ++b) { evals += sl.h_counters[8 + 2 * b]; lbytes += sl.h_counters[8 + 2 * b + 1]; }
     const Candidate* hm = sl.h_matches;
-    for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0;
+    if (sort_unique == 0 || sl.num_work == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
+    else nm = sl.h_counters[2];                        // counted on the device by k_dedupe: no pass over the raw records
     tm.coarse_candidates = (int64_t)ncand;
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
@@ -1121,9 +1123,9 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     // (k_dedupe) — what std::unique would leave of them anyway — canonically sorted + uniqued (1) or as they are (2)
     const bool use_distinct = sort_unique != 0 && sl.num_work > 0;
     const uint64_t nd = use_distinct ? sl.h_counters[1] : 0;
-    if (use_distinct && (nd > ncand || sl.h_counters[2] != nm))
-        return lm_set_error(LM_ERR_HIP, "duplicate removal out of step with the refinement (%llu distinct of %llu, %llu alive vs %llu)",
-                            (unsigned long long)nd, (unsigned long long)ncand, (unsigned long long)sl.h_counters[2], (unsigned long long)nm);
+    if (use_distinct && (nd > ncand || nd > nm || nm > ncand))
+        return lm_set_error(LM_ERR_HIP, "duplicate removal out of step with the refinement (%llu distinct of %llu alive, %llu candidates)",
+                            (unsigned long long)nd, (unsigned long long)nm, (unsigned long long)ncand);
     const size_t nrec = use_distinct ? (size_t)nd : (size_t)nm;
     lm_match* res = (lm_match*)malloc(std::max<size_t>(1, nrec) * sizeof(lm_match));
     if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");

@@ -106,7 +106,7 @@ struct lm_detector {
     DevBuf<Candidate> d_cands;
     DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K, duplicate removal)
     DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
-    DevBuf<Candidate> d_distinct_dev;               // HBM copy of the distinct records per result slot (multi-GPU exchange)
+    DevBuf<ulonglong2> d_distinct_keys;             // the distinct records as 128-bit sort keys, per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;
     uint32_t cand_cap = 1u << 18;
@@ -137,6 +137,7 @@ struct lm_detector {
     struct Exchange {
         hipStream_t stream = nullptr;
         DevBuf<int32_t> d_merged[kSlots];
+        DevBuf<ulonglong2> d_runs;                  // scratch of the per-rank sort
         int32_t* h_merged[kSlots] = {};             // pinned
         size_t h_words[kSlots] = {};
         hipEvent_t done[kSlots] = {};

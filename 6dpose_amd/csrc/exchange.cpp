@@ -18,6 +18,8 @@
 
 using namespace lm;
 
+static_assert(sizeof(lm_match) == 20, "lm_match is five 32-bit fields");
+
 static int ensure_exchange(lm_detector* d) {
     if (d->xchg.stream) return LM_OK;
     HIP_TRY(hipStreamCreateWithFlags(&d->xchg.stream, hipStreamNonBlocking));
@@ -49,9 +51,9 @@ extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int c
     lm_detector::Slot& sl = d->slot[slot];
     hipStream_t xs = d->xchg.stream;
     HIP_TRY(hipStreamWaitEvent(xs, sl.done, 0));                                    // records + counters of this frame are final
-    if (launch_exchange_pack(d->d_distinct_dev.p + (size_t)d->cand_cap * slot, d->d_counters.p + 8 * (size_t)slot, d->cand_cap,
-                             d->d_work_cls.p, d->d_work_tid.p, (uint32_t)capacity, (uint32_t*)send_block, xs))
-        return lm_set_error(LM_ERR_HIP, "cannot reserve %d bytes of LDS for the exchange sort", capacity * 16);
+    if ((rc = d->xchg.d_runs.ensure(kXchgMaxCapacity))) return rc;
+    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->cand_cap * slot, d->d_counters.p + 8 * (size_t)slot, d->cand_cap,
+                         (uint32_t)capacity, d->xchg.d_runs.p, (uint32_t*)send_block, xs);
     HIP_TRY(hipGetLastError());
     d->xchg.state[slot] = 1;
     d->xchg.cap[slot] = capacity;
@@ -84,9 +86,8 @@ extern "C" int lm_detector_exchange_merge(lm_detector* d, const void* recv_block
     return LM_OK;
 }
 
-extern "C" int lm_detector_exchange_collect(lm_detector* d, lm_match** out, size_t* n_out, int* failed) {
-    if (!d || !out || !n_out || !failed) return lm_set_error(LM_ERR_INVALID, "null argument");
-    *out = nullptr; *n_out = 0; *failed = 0;
+static int exchange_collect(lm_detector* d, lm_match* dst, size_t dst_capacity, lm_match** out, size_t* n_out, int* failed) {
+    *n_out = 0; *failed = 0;
     if (d->n_submitted == d->n_collected) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
     const int slot = (int)(d->n_collected % lm_detector::kSlots);
     if (d->xchg.state[slot] != 2) return lm_set_error(LM_ERR_INVALID, "the oldest frame in flight was not exchanged (pack + merge)");
@@ -107,17 +108,31 @@ extern "C" int lm_detector_exchange_collect(lm_detector* d, lm_match** out, size
     }
     const size_t total = (size_t)h[0];
     if (total > (size_t)d->xchg.world[slot] * (size_t)d->xchg.cap[slot]) return lm_set_error(LM_ERR_HIP, "exchange header inconsistent");
-    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, total) * sizeof(lm_match));
-    if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
+    lm_match* res = dst;
+    if (!res) {
+        res = (lm_match*)malloc(std::max<size_t>(1, total) * sizeof(lm_match));
+        if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
+    } else if (dst_capacity < total) {
+        return lm_set_error(LM_ERR_INVALID, "destination holds %zu records, the frame has up to %zu", dst_capacity, total);
+    }
     const int32_t* rec = h + kXchgHeaderWords;
     size_t w = 0;
     for (size_t i = 0; i < total; ++i, rec += 5) {
         if (rec[3] < 0) continue;                                                    // what std::unique removes (LL.cpp:1772-1774)
-        lm_match& m = res[w++];
-        m.x = rec[0]; m.y = rec[1];
-        memcpy(&m.similarity, &rec[2], 4);
-        m.class_index = rec[3]; m.template_id = rec[4];
+        memcpy(&res[w++], rec, sizeof(lm_match));                                    // same five 32-bit fields, same order
     }
-    *out = res; *n_out = w;
+    if (out) *out = res;
+    *n_out = w;
     return LM_OK;
+}
+
+extern "C" int lm_detector_exchange_collect(lm_detector* d, lm_match** out, size_t* n_out, int* failed) {
+    if (!d || !out || !n_out || !failed) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    return exchange_collect(d, nullptr, 0, out, n_out, failed);
+}
+
+extern "C" int lm_detector_exchange_collect_into(lm_detector* d, lm_match* dst, size_t capacity, size_t* n_out, int* failed) {
+    if (!d || !dst || !n_out || !failed) return lm_set_error(LM_ERR_INVALID, "null argument");
+    return exchange_collect(d, dst, capacity, nullptr, n_out, failed);
 }

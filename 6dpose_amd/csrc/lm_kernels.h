@@ -82,7 +82,8 @@ size_t topk_nms_scratch_bytes(uint32_t cap);
 // Exact-duplicate removal of the refined records of a frame (nms.hip): counters[0] = candidate slots (from launch_coarse),
 // counters[1] / [2] receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, Candidate* distinct_dev /*HBM copy, may be null*/, int blocks, hipStream_t s);
+                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys /*HBM: exchange keys of the distinct records, may be null*/,
+                   int blocks, hipStream_t s);
 size_t dedupe_table_slots(uint32_t cap);
 
 // ---- multi-GPU exchange of match records (exchange.hip) ----
@@ -91,9 +92,19 @@ constexpr uint32_t kXchgRunOverflow = 1;      // more distinct records than the 
 constexpr uint32_t kXchgCandOverflow = 2;     // the candidate buffer of the matching kernels overflowed: the frame has to be rerun
 constexpr uint32_t kXchgFieldOverflow = 4;    // |x|,|y| >= 32768: not representable in the key
 constexpr int kXchgHeaderWords = 256;         // result: {records, flags, world, capacity, -, -, -, -, count per rank...}, then 5-word records
-constexpr uint32_t kXchgMaxCapacity = 8192;   // keys one workgroup sorts in LDS (128 KB)
-int launch_exchange_pack(const Candidate* distinct, const unsigned long long* counters, uint32_t cand_cap, const int32_t* work_cls,
-                         const int32_t* work_tid, uint32_t cap, uint32_t* block, hipStream_t s);
+constexpr uint32_t kXchgMaxCapacity = 8192;
+// 128-bit sort key of a match: ascending key order = canonical order of SURVEY A12 (similarity desc, template id, class position, y, x);
+// it holds every field, so the records travel as keys.  .x = ~orderable(similarity) << 32 | template id, .y = class << 32 | y+32768 << 16 | x+32768.
+__device__ __forceinline__ ulonglong2 xchg_make_key(int x, int y, float sim, int cls, int tid) {
+    uint32_t u = __float_as_uint(sim);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;          // orders like the float
+    return make_ulonglong2(((unsigned long long)(~u) << 32) | (uint32_t)tid,
+                           ((unsigned long long)(uint32_t)cls << 32) | ((unsigned long long)(uint16_t)(y + 32768) << 16) | (uint16_t)(x + 32768));
+}
+__device__ __forceinline__ bool xchg_key_fits(int x, int y, int cls, int tid) { return x >= -32768 && x <= 32767 && y >= -32768 && y <= 32767 && cls >= 0 && tid >= 0; }
+// counters: [0] coarse candidates, [1] distinct records, [3] != 0: a record did not fit the key (all written by the matching stream)
+void launch_exchange_pack(const ulonglong2* distinct_keys, const unsigned long long* counters, uint32_t cand_cap, uint32_t cap,
+                          ulonglong2* runs_scratch /*cap keys*/, uint32_t* block, hipStream_t s);
 void launch_exchange_merge(const uint32_t* blocks, int world, uint32_t cap, int32_t* merged, hipStream_t s);
 
 }  // namespace lm

@@ -229,10 +229,12 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
 // adjacent in the canonical order and std::unique removes all but one (LL.cpp:1772-1774), so dropping them on the device
 // changes nothing and shrinks what the host converts / sorts and what the multi-GPU all-gather carries (typically 5x).
 // Persistent grid over the candidate slots; open-addressing hash on (x, y, work item); one atomic per wave appends the
-// survivors to `distinct` (pinned host memory).  counters[1] = distinct records, counters[2] = records alive before.
+// survivors to `distinct` (pinned host memory) and, as sort keys, to `distinct_keys` (HBM; exchange.hip).  counters[1] = distinct
+// records, counters[2] = records alive before, counters[3] != 0: a record does not fit the key.
 __global__ void __launch_bounds__(256)
 k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__ counters, uint32_t cap,
-         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct, Candidate* __restrict__ distinct_dev) {
+         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct,
+         const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid, ulonglong2* __restrict__ distinct_keys) {
     const unsigned long long nc = counters[0];
     const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
     const int lane = threadIdx.x & 63;
@@ -270,16 +272,20 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
             if (keep) {
                 const unsigned long long at = base + __popcll(mk & ((1ull << lane) - 1ull));
                 distinct[at] = c;
-                if (distinct_dev) distinct_dev[at] = c;
+                if (distinct_keys) {                                                 // the record as a sort key for the multi-GPU exchange
+                    const int cls = work_cls[c.work], tid = work_tid[c.work];
+                    distinct_keys[at] = xchg_make_key(c.x, c.y, c.score, cls, tid);
+                    if (!xchg_key_fits(c.x, c.y, cls, tid)) atomicOr(&counters[3], 1ull);
+                }
             }
         }
     }
 }
 
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, Candidate* distinct_dev, int blocks, hipStream_t s) {
+                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys, int blocks, hipStream_t s) {
     (void)hipMemsetAsync(table, 0xFF, table_slots * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, distinct_dev);
+    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, work_cls, work_tid, distinct_keys);
 }
 
 size_t dedupe_table_slots(uint32_t cap) {

@@ -163,6 +163,7 @@ def load_library():
     lib.lm_exchange_block_bytes.restype = ctypes.c_size_t
     lib.lm_detector_exchange_pack.argtypes = [P, P, I]
     lib.lm_detector_exchange_merge.argtypes = [P, P, I, I]
+    lib.lm_detector_exchange_collect_into.argtypes = [P, P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I)]
     lib.lm_detector_exchange_collect.argtypes = [P, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I)]
     lib.lm_detector_collect.argtypes = [P, I, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_last_timings.argtypes = [P, ctypes.POINTER(Timings)]
@@ -456,6 +457,18 @@ class Detector:
         if failed.value:
             return None, failed.value
         return self._take(out, n.value), 0
+
+    def exchangeCollectInto(self, dst: np.ndarray):
+        """Like exchangeCollect, written straight into `dst` (MATCH_DTYPE, >= world * capacity records): returns
+        (dst[:n] — a view —, 0) or (None, failed)."""
+        if dst.dtype != MATCH_DTYPE or not dst.flags.c_contiguous:
+            raise TypeError("dst must be a C-contiguous MATCH_DTYPE array")
+        n = ctypes.c_size_t(0)
+        failed = ctypes.c_int(0)
+        _check(self._lib.lm_detector_exchange_collect_into(self._h, dst.ctypes.data_as(ctypes.c_void_p), dst.size, ctypes.byref(n), ctypes.byref(failed)))
+        if failed.value:
+            return None, failed.value
+        return dst[:n.value], 0
 
     def _take(self, out, n) -> np.ndarray:
         try:

@@ -113,8 +113,10 @@ class DeviceExchange:
                 recv.copy_(torch.cat(parts), non_blocking=False)
         self.det.exchangeMerge(recv.data_ptr(), self.world, cap)
 
-    def collect(self) -> Optional[np.ndarray]:
-        out, failed = self.det.exchangeCollect()
+    def collect(self, into: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """Oldest frame in flight.  `into` (MATCH_DTYPE, world * capacity records) avoids the allocation and a copy; the
+        result is then a view of it."""
+        out, failed = self.det.exchangeCollect() if into is None else self.det.exchangeCollectInto(into)
         if failed > self.capacity and failed <= 8192 // 2:       # a run did not fit: larger blocks from the next submit on
             cap = self.capacity
             while cap < failed:

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--templates", type=int, default=N_TEMPLATES, help="template pyramids per object (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "host", "device"], default="auto",
+                    help="multi-GPU exchange of the match records: on the device (sharded.DeviceExchange; auto = when world > 1) or through the host")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +81,8 @@ def main():
         raise RuntimeError("bench.py needs a GPU (libamdlinemod has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (args.exchange == "device" and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     n_obj = max(1, world)
@@ -102,6 +105,28 @@ def main():
         classes.append(cid)
     det.setShard(rank, world)
 
+    # Multi-GPU: the exchange of the records as device work (per-rank sort, RCCL all-gather on the exchange stream, ranking
+    # merge).  Checked against the host path on one frame before anything is timed; all ranks agree on which one is used.
+    ex, exchange_mode = None, "none" if world == 1 else "host"
+    if args.exchange == "device" or (args.exchange == "auto" and world > 1):
+        ok = 1
+        try:
+            ex = sharded.DeviceExchange(det, dev, force=True)
+            det.selectFrame(0)
+            a = sharded.match_sharded(det, None, THRESHOLD, classes, device=dev, resident=True)
+            b = sharded.match_sharded(det, None, THRESHOLD, classes, device=dev, resident=True, exchange=ex)
+            ok = int(a.tobytes() == b.tobytes())
+        except Exception as e:   # noqa: BLE001 - any failure means the host path
+            sys.stderr.write("rank %d: device exchange unavailable (%s)\n" % (rank, e))
+            ok = 0
+        if use_dist:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        exchange_mode = "device" if ok else "host (device exchange failed its check)"
+        if not ok:
+            ex = None
+
     host_t = {"submit": 0.0, "collect": 0.0, "gather": 0.0, "merge": 0.0}
     keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms", "coarse_candidates", "local_evals",
             "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")
@@ -109,15 +134,29 @@ def main():
     last = {"n": 0}
 
     # Pipelined stream (depth 3): the GPU prepares frame k+2 and matches frame k+1 while the host collects / sorts / gathers frame k.
+    inflight_frames, redo = [], []
+    xbuf = np.empty(world * 8192, lm.MATCH_DTYPE) if ex is not None else None    # the exchange writes each frame's list here
+
     def submit(k):
         t0 = time.perf_counter()
         det.selectFrame(k % N_FRAMES)            # device-to-device copy of a frame parked in HBM
-        det.submit(THRESHOLD, classes)
+        if ex is not None:
+            ex.submit(THRESHOLD, classes)        # + sort / all-gather / merge of this frame on the exchange stream
+        else:
+            det.submit(THRESHOLD, classes)
+        inflight_frames.append(k)
         host_t["submit"] += time.perf_counter() - t0
 
     def finish():
         t0 = time.perf_counter()
-        if world == 1:        # Detector.match semantics: canonical sort + unique inside the library call
+        k = inflight_frames.pop(0)
+        if ex is not None:    # the merged, uniqued list of all ranks comes back from the device
+            out = ex.collect(into=xbuf)
+            t1 = t2 = t3 = time.perf_counter()
+            if out is None:   # a block overflowed (same verdict on every rank): this frame is redone through the host path
+                redo.append(k)
+                out = np.zeros(0, lm.MATCH_DTYPE)
+        elif world == 1:      # Detector.match semantics: canonical sort + unique inside the library call
             out = det.collect(sort_unique=True)
             t1 = t2 = t3 = time.perf_counter()
         else:                 # pre-unique records of this rank's shard -> all-gather -> merge on every rank
@@ -144,9 +183,14 @@ def main():
         while inflight:
             finish()
             inflight -= 1
+        while redo:           # nothing in flight here
+            k = redo.pop(0)
+            ex.grow_if_needed()
+            det.selectFrame(k % N_FRAMES)
+            last["n"] = len(sharded.match_sharded(det, None, THRESHOLD, classes, device=dev, resident=True))
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +229,7 @@ def main():
             "config": {"workload": "configs[1]: 1 object x %d templates per GPU, 640x480 RGB-D, Detector(150,[4,8]), threshold 75, planted synthetic bank"
                                    % args.templates,
                        "templates_total": total_templates, "objects": n_obj, "frames_in_stream": N_FRAMES,
-                       "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world,
+                       "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world, "exchange": exchange_mode,
                        "pipeline_depth": PIPELINE_DEPTH,
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
@@ -217,7 +261,7 @@ def main():
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -157,6 +157,8 @@ size_t lm_exchange_block_bytes(int capacity);
 int lm_detector_exchange_pack(lm_detector *d, void *send_block, int capacity);
 int lm_detector_exchange_merge(lm_detector *d, const void *recv_blocks, int world, int capacity);
 int lm_detector_exchange_collect(lm_detector *d, lm_match **out, size_t *n, int *failed);
+/* the same into caller memory (capacity records; world * capacity always suffices): no allocation, one pass */
+int lm_detector_exchange_collect_into(lm_detector *d, lm_match *dst, size_t capacity, size_t *n, int *failed);
 
 /* Detector::match (pybind11.cpp:32-33, LL.cpp:1702-1777).  class_ids may be NULL/0 = all classes.
  * masks: NULL, or two pointers (colour, depth modality), each NULL or a [height][width] uint8 mask.

@@ -294,9 +294,10 @@ def test_device_exchange_merges_shards_like_the_host(lm):
             counts = [int(b[:4].cpu().numpy().view(np.uint32)[0]) for b in send]
             pre = ref.matchResident(thr, ids, sort_unique=False, distinct=True)
             assert sum(counts) == len(pre), (counts, len(pre))
-            for d in dets:
+            into = np.empty(world * cap, lm.MATCH_DTYPE)
+            for r, d in enumerate(dets):
                 d.exchangeMerge(recv.data_ptr(), world, cap)
-                got, failed = d.exchangeCollect()
+                got, failed = d.exchangeCollect() if r % 2 == 0 else d.exchangeCollectInto(into)
                 assert failed == 0 and got.tobytes() == whole.tobytes(), (thr, cap, world, len(got), len(whole))
     # blocks too small for the records: every rank reports the same need, nothing is returned
     dets = [make() for _ in range(2)]
