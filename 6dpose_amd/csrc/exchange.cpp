@@ -22,7 +22,9 @@ static_assert(sizeof(lm_match) == 20, "lm_match is five 32-bit fields");
 
 static int ensure_exchange(lm_detector* d) {
     if (d->xchg.stream) return LM_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&d->xchg.stream, hipStreamNonBlocking));
+    int prio_least = 0, prio_greatest = 0;                                           // background work, and a hardware queue of its own
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);             // (see lm_detector_create)
+    HIP_TRY(hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio_least));
     for (int a = 0; a < lm_detector::kSlots; ++a) HIP_TRY(hipEventCreateWithFlags(&d->xchg.done[a], hipEventDisableTiming));
     return LM_OK;
 }

@@ -74,6 +74,9 @@ def main():
     import sharded
     import synth
 
+    # stdout carries exactly one line, the JSON: whatever libraries print on the way (the RCCL banner at communicator set-up) goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,8 +262,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out))
         sys.stdout.flush()
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
