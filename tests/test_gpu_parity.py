@@ -299,6 +299,22 @@ def test_device_exchange_merges_shards_like_the_host(lm):
                 d.exchangeMerge(recv.data_ptr(), world, cap)
                 got, failed = d.exchangeCollect() if r % 2 == 0 else d.exchangeCollectInto(into)
                 assert failed == 0 and got.tobytes() == whole.tobytes(), (thr, cap, world, len(got), len(whole))
+    # many ranks (more runs than one boundary group of the ranking kernel holds, most of them empty or tiny): one detector
+    # produces the blocks shard by shard, then merges them
+    d = make()
+    whole = ref.matchResident(75.0, ids)
+    for world, cap in ((70, 8192), (150, 4096)):
+        nb = lib.lm_exchange_block_bytes(cap)
+        send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
+        for r in range(world):
+            d.setShard(r, world); d.submit(75.0, ids); d.exchangePack(send[r].data_ptr(), cap)
+            d.collect(sort_unique=False)                                   # retires the frame without the exchange
+        recv = torch.cat(send)
+        d.setShard(0, world); d.submit(75.0, ids); d.exchangePack(send[0].data_ptr(), cap)
+        d.exchangeMerge(recv.data_ptr(), world, cap)
+        got, failed = d.exchangeCollect()
+        assert failed == 0 and got.tobytes() == whole.tobytes(), (world, cap, len(got), len(whole))
+    d.setShard(0, 1)
     # blocks too small for the records: every rank reports the same need, nothing is returned
     dets = [make() for _ in range(2)]
     nb = lib.lm_exchange_block_bytes(256)
