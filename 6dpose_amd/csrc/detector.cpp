@@ -121,7 +121,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
@@ -970,7 +970,12 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
         if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     }
-    if ((rc = d->d_counters.ensure(8 * lm_detector::kSlots))) return rc;          // per result slot
+    if (!d->d_counters.p) {                                                          // per result slot; zero from here on (see k_dedupe)
+        if ((rc = d->d_counters.ensure(8 * lm_detector::kSlots))) return rc;
+        if ((rc = d->d_final.ensure(8 * lm_detector::kSlots))) return rc;
+        HIP_TRY(hipMemset(d->d_counters.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d->d_final.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
+    }
     if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
     if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap)))) return rc;
@@ -979,6 +984,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     hipStream_t s = d->stream, ms = d->mstream;
     const int arena = (int)(d->n_submitted % lm_detector::kSlots);
     unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
+    unsigned long long* final_dev = d->d_final.p + 8 * (size_t)arena;
     Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
     ulonglong2* distinct_keys = d->d_distinct_keys.p + (size_t)d->cand_cap * arena;
     sl.t0 = std::chrono::steady_clock::now();
@@ -1003,7 +1009,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     };
     auto enqueue_match = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[2], ms));
-        HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(unsigned long long), ms));
+        // three kernels, nothing in between: the counters are zero on entry (reset by the previous frame's k_dedupe), k_local
+        // empties the hash table k_dedupe uses, k_dedupe publishes the counts to pinned memory itself
         launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
                       d->cand_cap, counters, ms);
         HIP_TRY(hipEventRecord(sl.ev[3], ms));
@@ -1011,13 +1018,15 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         // the per-block statistics and the results, stored straight into this slot's pinned host memory
         launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
                      d->d_work.p, d->d_cands.p, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
-                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, d->local_blocks, ms);
+                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, d->d_hash.p, (uint32_t)dedupe_table_slots(d->cand_cap),
+                     d->local_blocks, ms);
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
-        // exact duplicates out (they never survive std::unique), distinct records + counts to this slot's pinned memory
-        if (num_work > 0) {
-            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p, distinct_keys, d->num_cus * 2, ms);
-            HIP_TRY(hipMemcpyAsync(sl.h_counters + 1, counters + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
-        }
+        // exact duplicates out (they never survive std::unique): distinct records + counts to this slot's pinned memory
+        if (num_work > 0)
+            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p,
+                          distinct_keys, final_dev, d_hcounters, d->num_cus * 2, ms);
+        else
+            HIP_TRY(hipMemsetAsync(final_dev, 0, 8 * sizeof(unsigned long long), ms));   // nothing searched: no records for NMS / exchange
         return LM_OK;
     };
     auto capture = [&](hipStream_t st, hipGraph_t& g, hipGraphExec_t& ex, auto&& fn) -> bool {
@@ -1043,7 +1052,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8)};
+                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10)};
         if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
             if (ok) memcpy(sl.key, key, sizeof(key));

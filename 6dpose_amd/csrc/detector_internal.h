@@ -108,7 +108,8 @@ struct lm_detector {
     DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
     DevBuf<ulonglong2> d_distinct_keys;             // the distinct records as 128-bit sort keys, per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
-    DevBuf<unsigned long long> d_counters;
+    DevBuf<unsigned long long> d_counters;          // working counters per result slot: zero between frames (k_dedupe's last block resets them)
+    DevBuf<unsigned long long> d_final;             // per result slot: [0] candidates, [1] distinct, [2] alive, [3] key overflow of the finished frame
     uint32_t cand_cap = 1u << 18;
     // Result slots: the refinement kernel of a later frame writes into one pinned buffer while the host
     // collects an earlier frame from another (lm_detector_submit / lm_detector_collect).

@@ -54,7 +54,7 @@ extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int c
     hipStream_t xs = d->xchg.stream;
     HIP_TRY(hipStreamWaitEvent(xs, sl.done, 0));                                    // records + counters of this frame are final
     if ((rc = d->xchg.d_runs.ensure(kXchgMaxCapacity))) return rc;
-    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->cand_cap * slot, d->d_counters.p + 8 * (size_t)slot, d->cand_cap,
+    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->cand_cap,
                          (uint32_t)capacity, d->xchg.d_runs.p, (uint32_t*)send_block, xs);
     HIP_TRY(hipGetLastError());
     d->xchg.state[slot] = 1;

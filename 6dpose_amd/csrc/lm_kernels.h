@@ -59,7 +59,15 @@ struct FeatStrip {        // per feature of a level below the top: strip-plane b
 void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
-                  unsigned long long* block_stats, int grid_blocks, hipStream_t s);
+                  unsigned long long* block_stats, unsigned long long* dedupe_table /*may be null*/, uint32_t dedupe_cap_slots,
+                  int grid_blocks, hipStream_t s);
+// slots of k_dedupe's open-addressing table used for n records (power of two, >= 2n, <= cap_slots = dedupe_table_slots(cand_cap)):
+// k_local empties exactly these, k_dedupe hashes into exactly these
+__host__ __device__ inline uint32_t dedupe_slots_for(uint32_t n, uint32_t cap_slots) {
+    uint32_t t = 1024;
+    while (t < 2u * n && t < cap_slots) t <<= 1;
+    return t < cap_slots ? t : cap_slots;
+}
 
 // ---- on-device NMS + top-K (nms.hip): the caller-side loop of linemod_and_levelup_test.py:331-352 ----
 struct TopkSel {          // one kept detection
@@ -81,9 +89,12 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
 size_t topk_nms_scratch_bytes(uint32_t cap);
 // Exact-duplicate removal of the refined records of a frame (nms.hip): counters[0] = candidate slots (from launch_coarse),
 // counters[1] / [2] receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.
+// counters: the frame's working counters ([0] candidates from k_coarse, [1] distinct, [2] alive, [3] key overflow, [7] block ticket).
+// The last block to finish publishes them — final_dev[0..3] (HBM: on-device NMS, exchange) and final_host[1..3] (pinned) — and zeroes
+// the working set for the slot's next frame, so that no memset / copy node surrounds the matching kernels.
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
                    Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys /*HBM: exchange keys of the distinct records, may be null*/,
-                   int blocks, hipStream_t s);
+                   unsigned long long* final_dev, unsigned long long* final_host, int blocks, hipStream_t s);
 size_t dedupe_table_slots(uint32_t cap);
 
 // ---- multi-GPU exchange of match records (exchange.hip) ----

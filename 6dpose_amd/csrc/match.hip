@@ -223,7 +223,8 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
         float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
-        const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats) {
+        const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats,
+        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots) {
     __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -232,6 +233,11 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
     unsigned long long evals = 0, bytes = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) block_stats[0] = nc;   // candidate count for the host (pinned memory)
+    // the part of k_dedupe's hash table this frame will use, emptied here (k_dedupe runs next on the stream): no memset node
+    if (dedupe_table) {
+        const uint32_t tsize = dedupe_slots_for(num_cands, dedupe_cap_slots);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) dedupe_table[i] = ~0ull;
+    }
 
     for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
         const Candidate cd = cands[ci];
@@ -395,10 +401,11 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
                   const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
-                  unsigned long long* block_stats, int grid_blocks, hipStream_t s) {
+                  unsigned long long* block_stats, unsigned long long* dedupe_table, uint32_t dedupe_cap_slots, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
-                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats);
+                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
+                       dedupe_table, dedupe_cap_slots);
 }
 
 }  // namespace lm

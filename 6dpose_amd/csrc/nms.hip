@@ -233,10 +233,13 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
 // records, counters[2] = records alive before, counters[3] != 0: a record does not fit the key.
 __global__ void __launch_bounds__(256)
 k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__ counters, uint32_t cap,
-         unsigned long long* __restrict__ table, uint32_t table_mask, Candidate* __restrict__ distinct,
-         const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid, ulonglong2* __restrict__ distinct_keys) {
+         unsigned long long* __restrict__ table, uint32_t table_mask /*allocated slots - 1*/, Candidate* __restrict__ distinct,
+         const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid, ulonglong2* __restrict__ distinct_keys,
+         unsigned long long* __restrict__ final_dev, unsigned long long* __restrict__ final_host) {
+    __shared__ bool s_last;
     const unsigned long long nc = counters[0];
     const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
+    table_mask = dedupe_slots_for(n, table_mask + 1) - 1;                            // the slots k_local emptied for this frame
     const int lane = threadIdx.x & 63;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + threadIdx.x;
@@ -280,12 +283,26 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
             }
         }
     }
+    // Publish + reset by the last block to finish (every block has read counters[0] by then).  The counter atomics are
+    // performed at the device's coherence point, so all the ticket needs is that this block's atomics have completed — a wait
+    // on the memory counter.  (__threadfence() here is an agent-scope release = a write-back of the XCD's L2: 9 -> 37 us.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&counters[7], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        const unsigned long long nd = atomicAdd(&counters[1], 0ull), na = atomicAdd(&counters[2], 0ull), bad = atomicAdd(&counters[3], 0ull);
+        final_dev[0] = nc; final_dev[1] = nd; final_dev[2] = na; final_dev[3] = bad;
+        final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
+        for (int q = 0; q < 8; ++q) counters[q] = 0;
+    }
 }
 
 void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys, int blocks, hipStream_t s) {
-    (void)hipMemsetAsync(table, 0xFF, table_slots * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, work_cls, work_tid, distinct_keys);
+                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys,
+                   unsigned long long* final_dev, unsigned long long* final_host, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, work_cls, work_tid,
+                       distinct_keys, final_dev, final_host);
 }
 
 size_t dedupe_table_slots(uint32_t cap) {
