@@ -78,15 +78,27 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     }
     d->pyramid_levels = (int)d->T_at_level.size();
     d->device = device;
-    // The front end of frame k+1 has to overlap the matching kernels of frame k, so the two streams must not land on one hardware
-    // queue (streams sharing a queue run in submission order).  The HIP runtime pools its hardware queues (GPU_MAX_HW_QUEUES, 4 by
-    // default) PER PRIORITY and hands a new stream the least used queue of its pool: in a process that already holds several
-    // normal-priority streams (torch, RCCL) two streams of one priority can end up together — measured: 0.26 -> 0.34 ms/frame.
-    // Different priorities draw from different pools.
+    // Four streams: front end | coarse pass | refinement | duplicate removal + multi-GPU exchange.  Streams that share a hardware
+    // queue run in submission order, so they must land on different queues.  The HIP runtime pools its hardware queues
+    // (GPU_MAX_HW_QUEUES, 4 by default) PER PRIORITY and hands a new stream the least used queue of its pool; a process that
+    // holds other streams (torch's default stream, RCCL's high-priority one) competes for the same pools.  Spread over all three:
+    // front end and coarse pass HIGH (short kernels on the latency path of the next frame), the refinement — the one long kernel,
+    // which fills whatever the short ones leave free — alone in the LOW pool, duplicate removal + exchange NORMAL.
+    // Measured, ms/frame, stand-alone process / torch + RCCL process (world 1, device exchange):
+    //   everything normal 0.223 / 0.34 (front end and matching serialised on one queue);   this assignment 0.223 / 0.222;
+    //   coarse or front end at normal priority 0.223 / 0.230-0.237 (coarse shares a queue: half overlapped);
+    //   exchange at low priority: its five dependent steps take ~50 us each and the frames in flight no longer hide the latency;
+    //   GPU_MAX_HW_QUEUES=8: 0.223 / 0.40-0.50 (more queues than the hardware runs at once: they are time-sliced).
+    // LM_STREAM_PRIO="fcmx" overrides (digits: 0 normal, 1 low, 2 high).
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, 0) != hipSuccess ||
-        hipStreamCreateWithPriority(&d->mstream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+    int prio[4] = {prio_greatest, prio_greatest, prio_least, 0};
+    if (const char* pe = getenv("LM_STREAM_PRIO"))
+        for (int i = 0; i < 4 && pe[i]; ++i) prio[i] = pe[i] == '1' ? prio_least : (pe[i] == '2' ? prio_greatest : 0);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio[0]) != hipSuccess ||
+        hipStreamCreateWithPriority(&d->cstream, hipStreamNonBlocking, prio[1]) != hipSuccess ||
+        hipStreamCreateWithPriority(&d->mstream, hipStreamNonBlocking, prio[2]) != hipSuccess ||
+        hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio[3]) != hipSuccess) {
         delete d;
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
@@ -95,6 +107,8 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         for (auto& e : sl.ev) (void)hipEventCreate(&e);
         (void)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&sl.fe_done, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&sl.local_done, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&sl.coarse_done, hipEventDisableTiming);
     }
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
@@ -115,6 +129,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
+    if (d->cstream) (void)hipStreamSynchronize(d->cstream);
     d->frame_rgb.release(); d->frame_depth.release(); d->nrm_raw.release();
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
     for (auto& b : d->slot_rgb) b.release();
@@ -128,9 +143,9 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.graph) (void)hipGraphDestroy(sl.graph);
-        if (sl.mexec) (void)hipGraphExecDestroy(sl.mexec);
-        if (sl.mgraph) (void)hipGraphDestroy(sl.mgraph);
         if (sl.fe_done) (void)hipEventDestroy(sl.fe_done);
+        if (sl.local_done) (void)hipEventDestroy(sl.local_done);
+        if (sl.coarse_done) (void)hipEventDestroy(sl.coarse_done);
         for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
@@ -146,6 +161,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->mstream) (void)hipStreamDestroy(d->mstream);
+    if (d->cstream) (void)hipStreamDestroy(d->cstream);
     delete d;
 }
 
@@ -903,7 +919,7 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     }
     // frames in flight still read the device-resident work list: let them finish before it is replaced
     if (d->n_submitted != d->n_collected) {
-        HIP_TRY(hipStreamSynchronize(d->mstream));
+        HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
         if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     }
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
@@ -934,7 +950,13 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
 }
 
 static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t match_cap) {
-    if (!d->local_blocks) d->local_blocks = d->num_cus * 8;
+    if (!d->local_blocks) {
+        // 3 workgroups (12 waves) per CU: alone the refinement is as fast as with every wave slot taken (it is bound by the vector
+        // L1, not by latency), and the free slots let the coarse pass of the next frame and the front end run beside it
+        // (pipelined: 0.244 -> 0.222 ms/frame; 2 per CU is slower, 4 already crowds the others out)
+        d->local_blocks = d->num_cus * 3;
+        if (const char* lb = getenv("LM_LOCAL_BLOCKS")) { int v = atoi(lb); if (v > 0) d->local_blocks = v; }
+    }
     if (!sl.h_counters)
         HIP_TRY(hipHostMalloc((void**)&sl.h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
     if (match_cap > sl.match_cap) {
@@ -963,11 +985,11 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     }
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
-    if (d->d_cands.cap < d->cand_cap || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots ||
+    if (d->d_cands.cap < (size_t)d->cand_cap * lm_detector::kSlots || d->d_hash.cap < dedupe_table_slots(d->cand_cap) * lm_detector::kSlots || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots ||
         d->d_distinct_keys.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
         // buffers are about to be replaced (first use, or the candidate capacity was raised): frames still in flight keep
         // using the old ones until they are done
-        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
+        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
         if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     }
     if (!d->d_counters.p) {                                                          // per result slot; zero from here on (see k_dedupe)
@@ -976,15 +998,17 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipMemset(d->d_counters.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d->d_final.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
     }
-    if ((rc = d->d_cands.ensure(d->cand_cap))) return rc;
+    if ((rc = d->d_cands.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;   // per result slot: coarse(k+1) runs beside local(k)
     if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
-    if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap)))) return rc;
+    if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap) * lm_detector::kSlots))) return rc;   // one table per result slot
     if ((rc = d->d_distinct_keys.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream, ms = d->mstream;
     const int arena = (int)(d->n_submitted % lm_detector::kSlots);
     unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
     unsigned long long* final_dev = d->d_final.p + 8 * (size_t)arena;
+    Candidate* cands = d->d_cands.p + (size_t)d->cand_cap * arena;
+    unsigned long long* hash = d->d_hash.p + dedupe_table_slots(d->cand_cap) * (size_t)arena;
     Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
     ulonglong2* distinct_keys = d->d_distinct_keys.p + (size_t)d->cand_cap * arena;
     sl.t0 = std::chrono::steady_clock::now();
@@ -1007,26 +1031,33 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipEventRecord(sl.ev[1], s));
         return LM_OK;
     };
+    auto enqueue_coarse = [&](hipStream_t st) -> int {
+        HIP_TRY(hipEventRecord(sl.ev[2], st));
+        // the counters are zero on entry (reset by the slot's previous k_dedupe)
+        launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, cands,
+                      d->cand_cap, counters, st);
+        HIP_TRY(hipEventRecord(sl.ev[3], st));
+        return LM_OK;
+    };
     auto enqueue_match = [&]() -> int {
-        HIP_TRY(hipEventRecord(sl.ev[2], ms));
-        // three kernels, nothing in between: the counters are zero on entry (reset by the previous frame's k_dedupe), k_local
-        // empties the hash table k_dedupe uses, k_dedupe publishes the counts to pinned memory itself
-        launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->d_cands.p,
-                      d->cand_cap, counters, ms);
-        HIP_TRY(hipEventRecord(sl.ev[3], ms));
-        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like
-        // the per-block statistics and the results, stored straight into this slot's pinned host memory
+        HIP_TRY(hipEventRecord(sl.ev[5], ms));
+        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like the per-block
+        // statistics and the results, stored straight into this slot's pinned host memory; it also empties the hash table
+        // k_dedupe uses
         launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
-                     d->d_work.p, d->d_cands.p, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
-                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, d->d_hash.p, (uint32_t)dedupe_table_slots(d->cand_cap),
+                     d->d_work.p, cands, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
+                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, hash, (uint32_t)dedupe_table_slots(d->cand_cap),
                      d->local_blocks, ms);
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
-        // exact duplicates out (they never survive std::unique): distinct records + counts to this slot's pinned memory
+        return LM_OK;
+    };
+    // exact duplicates out (they never survive std::unique): distinct records + counts to this slot's pinned memory
+    auto enqueue_dedupe = [&](hipStream_t st) -> int {
         if (num_work > 0)
-            launch_dedupe(matches_dev, counters, d->cand_cap, d->d_hash.p, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p,
-                          distinct_keys, final_dev, d_hcounters, d->num_cus * 2, ms);
+            launch_dedupe(matches_dev, counters, d->cand_cap, hash, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p,
+                          distinct_keys, final_dev, d_hcounters, d->num_cus * 2, st);
         else
-            HIP_TRY(hipMemsetAsync(final_dev, 0, 8 * sizeof(unsigned long long), ms));   // nothing searched: no records for NMS / exchange
+            HIP_TRY(hipMemsetAsync(final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
         return LM_OK;
     };
     auto capture = [&](hipStream_t st, hipGraph_t& g, hipGraphExec_t& ex, auto&& fn) -> bool {
@@ -1050,32 +1081,48 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         memcpy(&thr_bits, &threshold, 4);
         const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
-                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)d->d_cands.p ^
+                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)cands ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)d->d_hash.p << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10)};
-        if (!sl.exec || !sl.mexec || memcmp(key, sl.key, sizeof(key)) != 0) {
-            const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe) && capture(ms, sl.mgraph, sl.mexec, enqueue_match);
+                                     ((uint64_t)(uintptr_t)hash << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10)};
+        if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
+            const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe);      // the front end: seven small kernels, one launch
             if (ok) memcpy(sl.key, key, sizeof(key));
             else {   // capture unavailable: fall back to plain launches for good
                 if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
                 if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
-                if (sl.mexec) { (void)hipGraphExecDestroy(sl.mexec); sl.mexec = nullptr; }
-                if (sl.mgraph) { (void)hipGraphDestroy(sl.mgraph); sl.mgraph = nullptr; }
                 d->use_graph = false;
             }
         }
     }
-    if (d->use_graph && sl.exec && sl.mexec) {
+    if (d->use_graph && sl.exec) {
         HIP_TRY(hipGraphLaunch(sl.exec, s));
         d->last_arena = arena;
     } else if ((rc = enqueue_fe())) return rc;
     // events recorded by graph nodes keep their previous state until the node runs: cross-stream ordering and the
     // host wait use eagerly recorded events
     HIP_TRY(hipEventRecord(sl.fe_done, s));
-    HIP_TRY(hipStreamWaitEvent(ms, sl.fe_done, 0));
-    if (d->use_graph && sl.exec && sl.mexec) HIP_TRY(hipGraphLaunch(sl.mexec, ms));
-    else if ((rc = enqueue_match())) return rc;
-    HIP_TRY(hipEventRecord(sl.done, ms));
+    // The three matching kernels (plain launches: a graph of so few nodes gains nothing).  Dependent kernels on one queue start
+    // ~15 us apart, and neither the coarse pass of frame k+1 nor the duplicate removal of frame k needs anything the refinement of
+    // the neighbouring frame touches (per-slot candidates, counters, records, hash table).  So with a frame already in flight each
+    // stage has its own stream — coarse(k+1) and dedupe(k) run beside local(k) / local(k+1) — while a lone frame (synchronous call,
+    // on-device pipeline) keeps all three on the matching stream: no extra cross-stream hops on the latency path.
+    if (d->n_submitted != d->n_collected) {
+        HIP_TRY(hipStreamWaitEvent(d->cstream, sl.fe_done, 0));
+        if ((rc = enqueue_coarse(d->cstream))) return rc;
+        HIP_TRY(hipEventRecord(sl.coarse_done, d->cstream));
+        HIP_TRY(hipStreamWaitEvent(ms, sl.coarse_done, 0));
+        if ((rc = enqueue_match())) return rc;
+        HIP_TRY(hipEventRecord(sl.local_done, ms));
+        HIP_TRY(hipStreamWaitEvent(d->xchg.stream, sl.local_done, 0));
+        if ((rc = enqueue_dedupe(d->xchg.stream))) return rc;
+        HIP_TRY(hipEventRecord(sl.done, d->xchg.stream));
+    } else {
+        HIP_TRY(hipStreamWaitEvent(ms, sl.fe_done, 0));
+        if ((rc = enqueue_coarse(ms))) return rc;
+        if ((rc = enqueue_match())) return rc;
+        if ((rc = enqueue_dedupe(ms))) return rc;
+        HIP_TRY(hipEventRecord(sl.done, ms));
+    }
     sl.t1 = std::chrono::steady_clock::now();
     sl.pending = true;
     ++d->n_submitted;
@@ -1120,7 +1167,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
     if (hipEventElapsedTime(&tm.frontend_ms, sl.ev[0], sl.ev[1]) != hipSuccess ||
         hipEventElapsedTime(&tm.coarse_ms, sl.ev[2], sl.ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, sl.ev[3], sl.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, sl.ev[5], sl.ev[4]) != hipSuccess ||
         hipEventElapsedTime(&tm.total_ms, sl.ev[0], sl.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
         if (d->use_graph && d->graph_events_ok) {   // event nodes of a graph are not timeable here: time with plain launches
@@ -1173,6 +1220,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     *out = res; *n_out = n;
     return LM_OK;
 }
+
+extern "C" int lm_detector_max_in_flight(void) { return lm_detector::kSlots; }
 
 extern "C" int lm_detector_submit(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");

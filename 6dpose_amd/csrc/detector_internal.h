@@ -59,7 +59,8 @@ struct lm_detector {
     // device
     int device = 0;
     hipStream_t stream = nullptr;       // frame upload / select + front end (and addTemplate)
-    hipStream_t mstream = nullptr;      // coarse + refinement (+ the pipeline's NMS / ICP): runs frame k while `stream` prepares frame k+1
+    hipStream_t mstream = nullptr;      // refinement (a lone frame: all three matching kernels; + the pipeline's NMS / ICP): frame k, while `stream` prepares frame k+1
+    hipStream_t cstream = nullptr;      // coarse pass of frame k+1 beside the refinement of frame k (pipelined submits only)
     hipEvent_t ev[8] = {};
     int shard_rank = 0, shard_world = 1;
 
@@ -69,7 +70,7 @@ struct lm_detector {
     DevBuf<uint8_t> frame_rgb;
     DevBuf<uint16_t> frame_depth;
     DevBuf<uint8_t> nrm_raw;                    // normals before the median (level 0)
-    static constexpr int kSlots = 3;            // frames in flight (lm_detector_submit / collect)
+    static constexpr int kSlots = 4;            // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight)
     DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
                                                 // while the matching kernels of frame k read the other
     int last_arena = 0;                         // set written by the most recent front end (lm_detector_read_stage)
@@ -118,12 +119,14 @@ struct lm_detector {
         Candidate* h_distinct = nullptr;            // pinned: the same without exact duplicates (k_dedupe), unordered
         uint32_t match_cap = 0;
         unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [1] distinct records, [2] records alive, [8..] 2 words of statistics per refinement block
-        hipGraph_t graph = nullptr, mgraph = nullptr;       // front end (on `stream`) / matching (on `mstream`), captured once each
-        hipGraphExec_t exec = nullptr, mexec = nullptr;
+        hipGraph_t graph = nullptr;                 // front end (on `stream`), captured once per configuration
+        hipGraphExec_t exec = nullptr;
         uint64_t key[8] = {};
-        hipEvent_t ev[5] = {};                      // stage timing (recorded inside the graph)
+        hipEvent_t ev[6] = {};                      // stage timing (recorded inside the graphs): front end 0-1, coarse 2-3 (on `stream`), refinement 5-4 (on `mstream`)
         hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
         hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
+        hipEvent_t coarse_done = nullptr;           // coarse pass of this slot finished (eager, on `cstream`): `mstream` waits for it
+        hipEvent_t local_done = nullptr;            // refinement of this slot finished (eager, on `mstream`): the exchange stream (duplicate removal) waits for it
         bool pending = false;
         float threshold = 0.f, h2d_ms = 0.f;
         int num_work = 0;
@@ -136,7 +139,7 @@ struct lm_detector {
     // multi-GPU exchange on the device (exchange.cpp): its own stream, so that the sort of frame k's records, the caller's
     // RCCL all-gather and the merge run beside the matching kernels of frame k+1
     struct Exchange {
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr;               // created with the detector; also runs the duplicate removal of pipelined frames
         DevBuf<int32_t> d_merged[kSlots];
         DevBuf<ulonglong2> d_runs;                  // scratch of the per-rank sort
         int32_t* h_merged[kSlots] = {};             // pinned

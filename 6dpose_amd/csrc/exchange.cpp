@@ -21,10 +21,7 @@ using namespace lm;
 static_assert(sizeof(lm_match) == 20, "lm_match is five 32-bit fields");
 
 static int ensure_exchange(lm_detector* d) {
-    if (d->xchg.stream) return LM_OK;
-    int prio_least = 0, prio_greatest = 0;                                           // background work, and a hardware queue of its own
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);             // (see lm_detector_create)
-    HIP_TRY(hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio_least));
+    if (d->xchg.done[0]) return LM_OK;                                               // the stream itself is created with the detector
     for (int a = 0; a < lm_detector::kSlots; ++a) HIP_TRY(hipEventCreateWithFlags(&d->xchg.done[a], hipEventDisableTiming));
     return LM_OK;
 }

@@ -157,6 +157,7 @@ def load_library():
     lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
                                                ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_submit.argtypes = [P, F, ctypes.POINTER(S), I]
+    lib.lm_detector_max_in_flight.restype = I
     lib.lm_detector_exchange_stream.argtypes = [P]
     lib.lm_detector_exchange_stream.restype = P
     lib.lm_exchange_block_bytes.argtypes = [I]

@@ -58,7 +58,7 @@ class DeviceExchange:
     """Sharded Detector.match with the exchange on the device (lm_detector_exchange_*; kernels in csrc/exchange.hip).
 
         ex = DeviceExchange(detector, device)            # after init_process_group; detector.setShard is done here
-        ex.submit(threshold, class_ids)                  # up to three frames in flight
+        ex.submit(threshold, class_ids)                  # up to lm_detector_max_in_flight() frames in flight
         records = ex.collect()                           # oldest frame: canonical list, identical on every rank
 
     collect() returns None when a rank had more distinct records than `capacity` or overflowed its candidate buffer —
@@ -79,7 +79,7 @@ class DeviceExchange:
         self.device_collective = self.collective and dist.get_backend(group) == "nccl"
         detector.setShard(self.rank, self.world)
         self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
-        self.slots = 3
+        self.slots = lm.load_library().lm_detector_max_in_flight()
         self.next = 0
         self._alloc(capacity)
 

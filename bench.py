@@ -39,7 +39,7 @@ NFEAT = (150, 75)
 N_TEMPLATES = 2000
 THRESHOLD = 75.0
 N_FRAMES = 4
-PIPELINE_DEPTH = 3         # frames in flight: front end of k+2 | matching of k+1 | host collects k
+PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "3"))   # frames in flight: front end of k+2 | matching of k+1 | host collects k
 HBM_PEAK_GBS = 8000.0
 
 
@@ -197,6 +197,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The roofline leg: frames one at a time, so that every kernel runs alone (in the pipelined region below the coarse pass of
+    # frame k+1 and the duplicate removal of frame k-1 share the GPU with the refinement of frame k, which stretches each
+    # kernel's own duration while shortening the frame).  HIP events on the kernels' stream, recorded by the library.
+    excl = {"coarse_ms": 0.0, "local_ms": 0.0, "coarse_bytes": 0.0, "local_bytes": 0.0}
+    EXCL = 20
+    for k in range(3 + EXCL):
+        det.selectFrame(k % N_FRAMES)
+        det.matchResident(THRESHOLD, classes, sort_unique=False, distinct=True)
+        if k >= 3:
+            tm = det.lastTimings()
+            for q in excl:
+                excl[q] += tm[q] / EXCL
+
     run(args.warmup)
     fence()
     for q in host_t:
@@ -218,12 +231,13 @@ def main():
     value = total_templates * (W * H / 1e6) * K / dt
 
     if rank == 0:
-        # dominant kernel of this rank
-        if mean["local_ms"] >= mean["coarse_ms"]:
-            kname, kms, kbytes = "k_local", mean["local_ms"], mean["local_bytes"]
+        # dominant kernel of this rank, timed alone (see the roofline leg above)
+        if excl["local_ms"] >= excl["coarse_ms"]:
+            kname, kms, kbytes, kpipe = "k_local", excl["local_ms"], excl["local_bytes"], mean["local_ms"]
         else:
-            kname, kms, kbytes = "k_coarse", mean["coarse_ms"], mean["coarse_bytes"]
+            kname, kms, kbytes, kpipe = "k_coarse", excl["coarse_ms"], excl["coarse_bytes"], mean["coarse_ms"]
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        gbps = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         out = {
             "metric": "templates*Mpixels matched/sec on 640x480 RGB-D",
             "value": value, "unit": "templates*Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,8 +256,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms,
-                         "other": {"k_coarse_GBps": (mean["coarse_bytes"] / (mean["coarse_ms"] * 1e-3) / 1e9) if mean["coarse_ms"] > 0 else 0.0,
-                                   "k_local_GBps": (mean["local_bytes"] / (mean["local_ms"] * 1e-3) / 1e9) if mean["local_ms"] > 0 else 0.0}},
+                         "duration_source": "HIP events around the kernel on its stream, %d frames submitted one at a time inside bench.py (the kernel alone on the GPU)" % EXCL,
+                         "in_pipelined_region": {"kernel_ms": kpipe, "GBps": gbps(kbytes, kpipe),
+                                                 "note": "same launches in the timed region, sharing the GPU with the next frame's coarse pass and front end; "
+                                                         "frame-level: (coarse + local algorithmic bytes) / ms_per_step = %.0f GB/s"
+                                                         % gbps(mean["coarse_bytes"] + mean["local_bytes"], dt / K * 1e3)},
+                         "other": {"k_coarse_GBps": gbps(excl["coarse_bytes"], excl["coarse_ms"]), "k_local_GBps": gbps(excl["local_bytes"], excl["local_ms"])}},
         }
         if world == 1:
             out["extras"] = {"synchronous_call": sync_latency(det, classes, args.templates),

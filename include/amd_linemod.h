@@ -148,10 +148,11 @@ int lm_detector_set_shard(lm_detector *d, int rank, int world);
  *   lm_detector_exchange_collect(d, &out, &n, &failed) waits for the oldest frame in flight: the same list on every rank,
  *                                                   identical to an unsharded lm_detector_match (lm_free(out))
  * pack / merge apply to the most recently submitted frame and only enqueue work on the exchange stream (hipStream_t
- * returned as void*); up to three frames can be in flight.  capacity: power of two in [256, 8192], the same on every rank.
+ * returned as void*); up to lm_detector_max_in_flight() frames can be in flight.  capacity: power of two in [256, 8192], the same on every rank.
  * *failed != 0 (on every rank alike, *out == NULL): > 0 some rank had that many distinct records (> capacity), < 0 a
  * candidate buffer overflowed or a field did not fit the key — rerun the frame through lm_detector_match_resident +
  * lm_merge_matches (sharded.py does). */
+int lm_detector_max_in_flight(void);
 void *lm_detector_exchange_stream(lm_detector *d);
 size_t lm_exchange_block_bytes(int capacity);
 int lm_detector_exchange_pack(lm_detector *d, void *send_block, int capacity);
@@ -185,7 +186,7 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
                                int sort_unique, lm_match **out, size_t *n);
 /* Pipelined stream mode: lm_detector_submit enqueues front end + matching of the current
  * frame and returns; lm_detector_collect waits for the OLDEST submitted frame and returns its matches.
- * Up to three frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
+ * Up to lm_detector_max_in_flight() (four) frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
  * streams while the host sorts frame k:
  *   select_frame(k+2); submit(); collect() -> frame k; ...
  * lm_detector_match_resident == submit + collect. */

@@ -345,11 +345,11 @@ def test_device_exchange_merges_shards_like_the_host(lm):
 
 
 def test_pipelined_submit_collect_equals_synchronous(lm):
-    """Stream mode: three frames in flight (front end of k+2 and matching of k+1 on two streams while the host
-    collects k) returns exactly what the synchronous calls return, frame by frame, also when the stream wraps around
-    the result slots; a fourth submit without a collect is refused."""
+    """Stream mode: the maximum number of frames in flight (front end of k+2, coarse pass / refinement of k+1 on their
+    streams while the host collects k) returns exactly what the synchronous calls return, frame by frame, also when the
+    stream wraps around the result slots; one more submit without a collect is refused."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
-    frames = [synth.make_frame(50 + i, W, H) for i in range(4)]
+    frames = [synth.make_frame(50 + i, W, H) for i in range(5)]
     od = lo.OracleDetector(nfeat[0], T)
     pyr = od.quantize_pyramid(*frames[0])
     bank = synth.make_planted_bank(61, 150, [(p[0], p[1]) for p in pyr], T, nfeat)
@@ -360,19 +360,19 @@ def test_pipelined_submit_collect_equals_synchronous(lm):
         det.storeFrame(i, f)
         want.append(det.matchArray(list(f), 70.0, ["o"]))
     assert len(want[0]) > 0
-    got = []
-    det.selectFrame(0); det.submit(70.0, ["o"])
-    det.selectFrame(1); det.submit(70.0, ["o"])
-    det.selectFrame(2); det.submit(70.0, ["o"])
+    depth = lm.load_library().lm_detector_max_in_flight()
+    assert depth >= 3
+    got, order = [], []
+    for k in range(depth):
+        det.selectFrame(k % 5); det.submit(70.0, ["o"]); order.append(k % 5)
     with pytest.raises(RuntimeError, match="in flight"):
         det.submit(70.0, ["o"])
     got.append(det.collect())
-    order = [0, 1, 2]
-    for k in range(3, 11):                                   # keep three in flight for a while
-        det.selectFrame(k % 4); det.submit(70.0, ["o"]); order.append(k % 4)
+    for k in range(depth, depth + 9):                         # keep the pipeline full for a while
+        det.selectFrame(k % 5); det.submit(70.0, ["o"]); order.append(k % 5)
         got.append(det.collect())
-    got.append(det.collect())
-    got.append(det.collect())
+    for _ in range(depth - 1):
+        got.append(det.collect())
     with pytest.raises(RuntimeError, match="no frame in flight"):
         det.collect()
     assert len(got) == len(order)
