@@ -79,7 +79,8 @@ def main():
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LM_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # LM_BENCH_DEVICE / LM_BENCH_BACKEND: rehearsal of the
+    backend = os.environ.get("LM_BENCH_BACKEND", "nccl")                                      # world > 1 path on a 1-GPU box (gloo, all ranks on one device)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU (libamdlinemod has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -87,7 +88,7 @@ def main():
     use_dist = world > 1 or (args.exchange == "device" and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     n_obj = max(1, world)
 
     det = lm.Detector(NFEAT[0], T_LEVELS, device=local_rank)

@@ -28,3 +28,6 @@ for hyp in range(min(n, 6)):
     d = ctx.read_debug(hyp, 3)
     print("hyp %d n_model %d n_scene %d n_src %d n_tgt %d grid %dx%d cell %.4f fitness %.3f iters %d" %
           (hyp, d[19], d[20], res[hyp]["n_source"], res[hyp]["n_target"], d[21], d[22], d[23], res[hyp]["residual"], res[hyp]["iterations"]), "rings", d[31], "generic", d[32])
+    it, clk = d[24], d[25:33]
+    ev = max(clk[5], 1)
+    print("        evals %2d  cycles/eval of workgroup 0: prologue %6.0f staging+transform %6.0f queue %6.0f search %6.0f sums %6.0f" % (clk[5], clk[0] / ev, clk[1] / ev, clk[2] / ev, clk[3] / ev, clk[4] / ev))
