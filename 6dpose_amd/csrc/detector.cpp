@@ -137,6 +137,8 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
     d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    for (int l = 0; l < kMaxLevels; ++l) { d->train.mask[l].release(); d->train.lab[l].release(); d->train.hrun[l].release(); }
+    d->train.keys.release(); d->train.counts.release(); d->train.bbox.release(); d->train.out.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
@@ -389,8 +391,35 @@ extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, cons
 }
 
 // render_train (linemod_and_levelup_test.py:170-252) on the device: the rendered colour / depth images go from the
-// rasteriser's buffers into the detector's frame buffers without touching the host; only the depth comes back (the
-// object mask depth > 0 and the extent of the rendering) together with the maps the greedy feature selection reads.
+// rasteriser's buffers into the detector's frame buffers without touching the host, the quantisers and the feature selection
+// (train.hip) run there too, and only the chosen features, the bounding boxes and the candidate counts come back — once per
+// chunk of views, not per view.  A view whose candidate lists exceed what the selection kernel sorts in LDS (very large
+// objects), or a detector with more than kTrainMaxFeatures features, takes the host selection (add_template_resident), which
+// yields the same templates; LM_TRAIN_HOST=1 forces it (tests compare the two).
+static int add_rendered_view_host(lm_detector* d, lm_mesh* m, int i, int width, int height, const char* class_id, std::vector<uint16_t>& hdepth,
+                                  std::vector<uint8_t>& hmask, int32_t* box_wh_view) {
+    const size_t npx = (size_t)width * height;
+    d->frame_valid = false;
+    d->have_mask[0] = d->have_mask[1] = false;
+    HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(hdepth.data(), m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    int x0 = width, y0 = height, x1 = -1, y1 = -1;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const bool on = hdepth[(size_t)y * width + x] > 0;
+            hmask[(size_t)y * width + x] = on ? 255 : 0;                       // mask = (depth > 0) * 255 (:238)
+            if (on) { x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y); }
+        }
+    if (box_wh_view) {                                                         // xmax - xmin, ymax - ymin (:235-236)
+        box_wh_view[0] = x1 >= 0 ? x1 - x0 : 0;
+        box_wh_view[1] = y1 >= 0 ? y1 - y0 : 0;
+    }
+    if (x1 < 0) return -1;
+    return add_template_resident(d, hmask.data(), width, height, class_id);
+}
+
 extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, const char* class_id, int count, int width, int height,
                                                   const float* Ks, const float* Rs, const float* ts, float clip_near, float clip_far,
                                                   float ambient, int ssaa, int32_t* template_ids, int32_t* box_wh) {
@@ -405,6 +434,12 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)2 << 30) / std::max<size_t>(per_view, 1)));
     std::vector<uint16_t> hdepth(npx);
     std::vector<uint8_t> hmask(npx);
+    const char* force_host = getenv("LM_TRAIN_HOST");
+    const bool on_device = !(force_host && force_host[0] && force_host[0] != '0') && d->num_features >= 1 && d->num_features <= kTrainMaxFeatures;
+    const int L = d->pyramid_levels;
+    const int nf_cap = std::max(1, d->num_features);
+    const size_t out_words = 4 + 3 * (size_t)nf_cap;
+    std::vector<int32_t> h_out, h_bbox;
     int rc;
     for (int c0 = 0; c0 < count; c0 += chunk) {
         const int n = std::min(chunk, count - c0);
@@ -412,29 +447,86 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
                                         ambient, ssaa, true, true)))
             return rc;
         HIP_TRY(hipStreamSynchronize(m->s));
-        for (int i = 0; i < n; ++i) {
-            d->frame_valid = false;
-            if ((rc = setup_geometry(d, width, height, false))) return rc;
-            d->have_mask[0] = d->have_mask[1] = false;
-            HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, d->stream));
-            HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, d->stream));
-            HIP_TRY(hipMemcpyAsync(hdepth.data(), m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToHost, d->stream));
-            HIP_TRY(hipStreamSynchronize(d->stream));
-            int x0 = width, y0 = height, x1 = -1, y1 = -1;
-            for (int y = 0; y < height; ++y)
-                for (int x = 0; x < width; ++x) {
-                    const bool on = hdepth[(size_t)y * width + x] > 0;
-                    hmask[(size_t)y * width + x] = on ? 255 : 0;                       // mask = (depth > 0) * 255 (:238)
-                    if (on) { x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y); }
-                }
-            if (box_wh) {                                                              // xmax - xmin, ymax - ymin (:235-236)
-                box_wh[2 * ((size_t)c0 + i)] = x1 >= 0 ? x1 - x0 : 0;
-                box_wh[2 * ((size_t)c0 + i) + 1] = y1 >= 0 ? y1 - y0 : 0;
-            }
-            int id = -1;
-            if (x1 >= 0) {
-                id = add_template_resident(d, hmask.data(), width, height, class_id);
+        if ((rc = setup_geometry(d, width, height, false))) return rc;
+        if (!on_device) {
+            for (int i = 0; i < n; ++i) {
+                const int id = add_rendered_view_host(d, m, i, width, height, class_id, hdepth, hmask, box_wh ? box_wh + 2 * ((size_t)c0 + i) : nullptr);
                 if (id < -1) return id;
+                template_ids[(size_t)c0 + i] = id;
+            }
+            continue;
+        }
+        // ---- device selection: prepare every view of the chunk, select them all in one launch ----
+        lm_detector::Train& T = d->train;
+        TrainGeom g{};
+        g.levels = L;
+        for (int l = 0; l < L; ++l) {
+            const LevelBufs& b = d->lvl[l];
+            const size_t nl = (size_t)b.W * b.H;
+            if ((rc = T.mask[l].ensure(nl)) || (rc = T.lab[l].ensure(nl)) || (rc = T.hrun[l].ensure(nl))) return rc;
+            g.W[l] = b.W; g.H[l] = b.H; g.mag[l] = b.mag.p; g.ang[l] = b.ang.p; g.nrm[l] = b.nrm.p;
+            g.mask[l] = T.mask[l].p; g.lab[l] = T.lab[l].p; g.hrun[l] = T.hrun[l].p;
+        }
+        const size_t keys_view = (size_t)L * 2 * kTrainCap, counts_view = (size_t)L * 16;
+        if ((rc = T.keys.ensure(keys_view * n)) || (rc = T.counts.ensure(counts_view * n)) || (rc = T.bbox.ensure(4 * (size_t)n)) ||
+            (rc = T.out.ensure((size_t)n * L * 2 * out_words)))
+            return rc;
+        hipStream_t s = d->stream;
+        HIP_TRY(hipMemsetAsync(T.counts.p, 0, counts_view * n * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(T.bbox.p, 0x80, 4 * (size_t)n * sizeof(int32_t), s));        // large negative: k_train_mask takes maxima
+        d->frame_valid = false;
+        d->have_mask[0] = d->have_mask[1] = false;
+        const float strong_sq = d->strong_threshold * d->strong_threshold;
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, s));
+            if ((rc = run_frontend(d, false))) return rc;
+            launch_train_prep(d->frame_depth.p, g, strong_sq, d->extract_threshold, T.keys.p + keys_view * i, kTrainCap, T.counts.p + counts_view * i,
+                              T.bbox.p + 4 * (size_t)i, s);
+        }
+        if (launch_train_select(T.keys.p, T.counts.p, g, kTrainCap, d->num_features, nf_cap, n, T.out.p, s))
+            return lm_set_error(LM_ERR_HIP, "cannot reserve LDS for the selection kernel");
+        HIP_TRY(hipGetLastError());
+        h_out.resize((size_t)n * L * 2 * out_words);
+        h_bbox.resize(4 * (size_t)n);
+        HIP_TRY(hipMemcpyAsync(h_out.data(), T.out.p, h_out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_bbox.data(), T.bbox.p, h_bbox.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<TemplatePyramid>& tps = d->class_templates[class_id];   // created even when every view fails, LL.cpp:1947
+        d->bank_dirty = true;
+        for (int i = 0; i < n; ++i) {
+            const int32_t* bb = &h_bbox[4 * (size_t)i];
+            const bool any = bb[2] >= 0;
+            int id = -1;
+            bool host_path = false;
+            if (any) {
+                bool ok = true;
+                for (int e = 0; e < 2 * L; ++e) {
+                    const int32_t st = h_out[((size_t)i * L * 2 + e) * out_words];
+                    host_path |= st == 2;
+                    ok &= st == 1;
+                }
+                if (host_path) {                                               // this view through the host selection, in view order
+                    id = add_rendered_view_host(d, m, i, width, height, class_id, hdepth, hmask, nullptr);
+                    if (id < -1) return id;
+                } else if (ok) {
+                    TemplatePyramid tp((size_t)2 * L);
+                    for (int e = 0; e < 2 * L; ++e) {
+                        const int32_t* o = &h_out[((size_t)i * L * 2 + e) * out_words];
+                        Template& t = tp[e];
+                        t.pyramid_level = e / 2;
+                        t.features.resize((size_t)o[1]);
+                        for (int k = 0; k < o[1]; ++k) t.features[k] = Feature{o[4 + 3 * k], o[4 + 3 * k + 1], o[4 + 3 * k + 2]};
+                    }
+                    crop_templates(tp);
+                    if ((rc = validate_pyramid(d, tp))) return rc;
+                    tps.push_back(std::move(tp));
+                    id = (int)tps.size() - 1;
+                }
+            }
+            if (box_wh) {                                                      // xmax - xmin, ymax - ymin (:235-236)
+                box_wh[2 * ((size_t)c0 + i)] = any ? bb[2] + bb[0] : 0;
+                box_wh[2 * ((size_t)c0 + i) + 1] = any ? bb[3] + bb[1] : 0;
             }
             template_ids[(size_t)c0 + i] = id;
         }

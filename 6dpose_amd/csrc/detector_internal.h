@@ -151,6 +151,15 @@ struct lm_detector {
     int local_blocks = 0;
     int num_cus = 256;
 
+    // template extraction on the device (train.hip): scratch of the view being prepared + per-view candidate lists of a chunk
+    struct Train {
+        DevBuf<uint8_t> mask[kMaxLevels], lab[kMaxLevels];
+        DevBuf<int32_t> hrun[kMaxLevels];
+        DevBuf<unsigned long long> keys;
+        DevBuf<uint32_t> counts;
+        DevBuf<int32_t> bbox, out;
+    } train;
+
     bool use_graph = true;
     bool graph_events_ok = true;
 

@@ -97,6 +97,26 @@ void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, u
                    unsigned long long* final_dev, unsigned long long* final_host, int blocks, hipStream_t s);
 size_t dedupe_table_slots(uint32_t cap);
 
+// ---- template extraction on the device (train.hip; LL.cpp:589-643, 888-966, 279-318) ----
+constexpr int kTrainMaxFeatures = 1024;       // features per template the selection kernel keeps in LDS
+constexpr uint32_t kTrainCap = 16384;         // candidates per (view, level, modality) sorted in LDS (128 KB); more -> host path
+struct TrainGeom {                            // the maps of the view being prepared (the detector's per-level buffers + scratch)
+    int levels;
+    int W[kMaxLevels], H[kMaxLevels];
+    const float* mag[kMaxLevels];
+    const uint8_t* ang[kMaxLevels];
+    const uint8_t* nrm[kMaxLevels];
+    uint8_t* mask[kMaxLevels];                // object mask pyramid
+    uint8_t* lab[kMaxLevels];                 // normal label + 1 inside the twice-eroded mask, else 0
+    int32_t* hrun[kMaxLevels];                // distance to the end of the pixel's same-label run along its row
+};
+// keys_view: [levels][2][cap] sort keys / (distance, position, label) records; counts_view: [levels][16]; bbox_view: [4] = {max(-x), max(-y), max(x), max(y)}
+void launch_train_prep(const uint16_t* depth, const TrainGeom& g, float strong_sq, int extract_threshold, unsigned long long* keys_view,
+                       uint32_t cap, uint32_t* counts_view, int32_t* bbox_view, hipStream_t s);
+// out: [views][levels][2][4 + 3 * nf_cap]: status (1 ok, 0 too few candidates, 2 leave it to the host path), count, -, -, then x, y, label
+int launch_train_select(const unsigned long long* keys, const uint32_t* counts, const TrainGeom& g, uint32_t cap, int num_features, int nf_cap,
+                        int views, int32_t* out, hipStream_t s);
+
 // ---- multi-GPU exchange of match records (exchange.hip) ----
 // Block a rank contributes to the all-gather: 4 header words {count, flags, capacity, 0} + capacity 128-bit keys (a sorted run).
 constexpr uint32_t kXchgRunOverflow = 1;      // more distinct records than the block holds (count says how many)

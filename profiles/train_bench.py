@@ -19,6 +19,15 @@ t0 = time.perf_counter(); depth = mesh.render((640, 480), K, Rs, ts, mode="depth
 t0 = time.perf_counter(); rgb, depth = mesh.render((640, 480), K, Rs, ts); t_both = time.perf_counter() - t0
 det = lm.Detector(150, [4, 8], device=0)
 t0 = time.perf_counter(); ids, wh = lm.add_templates_rendered(det, mesh, "obj", (640, 480), K, Rs, ts); t_train = time.perf_counter() - t0
-print(json.dumps({"views": n, "triangles": int(len(F)), "render_depth_views_per_s": n / t_depth, "render_rgb_depth_ssaa4_views_per_s": n / t_both,
+os.environ["LM_TRAIN_HOST"] = "1"
+det_h = lm.Detector(150, [4, 8], device=0)
+nh = min(n, 400)
+t0 = time.perf_counter(); ids_h, _ = lm.add_templates_rendered(det_h, mesh, "obj", (640, 480), K, Rs[:nh], ts[:nh]); t_host = time.perf_counter() - t0
+del os.environ["LM_TRAIN_HOST"]
+assert ids_h.tolist() == ids[:nh].tolist()
+for t in range(0, int((ids_h >= 0).sum()), 37):
+    for a, b in zip(det.getTemplates("obj", t), det_h.getTemplates("obj", t)):
+        assert np.array_equal(a.features, b.features) and (a.width, a.height) == (b.width, b.height)
+print(json.dumps({"views": n, "render_train_host_selection_views_per_s": nh / t_host, "triangles": int(len(F)), "render_depth_views_per_s": n / t_depth, "render_rgb_depth_ssaa4_views_per_s": n / t_both,
                   "render_train_views_per_s": n / t_train, "templates_added": int((ids >= 0).sum()),
                   "mean_object_pixels": float((depth > 0).sum() / n)}))

@@ -115,14 +115,17 @@ def test_ply_files_load_like_arrays(lm, tmp_path):
         lm.Mesh(str(tmp_path / "missing.ply"))
 
 
-def test_rendered_training_equals_the_host_round_trip(lm):
-    """render_train on the device (lm_detector_add_templates_rendered) adds exactly the templates that rendering to host
-    images and calling Detector.addTemplate per view adds (linemod_and_levelup_test.py:203-247), and reports the depth extent."""
-    V, F, N, C = icosphere(3, radius=70.0, seed=11)
+@pytest.mark.parametrize("nfeat,T,views,dist,level", [(63, [4, 8], 5, 520.0, 3), (150, [4, 8], 14, 450.0, 3), (64, [4, 4, 8], 6, 600.0, 2), (150, [4, 8], 4, 3000.0, 2)])
+def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist, level):
+    """render_train on the device (lm_detector_add_templates_rendered: rasteriser, quantisers AND the feature selection of
+    train.hip) adds exactly the templates that rendering to host images and calling Detector.addTemplate per view adds
+    (linemod_and_levelup_test.py:203-247; host selection pinned to the reference golden), and reports the depth extent.
+    The last case is an object too small to give enough features: -1 for every view, like the reference."""
+    V, F, N, C = icosphere(level, radius=70.0, seed=11)
     C[:] = (C // 64) * 64 + 30                                                             # blocky colours: gradients for the colour modality
-    Rs, ts = look_at_views(5, dist=520.0, seed=9)
+    Rs, ts = look_at_views(views, dist=dist, seed=9)
     mesh = lm.Mesh(V, F, normals=N, colors=C)
-    det_a, det_b = lm.Detector(63, [4, 8], device=0), lm.Detector(63, [4, 8], device=0)
+    det_a, det_b = lm.Detector(nfeat, T, device=0), lm.Detector(nfeat, T, device=0)
     ids, wh = lm.add_templates_rendered(det_a, mesh, "obj", (640, 480), K_CAM, Rs, ts)
     rgb, depth = mesh.render((640, 480), K_CAM, Rs, ts)
     want_ids = []
@@ -131,10 +134,19 @@ def test_rendered_training_equals_the_host_round_trip(lm):
         want_ids.append(det_b.addTemplate([rgb[i], depth[i]], "obj", mask))
         ys, xs = np.nonzero(depth[i])
         assert tuple(wh[i]) == (xs.max() - xs.min(), ys.max() - ys.min())
-    assert ids.tolist() == want_ids and max(want_ids) >= 0
+    assert ids.tolist() == want_ids
+    assert (max(want_ids) >= 0) == (dist < 2000)
     for t in [t for t in want_ids if t >= 0]:
         for a, b in zip(det_a.getTemplates("obj", t), det_b.getTemplates("obj", t)):
             assert (a.width, a.height, a.pyramid_level) == (b.width, b.height, b.pyramid_level) and np.array_equal(a.features, b.features)
+    if dist < 2000:                                                                        # the forced host selection gives the same bank
+        os.environ["LM_TRAIN_HOST"] = "1"
+        try:
+            det_c = lm.Detector(nfeat, T, device=0)
+            ids_c, _ = lm.add_templates_rendered(det_c, mesh, "obj", (640, 480), K_CAM, Rs[:3], ts[:3])
+        finally:
+            del os.environ["LM_TRAIN_HOST"]
+        assert ids_c.tolist() == want_ids[:3]
 
 
 def test_pipeline_views_rendered_on_the_device(lm):
