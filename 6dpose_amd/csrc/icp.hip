@@ -721,14 +721,37 @@ static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpSt
         bool exact = true;
         unsigned long long v = 0;
         {
-            // k-th smallest squared distance by bisection on the (non-negative) bit pattern
+            // k-th smallest squared distance by bisection on the (non-negative) bit pattern.  Invariant: `below` patterns are < v,
+            // `upto` are < v + 2^(bit+1), below < k <= upto; when one pattern is left in between it is the k-th smallest and the
+            // remaining bits need not be walked (typically after ~25 of the 63 steps)
+            int below = 0, upto = 0;
+#pragma unroll
+            for (int s = 0; s < kKnnSlots; ++s)
+                if (s < nslots) upto += __popcll(__ballot(dreg[s] == dreg[s]));          // every pattern is below 2^63 (no NaN in the cache)
             for (int bit = 62; bit >= 0; --bit) {
                 const unsigned long long t = v | (1ull << bit);
                 int c = 0;
 #pragma unroll
                 for (int s = 0; s < kKnnSlots; ++s)
                     if (s < nslots) c += __popcll(__ballot((unsigned long long)__double_as_longlong(dreg[s]) < t));
-                if (c < k) v = t;
+                if (c < k) { v = t; below = c; } else upto = c;
+                if (upto - below == 1 && upto >= k) {
+                    const unsigned long long top = bit == 0 ? v + 1 : (c < k ? v + (1ull << bit) : t);   // exclusive end of the interval
+                    unsigned long long mine = ~0ull;
+#pragma unroll
+                    for (int s = 0; s < kKnnSlots; ++s)
+                        if (s < nslots) {
+                            const unsigned long long u = (unsigned long long)__double_as_longlong(dreg[s]);
+                            if (u >= v && u < top && u < mine) mine = u;
+                        }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(mine >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mine, o, 64);
+                        mine = other < mine ? other : mine;
+                    }
+                    v = mine;
+                    break;
+                }
             }
             // lanes that kept only their smallest: a lane whose largest kept distance does not exceed the k-th smallest may
             // have dropped a neighbour -> the per-lane lists are not proof enough, take the pass-by-pass path
