@@ -499,8 +499,9 @@ class Detector:
         called by the caller, use `match_sharded` from `sharded.py` to gather all ranks."""
         recs = self.matchArray(sources, threshold, class_ids, masks)
         names = list(class_ids) if class_ids else self.classIds()
-        return [Match(int(r["x"]), int(r["y"]), float(r["similarity"]), names[int(r["class_index"])], int(r["template_id"]))
-                for r in recs]
+        # column lists first: indexing a structured array record by record costs ~5 us per match
+        cols = [recs[f].tolist() for f in ("x", "y", "similarity", "class_index", "template_id")]
+        return [Match(x, y, s, names[c], t) for x, y, s, c, t in zip(*cols)]
 
     def lastTimings(self) -> dict:
         t = Timings()
