@@ -117,11 +117,12 @@ class DeviceExchange:
         """Oldest frame in flight.  `into` (MATCH_DTYPE, world * capacity records) avoids the allocation and a copy; the
         result is then a view of it."""
         out, failed = self.det.exchangeCollect() if into is None else self.det.exchangeCollectInto(into)
-        if failed > self.capacity and failed <= 8192 // 2:       # a run did not fit: larger blocks from the next submit on
+        if out is None and failed > self.capacity:               # a run did not fit: larger blocks from the next submit on, if they exist
             cap = self.capacity
             while cap < failed:
                 cap *= 2
-            self._pending_capacity = cap
+            if cap <= 8192:
+                self._pending_capacity = cap
         return out
 
     def grow_if_needed(self) -> None:
