@@ -1123,7 +1123,7 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
             P[3 * (size_t)i + 2] = 0.0 * x + 0.0 * y + 1.0 * z + t2;
             prev[i] = -1;
             lb[i] = 0.0;
-            xmn = fmin(xmn, nx); xmx = fmax(xmx, nx);
+            xmn = fmin(xmn, nx - far * 1.001); xmx = fmax(xmx, nx + far * 1.001);
         }
     } else {
         double U[12];
@@ -1135,23 +1135,41 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
             const double ny = U[4] * x + U[5] * y + U[6] * z + U[7];
             const double nz = U[8] * x + U[9] * y + U[10] * z + U[11];
             P[3 * (size_t)i] = nx; P[3 * (size_t)i + 1] = ny; P[3 * (size_t)i + 2] = nz;
-            if (prev[i] < 0) lb[i] -= sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12;
-            xmn = fmin(xmn, nx); xmx = fmax(xmx, nx);
+            const int pj = prev[i];
+            // how far this point's search will reach (the same tests as the queue below): nothing when its previous
+            // correspondence is certified or it is provably out of range, the distance to the previous correspondence, or
+            // 1.5 max_dist for a point without one
+            double reach = 0.0;
+            if (pj < 0) {
+                const double nlb = lb[i] - (sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12);
+                lb[i] = nlb;
+                if (!(nlb > lb_need)) reach = far;
+            } else {
+                const double d = sqdist(nx, ny, nz, T[3 * (size_t)pj], T[3 * (size_t)pj + 1], T[3 * (size_t)pj + 2]);
+                if (!(d < r2 && 4.0 * d * (1.0 + 1e-9) < cov[(size_t)pj * kIcpCovStride + 10])) reach = sqrt(d < r2 ? d : r2);
+            }
+            reach = reach * (1.0 + 1e-6) + 1e-9;
+            xmn = fmin(xmn, nx - reach); xmx = fmax(xmx, nx + reach);
         }
     }
-    // the x slab of the grid this slice can reach (every search radius is <= 1.5 max_dist): a contiguous range of
-    // cells [c0, c1] and of sorted target points [p0, p1), staged in LDS when it fits
+    // the x slab of the grid this slice's searches can reach: a contiguous range of cells [c0, c1] and of sorted target
+    // points [p0, p1), staged in LDS when it fits (sized by the actual search radii: once most points keep their
+    // correspondence the slab is a few columns, not the 1.5 max_dist margin on either side)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { xmn = fmin(xmn, shfl_xor_d(xmn, o)); xmx = fmax(xmx, shfl_xor_d(xmx, o)); }
     if (lane == 0) { s_xmm[wave][0] = xmn; s_xmm[wave][1] = xmx; }
     __syncthreads();
     for (int w = 0; w < kSearchWG / 64; ++w) { xmn = fmin(xmn, s_xmm[w][0]); xmx = fmax(xmx, s_xmm[w][1]); }
-    const int xlo = grid_coord(xmn - far * 1.001, minx, inv, gx), xhi = grid_coord(xmx + far * 1.001, minx, inv, gx);
+    const int xlo = grid_coord(xmn, minx, inv, gx), xhi = grid_coord(xmx, minx, inv, gx);
     const int c0 = xlo * gy, c1 = (xhi + 1) * gy;
     const int c0a = c0 & ~7;                                  // 16-byte aligned start of the table copy
     const int p0 = cs[c0], p1 = cs[c1];
     const int np = p1 - p0;
     const bool kLds = np <= kSlabPts && c1 - c0a + 1 <= kSlabCells && nt < 65536;
+    if (tid == 0) {                                          // diagnostics: slices whose slab did not fit LDS, largest slab seen
+        if (!kLds) atomicAdd((unsigned long long*)&S.clk[6], 1ull);
+        atomicMax((unsigned long long*)&S.clk[7], (unsigned long long)np);
+    }
     if (kLds) {                                              // 16-byte copies of the prepared records / 16-bit cell table
         const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap + p0);
         uint4* dst = reinterpret_cast<uint4*>(s_tgt);

@@ -9,9 +9,10 @@ K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float
 rgb, dep = synth.make_frame(0, W, H)
 rng = np.random.default_rng(3)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+SCALE = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 rens, xy = [], []
 for i in range(n):
-    w, h = int(rng.integers(40, 131)), int(rng.integers(50, 146))
+    w, h = int(rng.integers(40, 131) * SCALE), int(rng.integers(50, 146) * SCALE)
     x, y = int(rng.integers(40, W - w - 40)), int(rng.integers(40, H - h - 40))
     ren = np.zeros((H, W), np.uint16)
     patch = dep[y:y + h, x:x + w]
@@ -30,4 +31,4 @@ for hyp in range(min(n, 6)):
           (hyp, d[19], d[20], res[hyp]["n_source"], res[hyp]["n_target"], d[21], d[22], d[23], res[hyp]["residual"], res[hyp]["iterations"]), "rings", d[31], "generic", d[32])
     it, clk = d[24], d[25:33]
     ev = max(clk[5], 1)
-    print("        evals %2d  cycles/eval of workgroup 0: prologue %6.0f staging+transform %6.0f queue %6.0f search %6.0f sums %6.0f" % (clk[5], clk[0] / ev, clk[1] / ev, clk[2] / ev, clk[3] / ev, clk[4] / ev))
+    print("        evals %2d  cycles/eval of workgroup 0: prologue %6.0f staging+transform %6.0f queue %6.0f search %6.0f sums %6.0f  | slabs not in LDS %d, largest slab %d points" % (clk[5], clk[0] / ev, clk[1] / ev, clk[2] / ev, clk[3] / ev, clk[4] / ev, clk[6], clk[7]))
