@@ -115,8 +115,13 @@ def test_ply_files_load_like_arrays(lm, tmp_path):
         lm.Mesh(str(tmp_path / "missing.ply"))
 
 
-@pytest.mark.parametrize("nfeat,T,views,dist,level", [(63, [4, 8], 5, 520.0, 3), (150, [4, 8], 14, 450.0, 3), (64, [4, 4, 8], 6, 600.0, 2), (150, [4, 8], 4, 3000.0, 2)])
-def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist, level):
+@pytest.mark.parametrize("nfeat,T,views,dist,level,shift", [
+    (63, [4, 8], 5, 520.0, 3, (0, 0)), (150, [4, 8], 14, 450.0, 3, (0, 0)), (64, [4, 4, 8], 6, 600.0, 2, (0, 0)),
+    (150, [4, 8], 4, 3000.0, 2, (0, 0)),          # too small for 150 features: -1 everywhere
+    (150, [4, 8], 6, 450.0, 3, (235, -160)),      # cut by the right and the top edge of the frame: replicate borders, runs that reach the border
+    (63, [4, 8], 3, 210.0, 3, (0, 0)),            # ~190 px radius: more candidates than the selection kernel sorts -> those views take the host path
+])
+def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist, level, shift):
     """render_train on the device (lm_detector_add_templates_rendered: rasteriser, quantisers AND the feature selection of
     train.hip) adds exactly the templates that rendering to host images and calling Detector.addTemplate per view adds
     (linemod_and_levelup_test.py:203-247; host selection pinned to the reference golden), and reports the depth extent.
@@ -124,6 +129,7 @@ def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist,
     V, F, N, C = icosphere(level, radius=70.0, seed=11)
     C[:] = (C // 64) * 64 + 30                                                             # blocky colours: gradients for the colour modality
     Rs, ts = look_at_views(views, dist=dist, seed=9)
+    ts[:, 0] += shift[0]; ts[:, 1] += shift[1]
     mesh = lm.Mesh(V, F, normals=N, colors=C)
     det_a, det_b = lm.Detector(nfeat, T, device=0), lm.Detector(nfeat, T, device=0)
     ids, wh = lm.add_templates_rendered(det_a, mesh, "obj", (640, 480), K_CAM, Rs, ts)
@@ -134,6 +140,8 @@ def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist,
         want_ids.append(det_b.addTemplate([rgb[i], depth[i]], "obj", mask))
         ys, xs = np.nonzero(depth[i])
         assert tuple(wh[i]) == (xs.max() - xs.min(), ys.max() - ys.min())
+        if shift != (0, 0):
+            assert xs.max() == 639 or ys.min() == 0                                          # really cut by the frame
     assert ids.tolist() == want_ids
     assert (max(want_ids) >= 0) == (dist < 2000)
     for t in [t for t in want_ids if t >= 0]:
