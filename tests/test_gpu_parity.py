@@ -436,6 +436,45 @@ def test_config4_shard_size(lm):
     assert tm["coarse_candidates"] == st["coarse_candidates"] > 50000 and tm["local_evals"] == st["local_evals"]
 
 
+def test_config3_size_eight_shards_through_the_device_exchange(lm):
+    """BASELINE configs[3]: 8 objects x 2000 templates at 640x480, one object's worth of templates per GPU.  The oracle pins the
+    whole 16k-template result (C loops, 32 host threads); eight shards of it — searched one after the other on this GPU, packed,
+    laid out like an all-gather and merged by the ranking kernel — must be that list, bit for bit."""
+    import torch
+    W, H, T, nfeat, per, world, cap = 640, 480, [4, 8], (150, 75), 2000, 8, 4096
+    rgb, dep = synth.make_frame(0, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    ids = ["obj%02d" % o for o in range(world)]
+    banks = [synth.make_planted_bank(1234 + o, per, [(p[0], p[1]) for p in pyr], T, nfeat) for o in range(world)]
+    det = lm.Detector(nfeat[0], T, device=0)
+    lms, sizes = od.linear_memories(rgb, dep)
+    raws = []
+    for o, (cid, bank) in enumerate(zip(ids, banks)):
+        det.addClassPacked(cid, *bank)
+        feat, offs, wh = bank
+        raw, _ = lo.match_bank_c(lo.PackedBank(per, 2, feat, offs, wh), lms, sizes, T, 75.0, nthreads=32)
+        raw["cls"] = o
+        raws.append(raw)
+    want = lo.canonical_sort_unique(np.concatenate(raws))
+    det.setFrame([rgb, dep])
+    whole = det.matchResident(75.0, ids)
+    same_records(whole, want)
+    assert len(whole) > 10000
+    nb = lm.load_library().lm_exchange_block_bytes(cap)
+    send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
+    for r in range(world):
+        det.setShard(r, world); det.submit(75.0, ids); det.exchangePack(send[r].data_ptr(), cap)
+        part = det.collect(sort_unique=False, distinct=True)
+        assert set(part["class_index"].tolist()) == {r}                    # shard r of 8 = object r
+    recv = torch.cat(send)
+    det.setShard(3, world); det.submit(75.0, ids); det.exchangePack(send[3].data_ptr(), cap)
+    det.exchangeMerge(recv.data_ptr(), world, cap)
+    got, failed = det.exchangeCollect()
+    det.setShard(0, 1)
+    assert failed == 0 and got.tobytes() == whole.tobytes()
+
+
 # ---------------------------------------------------------------------------------------------
 # addTemplate / YAML through the product
 # ---------------------------------------------------------------------------------------------
