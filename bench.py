@@ -248,8 +248,10 @@ def main():
             "value": value, "unit": "templates*Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 object x %d templates per GPU, 640x480 RGB-D, Detector(150,[4,8]), threshold 75, planted synthetic bank"
-                                   % args.templates,
+            "config": {"workload": ("configs[1]: 1 object x %d templates, 640x480 RGB-D, Detector(150,[4,8]), threshold 75, planted synthetic bank" % args.templates)
+                                   if world == 1 else
+                                   ("configs[1] scaled weakly (= configs[3] at 8 GPUs): %d objects x %d templates, bank sharded one object's worth per GPU, "
+                                    "640x480 RGB-D, Detector(150,[4,8]), threshold 75, planted synthetic banks" % (n_obj, args.templates)),
                        "templates_total": total_templates, "objects": n_obj, "frames_in_stream": N_FRAMES,
                        "features_per_template": [2 * NFEAT[0], 2 * NFEAT[1]], "parallelism": "bank-shard x%d + all-gather" % world, "exchange": exchange_mode, "exchange_capacity": (ex.capacity if ex is not None else None),
                        "pipeline_depth": PIPELINE_DEPTH,
