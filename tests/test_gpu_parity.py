@@ -303,7 +303,7 @@ def test_device_exchange_merges_shards_like_the_host(lm):
     # produces the blocks shard by shard, then merges them
     d = make()
     whole = ref.matchResident(75.0, ids)
-    for world, cap in ((70, 8192), (150, 4096)):
+    for world, cap in ((70, 8192), (150, 4096), (300, 256)):          # 300 ranks for 207 templates: shards without any work
         nb = lib.lm_exchange_block_bytes(cap)
         send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
         for r in range(world):
