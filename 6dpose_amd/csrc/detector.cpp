@@ -113,6 +113,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
+    if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
@@ -285,16 +286,34 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
 }
 
 // quantise every level; build_lm=false for addTemplate (only the quantised maps are needed)
-static int run_frontend(lm_detector* d, bool build_lm, int arena = 0) {
+static int run_frontend(lm_detector* d, bool build_lm, int arena = 0, bool share_launches = true) {
     // One stream: measured on MI355X, forking the colour / pyramid / depth chains onto three streams
     // (events, also inside the hipGraph) cost more in cross-stream synchronisation (+26 us) than the
-    // ~3 us kernels could overlap.
+    // ~3 us kernels could overlap.  Instead the jobs that do not depend on each other can share a LAUNCH (k_fe_stage): per
+    // level {colour chain, normals + median or their nearest-neighbour pyramid, pyrDown to the next level}, then the linear
+    // memories of all levels — 7 -> 3 launches at two levels.  That is what a LONE frame and the training views get (launch
+    // latency is their critical path: synchronous match 0.409 -> 0.390 ms).  With frames in flight the front end is off the
+    // critical path and the shared launches are a loss (0.227 -> 0.250 ms/frame, whatever the stream priorities: the bursts of
+    // mixed-body workgroups slow the refinement running beside them more than seven spaced launches do), so the captured
+    // per-slot graph keeps one launch per job.
     hipStream_t s = d->stream;
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
+    const bool fused = d->fe_fused && share_launches;
+    FeStage st{};
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
         const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
+        if (fused) {
+            st.njobs = 0;
+            fe_job_colour(st.job[st.njobs++], src, b.mag.p, b.ang.p, b.W, b.H, thr_sq);                                   // LL.cpp:367-504
+            if (l == 0) fe_job_normals(st.job[st.njobs++], d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+                                       d->difference_threshold);                                                          // LL.cpp:729-819
+            else fe_job_nn_down2(st.job[st.njobs++], d->lvl[l - 1].nrm.p, b.nrm.p, d->lvl[l - 1].W, d->lvl[l - 1].H);     // LL.cpp:857-880
+            if (l + 1 < L) fe_job_pyrdown(st.job[st.njobs++], src, d->lvl[l + 1].rgb.p, b.W, b.H);                        // LL.cpp:557-581
+            launch_fe_stage(st, s);
+            continue;
+        }
         if (l > 0) {
             const LevelBufs& a = d->lvl[l - 1];
             launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
@@ -304,17 +323,23 @@ static int run_frontend(lm_detector* d, bool build_lm, int arena = 0) {
                                  d->difference_threshold, s);                                 // LL.cpp:729-819
         }
         launch_color_quant(src, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                       // LL.cpp:367-504
-        if (build_lm) {
+    }
+    if (build_lm) {
+        st.njobs = 0;
+        for (int l = 0; l < L; ++l) {
+            LevelBufs& b = d->lvl[l];
             const LevelGeom& lv = d->geom.lv[l];
             const bool strips = l < L - 1;
             const uint8_t* quant[2] = {b.ang.p, b.nrm.p};
             const uint8_t* mask[2] = {d->have_mask[0] ? b.mask[0].p : nullptr, d->have_mask[1] ? b.mask[1].p : nullptr};
             uint8_t* lmp[2] = {d->lm_arena[arena].p + lv.lm_off[0], d->lm_arena[arena].p + lv.lm_off[1]};
             uint8_t* smp[2] = {strips ? d->sm_arena[arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[arena].p + lv.sm_off[1] : nullptr};
-            launch_build_lm(quant, mask, lmp, smp, b.W, b.H, lv.T, s);
+            if (fused) fe_job_build_lm(st.job[st.njobs++], quant, mask, lmp, smp, b.W, b.H, lv.T);
+            else launch_build_lm(quant, mask, lmp, smp, b.W, b.H, lv.T, s);
         }
+        if (fused) launch_fe_stage(st, s);
+        d->last_arena = arena;
     }
-    if (build_lm) d->last_arena = arena;
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
@@ -1118,7 +1143,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
     auto enqueue_fe = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[0], s));
-        int r = run_frontend(d, true, arena);
+        int r = run_frontend(d, true, arena, false);
         if (r) return r;
         HIP_TRY(hipEventRecord(sl.ev[1], s));
         return LM_OK;
@@ -1186,7 +1211,11 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
             }
         }
     }
-    if (d->use_graph && sl.exec) {
+    if (d->n_submitted == d->n_collected) {   // a lone frame: three shared launches, not the graph of seven (see run_frontend)
+        HIP_TRY(hipEventRecord(sl.ev[0], s));
+        if ((rc = run_frontend(d, true, arena, true))) return rc;
+        HIP_TRY(hipEventRecord(sl.ev[1], s));
+    } else if (d->use_graph && sl.exec) {
         HIP_TRY(hipGraphLaunch(sl.exec, s));
         d->last_arena = arena;
     } else if ((rc = enqueue_fe())) return rc;

@@ -161,6 +161,7 @@ struct lm_detector {
     } train;
 
     bool use_graph = true;
+    bool fe_fused = true;            // independent front-end jobs share a launch (k_fe_stage); LM_FE_FUSED=0: one launch per job
     bool graph_events_ok = true;
 
     lm_timings timings{};

@@ -53,15 +53,15 @@ static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // for (blur and Sobel replicate the border: smoothed(clamp(p)), not a blur centred outside the image), which makes the
 // fused kernel bit-identical to running the stages as separate whole-image passes (the oracle does exactly that).
 constexpr int kCTX = 32, kCTY = 16;           // output tile
-__global__ void __launch_bounds__(256)
-k_color_quant(const uint8_t* __restrict__ rgb, float* __restrict__ mag, uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
+static __device__ __forceinline__ void color_quant_body(const int bx, const int by, const uint8_t* __restrict__ rgb, float* __restrict__ mag,
+                                                        uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
     // virtual coordinates: tile origin (x0, y0); halos: rgb 5, blurred 2, quantised 1
     __shared__ uint8_t s_rgb[kCTY + 10][kCTX + 10][3];
     __shared__ uint16_t s_tmp[kCTY + 10][kCTX + 4][3];     // horizontal pass at columns clamp(x0-2 .. x0+TX+1), all halo rows
     __shared__ uint8_t s_sm[kCTY + 4][kCTX + 4][3];         // smoothed at clamp(y0-2 ..), clamp(x0-2 ..)
     __shared__ uint8_t s_q[kCTY + 2][kCTX + 2];             // 16-bin code & 7 at y0-1 .., x0-1 .. (0 outside the interior)
     __shared__ float s_mag[kCTY][kCTX];
-    const int x0 = blockIdx.x * kCTX, y0 = blockIdx.y * kCTY, tid = threadIdx.x;
+    const int x0 = bx * kCTX, y0 = by * kCTY, tid = threadIdx.x;
     const int w7[7] = {8, 28, 56, 72, 56, 28, 8};
     for (int i = tid; i < (kCTY + 10) * (kCTX + 10); i += 256) {
         const int ty = i / (kCTX + 10), tx = i - ty * (kCTX + 10);
@@ -150,6 +150,11 @@ k_color_quant(const uint8_t* __restrict__ rgb, float* __restrict__ mag, uint8_t*
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_color_quant(const uint8_t* __restrict__ rgb, float* __restrict__ mag, uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
+    color_quant_body(blockIdx.x, blockIdx.y, rgb, mag, onehot, W, H, thr_sq);
+}
+
 void launch_color_quant(const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq, hipStream_t s) {
     hipLaunchKernelGGL(k_color_quant, dim3((W + kCTX - 1) / kCTX, (H + kCTY - 1) / kCTY), dim3(256), 0, s, rgb, mag, onehot, W, H, thr_sq);
 }
@@ -161,8 +166,9 @@ static __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-__global__ void k_pyrdown_rgb(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H, int Wo, int Ho) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;   // i over Wo*3
+static __device__ __forceinline__ void pyrdown_body(const int bx, const int by, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H,
+                                                    int Wo, int Ho) {
+    int i = bx * 256 + threadIdx.x, y = by;   // i over Wo*3
     if (i >= Wo * 3) return;
     int x = i / 3, c = i - x * 3;
     const int w[5] = {1, 4, 6, 4, 1};
@@ -176,6 +182,10 @@ __global__ void k_pyrdown_rgb(const uint8_t* __restrict__ src, uint8_t* __restri
         s += w[j] * rs;
     }
     dst[(size_t)y * Wo * 3 + i] = (uint8_t)((s + 128) >> 8);
+}
+
+__global__ void __launch_bounds__(256) k_pyrdown_rgb(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H, int Wo, int Ho) {
+    pyrdown_body(blockIdx.x, blockIdx.y, src, dst, W, H, Wo, Ho);
 }
 
 void launch_pyrdown_rgb(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s) {
@@ -228,11 +238,10 @@ static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__
     return res;
 }
 
-__global__ void __launch_bounds__(256)
-k_normals_median(const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw, uint8_t* __restrict__ med, int W, int H, int dist_thr,
-                 int diff_thr) {
+static __device__ __forceinline__ void normals_median_body(const int bx, const int by, const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw,
+                                                           uint8_t* __restrict__ med, int W, int H, int dist_thr, int diff_thr) {
     __shared__ uint8_t s_raw[kCTY + 4][kCTX + 4];
-    const int x0 = blockIdx.x * kCTX, y0 = blockIdx.y * kCTY, tid = threadIdx.x;
+    const int x0 = bx * kCTX, y0 = by * kCTY, tid = threadIdx.x;
     for (int i = tid; i < (kCTY + 4) * (kCTX + 4); i += 256) {
         const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
         const int y = clampi(y0 - 2 + ty, 0, H - 1), x = clampi(x0 - 2 + tx, 0, W - 1);
@@ -265,16 +274,25 @@ k_normals_median(const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw, 
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_normals_median(const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw, uint8_t* __restrict__ med, int W, int H, int dist_thr,
+                 int diff_thr) {
+    normals_median_body(blockIdx.x, blockIdx.y, depth, raw, med, W, H, dist_thr, diff_thr);
+}
+
 void launch_normals_fused(const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr, hipStream_t s) {
     hipLaunchKernelGGL(k_normals_median, dim3((W + kCTX - 1) / kCTX, (H + kCTY - 1) / kCTY), dim3(256), 0, s, depth, raw, med, W, H, dist_thr,
                        diff_thr);
 }
 
 // cv::resize(INTER_NEAREST) to (cols/2, rows/2) (LL.cpp:576, 867, 877) = pixel (2y, 2x)
-__global__ void k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int Wo) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+static __device__ __forceinline__ void nn_down2_body(const int bx, const int by, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int Wo) {
+    int x = bx * 256 + threadIdx.x, y = by;
     if (x >= Wo) return;
     dst[(size_t)y * Wo + x] = src[(size_t)(2 * y) * W + 2 * x];
+}
+__global__ void __launch_bounds__(256) k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int Wo) {
+    nn_down2_body(blockIdx.x, blockIdx.y, src, dst, W, Wo);
 }
 
 void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t s) {
@@ -291,12 +309,9 @@ void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t
 // every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so that a 16x16 window
 // touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.  (The frame is a few hundred
 // KB: the T*T byte reads per thread hit L1/L2; what counts here is one launch instead of four.)
-struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
-
-__global__ void k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS) {
-    const LmJob J = blockIdx.z ? j1 : j0;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;   // decimated raster index
-    int phase = blockIdx.y;                              // r_start*T + c_start
+static __device__ __forceinline__ void build_lm_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS) {
+    int idx = bx * 256 + threadIdx.x;                    // decimated raster index
+    int phase = by;                                      // r_start*T + c_start
     int npos = Wd * Hd;
     if (idx >= npos) return;
     int ry = idx / Wd, rx = idx - ry * Wd;
@@ -326,11 +341,69 @@ __global__ void k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int 
     }
 }
 
+__global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS) {
+    build_lm_body(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
+}
+
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T, hipStream_t s) {
     int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
     LmJob j0{quant[0], mask[0], lm[0], strips[0]}, j1{quant[1], mask[1], lm[1], strips[1]};
     hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS);
+}
+
+// ---- several independent front-end jobs in ONE launch ---------------------------------------------------------------------
+// The seven kernels of a frame are small (5-17 us) and dependent kernels on a queue start ~7 us apart, so the front end is
+// mostly launch latency.  The jobs that do not depend on each other share a launch: stage k = {colour chain of level k,
+// normals + median (k = 0) or nearest-neighbour normals of level k, pyrDown to level k + 1}; the last launch builds the linear
+// memories of every level.  A job is a range of the flat block index; the bodies are the kernels above, unchanged.
+__global__ void __launch_bounds__(256)
+k_fe_stage(FeStage st) {
+    int j = 0;
+    while (j + 1 < st.njobs && (int)blockIdx.x >= st.job[j + 1].first) ++j;
+    const FeJob& J = st.job[j];
+    const int local = (int)blockIdx.x - J.first;
+    const int bx = local % J.gx, by = (local / J.gx) % J.gy, bz = local / (J.gx * J.gy);
+    switch (J.kind) {
+        case kFeColour: color_quant_body(bx, by, (const uint8_t*)J.in, (float*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.f); break;
+        case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
+        case kFePyrDown: pyrdown_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.H, J.a, J.b); break;
+        case kFeNnDown: nn_down2_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.a); break;
+        case kFeBuildLm: build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16); break;
+        default: break;
+    }
+}
+
+void fe_job_colour(FeJob& j, const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq) {
+    j = FeJob{}; j.kind = kFeColour; j.gx = (W + kCTX - 1) / kCTX; j.gy = (H + kCTY - 1) / kCTY; j.gz = 1;
+    j.in = rgb; j.out0 = mag; j.out1 = onehot; j.W = W; j.H = H; j.f = thr_sq;
+}
+void fe_job_normals(FeJob& j, const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr) {
+    j = FeJob{}; j.kind = kFeNormals; j.gx = (W + kCTX - 1) / kCTX; j.gy = (H + kCTY - 1) / kCTY; j.gz = 1;
+    j.in = depth; j.out0 = raw; j.out1 = med; j.W = W; j.H = H; j.a = dist_thr; j.b = diff_thr;
+}
+void fe_job_pyrdown(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H) {
+    j = FeJob{}; j.kind = kFePyrDown; j.a = W / 2; j.b = H / 2; j.gx = (j.a * 3 + 255) / 256; j.gy = j.b; j.gz = 1;
+    j.in = src; j.out0 = dst; j.W = W; j.H = H;
+}
+void fe_job_nn_down2(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H) {
+    j = FeJob{}; j.kind = kFeNnDown; j.a = W / 2; j.gx = (j.a + 255) / 256; j.gy = H / 2; j.gz = 1;
+    j.in = src; j.out0 = dst; j.W = W; j.H = H;
+}
+void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
+                     int W, int H, int T) {
+    j = FeJob{}; j.kind = kFeBuildLm; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
+    j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0]}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1]};
+}
+void launch_fe_stage(FeStage& st, hipStream_t s) {
+    int total = 0, n = 0;
+    for (int i = 0; i < st.njobs; ++i) {
+        const int blocks = st.job[i].gx * st.job[i].gy * st.job[i].gz;
+        if (blocks <= 0) continue;                         // an empty job (degenerate level) is dropped
+        st.job[n] = st.job[i]; st.job[n].first = total; total += blocks; ++n;
+    }
+    st.njobs = n;
+    if (total > 0) hipLaunchKernelGGL(k_fe_stage, dim3(total), dim3(256), 0, s, st);
 }
 
 }  // namespace lm

@@ -19,6 +19,26 @@ void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T, hipStream_t s);
 
+// several independent jobs of the front end in one launch (frontend.hip, k_fe_stage)
+struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
+enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm };
+struct FeJob {
+    int kind, gx, gy, gz, first;          // job kind, its block grid, its first flat block index (set by launch_fe_stage)
+    const void* in; void* out0; void* out1;
+    int W, H, a, b;                       // a, b: normals thresholds / pyrDown output size / T
+    float f;                              // colour: weak threshold squared
+    LmJob lm[2];                          // build_lm: [0] colour, [1] normals
+};
+constexpr int kFeMaxJobs = 8;             // = kMaxLevels (the last stage builds the linear memories of every level)
+struct FeStage { int njobs; FeJob job[kFeMaxJobs]; };
+void fe_job_colour(FeJob& j, const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq);
+void fe_job_normals(FeJob& j, const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr);
+void fe_job_pyrdown(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
+void fe_job_nn_down2(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
+void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
+                     int W, int H, int T);
+void launch_fe_stage(FeStage& st, hipStream_t s);
+
 // ---- matching (match.hip): reference A8-A11, LL.cpp:1284-1428, 1788-1941 ----
 struct LevelGeom {        // one pyramid level of the current frame
     int W, H, T, Wd, Hd;  // image size, sampling step, decimated size
