@@ -55,7 +55,10 @@ k_train_mask(const uint16_t* __restrict__ depth, TrainGeom g, int32_t* __restric
 
 // counts: [0] colour candidates, [1] normal candidates, [2] pixels inside erode^2(mask), [3..10] candidates per label
 __global__ void __launch_bounds__(256)
-k_train_prep(TrainGeom g, int l, float strong_sq, unsigned long long* __restrict__ ckeys, uint32_t cap, uint32_t* __restrict__ counts) {
+k_train_prep(TrainGeom g, float strong_sq, unsigned long long* __restrict__ keys_view, uint32_t cap, uint32_t* __restrict__ counts_view) {
+    const int l = blockIdx.y;                                 // one launch for all levels: grid.x covers level 0, higher levels leave early
+    unsigned long long* __restrict__ ckeys = keys_view + ((size_t)l * 2 + 0) * cap;
+    uint32_t* __restrict__ counts = counts_view + (size_t)l * 16;
     const int W = g.W[l], H = g.H[l];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint8_t* mask = g.mask[l];
@@ -101,7 +104,8 @@ k_train_prep(TrainGeom g, int l, float strong_sq, unsigned long long* __restrict
 }
 
 __global__ void __launch_bounds__(256)
-k_train_runs(TrainGeom g, int l) {
+k_train_runs(TrainGeom g) {
+    const int l = blockIdx.y;
     const int W = g.W[l], H = g.H[l];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
@@ -118,7 +122,11 @@ k_train_runs(TrainGeom g, int l) {
 }
 
 __global__ void __launch_bounds__(256)
-k_train_dt(TrainGeom g, int l, int extract_threshold, unsigned long long* __restrict__ nkeys, uint32_t cap, uint32_t* __restrict__ counts) {
+k_train_dt(TrainGeom g, int extract_threshold0, unsigned long long* __restrict__ keys_view, uint32_t cap, uint32_t* __restrict__ counts_view) {
+    const int l = blockIdx.y;
+    const int extract_threshold = extract_threshold0 >> l;    // extract_threshold /= 2 per level (LL.cpp:861)
+    unsigned long long* __restrict__ nkeys = keys_view + ((size_t)l * 2 + 1) * cap;
+    uint32_t* __restrict__ counts = counts_view + (size_t)l * 16;
     const int W = g.W[l], H = g.H[l];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool cand = false;
@@ -255,18 +263,10 @@ void launch_train_prep(const uint16_t* depth, const TrainGeom& g, float strong_s
                        uint32_t cap, uint32_t* counts_view, int32_t* bbox_view, hipStream_t s) {
     const int n0 = g.W[0] * g.H[0];
     hipLaunchKernelGGL(k_train_mask, dim3((n0 + 255) / 256), dim3(256), 0, s, depth, g, bbox_view);
-    int ext = extract_threshold;
-    for (int l = 0; l < g.levels; ++l) {
-        if (l > 0) ext /= 2;                                  // LL.cpp:861
-        const int n = g.W[l] * g.H[l];
-        const dim3 grid((n + 255) / 256);
-        unsigned long long* ck = keys_view + ((size_t)l * 2 + 0) * cap;
-        unsigned long long* nk = keys_view + ((size_t)l * 2 + 1) * cap;
-        uint32_t* cnt = counts_view + (size_t)l * 16;
-        hipLaunchKernelGGL(k_train_prep, grid, dim3(256), 0, s, g, l, strong_sq, ck, cap, cnt);
-        hipLaunchKernelGGL(k_train_runs, grid, dim3(256), 0, s, g, l);
-        hipLaunchKernelGGL(k_train_dt, grid, dim3(256), 0, s, g, l, ext, nk, cap, cnt);
-    }
+    const dim3 grid((n0 + 255) / 256, g.levels);              // level l uses the first W_l * H_l / 256 blocks of its row
+    hipLaunchKernelGGL(k_train_prep, grid, dim3(256), 0, s, g, strong_sq, keys_view, cap, counts_view);
+    hipLaunchKernelGGL(k_train_runs, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(k_train_dt, grid, dim3(256), 0, s, g, extract_threshold < 0 ? 0 : extract_threshold, keys_view, cap, counts_view);
 }
 
 int launch_train_select(const unsigned long long* keys, const uint32_t* counts, const TrainGeom& g, uint32_t cap, int num_features, int nf_cap,
