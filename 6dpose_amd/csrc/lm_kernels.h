@@ -68,7 +68,9 @@ struct Candidate {        // coarse hit, and (same layout) final match record
 // counters[0] = number of candidates produced (may exceed cap: nothing is written past cap).
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, hipStream_t s);
+                   unsigned long long* counters, uint32_t* tcount /*per work item, may be null*/, uint32_t* tlist /*[work][kRegionK] candidate slots*/,
+                   uint8_t* todo /*[cap] 1 = not refined yet*/, hipStream_t s);
+constexpr int kRegionK = 32;      // candidates per template that k_local_region groups (more: the template is left to k_local)
 // Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
 // matches[ci] = refined candidate ci (work = -1: dropped); block_stats (pinned host memory): [0] = candidate count,
 // [8+2*b], [8+2*b+1] = 16x16 evaluations / their algorithmic bytes of block b.
@@ -80,7 +82,13 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
                   unsigned long long* block_stats, unsigned long long* dedupe_table /*may be null*/, uint32_t dedupe_cap_slots,
-                  int grid_blocks, hipStream_t s);
+                  const uint8_t* todo /*null: every candidate; else only those with todo[ci] != 0*/, int grid_blocks, hipStream_t s);
+// Two-level pyramids: refines the candidates of every template with 1..kRegionK candidates region by region (match.hip) and
+// clears their todo flag; counters[4] / [5] += 16x16 evaluations / their algorithmic bytes.
+void launch_local_region(const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries, const FeatStrip* feat_strip,
+                         const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap, float threshold, Candidate* matches,
+                         Candidate* matches_dev, uint32_t cap, uint32_t* tcount, const uint32_t* tlist, uint8_t* todo, int num_work,
+                         unsigned long long* counters, int grid_blocks, hipStream_t s);
 // slots of k_dedupe's open-addressing table used for n records (power of two, >= 2n, <= cap_slots = dedupe_table_slots(cand_cap)):
 // k_local empties exactly these, k_dedupe hashes into exactly these
 __host__ __device__ inline uint32_t dedupe_slots_for(uint32_t n, uint32_t cap_slots) {

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(1024)
 k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
          const int32_t* __restrict__ work_pyramids, float threshold, Candidate* __restrict__ cands, uint32_t cap,
-         unsigned long long* __restrict__ counters) {
+         unsigned long long* __restrict__ counters, uint32_t* __restrict__ tcount, uint32_t* __restrict__ tlist, uint8_t* __restrict__ todo) {
     const int work = blockIdx.x;
     const int pyr = work_pyramids[work];
     const TemplEntry e = entries[(size_t)pyr * levels + level];
@@ -171,6 +171,11 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
                         Candidate c;
                         c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc[k]; c.work = work;
                         cands[slot] = c;
+                        if (tcount) {                          // the template's own candidate list (k_local_region); todo = 1: not refined yet
+                            todo[slot] = 1;
+                            const uint32_t ti = atomicAdd(&tcount[work], 1u);
+                            if (ti < (uint32_t)kRegionK) tlist[(size_t)work * kRegionK + ti] = (uint32_t)slot;
+                        }
                     }
                     ++slot;
                 }
@@ -181,7 +186,7 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
 
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, hipStream_t s) {
+                   unsigned long long* counters, uint32_t* tcount, uint32_t* tlist, uint8_t* todo, hipStream_t s) {
     if (num_work <= 0) return;
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
@@ -190,7 +195,7 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
     if (waves > 16) waves = 16;
     if (waves < 1) waves = 1;
     hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(waves * 64), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
-                       work_pyramids, threshold, cands, cap, counters);
+                       work_pyramids, threshold, cands, cap, counters, tcount, tlist, todo);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,7 +229,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
         float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
         const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats,
-        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots) {
+        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* __restrict__ todo) {
     __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -240,6 +245,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     }
 
     for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
+        if (todo && !todo[ci]) continue;                     // refined by k_local_region already (wave-uniform)
         const Candidate cd = cands[ci];
         const int work = __builtin_amdgcn_readfirstlane(cd.work);
         const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
@@ -401,11 +407,216 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
                   const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
-                  unsigned long long* block_stats, unsigned long long* dedupe_table, uint32_t dedupe_cap_slots, int grid_blocks, hipStream_t s) {
+                  unsigned long long* block_stats, unsigned long long* dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* todo,
+                  int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
                        feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
-                       dedupe_table, dedupe_cap_slots);
+                       dedupe_table, dedupe_cap_slots, todo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Region refinement (two-level pyramids): the coarse candidates of ONE template sit a few cells apart, so their 16x16
+// windows overlap — on the bench frame their union has 3x fewer cells than their sum (tests/analysis/candidate_clusters.py).
+// One wave per template: its candidates (k_coarse's per-template list) are grouped into regions of <= 48 columns x 64 rows
+// around a seed; the similarity of the whole region is accumulated ONCE — lane = row, per feature the 16-byte rows of the
+// 3-4 strips the region touches, features of one alignment class summed in packed bytes and realigned once per class, like
+// the coarse pass — into u16 sums in LDS, and every candidate then takes the first strict maximum of its own window from
+// there.  The sums are the integers the per-candidate kernel computes, so the records are identical.  Candidates on the
+// slow path, templates with more than kRegionK candidates and deeper pyramids are left to k_local (todo stays 1).
+// STATUS: exact (the parity tests pass with LM_REGION=1) but OFF by default: 0.38 ms against k_local's 0.17 ms on the bench
+// frame.  It reads 2x fewer cache lines but issues 1.6x MORE load instructions (one per feature, strip and region — 2.4
+// regions per template, most lanes idle), and the vector L1 charges per instruction (~36 cycles, profiles/r01_tcp_microbench.txt),
+// not per line.  What it needs is a lane = (region, row, strip) slot mapping that fills the 64 lanes of every load with the
+// slots of ALL regions of a template (~2 instructions per feature and template instead of 7.5 half-instructions).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRegCols = 48, kRegRows = 64;
+
+__global__ void __launch_bounds__(256)
+k_local_region(const uint8_t* __restrict__ sm_arena, FrameGeom g, const TemplEntry* __restrict__ entries, const FeatStrip* __restrict__ feat_strip,
+               const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap, float threshold,
+               Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap, uint32_t* __restrict__ tcount,
+               const uint32_t* __restrict__ tlist, uint8_t* __restrict__ todo, int num_work, unsigned long long* __restrict__ counters) {
+    // one WORKGROUP per template: its four waves split the features (each sums its share of the region into its own LDS
+    // plane) and then the members (a window cell = the sum of the four planes)
+    __shared__ uint16_t s_sum[4][kRegRows][kRegCols + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const LevelGeom lv = g.lv[0];
+    const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
+    const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+    unsigned long long evals = 0, bytes = 0;
+    uint16_t (*sum)[kRegCols + 2] = s_sum[wv];
+
+    for (int work = blockIdx.x; work < num_work; work += gridDim.x) {
+        const uint32_t n = tcount[work];
+        __syncthreads();                                      // every wave has read the count (and is done with the previous template's LDS)
+        if (n == 0) continue;
+        if (threadIdx.x == 0) tcount[work] = 0;               // the list is consumed: empty for the slot's next frame
+        if (n > (uint32_t)kRegionK) continue;                 // more candidates than the list holds: all of them stay with k_local
+        const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
+        const TemplEntry e = entries[(size_t)pyr * g.levels];
+        const int nf = e.nf, nfp = e.nf_padded;
+        const int max_x = W - e.width - border, max_y = H - e.height - border;
+        // this lane's candidate (every wave holds the same list)
+        uint32_t ci = 0;
+        int gx = 0, gy = 0, px = 0, py = 0;
+        bool open = false;
+        if (lane < (int)n) {
+            ci = tlist[(size_t)work * kRegionK + lane];
+            const Candidate cd = cands[ci];
+            int x = cd.x * 2 + 1, y = cd.y * 2 + 1;             // LL.cpp:1871-1880
+            x = x > border ? x : border;  y = y > border ? y : border;
+            x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
+            px = x; py = y;
+            gx = x / T - 8; gy = y / T - 8;
+            open = ci < cap && e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 && ((e.max_x + gx * T) / T + 16 <= Wd) &&
+                   ((e.max_y + gy * T) / T + 16 <= Hd);          // the fast-path test of k_local
+        }
+        for (;;) {
+            const unsigned long long pending = __ballot(open);
+            if (!pending) break;
+            const int seed = __ffsll((long long)pending) - 1;
+            const int sgx = __shfl(gx, seed, 64), sgy = __shfl(gy, seed, 64);
+            const bool member = open && gx >= sgx - 16 && gx <= sgx + 16 && gy >= sgy - 24 && gy <= sgy + 24;
+            int X0 = member ? gx : INT_MAX, X1 = member ? gx + 16 : INT_MIN, Y0 = member ? gy : INT_MAX, Y1 = member ? gy + 16 : INT_MIN;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
+                Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
+            }
+            const int Wr = X1 - X0, Hr = Y1 - Y0;             // <= 48, <= 64 by construction of `member`
+            // ---- this wave's share of the features over the region: lane = row ----
+            uint32_t accE[12], accO[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { accE[j] = 0; accO[j] = 0; }
+            {
+                const FeatStrip* fs = feat_strip + e.feat_start;
+                const bool rowin = lane < Hr;
+                uint32_t r8[16];                               // packed byte sums of 4 strips
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r8[k] = 0;
+                int cur = -1, cnt = 0;
+                auto flush = [&](int cls) {
+                    const int c0 = (cls + X0) & 15;
+                    const uint32_t sb = (uint32_t)(c0 & 3);
+                    uint32_t o12[12];
+                    switch (c0 >> 2) {                         // wave-uniform
+                        case 0:
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 1], r8[j], sb);
+                            break;
+                        case 1:
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 2], r8[j + 1], sb);
+                            break;
+                        case 2:
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 3], r8[j + 2], sb);
+                            break;
+                        default:
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(j + 4 < 16 ? r8[j + 4] : 0u, r8[j + 3], sb);
+                            break;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) add_bytes(o12[j], accE[j], accO[j]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) r8[k] = 0;
+                };
+                for (int f = 4 * wv; f < nfp; f += 16) {       // nf_padded is a multiple of kFeatBatch (8): batches of 4, dealt round-robin to the waves
+                    FeatStrip c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = fs[f + u];                       // wave-uniform -> SMEM
+                    uint4 v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t pc = (c[u].cell & 0xFFFF) + (uint32_t)X0, row = (c[u].cell >> 16) + (uint32_t)Y0 + (uint32_t)lane;
+                        const int ns = (int)(((pc & 15) + (uint32_t)Wr + 15) >> 4);       // strips this class touches (wave-uniform)
+                        const uint8_t* p = sm_arena + c[u].sbase + (((pc >> 4) * (uint32_t)Hd) + row) * 16u;
+                        const uint32_t stride = (uint32_t)Hd * 16u;
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            v[u][sidx] = (rowin && sidx < ns) ? ld_aligned16(p + sidx * stride) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cls = (int)(c[u].cell & 15);
+                        if (cls != cur || cnt == 63) {
+                            if (cur >= 0) flush(cur);
+                            cur = cls; cnt = 0;
+                        }
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) {
+                            r8[4 * sidx] += v[u][sidx].x; r8[4 * sidx + 1] += v[u][sidx].y; r8[4 * sidx + 2] += v[u][sidx].z; r8[4 * sidx + 3] += v[u][sidx].w;
+                        }
+                        ++cnt;
+                    }
+                }
+                if (cur >= 0) flush(cur);
+            }
+            // this wave's partial sums to its LDS plane: row = lane, columns 4j .. 4j+3 from accumulator j
+            if (lane < Hr) {
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    sum[lane][4 * j] = (uint16_t)(accE[j] & 0xFFFF); sum[lane][4 * j + 1] = (uint16_t)(accO[j] & 0xFFFF);
+                    sum[lane][4 * j + 2] = (uint16_t)(accE[j] >> 16); sum[lane][4 * j + 3] = (uint16_t)(accO[j] >> 16);
+                }
+            }
+            __syncthreads();
+            // ---- the members, dealt to the waves: first strict maximum of the member's own window (LL.cpp:1910-1931) ----
+            unsigned long long mm = __ballot(member);
+            int turn = 0;
+            while (mm) {
+                const int m = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                if ((turn++ & 3) != wv) continue;
+                const int wx = __shfl(gx, m, 64) - X0, wy = __shfl(gy, m, 64) - Y0;
+                uint32_t key = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = lane * 4 + k, r = idx >> 4, cc = idx & 15;
+                    const uint32_t raw = (uint32_t)s_sum[0][wy + r][wx + cc] + s_sum[1][wy + r][wx + cc] + s_sum[2][wy + r][wx + cc] + s_sum[3][wy + r][wx + cc];
+                    const uint32_t kk = (raw << 8) | (255u - (uint32_t)idx);
+                    key = kk > key ? kk : key;
+                }
+                const uint32_t kbest = wave_max_u32(key);
+                const int raw = (int)(kbest >> 8);
+                int br = -1, bc = -1;
+                float best = 0.f;
+                if (raw > 0) {
+                    const int idx = 255 - (int)(kbest & 0xFF);
+                    br = idx >> 4; bc = idx & 15;
+                    best = score_of(raw, nf);
+                }
+                const int mpx = __shfl(px, m, 64), mpy = __shfl(py, m, 64);
+                const uint32_t mci = (uint32_t)__shfl((int)ci, m, 64);
+                if (lane == 0) {
+                    Candidate out;
+                    out.x = (mpx / T - 8 + bc) * T + offset;   // LL.cpp:1930-1931
+                    out.y = (mpy / T - 8 + br) * T + offset;
+                    out.score = best;
+                    out.work = best < threshold ? -1 : work;   // remove_if(MatchPredicate), LL.cpp:1935
+                    matches[mci] = out;
+                    matches_dev[mci] = out;
+                    todo[mci] = 0;
+                }
+                ++evals;
+                bytes += 256ull * nf;
+            }
+            __syncthreads();                                   // the planes are free for the next region
+            if (member) open = false;
+        }
+    }
+    if (lane == 0 && evals) { atomicAdd(&counters[4], evals); atomicAdd(&counters[5], bytes); }
+}
+
+void launch_local_region(const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries, const FeatStrip* feat_strip,
+                         const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap, float threshold, Candidate* matches,
+                         Candidate* matches_dev, uint32_t cap, uint32_t* tcount, const uint32_t* tlist, uint8_t* todo, int num_work,
+                         unsigned long long* counters, int grid_blocks, hipStream_t s) {
+    if (grid_blocks <= 0 || num_work <= 0) return;
+    hipLaunchKernelGGL(k_local_region, dim3(grid_blocks), dim3(256), 0, s, sm_arena, g, entries, feat_strip, work_pyramids, cands, cand_cap,
+                       threshold, matches, matches_dev, cap, tcount, tlist, todo, num_work, counters);
 }
 
 }  // namespace lm

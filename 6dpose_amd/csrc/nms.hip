@@ -294,6 +294,7 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
         const unsigned long long nd = atomicAdd(&counters[1], 0ull), na = atomicAdd(&counters[2], 0ull), bad = atomicAdd(&counters[3], 0ull);
         final_dev[0] = nc; final_dev[1] = nd; final_dev[2] = na; final_dev[3] = bad;
         final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
+        final_host[4] = atomicAdd(&counters[4], 0ull); final_host[5] = atomicAdd(&counters[5], 0ull);   // region refinement: evaluations, bytes
         for (int q = 0; q < 8; ++q) counters[q] = 0;
     }
 }

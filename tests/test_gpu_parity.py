@@ -226,6 +226,42 @@ def test_match_edge_cases(lm):
         det.addClassPacked("hand", *bank)               # class already present
 
 
+def test_region_refinement_is_exact(lm):
+    """LM_REGION=1: the candidates of a template refined region by region (k_local_region: the union of their windows summed once)
+    give the records of the per-candidate kernel, pre-unique multiset and evaluation count included — on a planted bank (clusters
+    of neighbouring candidates), a random one (isolated candidates) and with oversized templates that stay on the slow path."""
+    W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+    rgb, dep = synth.make_frame(5, W, H)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    banks = {"planted": synth.make_planted_bank(17, 300, [(p[0], p[1]) for p in pyr], T, nfeat), "random": synth.make_random_bank(18, 200, W, H, nfeat)}
+    plain = lm.Detector(nfeat[0], T, device=0)
+    os.environ["LM_REGION"] = "1"
+    try:
+        region = lm.Detector(nfeat[0], T, device=0)
+    finally:
+        del os.environ["LM_REGION"]
+    for d in (plain, region):
+        for c, b in banks.items():
+            d.addClassPacked(c, *b)
+        d.setFrame([rgb, dep])
+    for thr, ids in ((75.0, ["planted"]), (60.0, ["random", "planted"]), (88.0, [])):
+        a = plain.matchResident(thr, ids)
+        b = region.matchResident(thr, ids)
+        assert len(a) > 0 and a.tobytes() == b.tobytes(), (thr, ids, len(a), len(b))
+        ta, tb = plain.lastTimings(), region.lastTimings()
+        assert ta["local_evals"] == tb["local_evals"] and ta["matches_pre_unique"] == tb["matches_pre_unique"] and ta["local_bytes"] == tb["local_bytes"]
+        ra = plain.matchResident(thr, ids, sort_unique=False)
+        rb = region.matchResident(thr, ids, sort_unique=False)
+        names = ["x", "y", "similarity", "class_index", "template_id"]
+        assert as_multiset(ra, names) == as_multiset(rb, names)
+    for k in range(6):                                          # pipelined, slots reused
+        region.submit(75.0, ["planted"])
+        if k >= 2:
+            assert region.collect().tobytes() == plain.matchResident(75.0, ["planted"]).tobytes()
+    region.collect(); region.collect()
+
+
 def test_sharded_equals_unsharded_on_one_device(lm):
     """N logical shards on one device through the same slice + merge code the multi-GPU path uses."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
