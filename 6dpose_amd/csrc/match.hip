@@ -424,28 +424,40 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
 // the coarse pass — into u16 sums in LDS, and every candidate then takes the first strict maximum of its own window from
 // there.  The sums are the integers the per-candidate kernel computes, so the records are identical.  Candidates on the
 // slow path, templates with more than kRegionK candidates and deeper pyramids are left to k_local (todo stays 1).
-// STATUS: exact (the parity tests pass with LM_REGION=1) but OFF by default: 0.38 ms against k_local's 0.17 ms on the bench
-// frame.  It reads 2x fewer cache lines but issues 1.6x MORE load instructions (one per feature, strip and region — 2.4
-// regions per template, most lanes idle), and the vector L1 charges per instruction (~36 cycles, profiles/r01_tcp_microbench.txt),
-// not per line.  What it needs is a lane = (region, row, strip) slot mapping that fills the 64 lanes of every load with the
-// slots of ALL regions of a template (~2 instructions per feature and template instead of 7.5 half-instructions).
+// STATUS: exact (the parity tests pass with LM_REGION=1) but OFF by default: 0.39 ms against k_local's 0.17 ms on the bench
+// frame.  Two versions were measured.  (1) one pass per region, lane = row, one load per feature and strip: half the cache
+// lines of k_local but 1.6x MORE load instructions, 0.38 ms.  (2) this one: every 64-lane load carries (region, row, strip)
+// slots of all regions of the template, ~2.5 loads per feature and template instead of k_local's 3.7: 0.39 ms.  So it is not
+// the vector L1 that bounds these kernels but their own overhead per template — wave 0 building the regions while three waves
+// wait, per-lane slot descriptors and address arithmetic, a per-lane byte realignment at the end of each of the ~16 class
+// runs, three barriers, and 183 VGPRs (2 waves per SIMD) — about 100 us per template and workgroup, where k_local's tight
+// per-candidate loop needs 11 us per candidate.  Closing that gap means making the setup as cheap as k_local's (regions and
+// slots prepared by a separate pass, uniform slot shapes so that addresses and realignment are wave-uniform again).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRegCols = 48, kRegRows = 64;
+constexpr int kSlotGroups = 4;        // 64-lane load groups per feature: up to 256 (region, row, strip) slots per template
+constexpr int kMaxRegions = 8;
 
 __global__ void __launch_bounds__(256)
 k_local_region(const uint8_t* __restrict__ sm_arena, FrameGeom g, const TemplEntry* __restrict__ entries, const FeatStrip* __restrict__ feat_strip,
                const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap, float threshold,
                Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap, uint32_t* __restrict__ tcount,
                const uint32_t* __restrict__ tlist, uint8_t* __restrict__ todo, int num_work, unsigned long long* __restrict__ counters) {
-    // one WORKGROUP per template: its four waves split the features (each sums its share of the region into its own LDS
-    // plane) and then the members (a window cell = the sum of the four planes)
-    __shared__ uint16_t s_sum[4][kRegRows][kRegCols + 2];
+    // One workgroup per template.  Its candidates are grouped into regions (<= 48 columns x 64 rows around a seed); every
+    // (region, row, 16-column strip) is a SLOT = one lane of a load, so that a 64-lane load carries the rows of several regions at
+    // once: a region of NC 16-column chunks takes NC + 1 adjacent lanes per row (the strips a misaligned feature plane needs), rows
+    // never straddle a 64-lane group.  Per feature: one 16-byte load per slot; packed byte sums per alignment class; at the end of
+    // a class run every lane realigns {its strip, the next lane's strip} by the class's byte phase in ITS region and adds the 16
+    // bytes to its u16 column sums.  The four waves split the features (one LDS plane of sums each) and then the members.
+    __shared__ uint16_t s_sum[4][kSlotGroups * 64 * 16];
+    __shared__ int s_reg[kMaxRegions][8];                      // X0, Y0, Hr, NC, first slot, LDS offset of the sums
+    __shared__ int s_nreg, s_groups;
+    __shared__ unsigned char s_regof[64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const LevelGeom lv = g.lv[0];
     const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
     unsigned long long evals = 0, bytes = 0;
-    uint16_t (*sum)[kRegCols + 2] = s_sum[wv];
+    uint16_t* sum = s_sum[wv];
 
     for (int work = blockIdx.x; work < num_work; work += gridDim.x) {
         const uint32_t n = tcount[work];
@@ -472,139 +484,179 @@ k_local_region(const uint8_t* __restrict__ sm_arena, FrameGeom g, const TemplEnt
             open = ci < cap && e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 && ((e.max_x + gx * T) / T + 16 <= Wd) &&
                    ((e.max_y + gy * T) / T + 16 <= Hd);          // the fast-path test of k_local
         }
-        for (;;) {
-            const unsigned long long pending = __ballot(open);
-            if (!pending) break;
-            const int seed = __ffsll((long long)pending) - 1;
-            const int sgx = __shfl(gx, seed, 64), sgy = __shfl(gy, seed, 64);
-            const bool member = open && gx >= sgx - 16 && gx <= sgx + 16 && gy >= sgy - 24 && gy <= sgy + 24;
-            int X0 = member ? gx : INT_MAX, X1 = member ? gx + 16 : INT_MIN, Y0 = member ? gy : INT_MAX, Y1 = member ? gy + 16 : INT_MIN;
+        // ---- regions and their slots (wave 0) ----
+        if (wv == 0) {
+            int nreg = 0, pos = 0, lds = 0, regof = 255;
+            bool rem = open;
+            while (nreg < kMaxRegions) {
+                const unsigned long long pending = __ballot(rem);
+                if (!pending) break;
+                const int seed = __ffsll((long long)pending) - 1;
+                const int sgx = __shfl(gx, seed, 64), sgy = __shfl(gy, seed, 64);
+                const bool member = rem && gx >= sgx - 16 && gx <= sgx + 16 && gy >= sgy - 24 && gy <= sgy + 24;
+                int X0 = member ? gx : INT_MAX, X1 = member ? gx + 16 : INT_MIN, Y0 = member ? gy : INT_MAX, Y1 = member ? gy + 16 : INT_MIN;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
-                Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
-            }
-            const int Wr = X1 - X0, Hr = Y1 - Y0;             // <= 48, <= 64 by construction of `member`
-            // ---- this wave's share of the features over the region: lane = row ----
-            uint32_t accE[12], accO[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) { accE[j] = 0; accO[j] = 0; }
-            {
-                const FeatStrip* fs = feat_strip + e.feat_start;
-                const bool rowin = lane < Hr;
-                uint32_t r8[16];                               // packed byte sums of 4 strips
-#pragma unroll
-                for (int k = 0; k < 16; ++k) r8[k] = 0;
-                int cur = -1, cnt = 0;
-                auto flush = [&](int cls) {
-                    const int c0 = (cls + X0) & 15;
-                    const uint32_t sb = (uint32_t)(c0 & 3);
-                    uint32_t o12[12];
-                    switch (c0 >> 2) {                         // wave-uniform
-                        case 0:
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 1], r8[j], sb);
-                            break;
-                        case 1:
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 2], r8[j + 1], sb);
-                            break;
-                        case 2:
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(r8[j + 3], r8[j + 2], sb);
-                            break;
-                        default:
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) o12[j] = __builtin_amdgcn_alignbyte(j + 4 < 16 ? r8[j + 4] : 0u, r8[j + 3], sb);
-                            break;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) add_bytes(o12[j], accE[j], accO[j]);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) r8[k] = 0;
-                };
-                for (int f = 4 * wv; f < nfp; f += 16) {       // nf_padded is a multiple of kFeatBatch (8): batches of 4, dealt round-robin to the waves
-                    FeatStrip c[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) c[u] = fs[f + u];                       // wave-uniform -> SMEM
-                    uint4 v[4][4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t pc = (c[u].cell & 0xFFFF) + (uint32_t)X0, row = (c[u].cell >> 16) + (uint32_t)Y0 + (uint32_t)lane;
-                        const int ns = (int)(((pc & 15) + (uint32_t)Wr + 15) >> 4);       // strips this class touches (wave-uniform)
-                        const uint8_t* p = sm_arena + c[u].sbase + (((pc >> 4) * (uint32_t)Hd) + row) * 16u;
-                        const uint32_t stride = (uint32_t)Hd * 16u;
-#pragma unroll
-                        for (int sidx = 0; sidx < 4; ++sidx)
-                            v[u][sidx] = (rowin && sidx < ns) ? ld_aligned16(p + sidx * stride) : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int cls = (int)(c[u].cell & 15);
-                        if (cls != cur || cnt == 63) {
-                            if (cur >= 0) flush(cur);
-                            cur = cls; cnt = 0;
-                        }
-#pragma unroll
-                        for (int sidx = 0; sidx < 4; ++sidx) {
-                            r8[4 * sidx] += v[u][sidx].x; r8[4 * sidx + 1] += v[u][sidx].y; r8[4 * sidx + 2] += v[u][sidx].z; r8[4 * sidx + 3] += v[u][sidx].w;
-                        }
-                        ++cnt;
-                    }
+                for (int o = 32; o > 0; o >>= 1) {
+                    X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
+                    Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
                 }
-                if (cur >= 0) flush(cur);
+                const int Wr = X1 - X0, Hr = Y1 - Y0;         // <= 48, <= 64 by construction of `member`
+                const int NC = (Wr + 15) >> 4, w = NC + 1, rpg = 64 / w;
+                const int off = pos & 63, rf = (64 - off) / w;
+                int end;
+                if (Hr <= rf) end = pos + Hr * w;
+                else { const int rest = Hr - rf - 1; end = ((pos >> 6) + 1 + rest / rpg) * 64 + (rest % rpg) * w + w; }
+                if (end > kSlotGroups * 64) break;            // no slots left: the remaining candidates stay with k_local
+                if (lane == 0) { s_reg[nreg][0] = X0; s_reg[nreg][1] = Y0; s_reg[nreg][2] = Hr; s_reg[nreg][3] = NC; s_reg[nreg][4] = pos; s_reg[nreg][5] = lds; }
+                if (member) { regof = nreg; rem = false; }
+                pos = end; lds += Hr * 16 * NC; ++nreg;
             }
-            // this wave's partial sums to its LDS plane: row = lane, columns 4j .. 4j+3 from accumulator j
-            if (lane < Hr) {
+            s_regof[lane] = (unsigned char)regof;
+            if (lane == 0) { s_nreg = nreg; s_groups = (pos + 63) >> 6; }
+        }
+        __syncthreads();
+        const int nreg = s_nreg, G = s_groups;
+        if (nreg == 0) continue;                               // uniform
+        // ---- this lane's slot in each load group ----
+        int dX0[kSlotGroups], dRow[kSlotGroups], dS[kSlotGroups], dLds[kSlotGroups];
+        bool dValid[kSlotGroups], dOwn[kSlotGroups];           // a slot exists / it owns 16 region columns (not the extra right-hand strip)
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    sum[lane][4 * j] = (uint16_t)(accE[j] & 0xFFFF); sum[lane][4 * j + 1] = (uint16_t)(accO[j] & 0xFFFF);
-                    sum[lane][4 * j + 2] = (uint16_t)(accE[j] >> 16); sum[lane][4 * j + 3] = (uint16_t)(accO[j] >> 16);
+        for (int q = 0; q < kSlotGroups; ++q) { dX0[q] = 0; dRow[q] = 0; dS[q] = 0; dLds[q] = 0; dValid[q] = false; dOwn[q] = false; }
+        for (int r = 0; r < nreg; ++r) {
+            const int X0 = s_reg[r][0], Y0 = s_reg[r][1], Hr = s_reg[r][2], NC = s_reg[r][3], pos = s_reg[r][4], lds = s_reg[r][5];
+            const int w = NC + 1, rpg = 64 / w, off = pos & 63, g0 = pos >> 6, rf = (64 - off) / w;
+#pragma unroll
+            for (int q = 0; q < kSlotGroups; ++q) {
+                int row = -1, sidx = 0;
+                if (q == g0) {
+                    const int local = lane - off;
+                    if (local >= 0) { row = local / w; sidx = local - row * w; if (row >= rf) row = -1; }
+                } else if (q > g0) {
+                    const int j = lane / w;
+                    sidx = lane - j * w;
+                    if (j < rpg) row = rf + (q - g0 - 1) * rpg + j;
+                }
+                if (row >= 0 && row < Hr) {
+                    dX0[q] = X0; dRow[q] = Y0 + row; dS[q] = sidx; dValid[q] = true; dOwn[q] = sidx < NC;
+                    dLds[q] = lds + row * 16 * NC + 16 * sidx;
                 }
             }
-            __syncthreads();
-            // ---- the members, dealt to the waves: first strict maximum of the member's own window (LL.cpp:1910-1931) ----
-            unsigned long long mm = __ballot(member);
-            int turn = 0;
-            while (mm) {
-                const int m = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                if ((turn++ & 3) != wv) continue;
-                const int wx = __shfl(gx, m, 64) - X0, wy = __shfl(gy, m, 64) - Y0;
-                uint32_t key = 0;
+        }
+        // ---- this wave's share of the features ----
+        uint32_t accE[kSlotGroups][4], accO[kSlotGroups][4], r8[kSlotGroups][4];
+#pragma unroll
+        for (int q = 0; q < kSlotGroups; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { accE[q][k] = 0; accO[q][k] = 0; r8[q][k] = 0; }
+        {
+            const FeatStrip* fs = feat_strip + e.feat_start;
+            int cur = -1, cnt = 0;
+            auto flush = [&](int cls) {
+#pragma unroll
+                for (int q = 0; q < kSlotGroups; ++q) {
+                    if (q < G) {                               // uniform
+                        const int c0 = (cls + dX0[q]) & 15;   // byte phase of this class in this lane's region
+                        const int dsel = c0 >> 2;
+                        const uint32_t sb = (uint32_t)(c0 & 3);
+                        uint32_t x[9];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { x[k] = r8[q][k]; x[4 + k] = (uint32_t)__shfl_down((int)r8[q][k], 1, 64); r8[q][k] = 0; }
+                        x[8] = 0;
+                        uint32_t y[5];
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) y[k] = dsel == 0 ? x[k] : dsel == 1 ? x[k + 1] : dsel == 2 ? x[k + 2] : x[k + 3];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) add_bytes(__builtin_amdgcn_alignbyte(y[k + 1], y[k], sb), accE[q][k], accO[q][k]);
+                    }
+                }
+            };
+            for (int f = 4 * wv; f < nfp; f += 16) {           // nf_padded is a multiple of kFeatBatch (8): batches of 4, dealt round-robin to the waves
+                FeatStrip c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = fs[f + u];                           // wave-uniform -> SMEM
+                uint4 v[4][kSlotGroups];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t lx = c[u].cell & 0xFFFF, ly = c[u].cell >> 16;
+#pragma unroll
+                    for (int q = 0; q < kSlotGroups; ++q) {
+                        v[u][q] = make_uint4(0, 0, 0, 0);
+                        if (q < G && dValid[q]) {
+                            const uint32_t pc = lx + (uint32_t)dX0[q];
+                            v[u][q] = ld_aligned16(sm_arena + c[u].sbase + ((((pc >> 4) + (uint32_t)dS[q]) * (uint32_t)Hd) + ly + (uint32_t)dRow[q]) * 16u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cls = (int)(c[u].cell & 15);
+                    if (cls != cur || cnt == 63) {
+                        if (cur >= 0) flush(cur);
+                        cur = cls; cnt = 0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < kSlotGroups; ++q) { r8[q][0] += v[u][q].x; r8[q][1] += v[u][q].y; r8[q][2] += v[u][q].z; r8[q][3] += v[u][q].w; }
+                    ++cnt;
+                }
+            }
+            if (cur >= 0) flush(cur);
+        }
+        // this wave's partial sums to its LDS plane: 16 columns per owning slot
+#pragma unroll
+        for (int q = 0; q < kSlotGroups; ++q) {
+            if (q < G && dOwn[q]) {
+                uint16_t* o = sum + dLds[q];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int idx = lane * 4 + k, r = idx >> 4, cc = idx & 15;
-                    const uint32_t raw = (uint32_t)s_sum[0][wy + r][wx + cc] + s_sum[1][wy + r][wx + cc] + s_sum[2][wy + r][wx + cc] + s_sum[3][wy + r][wx + cc];
-                    const uint32_t kk = (raw << 8) | (255u - (uint32_t)idx);
-                    key = kk > key ? kk : key;
+                    o[4 * k] = (uint16_t)(accE[q][k] & 0xFFFF); o[4 * k + 1] = (uint16_t)(accO[q][k] & 0xFFFF);
+                    o[4 * k + 2] = (uint16_t)(accE[q][k] >> 16); o[4 * k + 3] = (uint16_t)(accO[q][k] >> 16);
                 }
-                const uint32_t kbest = wave_max_u32(key);
-                const int raw = (int)(kbest >> 8);
-                int br = -1, bc = -1;
-                float best = 0.f;
-                if (raw > 0) {
-                    const int idx = 255 - (int)(kbest & 0xFF);
-                    br = idx >> 4; bc = idx & 15;
-                    best = score_of(raw, nf);
-                }
-                const int mpx = __shfl(px, m, 64), mpy = __shfl(py, m, 64);
-                const uint32_t mci = (uint32_t)__shfl((int)ci, m, 64);
-                if (lane == 0) {
-                    Candidate out;
-                    out.x = (mpx / T - 8 + bc) * T + offset;   // LL.cpp:1930-1931
-                    out.y = (mpy / T - 8 + br) * T + offset;
-                    out.score = best;
-                    out.work = best < threshold ? -1 : work;   // remove_if(MatchPredicate), LL.cpp:1935
-                    matches[mci] = out;
-                    matches_dev[mci] = out;
-                    todo[mci] = 0;
-                }
-                ++evals;
-                bytes += 256ull * nf;
             }
-            __syncthreads();                                   // the planes are free for the next region
-            if (member) open = false;
+        }
+        __syncthreads();
+        // ---- the members, dealt to the waves: first strict maximum of the member's own window (LL.cpp:1910-1931) ----
+        const int myreg = s_regof[lane];
+        unsigned long long mm = __ballot(myreg != 255);
+        int turn = 0;
+        while (mm) {
+            const int m = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            if ((turn++ & 3) != wv) continue;
+            const int r = __shfl(myreg, m, 64);
+            const int X0 = s_reg[r][0], Y0 = s_reg[r][1], stride = 16 * s_reg[r][3], lds = s_reg[r][5];
+            const int wx = __shfl(gx, m, 64) - X0, wy = __shfl(gy, m, 64) - Y0;
+            uint32_t key = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane * 4 + k, rr = idx >> 4, cc = idx & 15;
+                const int at = lds + (wy + rr) * stride + wx + cc;
+                const uint32_t raw = (uint32_t)s_sum[0][at] + s_sum[1][at] + s_sum[2][at] + s_sum[3][at];
+                const uint32_t kk = (raw << 8) | (255u - (uint32_t)idx);
+                key = kk > key ? kk : key;
+            }
+            const uint32_t kbest = wave_max_u32(key);
+            const int raw = (int)(kbest >> 8);
+            int br = -1, bc = -1;
+            float best = 0.f;
+            if (raw > 0) {
+                const int idx = 255 - (int)(kbest & 0xFF);
+                br = idx >> 4; bc = idx & 15;
+                best = score_of(raw, nf);
+            }
+            const int mpx = __shfl(px, m, 64), mpy = __shfl(py, m, 64);
+            const uint32_t mci = (uint32_t)__shfl((int)ci, m, 64);
+            if (lane == 0) {
+                Candidate out;
+                out.x = (mpx / T - 8 + bc) * T + offset;       // LL.cpp:1930-1931
+                out.y = (mpy / T - 8 + br) * T + offset;
+                out.score = best;
+                out.work = best < threshold ? -1 : work;       // remove_if(MatchPredicate), LL.cpp:1935
+                matches[mci] = out;
+                matches_dev[mci] = out;
+                todo[mci] = 0;
+            }
+            ++evals;
+            bytes += 256ull * nf;
         }
     }
     if (lane == 0 && evals) { atomicAdd(&counters[4], evals); atomicAdd(&counters[5], bytes); }
