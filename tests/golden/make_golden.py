@@ -3,7 +3,8 @@
 
 Inputs copied verbatim (they are the reference's own test fixtures, SURVEY Appendix D — data, not
 source): training images + golden template YAML (`test.cpp:36-51`), scene frame 0000, template
-banks 63/127 (gzipped), the poseRefine depth images.  `expected.json` records the stage hashes and
+its half-occluded variant (test.cpp:95-96), template
+banks 63/127/600 (gzipped), the poseRefine depth images.  `expected.json` records the stage hashes and
 match lists of SURVEY Appendix C.2 (produced by an independent numpy restatement that reproduced
 the golden YAML), which pin oracle/linemod_oracle.py + oracle/match_oracle.c.
 """
@@ -16,12 +17,13 @@ sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 
 
 def main():
-    for f in ["train_rgb.png", "train_dep.png", "train_mask.png", "0000_rgb.png", "0000_dep.png"]:
+    for f in ["train_rgb.png", "train_dep.png", "train_mask.png", "0000_rgb.png", "0000_dep.png",
+              "0000_rgb_half.png", "0000_dep_half.png"]:
         shutil.copyfile(REF + f, os.path.join(HERE, f))
     shutil.copyfile(REF + "pose/depth_ren.png", os.path.join(HERE, "pose_depth_ren.png"))
     shutil.copyfile(REF + "pose/0003.png", os.path.join(HERE, "pose_0003.png"))
     shutil.copyfile(REF + "writeClasses/06_template.yaml", os.path.join(HERE, "writeClasses_06_template.yaml"))
-    for bank in ["63", "127"]:
+    for bank in ["63", "127", "600"]:
         with open(REF + bank + "/06_template.yaml", "rb") as fi, \
                 gzip.GzipFile(os.path.join(HERE, "bank%s_06_template.yaml.gz" % bank), "wb", mtime=0) as fo:
             fo.write(fi.read())
