@@ -133,6 +133,13 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
     if (d->cstream) (void)hipStreamSynchronize(d->cstream);
     d->frame_rgb.release(); d->frame_depth.release(); d->nrm_raw.release();
+    for (int i = 0; i < lm_detector::kSlots; ++i) {
+        if (d->ingest.pinned[i]) (void)hipHostFree(d->ingest.pinned[i]);
+        d->ingest.d_rgb[i].release(); d->ingest.d_depth[i].release();
+        if (d->ingest.t0[i]) (void)hipEventDestroy(d->ingest.t0[i]);
+        if (d->ingest.t1[i]) (void)hipEventDestroy(d->ingest.t1[i]);
+    }
+    if (d->ingest.stream) (void)hipStreamDestroy(d->ingest.stream);
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
@@ -252,8 +259,11 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
     if (W < 16 || H < 16 || W > 16384 || H > 16384) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", W, H);
     HIP_TRY(hipSetDevice(d->device));
     d->frame_valid = false;
+    if (d->n_submitted != d->n_collected)   // the front end's buffers (and, on a size change, the arenas) belong to the frames in flight
+        return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them before uploading another frame this way (lm_detector_submit_frame streams)");
     int rc = setup_geometry(d, W, H, check_match_preconditions);
     if (rc) return rc;
+    d->cur_rgb = d->frame_rgb.p; d->cur_depth = d->frame_depth.p;
     const size_t n = (size_t)W * H;
     const bool m0 = masks && masks[0], m1 = masks && masks[1];
     size_t bytes = n * 3 + n * 2 + (m0 ? n : 0) + (m1 ? n : 0);
@@ -304,11 +314,11 @@ static int run_frontend(lm_detector* d, bool build_lm, int arena = 0, bool share
     FeStage st{};
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
-        const uint8_t* src = l == 0 ? d->frame_rgb.p : b.rgb.p;
+        const uint8_t* src = l == 0 ? d->cur_rgb : b.rgb.p;
         if (fused) {
             st.njobs = 0;
             fe_job_colour(st.job[st.njobs++], src, b.mag.p, b.ang.p, b.W, b.H, thr_sq);                                   // LL.cpp:367-504
-            if (l == 0) fe_job_normals(st.job[st.njobs++], d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+            if (l == 0) fe_job_normals(st.job[st.njobs++], d->cur_depth, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
                                        d->difference_threshold);                                                          // LL.cpp:729-819
             else fe_job_nn_down2(st.job[st.njobs++], d->lvl[l - 1].nrm.p, b.nrm.p, d->lvl[l - 1].W, d->lvl[l - 1].H);     // LL.cpp:857-880
             if (l + 1 < L) fe_job_pyrdown(st.job[st.njobs++], src, d->lvl[l + 1].rgb.p, b.W, b.H);                        // LL.cpp:557-581
@@ -317,10 +327,10 @@ static int run_frontend(lm_detector* d, bool build_lm, int arena = 0, bool share
         }
         if (l > 0) {
             const LevelBufs& a = d->lvl[l - 1];
-            launch_pyrdown_rgb(l == 1 ? d->frame_rgb.p : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
+            launch_pyrdown_rgb(l == 1 ? d->cur_rgb : a.rgb.p, b.rgb.p, a.W, a.H, s);   // LL.cpp:557-581
             launch_nn_down2(a.nrm.p, b.nrm.p, a.W, a.H, s);                                   // LL.cpp:857-880
         } else {
-            launch_normals_fused(d->frame_depth.p, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
+            launch_normals_fused(d->cur_depth, d->nrm_raw.p, b.nrm.p, b.W, b.H, d->distance_threshold,
                                  d->difference_threshold, s);                                 // LL.cpp:729-819
         }
         launch_color_quant(src, b.mag.p, b.ang.p, b.W, b.H, thr_sq, s);                       // LL.cpp:367-504
@@ -427,6 +437,7 @@ static int add_rendered_view_host(lm_detector* d, lm_mesh* m, int i, int width, 
     const size_t npx = (size_t)width * height;
     d->frame_valid = false;
     d->have_mask[0] = d->have_mask[1] = false;
+    d->cur_rgb = d->frame_rgb.p; d->cur_depth = d->frame_depth.p;
     HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(hdepth.data(), m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToHost, d->stream));
@@ -504,6 +515,7 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
         d->have_mask[0] = d->have_mask[1] = false;
         const float strong_sq = d->strong_threshold * d->strong_threshold;
         for (int i = 0; i < n; ++i) {
+            d->cur_rgb = d->frame_rgb.p; d->cur_depth = d->frame_depth.p;
             HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, s));
             if ((rc = run_frontend(d, false))) return rc;
@@ -964,6 +976,7 @@ extern "C" int lm_detector_set_frame(lm_detector* d, const uint8_t* rgb, const u
 
 extern "C" int lm_detector_store_frame(lm_detector* d, int slot, const uint8_t* rgb, const uint16_t* depth, int width, int height) {
     if (!d || !rgb || !depth || slot < 0 || slot > 4095) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (width < 16 || height < 16 || width > 16384 || height > 16384) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", width, height);
     HIP_TRY(hipSetDevice(d->device));
     if ((size_t)slot >= d->slot_rgb.size()) {
         d->slot_rgb.resize(slot + 1); d->slot_depth.resize(slot + 1);
@@ -971,10 +984,19 @@ extern "C" int lm_detector_store_frame(lm_detector* d, int slot, const uint8_t* 
     }
     const size_t n = (size_t)width * height;
     int rc;
+    if (d->slot_rgb[slot].cap < n * 3 || d->slot_depth[slot].cap < n)       // about to be reallocated: a frame in flight may still be
+        HIP_TRY(hipStreamSynchronize(d->stream));                          // copying out of the old buffer
     if ((rc = d->slot_rgb[slot].ensure(n * 3))) return rc;
     if ((rc = d->slot_depth[slot].ensure(n))) return rc;
-    HIP_TRY(hipMemcpy(d->slot_rgb[slot].p, rgb, n * 3, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->slot_depth[slot].p, depth, n * 2, hipMemcpyHostToDevice));
+    // staged through the detector's pinned buffer like every other upload (a pageable hipMemcpy stages internally, chunk by chunk)
+    if ((rc = ensure_pinned(d, n * 5))) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));                              // the staging buffer is shared with upload_frame
+    uint8_t* st = (uint8_t*)d->pinned;
+    memcpy(st, rgb, n * 3);
+    memcpy(st + n * 3, depth, n * 2);
+    HIP_TRY(hipMemcpyAsync(d->slot_rgb[slot].p, st, n * 3, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->slot_depth[slot].p, st + n * 3, n * 2, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     d->slot_w[slot] = width; d->slot_h[slot] = height;
     return LM_OK;
 }
@@ -983,13 +1005,17 @@ extern "C" int lm_detector_select_frame(lm_detector* d, int slot) {
     if (!d || slot < 0 || (size_t)slot >= d->slot_rgb.size() || d->slot_w[slot] <= 0)
         return lm_set_error(LM_ERR_INVALID, "no frame stored in slot %d", slot);
     HIP_TRY(hipSetDevice(d->device));
-    d->frame_valid = false;
     const int W = d->slot_w[slot], H = d->slot_h[slot];
     if (W != d->fW || H != d->fH || d->lm_arena[0].cap == 0) {
+        if (d->n_submitted != d->n_collected)   // setup_geometry reallocates and clears the arenas the frames in flight are reading
+            return lm_set_error(LM_ERR_INVALID, "frame size changes (%dx%d -> %dx%d) with frames in flight: collect them first", d->fW, d->fH, W, H);
+        d->frame_valid = false;
         int rc = setup_geometry(d, W, H, true);
         if (rc) return rc;
     }
+    d->frame_valid = false;
     const size_t n = (size_t)W * H;
+    d->cur_rgb = d->frame_rgb.p; d->cur_depth = d->frame_depth.p;
     HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, d->slot_rgb[slot].p, n * 3, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(d->frame_depth.p, d->slot_depth[slot].p, n * 2, hipMemcpyDeviceToDevice, d->stream));
     d->have_mask[0] = d->have_mask[1] = false;
@@ -1222,7 +1248,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
                                  ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)cands ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)hash << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10)};
+                                     ((uint64_t)(uintptr_t)hash << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10) ^
+                                     ((uint64_t)(uintptr_t)d->cur_rgb << 11) ^ ((uint64_t)(uintptr_t)d->cur_depth << 12)};
         if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe);      // the front end: seven small kernels, one launch
             if (ok) memcpy(sl.key, key, sizeof(key));
@@ -1298,6 +1325,14 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     }
     lm_timings tm{};
     tm.h2d_ms = sl.h2d_ms; tm.templates = sl.num_work; tm.coarse_bytes = sl.coarse_bytes;
+    {
+        const int r = (int)((d->n_collected - 1) % lm_detector::kSlots);
+        if (d->ingest.used[r]) {   // streamed frame: its H2D ran on the copy stream
+            d->ingest.used[r] = false;
+            float h = 0.f;
+            if (hipEventElapsedTime(&h, d->ingest.t0[r], d->ingest.t1[r]) == hipSuccess) tm.h2d_ms = h;
+        }
+    }
     uint64_t evals = 0, lbytes = 0, nm = 0;
     for (int b = 0; b < d->local_blocks; ++b) { evals += sl.h_counters[8 + 2 * b]; lbytes += sl.h_counters[8 + 2 * b + 1]; }
     if (sl.num_work > 0) { evals += sl.h_counters[4]; lbytes += sl.h_counters[5]; }   // what k_local_region refined (published by k_dedupe)
@@ -1370,6 +1405,86 @@ extern "C" int lm_detector_max_in_flight(void) { return lm_detector::kSlots; }
 extern "C" int lm_detector_submit(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
     return lm_submit_frame(d, threshold, class_ids, num_class_ids);
+}
+
+// ---- live-stream ingest ---------------------------------------------------------------------------
+// The per-frame call of a camera / dataset loop (linemod_ros/detect.py:83-138, linemod_and_levelup_test.py:314-327 hand a NEW
+// host frame to every match): stage -> H2D on the copy stream -> front end + matching of lm_detector_submit, up to kSlots
+// frames in flight; results come back through lm_detector_collect in submission order.
+static int ingest_entry(lm_detector* d, int r, size_t n) {
+    lm_detector::Ingest& g = d->ingest;
+    if (!g.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        for (int i = 0; i < lm_detector::kSlots; ++i) { HIP_TRY(hipEventCreate(&g.t0[i])); HIP_TRY(hipEventCreate(&g.t1[i])); }
+    }
+    if (g.pinned_bytes[r] < n * 5) {
+        if (g.pinned[r]) (void)hipHostFree(g.pinned[r]);
+        g.pinned[r] = nullptr; g.pinned_bytes[r] = 0;
+        HIP_TRY(hipHostMalloc(&g.pinned[r], n * 5, hipHostMallocDefault));
+        g.pinned_bytes[r] = n * 5;
+    }
+    int rc;
+    if ((rc = g.d_rgb[r].ensure(n * 3))) return rc;
+    if ((rc = g.d_depth[r].ensure(n))) return rc;
+    return LM_OK;
+}
+
+static int ingest_geometry(lm_detector* d, int width, int height) {
+    if (width < 16 || height < 16 || width > 16384 || height > 16384) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", width, height);
+    if (width != d->fW || height != d->fH || d->lm_arena[0].cap == 0) {
+        if (d->n_submitted != d->n_collected)
+            return lm_set_error(LM_ERR_INVALID, "frame size changes (%dx%d -> %dx%d) with frames in flight: collect them first", d->fW, d->fH, width, height);
+        d->frame_valid = false;
+        int rc = setup_geometry(d, width, height, true);
+        if (rc) return rc;
+    }
+    return LM_OK;
+}
+
+extern "C" int lm_detector_ingest_buffer(lm_detector* d, int width, int height, uint8_t** rgb, uint16_t** depth) {
+    if (!d || !rgb || !depth) return lm_set_error(LM_ERR_INVALID, "null argument");
+    *rgb = nullptr; *depth = nullptr;
+    if (d->n_submitted - d->n_collected >= (uint64_t)lm_detector::kSlots)
+        return lm_set_error(LM_ERR_INVALID, "%d frames already in flight: call lm_detector_collect first", lm_detector::kSlots);
+    HIP_TRY(hipSetDevice(d->device));
+    int rc = ingest_geometry(d, width, height);
+    if (rc) return rc;
+    const int r = (int)(d->n_submitted % lm_detector::kSlots);
+    const size_t n = (size_t)width * height;
+    if ((rc = ingest_entry(d, r, n))) return rc;
+    *rgb = (uint8_t*)d->ingest.pinned[r];
+    *depth = (uint16_t*)((uint8_t*)d->ingest.pinned[r] + n * 3);
+    return LM_OK;
+}
+
+extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int width, int height, float threshold,
+                                        const char* const* class_ids, int num_class_ids) {
+    if (!d || !rgb || !depth) return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (d->n_submitted - d->n_collected >= (uint64_t)lm_detector::kSlots)
+        return lm_set_error(LM_ERR_INVALID, "%d frames already in flight: call lm_detector_collect first", lm_detector::kSlots);
+    HIP_TRY(hipSetDevice(d->device));
+    int rc = ingest_geometry(d, width, height);
+    if (rc) return rc;
+    const int r = (int)(d->n_submitted % lm_detector::kSlots);   // ring entry == result slot: free, its previous frame was collected
+    const size_t n = (size_t)width * height;
+    if ((rc = ingest_entry(d, r, n))) return rc;
+    lm_detector::Ingest& g = d->ingest;
+    uint8_t* st = (uint8_t*)g.pinned[r];
+    if (rgb != st) memcpy(st, rgb, n * 3);                        // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
+    if ((const uint8_t*)depth != st + n * 3) memcpy(st + n * 3, depth, n * 2);
+    HIP_TRY(hipEventRecord(g.t0[r], g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_rgb[r].p, st, n * 3, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_depth[r].p, st + n * 3, n * 2, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipEventRecord(g.t1[r], g.stream));
+    HIP_TRY(hipStreamWaitEvent(d->stream, g.t1[r], 0));           // the front end starts when the frame has arrived
+    d->cur_rgb = g.d_rgb[r].p; d->cur_depth = g.d_depth[r].p;
+    d->have_mask[0] = d->have_mask[1] = false;
+    d->last_h2d_ms = 0.f;
+    d->frame_valid = true;
+    const uint64_t before = d->n_submitted;
+    rc = lm_submit_frame(d, threshold, class_ids, num_class_ids);
+    if (rc == LM_OK && d->n_submitted == before + 1) g.used[r] = true;
+    return rc;
 }
 
 extern "C" int lm_detector_collect(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {

@@ -69,6 +69,8 @@ struct lm_detector {
     bool frame_valid = false, have_mask[2] = {false, false};
     DevBuf<uint8_t> frame_rgb;
     DevBuf<uint16_t> frame_depth;
+    const uint8_t* cur_rgb = nullptr;           // what the front end reads: frame_rgb / frame_depth, or — for a frame that came in through
+    const uint16_t* cur_depth = nullptr;        // lm_detector_submit_frame — the ingest ring's device buffers (no device-to-device copy)
     DevBuf<uint8_t> nrm_raw;                    // normals before the median (level 0)
     static constexpr int kSlots = 4;            // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight)
     DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
@@ -139,6 +141,20 @@ struct lm_detector {
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
     uint64_t n_submitted = 0, n_collected = 0;
+
+    // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's
+    // pinned buffer (or written there by the caller: lm_detector_ingest_buffer), copied to the entry's device buffers on a
+    // dedicated copy stream — the H2D of frame k+1 runs beside the front end of frame k and the matching kernels of k-1 —
+    // and the front end reads it there.  An entry is free again when its frame was collected.
+    struct Ingest {
+        hipStream_t stream = nullptr;
+        void* pinned[kSlots] = {};
+        size_t pinned_bytes[kSlots] = {};
+        DevBuf<uint8_t> d_rgb[kSlots];
+        DevBuf<uint16_t> d_depth[kSlots];
+        hipEvent_t t0[kSlots] = {}, t1[kSlots] = {};   // timing of the H2D (copy stream)
+        bool used[kSlots] = {};                        // the slot's frame came in through the ring (lm_timings.h2d_ms from t0/t1)
+    } ingest;
 
     // multi-GPU exchange on the device (exchange.cpp): its own stream, so that the sort of frame k's records, the caller's
     // RCCL all-gather and the merge run beside the matching kernels of frame k+1

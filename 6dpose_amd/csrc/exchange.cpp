@@ -36,6 +36,8 @@ extern "C" void* lm_detector_exchange_stream(lm_detector* d) {
     return (void*)d->xchg.stream;
 }
 
+extern "C" int lm_exchange_max_capacity(void) { return (int)kXchgMaxCapacity; }
+
 extern "C" size_t lm_exchange_block_bytes(int capacity) { return valid_capacity(capacity) ? 16 + (size_t)capacity * 16 : 0; }
 
 extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int capacity) {

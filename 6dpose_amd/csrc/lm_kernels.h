@@ -151,7 +151,8 @@ constexpr uint32_t kXchgRunOverflow = 1;      // more distinct records than the 
 constexpr uint32_t kXchgCandOverflow = 2;     // the candidate buffer of the matching kernels overflowed: the frame has to be rerun
 constexpr uint32_t kXchgFieldOverflow = 4;    // |x|,|y| >= 32768: not representable in the key
 constexpr int kXchgHeaderWords = 256;         // result: {records, flags, world, capacity, -, -, -, -, count per rank...}, then 5-word records
-constexpr uint32_t kXchgMaxCapacity = 8192;
+constexpr uint32_t kXchgMaxCapacity = 65536;   // per rank and frame; the ranking kernels take any power of two (more tiles / passes), the blocks and the
+                                               // copy-out grow with it, so callers start small (4096) and double on demand
 // 128-bit sort key of a match: ascending key order = canonical order of SURVEY A12 (similarity desc, template id, class position, y, x);
 // it holds every field, so the records travel as keys.  .x = ~orderable(similarity) << 32 | template id, .y = class << 32 | y+32768 << 16 | x+32768.
 __device__ __forceinline__ ulonglong2 xchg_make_key(int x, int y, float sim, int cls, int tid) {

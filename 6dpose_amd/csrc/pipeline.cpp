@@ -259,7 +259,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         launch_icp_bind(p->d_sel, p->d_nsel, p->d_class_base, p->d_view_K, p->d_view_valid, p->num_views, c->d_in, c->d_st, top_k, s);
         HIP_TRY(hipEventRecord(p->e2, s));
         IcpBuffers B = c->B;
-        B.scene = d->frame_depth.p; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
+        B.scene = d->cur_depth; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
         B.count = top_k;
         memcpy(B.sK, scene_K, sizeof(B.sK));
         launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, s);

@@ -157,7 +157,10 @@ def load_library():
     lib.lm_detector_match_resident.argtypes = [P, F, ctypes.POINTER(S), I, I,
                                                ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
     lib.lm_detector_submit.argtypes = [P, F, ctypes.POINTER(S), I]
+    lib.lm_detector_submit_frame.argtypes = [P, P, P, I, I, F, ctypes.POINTER(S), I]
+    lib.lm_detector_ingest_buffer.argtypes = [P, I, I, ctypes.POINTER(P), ctypes.POINTER(P)]
     lib.lm_detector_max_in_flight.restype = I
+    lib.lm_exchange_max_capacity.restype = I
     lib.lm_detector_exchange_stream.argtypes = [P]
     lib.lm_detector_exchange_stream.restype = P
     lib.lm_exchange_block_bytes.argtypes = [I]
@@ -410,6 +413,8 @@ class Detector:
     def storeFrame(self, slot: int, sources) -> None:
         """Parks a frame in HBM slot `slot` (lm_detector_store_frame)."""
         rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        if rgb.shape[:2] != depth.shape:
+            raise RuntimeError("rgb and depth sizes differ")
         _check(self._lib.lm_detector_store_frame(self._h, slot, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0]))
 
     def selectFrame(self, slot: int) -> None:
@@ -428,6 +433,68 @@ class Detector:
         """Pipelined mode: enqueue front end + matching of the current frame and return (lm_detector_submit)."""
         carr, n, _names = self._class_args(class_ids)
         _check(self._lib.lm_detector_submit(self._h, float(threshold), carr, n))
+
+    def submitFrame(self, sources, threshold: float, class_ids: Sequence[str] = ()) -> None:
+        """Live-stream ingest (lm_detector_submit_frame): hands a NEW host frame to the detector and returns as soon as its
+        upload (pinned ring, copy stream), front end and matching are enqueued; collect() returns the results in submission
+        order.  Up to lm_detector_max_in_flight() frames in flight.  `sources` are borrowed only during the call; arrays
+        obtained from ingestBuffers() skip the staging copy."""
+        rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
+        if rgb.shape[:2] != depth.shape:
+            raise RuntimeError("rgb and depth sizes differ")
+        carr, n, _names = self._class_args(class_ids)
+        _check(self._lib.lm_detector_submit_frame(self._h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], float(threshold), carr, n))
+
+    def ingestBuffers(self, width: int, height: int):
+        """(rgb uint8 HxWx3, depth uint16 HxW) views of the pinned staging memory the NEXT submitFrame() will upload from
+        (lm_detector_ingest_buffer): fill them in place and pass them to submitFrame — no staging copy.  Valid until that
+        frame has been collected."""
+        pr, pd = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(self._lib.lm_detector_ingest_buffer(self._h, int(width), int(height), ctypes.byref(pr), ctypes.byref(pd)))
+        n = int(width) * int(height)
+        rgb = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_uint8)), shape=(n * 3,)).reshape(height, width, 3)
+        depth = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint16)), shape=(n,)).reshape(height, width)
+        return rgb, depth
+
+    def matchStream(self, frames, threshold: float, class_ids: Sequence[str] = (), depth: int = 3):
+        """The dataset / camera loop of the reference (linemod_and_levelup_test.py:314-327: one Detector.match per frame) as a
+        generator: yields Detector.match's result (MATCH_DTYPE records, canonical order) for every (rgb, depth) of `frames`,
+        in order, keeping up to `depth` frames in flight so that upload, front end, matching and the host-side merge of
+        neighbouring frames overlap.  A frame whose candidate buffer overflowed is redone synchronously."""
+        depth = max(1, min(int(depth), self._lib.lm_detector_max_in_flight()))
+        pending = []
+
+        def collect_or_none():
+            try:
+                return self.collect()
+            except RuntimeError as e:
+                if "overflow" not in str(e):
+                    raise
+                return None                  # capacity has been raised by the library; the frame is redone below
+
+        def drain():
+            """Everything in flight, in order; overflowed frames are redone one at a time once nothing is in flight."""
+            outs = [collect_or_none() for _ in pending]
+            res = [o if o is not None else self.matchArray(list(src), threshold, class_ids) for src, o in zip(pending, outs)]
+            del pending[:]
+            return res
+
+        for src in frames:
+            self.submitFrame(src, threshold, class_ids)
+            pending.append(src)
+            if len(pending) == depth:
+                out = collect_or_none()
+                if out is not None:
+                    pending.pop(0)
+                    yield out
+                else:
+                    first = pending.pop(0)
+                    rest = drain()
+                    yield self.matchArray(list(first), threshold, class_ids)
+                    for r in rest:
+                        yield r
+        for r in drain():
+            yield r
 
     def collect(self, sort_unique: bool = True, distinct: bool = False) -> np.ndarray:
         """Pipelined mode: matches of the oldest submitted frame (lm_detector_collect)."""

@@ -66,7 +66,7 @@ class DeviceExchange:
     for the following frames when that helps.  With a backend that cannot gather device tensors (gloo in the tests)
     the blocks are staged through the host; the kernels are the same."""
 
-    def __init__(self, detector: "lm.Detector", device, group=None, capacity: int = 4096, force: bool = False):
+    def __init__(self, detector: "lm.Detector", device, group=None, capacity: int = 4096, force: bool = False, shard: bool = True):
         import torch
         import torch.distributed as dist
         self.det, self.group = detector, group
@@ -77,7 +77,8 @@ class DeviceExchange:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.collective = self.dist is not None and (self.world > 1 or force)
         self.device_collective = self.collective and dist.get_backend(group) == "nccl"
-        detector.setShard(self.rank, self.world)
+        if shard:                      # shard=False: the caller partitioned the bank itself (e.g. whole classes per rank)
+            detector.setShard(self.rank, self.world)
         self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
         self.slots = lm.load_library().lm_detector_max_in_flight()
         self.next = 0
@@ -88,16 +89,21 @@ class DeviceExchange:
         self.capacity = capacity
         nbytes = lm.load_library().lm_exchange_block_bytes(capacity)
         if nbytes == 0:
-            raise ValueError("capacity must be a power of two in [256, 8192]")
+            raise ValueError("capacity must be a power of two in [256, %d]" % lm.load_library().lm_exchange_max_capacity())
         self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
         self.recv = [torch.zeros(nbytes * self.world, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
         self.cap_of = [capacity] * self.slots
 
-    def submit(self, threshold: float, class_ids: Sequence[str] = ()) -> None:
+    def submit(self, threshold: float, class_ids: Sequence[str] = (), frame=None) -> None:
+        """frame=None: the detector's current frame (setFrame / selectFrame); frame=(rgb, depth): a new host frame through
+        the live-stream ingest (Detector.submitFrame)."""
         import torch
         k = self.next
         self.next = (k + 1) % self.slots
-        self.det.submit(threshold, class_ids)
+        if frame is None:
+            self.det.submit(threshold, class_ids)
+        else:
+            self.det.submitFrame(frame, threshold, class_ids)
         send, recv, cap = self.send[k], self.recv[k], self.cap_of[k]
         self.det.exchangePack(send.data_ptr(), cap)
         if not self.collective:
@@ -121,8 +127,12 @@ class DeviceExchange:
             cap = self.capacity
             while cap < failed:
                 cap *= 2
-            if cap <= 8192:
+            if cap <= lm.load_library().lm_exchange_max_capacity():
                 self._pending_capacity = cap
+            else:
+                import warnings
+                warnings.warn("DeviceExchange: a rank produced %d distinct records, more than the largest block (%d): such frames take the host path"
+                              % (failed, lm.load_library().lm_exchange_max_capacity()))
         return out
 
     def grow_if_needed(self) -> None:
@@ -135,14 +145,16 @@ class DeviceExchange:
 
 
 def match_sharded(detector: "lm.Detector", sources, threshold: float, class_ids: Sequence[str] = (), masks=(),
-                  device=None, group=None, resident: bool = False, exchange: Optional[DeviceExchange] = None) -> np.ndarray:
+                  device=None, group=None, resident: bool = False, exchange: Optional[DeviceExchange] = None,
+                  shard: bool = True) -> np.ndarray:
     """Detector.match across all ranks of the process group: identical, canonically ordered result on
     every rank.  The detector must hold the full bank on every rank (template ids stay global)."""
     import torch.distributed as dist
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-    detector.setShard(rank, world)
+    if shard:                # shard=False: the caller partitioned the bank itself (whole classes per rank) — every rank searches
+        detector.setShard(rank, world)   # all the templates it holds; class positions and template ids are global either way
     if not resident:
         detector.setFrame(sources, masks)
     if exchange is not None:                                     # sort / gather / merge on the device

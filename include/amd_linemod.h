@@ -148,10 +148,11 @@ int lm_detector_set_shard(lm_detector *d, int rank, int world);
  *   lm_detector_exchange_collect(d, &out, &n, &failed) waits for the oldest frame in flight: the same list on every rank,
  *                                                   identical to an unsharded lm_detector_match (lm_free(out))
  * pack / merge apply to the most recently submitted frame and only enqueue work on the exchange stream (hipStream_t
- * returned as void*); up to lm_detector_max_in_flight() frames can be in flight.  capacity: power of two in [256, 8192], the same on every rank.
+ * returned as void*); up to lm_detector_max_in_flight() frames can be in flight.  capacity: power of two in [256, lm_exchange_max_capacity()] (65536), the same on every rank.
  * *failed != 0 (on every rank alike, *out == NULL): > 0 some rank had that many distinct records (> capacity), < 0 a
  * candidate buffer overflowed or a field did not fit the key — rerun the frame through lm_detector_match_resident +
  * lm_merge_matches (sharded.py does). */
+int lm_exchange_max_capacity(void);
 int lm_detector_max_in_flight(void);
 void *lm_detector_exchange_stream(lm_detector *d);
 size_t lm_exchange_block_bytes(int capacity);
@@ -192,6 +193,20 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
  * lm_detector_match_resident == submit + collect. */
 int lm_detector_submit(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids);
 int lm_detector_collect(lm_detector *d, int sort_unique, lm_match **out, size_t *n);
+/* Live-stream ingest (the per-frame call of linemod_ros/detect.py:83-138 and of the dataset loop
+ * linemod_and_levelup_test.py:314-327, which hand a NEW host frame to every Detector.match): lm_detector_submit_frame =
+ * "upload this host frame + lm_detector_submit" without blocking.  The frame is staged in a ring of pinned buffers (one per
+ * frame in flight), copied to HBM on a dedicated copy stream — the H2D of frame k+1 overlaps the front end of frame k and
+ * the matching kernels of frame k-1 — and the call returns as soon as everything is enqueued; rgb / depth are borrowed
+ * only until it returns.  Results come back through lm_detector_collect in submission order:
+ *   submit_frame(f0); submit_frame(f1); submit_frame(f2); collect() -> f0; submit_frame(f3); collect() -> f1; ...
+ * Zero-copy variant: lm_detector_ingest_buffer returns the pinned staging pointers the NEXT lm_detector_submit_frame will
+ * use (a camera driver / decoder writes the frame there); passing exactly these pointers skips the staging copy.
+ * No masks (the reference's callers pass masks=[]).  The frame size may change only with no frame in flight
+ * (LM_ERR_INVALID otherwise).  After LM_ERR_OVERFLOW from collect, submit that frame again. */
+int lm_detector_submit_frame(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
+                             float threshold, const char *const *class_ids, int num_class_ids);
+int lm_detector_ingest_buffer(lm_detector *d, int width, int height, uint8_t **rgb, uint16_t **depth);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity

@@ -335,6 +335,30 @@ def test_device_exchange_merges_shards_like_the_host(lm):
                 d.exchangeMerge(recv.data_ptr(), world, cap)
                 got, failed = d.exchangeCollect() if r % 2 == 0 else d.exchangeCollectInto(into)
                 assert failed == 0 and got.tobytes() == whole.tobytes(), (thr, cap, world, len(got), len(whole))
+    # a rank with more distinct records than the former 8192-record limit of a block: blocks of up to
+    # lm_exchange_max_capacity() records, several LDS tiles per run in the ranking kernel
+    assert lib.lm_exchange_max_capacity() >= 65536
+    big_thr = None
+    for thr in (55.0, 50.0, 45.0, 40.0, 35.0):
+        if len(ref.matchResident(thr, ids, sort_unique=False, distinct=True)) > 10000:
+            big_thr = thr
+            break
+    assert big_thr is not None, "no threshold yields more than 10000 distinct records"
+    whole = ref.matchResident(big_thr, ids)
+    for world, cap in ((1, 16384), (2, 32768), (3, 65536)):
+        dets = [make() for _ in range(world)]
+        nb = lib.lm_exchange_block_bytes(cap)
+        send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
+        for r, d in enumerate(dets):
+            d.setShard(r, world); d.submit(big_thr, ids); d.exchangePack(send[r].data_ptr(), cap)
+            torch.cuda.ExternalStream(d.exchangeStream(), device="cuda:0").synchronize()
+        counts = [int(b[:4].cpu().numpy().view(np.uint32)[0]) for b in send]
+        assert world > 1 or counts[0] > 8192, counts
+        recv = torch.cat(send)
+        for d in dets:
+            d.exchangeMerge(recv.data_ptr(), world, cap)
+            got, failed = d.exchangeCollect()
+            assert failed == 0 and got.tobytes() == whole.tobytes(), (big_thr, cap, world, len(got), len(whole))
     # many ranks (more runs than one boundary group of the ranking kernel holds, most of them empty or tiny): one detector
     # produces the blocks shard by shard, then merges them
     d = make()
@@ -414,6 +438,79 @@ def test_pipelined_submit_collect_equals_synchronous(lm):
     assert len(got) == len(order)
     for g, fi in zip(got, order):
         assert g.tobytes() == want[fi].tobytes()
+
+
+def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
+    """SURVEY §8f N4 proper: a NEW host frame per step (linemod_ros/detect.py:83-138, linemod_and_levelup_test.py:314-327)
+    through lm_detector_submit_frame — pinned ring + copy stream, up to four frames in flight, every frame different —
+    returns, frame by frame, exactly what the oracle and the synchronous Detector.match return; also through the zero-copy
+    ring buffers, the matchStream generator, mixed with parked-frame submits, and across a frame-size change."""
+    W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+    n_frames = 11
+    frames = [synth.make_frame(150 + i, W, H) for i in range(n_frames)]
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(*frames[0])
+    bank = synth.make_planted_bank(71, 120, [(p[0], p[1]) for p in pyr], T, nfeat)
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("o", *bank)
+    want = [det.matchArray(list(f), 70.0, ["o"]) for f in frames]
+    for i in (0, 5, 10):                                        # the synchronous call itself against the oracle
+        raw, _ = oracle_matches(od, frames[i][0], frames[i][1], bank, T, 70.0)
+        same_records(want[i], lo.canonical_sort_unique(raw))
+    assert len(want[0]) > 0 and len({w.tobytes() for w in want}) > 1, "frames must differ"
+    depth = lm.load_library().lm_detector_max_in_flight()
+    # (1) host arrays, the ring kept full, wrapping around it several times
+    got = []
+    for k, f in enumerate(frames):
+        scratch = (f[0].copy(), f[1].copy())
+        det.submitFrame(scratch, 70.0, ["o"])
+        scratch[0][:] = 0; scratch[1][:] = 0                     # borrowed only during the call
+        if k >= depth - 1:
+            got.append(det.collect())
+    with pytest.raises(RuntimeError, match="in flight"):
+        det.setFrame(list(frames[0]))                            # the blocking upload would pull the rug from under frames in flight
+    while len(got) < n_frames:
+        got.append(det.collect())
+    for g, w in zip(got, want):
+        assert g.tobytes() == w.tobytes()
+    assert det.lastTimings()["h2d_ms"] > 0
+    # (2) zero-copy: the caller writes into the pinned ring entry the next submit uploads from
+    got = []
+    for k, f in enumerate(frames):
+        rgb_buf, dep_buf = det.ingestBuffers(W, H)
+        rgb_buf[:] = f[0]; dep_buf[:] = f[1]
+        det.submitFrame((rgb_buf, dep_buf), 70.0, ["o"])
+        if k >= 2:
+            got.append(det.collect())
+    while len(got) < n_frames:
+        got.append(det.collect())
+    for g, w in zip(got, want):
+        assert g.tobytes() == w.tobytes()
+    # (3) the generator form of the dataset loop, at every depth
+    for dpt in (1, 2, depth):
+        for g, w in zip(det.matchStream(iter(frames), 70.0, ["o"], depth=dpt), want):
+            assert g.tobytes() == w.tobytes()
+    # (4) streamed and parked frames interleaved (the front end's source pointers alternate)
+    det.storeFrame(0, frames[3])
+    det.submitFrame(frames[1], 70.0, ["o"])
+    det.selectFrame(0); det.submit(70.0, ["o"])
+    det.submitFrame(frames[2], 70.0, ["o"])
+    for i in (1, 3, 2):
+        assert det.collect().tobytes() == want[i].tobytes()
+    # (5) frame-size change: refused with frames in flight, fine once they are collected
+    small = synth.make_frame(7, 320, 240, 14)
+    det.submitFrame(frames[4], 70.0, ["o"])
+    with pytest.raises(RuntimeError, match="in flight"):
+        det.submitFrame(small, 70.0, ["o"])
+    with pytest.raises(RuntimeError, match="in flight"):
+        det.storeFrame(1, small); det.selectFrame(1)
+    assert det.collect().tobytes() == want[4].tobytes()
+    det.submitFrame(small, 70.0, ["o"])
+    s1 = det.collect()
+    assert s1.tobytes() == det.matchArray(list(small), 70.0, ["o"]).tobytes()
+    assert det.matchArray(list(frames[6]), 70.0, ["o"]).tobytes() == want[6].tobytes()
+    with pytest.raises(RuntimeError):
+        det.submitFrame((frames[0][0], frames[0][1][:100]), 70.0, ["o"])
 
 
 def test_config1_size_2k_templates_bit_exact(lm):
@@ -965,3 +1062,26 @@ def test_match_sharded_two_processes_one_gpu_gloo(lm, tmp_path):
 def test_match_sharded_rccl_single_rank(lm, tmp_path):
     """The RCCL (backend "nccl") all-gather path with the one rank a 1-GPU box allows."""
     _run_workers(tmp_path, 1, "nccl")
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launcher_runs_two_ranks(lm, scaling):
+    """`python bench.py --gpus 2` (no torchrun around it) spawns two ranks — here both on the one GPU with the gloo
+    backend — and rank 0 prints ONE JSON line with n_gpus = 2, the live-stream frame source and the device exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_BENCH_BACKEND="gloo", LM_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--templates", "150", "--scaling", scaling, "--no-extras", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_observed"] == 2 and j["scaling"] == scaling
+    assert j["config"]["templates_total"] == (1200 if scaling == "strong" else 300)
+    assert "host memory" in j["config"]["frame_source"] and j["stages_ms"]["h2d_ms"] > 0
+    assert j["config"]["exchange"] == "device" and j["value"] > 0 and j["config"]["matches_final_last_step"] > 0

@@ -224,3 +224,32 @@ def test_packed_bank_file_header_and_rejections(lib, tmp_path):
             lm.bank_file_info(tmp_path / "bad.lmb")
     with pytest.raises(RuntimeError, match="cannot open"):
         lm.bank_file_info(tmp_path / "missing.lmb")
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` started without a launcher re-executes itself under torch.distributed.run with N
+    ranks on 127.0.0.1 (round-1 finding: the flag was parsed and never read).  CPU: only the command is checked; the
+    GPU suite runs it for real (test_bench_launcher_runs_two_ranks)."""
+    import argparse
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--scaling", "strong"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(bench.__file__ if bench.__file__ in cmd else os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--scaling", "strong"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
