@@ -187,7 +187,7 @@ extern "C" int lm_bank_file_class_id(const char* path, int index, char* out, int
     int rc = map_bank(path, m, h, dir);
     if (rc) return rc;
     if (index < 0 || (uint32_t)index >= h.num_classes) return lm_set_error(LM_ERR_INVALID, "class index out of range");
-    if ((int)dir[index].name_len >= capacity) return lm_set_error(LM_ERR_INVALID, "class id needs %u bytes", dir[index].name_len + 1);
+    if (dir[index].name_len >= (uint32_t)INT32_MAX || (int)dir[index].name_len >= capacity) return lm_set_error(LM_ERR_INVALID, "class id needs %u bytes", dir[index].name_len + 1);
     memcpy(out, m.p + dir[index].name_offset, dir[index].name_len);
     out[dir[index].name_len] = 0;
     return LM_OK;
@@ -224,7 +224,9 @@ extern "C" int lm_detector_read_bank(lm_detector* d, const char* path, const cha
         if (d->class_templates.count(cid)) return lm_set_error(LM_ERR_INVALID, "class '%s' already present [LL.cpp:2059]", cid.c_str());
         for (auto& kv : loaded) if (kv.first == cid) return lm_set_error(LM_ERR_INVALID, "class '%s' named twice", cid.c_str());
         const uint64_t nrec = (uint64_t)cr.num_pyramids * E + 1;
-        if (!m.span(cr.templ_offset, nrec * sizeof(TemplRec)) || !m.span(cr.feat_offset, cr.num_features * sizeof(uint32_t)))
+        // file-supplied counts: bounded by the file size BEFORE they are multiplied (a crafted num_features >= 2^62 would wrap)
+        if (cr.num_features > m.n / sizeof(uint32_t) || nrec > m.n / sizeof(TemplRec) ||
+            !m.span(cr.templ_offset, nrec * sizeof(TemplRec)) || !m.span(cr.feat_offset, cr.num_features * sizeof(uint32_t)))
             return lm_set_error(LM_ERR_IO, "arrays of class '%s' outside the file", cid.c_str());
         const TemplRec* recs = (const TemplRec*)(m.p + cr.templ_offset);
         const uint32_t* feats = (const uint32_t*)(m.p + cr.feat_offset);

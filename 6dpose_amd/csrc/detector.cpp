@@ -967,6 +967,67 @@ extern "C" int lm_nms_boxes(const double* boxes, const double* scores, int n, do
     return kept;
 }
 
+// Translation NMS over refined poses (linemod_ros/detect.py:41-51, `nms_norms(ts, ts_scores, 40.0)` at :128): visit by
+// score descending (scores.argsort()[::-1]: among equal scores the higher index first, as in lm_nms_boxes), keep, drop every
+// later pose whose translation is within `thresh` of it (kept iff ||t_i - t_j|| > thresh, double precision, numpy's
+// sqrt(dx*dx + dy*dy + dz*dz)).
+extern "C" int lm_nms_norms(const double* ts, const double* scores, int n, double thresh, int32_t* keep) {
+    if (n <= 0 || !ts || !scores || !keep) return 0;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] < scores[b]; });
+    std::reverse(order.begin(), order.end());
+    std::vector<char> dead((size_t)n, 0);
+    int kept = 0;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        if (dead[i]) continue;
+        keep[kept++] = i;
+        for (int oj = oi + 1; oj < n; ++oj) {
+            const int j = order[oj];
+            if (dead[j]) continue;
+            const double dx = ts[3 * i] - ts[3 * j], dy = ts[3 * i + 1] - ts[3 * j + 1], dz = ts[3 * i + 2] - ts[3 * j + 2];
+            const double norm = sqrt(dx * dx + dy * dy + dz * dz);
+            if (!(norm > thresh)) dead[j] = 1;
+        }
+    }
+    return kept;
+}
+
+// cv::dnn::NMSBoxes(std::vector<Rect>, scores, score_threshold, nms_threshold, indices, eta, top_k) as linemodLevelup/test.cpp:
+// 132-144 uses it (40x40 boxes at the match positions, score_threshold 0, nms_threshold 0.4).  OpenCV is un-vendored and its
+// version unpinned; this follows the published algorithm of OpenCV 3.4's dnn/src/nms.inl.hpp (NMSFast_): candidates with
+// score > score_threshold, std::stable_sort by score descending (ties keep input order), optional top_k cut, then greedily keep
+// a box iff its overlap with every box kept so far is <= the adaptive threshold (which shrinks by eta after each keep while
+// > 0.5 and eta < 1).  overlap = 1.f - float(jaccardDistance(a, b)), jaccardDistance in double on integer rectangle areas,
+// 0 when both are empty.  rects: [n][4] int32 x, y, width, height.
+extern "C" int lm_nms_boxes_cv(const int32_t* rects, const float* scores, int n, float score_threshold, float nms_threshold, float eta,
+                               int top_k, int32_t* keep) {
+    if (n <= 0 || !rects || !scores || !keep) return 0;
+    std::vector<int> order;
+    for (int i = 0; i < n; ++i) if (scores[i] > score_threshold) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+    if (top_k > 0 && (size_t)top_k < order.size()) order.resize((size_t)top_k);
+    auto overlap = [&](int a, int b) -> float {
+        const int32_t* A = rects + 4 * a; const int32_t* B = rects + 4 * b;
+        const double Aa = (double)A[2] * A[3], Ab = (double)B[2] * B[3];
+        if ((Aa + Ab) <= 2.220446049250313e-16) return 1.f - 0.f;                       // jaccardDistance: "identical": distance 0
+        const int x1 = std::max(A[0], B[0]), y1 = std::max(A[1], B[1]);
+        const int x2 = std::min(A[0] + A[2], B[0] + B[2]), y2 = std::min(A[1] + A[3], B[1] + B[3]);
+        const double Aab = (x2 > x1 && y2 > y1) ? (double)(x2 - x1) * (y2 - y1) : 0.0;     // (a & b).area(): empty unless both extents positive
+        return 1.f - (float)(1.0 - Aab / (Aa + Ab - Aab));
+    };
+    float adaptive = nms_threshold;
+    int kept = 0;
+    for (int idx : order) {
+        bool ok = true;
+        for (int k = 0; k < kept && ok; ++k) ok = overlap(idx, keep[k]) <= adaptive;
+        if (ok) keep[kept++] = idx;
+        if (ok && eta < 1.f && adaptive > 0.5f) adaptive *= eta;
+    }
+    return kept;
+}
+
 // ---- match ----------------------------------------------------------------------------------------
 extern "C" int lm_detector_set_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, int width, int height,
                                      const uint8_t* const* masks) {

@@ -176,6 +176,8 @@ def load_library():
     lib.lm_merge_matches.argtypes = [P, ctypes.c_size_t]
     lib.lm_merge_matches.restype = ctypes.c_size_t
     lib.lm_nms_boxes.argtypes = [P, P, I, ctypes.c_double, P]
+    lib.lm_nms_norms.argtypes = [P, P, I, ctypes.c_double, P]
+    lib.lm_nms_boxes_cv.argtypes = [P, P, I, F, F, F, I, P]
     lib.lm_free.argtypes = [P]
     lib.lm_free.restype = None
     lib.lm_pose_refine.argtypes = [I, P, P, I, I, P, P, P, P, I, I, I, ctypes.POINTER(_CPoseResult)]
@@ -614,6 +616,29 @@ def nms(dets: np.ndarray, thresh: float) -> List[int]:
     scores = np.ascontiguousarray(dets[:, 4])
     keep = np.zeros(len(dets), np.int32)
     n = load_library().lm_nms_boxes(_ptr(boxes), _ptr(scores), len(dets), float(thresh), _ptr(keep))
+    return keep[:n].tolist()
+
+
+def nms_norms(ts: np.ndarray, scores: np.ndarray, thresh: float) -> List[int]:
+    """Translation NMS over refined poses: linemod_ros/detect.py:41-51 (`nms_norms(ts, ts_scores, 40.0)`)."""
+    ts = np.ascontiguousarray(np.asarray(ts, np.float64).reshape(-1, 3))
+    scores = np.ascontiguousarray(scores, np.float64)
+    if len(ts) == 0:
+        return []
+    keep = np.zeros(len(ts), np.int32)
+    n = load_library().lm_nms_norms(_ptr(ts), _ptr(scores), len(ts), float(thresh), _ptr(keep))
+    return keep[:n].tolist()
+
+
+def NMSBoxes(bboxes, scores, score_threshold: float, nms_threshold: float, eta: float = 1.0, top_k: int = 0) -> List[int]:
+    """cv::dnn::NMSBoxes / cv2.dnn.NMSBoxes on integer rectangles (x, y, width, height), as linemodLevelup/test.cpp:132-144
+    filters the matches (40x40 boxes, score_threshold 0, nms_threshold 0.4)."""
+    rects = np.ascontiguousarray(np.asarray(bboxes, np.int32).reshape(-1, 4))
+    sc = np.ascontiguousarray(scores, np.float32)
+    if len(rects) == 0:
+        return []
+    keep = np.zeros(len(rects), np.int32)
+    n = load_library().lm_nms_boxes_cv(_ptr(rects), _ptr(sc), len(rects), float(score_threshold), float(nms_threshold), float(eta), int(top_k), _ptr(keep))
     return keep[:n].tolist()
 
 

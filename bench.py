@@ -459,11 +459,11 @@ def sync_latency(det, classes, n_templates, steps=20):
     """One frame at a time (submit + collect back to back, frame resident in HBM): the latency of a
     synchronous Detector.match call without the host<->device frame copy."""
     for k in range(3):
-        det.selectFrame(k % N_FRAMES)
+        det.selectFrame(k % N_PARKED)
         det.matchResident(THRESHOLD, classes)
     t0 = time.perf_counter()
     for k in range(steps):
-        det.selectFrame(k % N_FRAMES)
+        det.selectFrame(k % N_PARKED)
         det.matchResident(THRESHOLD, classes)
     dt = (time.perf_counter() - t0) / steps
     return {"ms_per_frame": dt * 1e3, "value": n_templates * (W * H / 1e6) / dt, "unit": "templates*Mpx/s"}

@@ -224,6 +224,16 @@ size_t lm_merge_matches(lm_match *m, size_t n);
  * input order as numpy argsort()[::-1] is NOT guaranteed — ties broken by higher index first).
  * boxes: [n][4] float64 x1,y1,x2,y2; scores [n] float64.  keep: [n] int32 out; returns #kept. */
 int lm_nms_boxes(const double *boxes, const double *scores, int n, double thresh, int32_t *keep);
+/* Translation NMS over refined poses, numpy `nms_norms` of linemod_ros/detect.py:41-51 (used at :128 with thresh 40.0 on
+ * poseRefine translations, score = -residual): score-descending, a later pose survives iff ||t_i - t_j|| > thresh.
+ * ts: [n][3] float64.  keep: [n] int32 out; returns #kept. */
+int lm_nms_norms(const double *ts, const double *scores, int n, double thresh, int32_t *keep);
+/* cv::dnn::NMSBoxes on integer rectangles as linemodLevelup/test.cpp:132-144 calls it (40x40 boxes, score_threshold 0,
+ * nms_threshold 0.4): the published algorithm of OpenCV 3.4 dnn (NMSFast_) — OpenCV is un-vendored and unpinned, so
+ * parity is with that algorithm, not with a binary.  rects: [n][4] int32 x, y, width, height; eta = 1, top_k = 0 are
+ * OpenCV's defaults.  keep: [n] int32 out; returns #kept. */
+int lm_nms_boxes_cv(const int32_t *rects, const float *scores, int n, float score_threshold, float nms_threshold, float eta,
+                    int top_k, int32_t *keep);
 
 void lm_free(void *p);
 

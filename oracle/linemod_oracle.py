@@ -740,6 +740,53 @@ def nms_boxes(dets: np.ndarray, thresh: float) -> List[int]:
     return keep
 
 
+def nms_norms(ts: np.ndarray, scores: np.ndarray, thresh: float) -> List[int]:
+    """linemod_ros/detect.py:41-51, statement for statement (it IS the reference: plain numpy)."""
+    order = scores.argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        norms = np.linalg.norm(ts[i] - ts[order[1:]], axis=1)
+        inds = np.where(norms > thresh)[0]
+        order = order[inds + 1]
+    return keep
+
+
+def nms_boxes_cv(rects: np.ndarray, scores: np.ndarray, score_threshold: float, nms_threshold: float,
+                 eta: float = 1.0, top_k: int = 0) -> List[int]:
+    """cv::dnn::NMSBoxes(vector<Rect>, ...) as test.cpp:132-144 calls it — restatement of OpenCV 3.4's published
+    NMSFast_ (dnn/src/nms.inl.hpp) + jaccardDistance (core/types.hpp); OpenCV is un-vendored, version unpinned:
+    PARITY UNPINNED.  Pure-Python loops (small inputs only)."""
+    rects = np.asarray(rects, np.int64)
+    cand = [i for i in range(len(rects)) if np.float32(scores[i]) > np.float32(score_threshold)]
+    cand.sort(key=lambda i: -float(np.float32(scores[i])))            # Python's sort is stable, like std::stable_sort
+    if top_k > 0:
+        cand = cand[:top_k]
+
+    def overlap(a, b):
+        ax, ay, aw, ah = (int(v) for v in rects[a]); bx, by, bw, bh = (int(v) for v in rects[b])
+        Aa, Ab = float(aw * ah), float(bw * bh)
+        if Aa + Ab <= np.finfo(np.float64).eps:
+            return np.float32(1.0)
+        w, h = min(ax + aw, bx + bw) - max(ax, bx), min(ay + ah, by + bh) - max(ay, by)
+        Aab = float(w * h) if (w > 0 and h > 0) else 0.0
+        return np.float32(1.0) - np.float32(1.0 - Aab / (Aa + Ab - Aab))
+
+    keep, adaptive = [], np.float32(nms_threshold)
+    for idx in cand:
+        ok = True
+        for k in keep:
+            if not (overlap(idx, k) <= adaptive):
+                ok = False
+                break
+        if ok:
+            keep.append(idx)
+            if eta < 1 and adaptive > 0.5:
+                adaptive = np.float32(adaptive * np.float32(eta))
+    return keep
+
+
 # --------------------------------------------------------------------------------------
 # poseRefine (LL.cpp:27-170) + Open3D pieces (SURVEY Appendix B) — PARITY UNPINNED
 # --------------------------------------------------------------------------------------

@@ -345,12 +345,17 @@ def test_device_exchange_merges_shards_like_the_host(lm):
             break
     assert big_thr is not None, "no threshold yields more than 10000 distinct records"
     whole = ref.matchResident(big_thr, ids)
-    for world, cap in ((1, 16384), (2, 32768), (3, 65536)):
+    n_distinct = len(ref.matchResident(big_thr, ids, sort_unique=False, distinct=True))
+    fit = 1 << int(np.ceil(np.log2(n_distinct)))
+    assert 8192 < fit <= 65536, n_distinct
+    for world, cap in ((1, fit), (2, min(65536, 2 * fit)), (3, 65536)):
         dets = [make() for _ in range(world)]
         nb = lib.lm_exchange_block_bytes(cap)
         send = [torch.zeros(nb, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
         for r, d in enumerate(dets):
-            d.setShard(r, world); d.submit(big_thr, ids); d.exchangePack(send[r].data_ptr(), cap)
+            d.setShard(r, world)
+            d.matchResident(big_thr, ids)          # a threshold this low outgrows the default candidate buffer: the synchronous call grows it
+            d.submit(big_thr, ids); d.exchangePack(send[r].data_ptr(), cap)
             torch.cuda.ExternalStream(d.exchangeStream(), device="cuda:0").synchronize()
         counts = [int(b[:4].cpu().numpy().view(np.uint32)[0]) for b in send]
         assert world > 1 or counts[0] > 8192, counts
@@ -358,7 +363,8 @@ def test_device_exchange_merges_shards_like_the_host(lm):
         for d in dets:
             d.exchangeMerge(recv.data_ptr(), world, cap)
             got, failed = d.exchangeCollect()
-            assert failed == 0 and got.tobytes() == whole.tobytes(), (big_thr, cap, world, len(got), len(whole))
+            assert failed == 0, (failed, counts, big_thr, cap, world)
+            assert got.tobytes() == whole.tobytes(), (big_thr, cap, world, len(got), len(whole))
     # many ranks (more runs than one boundary group of the ranking kernel holds, most of them empty or tiny): one detector
     # produces the blocks shard by shard, then merges them
     d = make()
