@@ -114,7 +114,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     d->work_tid = std::make_shared<std::vector<int32_t>>();
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
-    if (const char* rg = getenv("LM_REGION")) d->use_region = rg[0] && rg[0] != '0';
+    if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
@@ -145,7 +145,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
-    d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_tcount.release(); d->d_tlist.release(); d->d_todo.release(); d->d_work_cls.release(); d->d_work_tid.release();
+    d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_tiles.release(); d->d_todo.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (int l = 0; l < kMaxLevels; ++l) { d->train.mask[l].release(); d->train.lab[l].release(); d->train.hrun[l].release(); }
     d->train.keys.release(); d->train.counts.release(); d->train.bbox.release(); d->train.out.release();
     for (auto& sl : d->slot) {
@@ -1156,10 +1156,13 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
 
 static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t match_cap) {
     if (!d->local_blocks) {
-        // 3 workgroups (12 waves) per CU: alone the refinement is as fast as with every wave slot taken (it is bound by the vector
-        // L1, not by latency), and the free slots let the coarse pass of the next frame and the front end run beside it
-        // (pipelined: 0.244 -> 0.222 ms/frame; 2 per CU is slower, 4 already crowds the others out)
-        d->local_blocks = d->num_cus * 3;
+        // Grid of the refinement kernel.  Per-candidate path (LM_TILES=0): 3 workgroups (12 waves) per CU — alone it is as fast as
+        // with every wave slot taken (it is bound by the vector L1, not by latency), and the free slots let the coarse pass of the next
+        // frame and the front end run beside it (pipelined: 0.244 -> 0.222 ms/frame; 2 per CU is slower, 4 crowds the others out).  With tiles the
+        // work items are fewer and larger (a tile = two singles' worth of loads; ~5k items per 2k templates): a grid with more waves
+        // than items gives every wave at most one item and lets the hardware's workgroup dispatch do the balancing — 171 us (3 per CU,
+        // items dealt round-robin, slowest wave 2 tiles + 1 single) -> 122 (8) -> 103 (16 and more), profiles/r02_sweep_local_blocks.txt.
+        d->local_blocks = d->num_cus * (d->use_tiles ? 16 : 3);
         if (const char* lb = getenv("LM_LOCAL_BLOCKS")) { int v = atoi(lb); if (v > 0) d->local_blocks = v; }
     }
     if (!sl.h_counters)
@@ -1207,17 +1210,13 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap) * lm_detector::kSlots))) return rc;   // one table per result slot
     if ((rc = d->d_distinct_keys.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
-    const bool region = d->use_region && d->pyramid_levels == 2 && num_work > 0;
-    if (region) {
-        if (d->region_work_cap < (size_t)num_work || d->d_todo.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
-            HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
-            const size_t wcap = std::max<size_t>((size_t)num_work, d->region_work_cap);
-            if ((rc = d->d_tcount.ensure(wcap * lm_detector::kSlots))) return rc;
-            if ((rc = d->d_tlist.ensure(wcap * kRegionK * lm_detector::kSlots))) return rc;
-            if ((rc = d->d_todo.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
-            HIP_TRY(hipMemset(d->d_tcount.p, 0, d->d_tcount.cap * sizeof(uint32_t)));   // the lists are empty between frames
-            d->region_work_cap = wcap;
-        }
+    // tile refinement (match.hip): two-level pyramids with a tileable geometry; the buffers exist per result slot
+    const bool tiled = d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
+    const uint32_t tile_cap = d->cand_cap / 2;      // a tile has at least two members
+    if (tiled && (d->d_tiles.cap < (size_t)tile_cap * lm_detector::kSlots || d->d_todo.cap < (size_t)d->cand_cap * lm_detector::kSlots)) {
+        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
+        if ((rc = d->d_tiles.ensure((size_t)tile_cap * lm_detector::kSlots))) return rc;
+        if ((rc = d->d_todo.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     }
     if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
     hipStream_t s = d->stream, ms = d->mstream;
@@ -1225,9 +1224,8 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
     unsigned long long* final_dev = d->d_final.p + 8 * (size_t)arena;
     Candidate* cands = d->d_cands.p + (size_t)d->cand_cap * arena;
-    uint32_t* tcount = region ? d->d_tcount.p + d->region_work_cap * arena : nullptr;
-    uint32_t* tlist = region ? d->d_tlist.p + d->region_work_cap * kRegionK * arena : nullptr;
-    uint8_t* todo = region ? d->d_todo.p + (size_t)d->cand_cap * arena : nullptr;
+    TileRec* tiles = tiled ? d->d_tiles.p + (size_t)tile_cap * arena : nullptr;
+    uint8_t* todo = tiled ? d->d_todo.p + (size_t)d->cand_cap * arena : nullptr;
     unsigned long long* hash = d->d_hash.p + dedupe_table_slots(d->cand_cap) * (size_t)arena;
     Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
     ulonglong2* distinct_keys = d->d_distinct_keys.p + (size_t)d->cand_cap * arena;
@@ -1255,7 +1253,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         HIP_TRY(hipEventRecord(sl.ev[2], st));
         // the counters are zero on entry (reset by the slot's previous k_dedupe)
         launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, cands,
-                      d->cand_cap, counters, tcount, tlist, todo, st);
+                      d->cand_cap, counters, tiles, tile_cap, todo, st);
         HIP_TRY(hipEventRecord(sl.ev[3], st));
         return LM_OK;
     };
@@ -1264,16 +1262,12 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
         // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like the per-block
         // statistics and the results, stored straight into this slot's pinned host memory; it also empties the hash table
         // k_dedupe uses
-        // two-level pyramids: the candidates of a template region by region first (they share most of their windows); what that
-        // leaves (slow path, crowded templates) and every deeper pyramid goes through the per-candidate kernel
-        if (region)
-            launch_local_region(d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_strip.p, d->d_work.p, cands, d->cand_cap, threshold,
-                                d_matches, matches_dev, std::min<uint32_t>(sl.match_cap, d->cand_cap), tcount, tlist, todo, num_work, counters,
-                                d->local_blocks, ms);
+        // tiles first (the candidates of a template that share most of their windows, accumulated once per tile), then the
+        // candidates no tile serves — both phases of the one persistent kernel
         launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
                      d->d_work.p, cands, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
                      std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, hash, (uint32_t)dedupe_table_slots(d->cand_cap), todo,
-                     d->local_blocks, ms);
+                     tiles, tile_cap, d->local_blocks, ms);
         HIP_TRY(hipEventRecord(sl.ev[4], ms));
         return LM_OK;
     };
@@ -1310,7 +1304,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
                                  (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)cands ^
                                      ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
                                      ((uint64_t)(uintptr_t)hash << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10) ^
-                                     ((uint64_t)(uintptr_t)d->cur_rgb << 11) ^ ((uint64_t)(uintptr_t)d->cur_depth << 12)};
+                                     ((uint64_t)(uintptr_t)d->cur_rgb << 11) ^ ((uint64_t)(uintptr_t)d->cur_depth << 12) ^ ((uint64_t)(uintptr_t)tiles << 13)};
         if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
             const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe);      // the front end: seven small kernels, one launch
             if (ok) memcpy(sl.key, key, sizeof(key));
@@ -1396,7 +1390,6 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     }
     uint64_t evals = 0, lbytes = 0, nm = 0;
     for (int b = 0; b < d->local_blocks; ++b) { evals += sl.h_counters[8 + 2 * b]; lbytes += sl.h_counters[8 + 2 * b + 1]; }
-    if (sl.num_work > 0) { evals += sl.h_counters[4]; lbytes += sl.h_counters[5]; }   // what k_local_region refined (published by k_dedupe)
     const Candidate* hm = sl.h_matches;
     if (sort_unique == 0 || sl.num_work == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
     else nm = sl.h_counters[2];                        // counted on the device by k_dedupe: no pass over the raw records

@@ -109,10 +109,9 @@ struct lm_detector {
     DevBuf<Candidate> d_cands;
     DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K, duplicate removal)
     DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
-    DevBuf<uint32_t> d_tcount, d_tlist;             // per result slot: candidates per work item / their slots (k_local_region)
-    DevBuf<uint8_t> d_todo;                         // per result slot: 1 = candidate not refined yet
-    size_t region_work_cap = 0;                     // work items the per-template lists are sized for
-    bool use_region = false;                        // LM_REGION=1: region refinement for two-level pyramids (exact, but 2.2x slower than k_local as it stands)
+    DevBuf<TileRec> d_tiles;                        // per result slot: the tiles k_coarse planned (cand_cap / 2 records each)
+    DevBuf<uint8_t> d_todo;                         // per result slot: 1 = candidate that no tile serves (refined on its own)
+    bool use_tiles = true;                          // LM_TILES=0: every candidate on its own (the round-1 refinement)
     DevBuf<ulonglong2> d_distinct_keys;             // the distinct records as 128-bit sort keys, per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;          // working counters per result slot: zero between frames (k_dedupe's last block resets them)

@@ -65,13 +65,29 @@ struct Candidate {        // coarse hit, and (same layout) final match record
     int32_t work;         // index into the work list (-> class position, template id)
 };
 
-// counters[0] = number of candidates produced (may exceed cap: nothing is written past cap).
+// Tile refinement (match.hip): candidates of one template whose coarse cells are neighbours share most of their level-0
+// windows; k_coarse groups them into tiles, k_local accumulates a tile's window region once for all its members.
+constexpr int kTileStep = 4;      // level-0 cells between the windows of neighbouring coarse cells: 2 * T_top / T_0 must equal this
+constexpr int kTileNx = 5;        // coarse cells per tile: 16 + 4 * 4 = 32 columns = the part of 3 strips that survives any byte phase
+constexpr int kTileNy = 2;        //                        16 + 4 rows; 20 rows x 3 strips = 60 of the 64 lanes of a load
+struct TileRec {
+    int32_t work;                 // work-list index (-> template pyramid)
+    uint32_t gxy;                 // int16 gx0 | int16 gy0 << 16: level-0 cell of the first member's window origin (x / T - 8, LL.cpp:1380)
+    uint32_t slot_base;           // its members own the candidate slots [slot_base, slot_base + popcount(mask)), row-major by (j, i)
+    uint32_t mask;                // bit i + kTileNx * j: the candidate of coarse cell (c0 + i, r0 + j) is a member
+};
+// counters[0] of a frame's working counters: candidates in the low kCandBits bits, tiles planned above them (one atomic of
+// k_coarse reserves both)
+constexpr int kCandBits = 40;
+constexpr unsigned long long kCandMask = (1ull << kCandBits) - 1ull;
+bool tile_plan_possible(const FrameGeom& g);
+size_t coarse_plan_lds_bytes(int Wd, int Hd);
+// counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with `tiles` (and a geometry
+// tile_plan_possible accepts) also counters[0] >> kCandBits = number of tiles, todo[slot] = 1 for the candidates no tile serves.
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, uint32_t* tcount /*per work item, may be null*/, uint32_t* tlist /*[work][kRegionK] candidate slots*/,
-                   uint8_t* todo /*[cap] 1 = not refined yet*/, hipStream_t s);
-constexpr int kRegionK = 32;      // candidates per template that k_local_region groups (more: the template is left to k_local)
-// Persistent grid: waves stride over min(counters[0], cand_cap) candidates (count read on the device).
+                   unsigned long long* counters, TileRec* tiles /*may be null: no tiles*/, uint32_t tile_cap, uint8_t* todo /*[cap]*/, hipStream_t s);
+// Persistent grid: waves stride over the tiles, then over min(counters[0], cand_cap) candidates (counts read on the device).
 // matches[ci] = refined candidate ci (work = -1: dropped); block_stats (pinned host memory): [0] = candidate count,
 // [8+2*b], [8+2*b+1] = 16x16 evaluations / their algorithmic bytes of block b.
 struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
@@ -82,13 +98,8 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
                   unsigned long long* block_stats, unsigned long long* dedupe_table /*may be null*/, uint32_t dedupe_cap_slots,
-                  const uint8_t* todo /*null: every candidate; else only those with todo[ci] != 0*/, int grid_blocks, hipStream_t s);
-// Two-level pyramids: refines the candidates of every template with 1..kRegionK candidates region by region (match.hip) and
-// clears their todo flag; counters[4] / [5] += 16x16 evaluations / their algorithmic bytes.
-void launch_local_region(const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries, const FeatStrip* feat_strip,
-                         const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap, float threshold, Candidate* matches,
-                         Candidate* matches_dev, uint32_t cap, uint32_t* tcount, const uint32_t* tlist, uint8_t* todo, int num_work,
-                         unsigned long long* counters, int grid_blocks, hipStream_t s);
+                  const uint8_t* todo /*with tiles: only candidates with todo[ci] != 0 are refined one by one*/,
+                  const TileRec* tiles /*may be null*/, uint32_t tile_cap, int grid_blocks, hipStream_t s);
 // slots of k_dedupe's open-addressing table used for n records (power of two, >= 2n, <= cap_slots = dedupe_table_slots(cand_cap)):
 // k_local empties exactly these, k_dedupe hashes into exactly these
 __host__ __device__ inline uint32_t dedupe_slots_for(uint32_t n, uint32_t cap_slots) {

@@ -15,6 +15,10 @@
 //             offset stays exact).  At the top level, features outside the image (LL.cpp:1330) are
 //             already redirected to the zero tail.  feat_xy[] = int16 x | int16 y << 16 is only
 //             read on the slow path of the refinement (bounds test of LL.cpp:1394).
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "lm_kernels.h"
 
 namespace lm {
@@ -49,6 +53,15 @@ static __device__ __forceinline__ void add_bytes(uint32_t v, uint32_t& e, uint32
     o += (v >> 8) & 0x00FF00FFu;
 }
 
+static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Coarse pass (LL.cpp:1284-1354 similarity + :1835-1852 scan): one workgroup per template pyramid.
 // Lane i of wave w owns the 16 positions [16*(63w+i), +16) of the decimated top-level grid and loads
@@ -56,13 +69,58 @@ static __device__ __forceinline__ void add_bytes(uint32_t v, uint32_t& e, uint32
 // i+1's chunk, hence 63 producing lanes per wave plus one feeder lane.
 // ---------------------------------------------------------------------------------------------
 constexpr int kChunksPerWave = 63;
+constexpr int kMaxTilesPerTemplate = 48;       // tiles planned per template and frame (more candidates stay singles)
+constexpr int kPlanHits = 64;                  // hits per template (raster order) the planner looks at: one per lane
 
+// Everything the planner of k_coarse needs to know about the level below the top (two-level pyramids whose coarse cells are
+// kTileStep fine cells apart; plan.enabled == 0 otherwise).
+struct TilePlanGeom {
+    int enabled;
+    int W0, H0, T0, Wd0, Hd0;                  // level 0: image size, step, decimated grid
+    uint32_t tile_cap;
+    int dbg;                                   // LM_COARSE_DBG (timing experiments only): 1 = no grouping, 2 = no global atomic (wrong results)
+};
+
+static __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+static __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src) {
+    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
+// exclusive prefix of `mine` over the lanes of the wave; total = the wave's sum
+static __device__ __forceinline__ int wave_excl_scan(int mine, int lane, int& total) {
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - mine;
+}
+
+// A workgroup serves `group` templates at once, `wpt` waves each (blockDim = group * wpt * 64).  With tile planning ONE atomic
+// per WORKGROUP reserves the candidate slots and the tile records of all its templates.  (Measured, 2000 templates at VGA: a
+// workgroup per template with its own atomic on the frame's counter word takes 47 us, 17 us of them queueing at that word —
+// the L2 serialises same-address atomics at ~120 per us — and a second atomic for the tiles another 20 us; without atomics the
+// pass takes 31 us.)  The two counts share counters[0]: candidates in the low kCandBits bits, tiles above.
+// Dynamic LDS when tiles are planned, per template of the group: [npos] f32 score of every hit | [nw] hit bitmap |
+// kMaxTilesPerTemplate x 4 words of tile records | the first kPlanHits hit positions; then 4 words per template + 4 for the
+// group's scan.
 __global__ void __launch_bounds__(1024)
 k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-         const int32_t* __restrict__ work_pyramids, float threshold, Candidate* __restrict__ cands, uint32_t cap,
-         unsigned long long* __restrict__ counters, uint32_t* __restrict__ tcount, uint32_t* __restrict__ tlist, uint8_t* __restrict__ todo) {
-    const int work = blockIdx.x;
+         const int32_t* __restrict__ work_pyramids, int num_work, int wpt, float threshold, Candidate* __restrict__ cands, uint32_t cap,
+         unsigned long long* __restrict__ counters, TilePlanGeom plan, TileRec* __restrict__ tiles, uint8_t* __restrict__ todo) {
+    extern __shared__ uint32_t s_dyn[];
+    const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const int group = (int)(blockDim.x >> 6) / wpt;
+    const int tslot = wave_in_block / wpt, wave = wave_in_block - tslot * wpt, nwaves = wpt;
+    const int work_raw = blockIdx.x * group + tslot;
+    const bool live = work_raw < num_work;
+    const int work = live ? work_raw : num_work - 1;              // idle slots of the last workgroup shadow a real template and write nothing
     const int pyr = work_pyramids[work];
     const TemplEntry e = entries[(size_t)pyr * levels + level];
     const int nf = e.nf, nfp = e.nf_padded;
@@ -73,7 +131,18 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
     const int wf = (e.width - 1) / T + 1, hf = (e.height - 1) / T + 1;
     const int tp = (Hd - hf) * Wd + (Wd - wf) + 1;
     const int offset = T / 2 + (T % 2 - 1);   // LL.cpp:1846
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int nw = (npos + 31) >> 5;
+    const int per_template = npos + nw + 4 * kMaxTilesPerTemplate + kPlanHits;
+    uint32_t* s_mine = s_dyn + (size_t)tslot * per_template;
+    float* s_score = reinterpret_cast<float*>(s_mine);
+    volatile uint32_t* s_hit = s_mine + npos;
+    volatile uint32_t* s_tile = s_mine + npos + nw;
+    volatile uint32_t* s_list = s_tile + 4 * kMaxTilesPerTemplate;
+    volatile uint32_t* s_agg = s_dyn + (size_t)group * per_template;       // [group][4]: hits, tiles, first slot, first tile; then the atomic's result
+    if (plan.enabled) {
+        for (int i = wave * 64 + lane; i < nw; i += wpt * 64) s_hit[i] = 0;
+        __syncthreads();
+    }
 
     for (int chunk0 = wave * kChunksPerWave; chunk0 * 16 < npos; chunk0 += nwaves * kChunksPerWave) {
         const int j0 = (chunk0 + lane) * 16;                   // first position owned by this lane
@@ -136,9 +205,7 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
             }
             if (cur >= 0) flush(cur);
         }
-        // Threshold scan (LL.cpp:1835-1852).  One atomicAdd per WAVE reserves the slots of all its hits (a
-        // single counter word saturates at ~90 atomics/us on this chip: per-candidate atomics made the pass
-        // atomic-bound), then every lane writes its hits at the reserved base + its exclusive prefix.
+        // Threshold scan (LL.cpp:1835-1852).
         uint32_t hit_mask = 0;
         float sc[16];
 #pragma unroll
@@ -148,20 +215,26 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
             const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
             const int r = j < tp ? rawk : 0;                  // positions >= template_positions stay 0
             sc[k] = score_of(r, nf);
-            if (lane < kChunksPerWave && j < npos && sc[k] > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
+            if (live && lane < kChunksPerWave && j < npos && sc[k] > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
         }
-        int mine = __popc(hit_mask), incl = mine;
+        if (plan.enabled) {
+            // the hits of the whole template are collected in LDS; slots, tiles and records follow once all of them are known
+            if (hit_mask) {
+                atomicOr(const_cast<uint32_t*>(&s_hit[j0 >> 5]), hit_mask << (j0 & 31));
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+                for (int k = 0; k < 16; ++k) if (hit_mask & (1u << k)) s_score[j0 + k] = sc[k];
+            }
+            continue;
         }
-        const int total = __shfl(incl, 63, 64);
+        // Without planning: one atomicAdd per WAVE reserves the slots of all its hits, then every lane writes its hits at the
+        // reserved base + its exclusive prefix.
+        int total;
+        const int before = wave_excl_scan(__popc(hit_mask), lane, total);
         if (total > 0) {                                       // wave-uniform
             unsigned long long wbase = 0;
             if (lane == 0) wbase = atomicAdd(&counters[0], (unsigned long long)total);
-            wbase = ((unsigned long long)(uint32_t)__shfl((int)(wbase >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0, 64);
-            unsigned long long slot = wbase + (unsigned long long)(incl - mine);
+            wbase = bcast_u64(wbase, 0);
+            unsigned long long slot = wbase + (unsigned long long)before;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (hit_mask & (1u << k)) {
@@ -171,22 +244,173 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
                         Candidate c;
                         c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc[k]; c.work = work;
                         cands[slot] = c;
-                        if (tcount) {                          // the template's own candidate list (k_local_region); todo = 1: not refined yet
-                            todo[slot] = 1;
-                            const uint32_t ti = atomicAdd(&tcount[work], 1u);
-                            if (ti < (uint32_t)kRegionK) tlist[(size_t)work * kRegionK + ti] = (uint32_t)slot;
-                        }
                     }
                     ++slot;
                 }
             }
         }
     }
+    if (!plan.enabled) return;
+
+    // ---- planning (the first wave of every template): hits whose level-0 windows lie kTileStep cells apart are grouped into
+    // tiles of kTileNx x kTileNy coarse cells (one accumulation of the shared window region in k_local instead of one per
+    // candidate); the rest are singles (todo = 1).  See "Tile refinement" below.  The first kPlanHits hits (raster order) sit
+    // one per lane and the grouping is ballots over those lanes — no serial pass over the grid.
+    __syncthreads();
+    const bool planner = wave == 0 && live;
+    uint32_t nhit = 0;
+    if (planner) {
+        for (int w = lane; w < nw; w += 64) nhit += (uint32_t)__popc(s_hit[w]);
+        nhit = wave_sum_u32(nhit);
+    }
+    int ntile = 0, nplan = 0, p = 0;
+    uint32_t my_rel = 0;                                                    // this lane's slot relative to the template's first; top bit: a single
+    if (planner && nhit > 0) {
+        // hit h (raster order) -> lane h for h < kPlanHits (through LDS)
+        uint32_t before = 0;
+        for (int w0 = 0; w0 < nw && before < (uint32_t)kPlanHits; w0 += 64) {
+            uint32_t w = (w0 + lane < nw) ? s_hit[w0 + lane] : 0u;
+            int total;
+            uint32_t h = before + (uint32_t)wave_excl_scan(__popc(w), lane, total);
+            while (w && h < (uint32_t)kPlanHits) {
+                const int b = __ffs((int)w) - 1;
+                w &= w - 1;
+                s_list[h++] = (uint32_t)((w0 + lane) * 32 + b);
+            }
+            before += (uint32_t)total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nplan = nhit < (uint32_t)kPlanHits ? (int)nhit : kPlanHits;
+        const TemplEntry e0 = entries[(size_t)pyr * levels];
+        const int T0 = plan.T0, border = 8 * T0;
+        const int max_x = plan.W0 - e0.width - border, max_y = plan.H0 - e0.height - border;
+        auto fine_x0 = [&](int c) { return (c * T + offset) * 2 + 1; };   // LL.cpp:1868-1869 for the coarse cell's candidate
+        int cx = -100, cy = -100;
+        bool elig = false;
+        if (lane < nplan) {
+            p = (int)s_list[lane];
+            cy = p / Wd; cx = p - cy * Wd;
+            // a tile may serve the hit iff LL.cpp:1871-1880 does not clamp it and it is on the fast path of the refinement (all
+            // windows inside their planes) — from the entry's feature bounding box, exactly like k_local's `all_in`
+            const int x = fine_x0(cx), y = fine_x0(cy);
+            if (e0.min_x >= 0 && e0.min_y >= 0 && e0.nf_padded > 0 && x >= border && x <= max_x && y >= border && y <= max_y) {
+                const int gx = x / T0 - 8, gy = y / T0 - 8;
+                elig = gx >= 0 && gy >= 0 && (e0.max_x + gx * T0) / T0 + 16 <= plan.Wd0 && (e0.max_y + gy * T0) / T0 + 16 <= plan.Hd0;
+            }
+        }
+        uint32_t next = 0;                                                  // slots handed out so far
+        bool member = false;
+        while (ntile < kMaxTilesPerTemplate && !(plan.dbg & 1)) {
+            const unsigned long long eb = __ballot(elig);
+            if (!eb) break;
+            const int seed = __ffsll((long long)eb) - 1;                   // first eligible hit in raster order: top row of its block
+            const int r = __shfl(cy, seed, 64), c = __shfl(cx, seed, 64);
+            // the block of kTileNx x kTileNy cells holding the seed and the most eligible hits (how far it reaches to the left)
+            int best_n = 0, best_c0 = c;
+#pragma unroll
+            for (int dc = 0; dc < kTileNx; ++dc) {
+                const int c0 = c - dc < 0 ? 0 : c - dc;
+                const int n = __popcll(__ballot(elig && (cy == r || cy == r + 1) && cx >= c0 && cx < c0 + kTileNx));
+                if (n > best_n) { best_n = n; best_c0 = c0; }
+            }
+            if (best_n < 2) {                                               // alone in its neighbourhood: a single
+                if (lane == seed) elig = false;
+                continue;
+            }
+            const bool in = elig && (cy == r || cy == r + 1) && cx >= best_c0 && cx < best_c0 + kTileNx;
+            int c0 = best_c0;
+#pragma unroll
+            for (int sft = 0; sft < kTileNx - 1; ++sft)                     // tight on the left: a lone column of members needs two strips, not three
+                if (!__ballot(in && cx == c0)) ++c0;
+            const int bit = in ? (cx - c0) + kTileNx * (cy - r) : 0;
+            uint32_t mask = in ? 1u << bit : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mask |= (uint32_t)__shfl_xor((int)mask, o, 64);
+            if (in) { my_rel = next + (uint32_t)__popc(mask & ((1u << bit) - 1u)); member = true; elig = false; }
+            if (lane == seed) {
+                s_tile[4 * ntile + 0] = (uint32_t)work;
+                s_tile[4 * ntile + 1] = (uint32_t)(uint16_t)(int16_t)(fine_x0(c0) / T0 - 8) | ((uint32_t)(uint16_t)(int16_t)(fine_x0(r) / T0 - 8) << 16);
+                s_tile[4 * ntile + 2] = next;
+                s_tile[4 * ntile + 3] = mask;
+            }
+            next += (uint32_t)best_n;
+            ++ntile;
+        }
+        const bool single = lane < nplan && !member;
+        const unsigned long long sb = __ballot(single);
+        if (single) my_rel = (next + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull))) | 0x80000000u;
+    }
+    // the workgroup's templates line up: exclusive scan of their hit / tile counts, one atomic on the packed counter
+    if (wave == 0 && lane == 0) { s_agg[4 * tslot] = nhit; s_agg[4 * tslot + 1] = (uint32_t)ntile; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long hs = 0, ts = 0;
+        for (int t = 0; t < group; ++t) {
+            const uint32_t h = s_agg[4 * t], n = s_agg[4 * t + 1];
+            s_agg[4 * t + 2] = (uint32_t)hs; s_agg[4 * t + 3] = (uint32_t)ts;
+            hs += h; ts += n;
+        }
+        unsigned long long got = 0;
+        if (hs && !(plan.dbg & 2)) got = atomicAdd(&counters[0], hs | (ts << kCandBits));
+        s_agg[4 * group] = (uint32_t)got; s_agg[4 * group + 1] = (uint32_t)(got >> 32);
+    }
+    __syncthreads();
+    if (!planner || nhit == 0) return;
+    const unsigned long long packed = (unsigned long long)s_agg[4 * group] | ((unsigned long long)s_agg[4 * group + 1] << 32);
+    const unsigned long long base = (packed & kCandMask) + s_agg[4 * tslot + 2];
+    const unsigned long long tbase = (packed >> kCandBits) + s_agg[4 * tslot + 3];
+    auto put = [&](unsigned long long slot, int pos, int flag) {            // candidate record of coarse position pos
+        if (slot >= cap) return;
+        const int py = pos / Wd, px = pos - py * Wd;
+        Candidate c;
+        c.x = px * T + offset; c.y = py * T + offset; c.score = s_score[pos]; c.work = work;
+        cands[slot] = c;
+        todo[slot] = (uint8_t)flag;
+    };
+    if (lane < nplan) put(base + (my_rel & 0x7FFFFFFFu), p, (int)(my_rel >> 31));
+    if (nhit > (uint32_t)kPlanHits) {                                       // hits beyond the planned ones: singles, slot = first + h
+        uint32_t before = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            uint32_t w = (w0 + lane < nw) ? s_hit[w0 + lane] : 0u;
+            int total;
+            uint32_t h = before + (uint32_t)wave_excl_scan(__popc(w), lane, total);
+            while (w) {
+                const int b = __ffs((int)w) - 1;
+                w &= w - 1;
+                if (h >= (uint32_t)kPlanHits) put(base + h, (w0 + lane) * 32 + b, 1);
+                ++h;
+            }
+            before += (uint32_t)total;
+        }
+    }
+    if (lane < ntile && tbase + lane < plan.tile_cap) {
+        TileRec t;
+        t.work = (int32_t)s_tile[4 * lane]; t.gxy = s_tile[4 * lane + 1];
+        t.slot_base = (uint32_t)(base + s_tile[4 * lane + 2]); t.mask = s_tile[4 * lane + 3];
+        tiles[tbase + lane] = t;
+    }
+}
+
+// Tiles are planned for two-level pyramids whose coarse cells lie exactly kTileStep fine cells apart (T = {4, 8}, {2, 4}, ...)
+// and whose coarse grid fits the planner's LDS; anything else keeps the plain per-wave candidate emission.
+bool tile_plan_possible(const FrameGeom& g) {
+    if (g.levels != 2) return false;
+    const LevelGeom& top = g.lv[1];
+    const LevelGeom& l0 = g.lv[0];
+    if (2 * top.T != kTileStep * l0.T) return false;
+    const size_t npos = (size_t)top.Wd * top.Hd;
+    return npos >= 1 && coarse_plan_lds_bytes(top.Wd, top.Hd) <= 60 * 1024;   // at least one template per workgroup
+}
+
+size_t coarse_plan_lds_bytes(int Wd, int Hd) {                 // per template of a workgroup
+    const size_t npos = (size_t)Wd * Hd, nw = (npos + 31) / 32;
+    return (npos + nw + 4 * (size_t)kMaxTilesPerTemplate + kPlanHits) * sizeof(uint32_t);   // scores | hit bitmap | tile records | hit list
 }
 
 void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
                    const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, uint32_t* tcount, uint32_t* tlist, uint8_t* todo, hipStream_t s) {
+                   unsigned long long* counters, TileRec* tiles, uint32_t tile_cap, uint8_t* todo, hipStream_t s) {
     if (num_work <= 0) return;
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
@@ -194,8 +418,24 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
     int waves = (npos + kChunksPerWave * 16 - 1) / (kChunksPerWave * 16);
     if (waves > 16) waves = 16;
     if (waves < 1) waves = 1;
-    hipLaunchKernelGGL(k_coarse, dim3(num_work), dim3(waves * 64), 0, s, lm_arena, lv, level, g.levels, entries, feat_off,
-                       work_pyramids, threshold, cands, cap, counters, tcount, tlist, todo);
+    TilePlanGeom plan{};
+    size_t lds = 0;
+    int group = 1;
+    if (tiles && todo && tile_cap > 0 && tile_plan_possible(g)) {
+        plan.enabled = 1;
+        plan.W0 = g.lv[0].W; plan.H0 = g.lv[0].H; plan.T0 = g.lv[0].T; plan.Wd0 = g.lv[0].Wd; plan.Hd0 = g.lv[0].Hd;
+        plan.tile_cap = tile_cap;
+        static const int dbg = getenv("LM_COARSE_DBG") ? atoi(getenv("LM_COARSE_DBG")) : 0;
+        static const int max_group = getenv("LM_COARSE_GROUP") ? atoi(getenv("LM_COARSE_GROUP")) : 8;
+        plan.dbg = dbg;
+        // templates per workgroup: as many as 16 waves and 64 KB of LDS hold, at most 8
+        const size_t per = coarse_plan_lds_bytes(lv.Wd, lv.Hd);
+        group = std::min(std::max(1, max_group), std::min(16 / waves, (int)((64 * 1024 - 256) / per)));
+        if (group < 1) group = 1;
+        lds = per * group + (4 * (size_t)group + 4) * sizeof(uint32_t);
+    }
+    hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group), dim3(group * waves * 64), lds, s, lm_arena, lv, level, g.levels, entries,
+                       feat_off, work_pyramids, num_work, waves, threshold, cands, cap, counters, plan, tiles, todo);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -213,14 +453,6 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
 // Slow path: flat layout, per-feature bounds test, exactly the reference's reads (wrap-around included).
 // First strict maximum (LL.cpp:1920) = wave max-reduction of the packed key (raw << 8 | 255 - index).
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
-}
 
 __global__ void __launch_bounds__(256)
 k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_arena, FrameGeom g,
@@ -229,12 +461,14 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
         float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
         const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats,
-        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* __restrict__ todo) {
+        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* __restrict__ todo,
+        const TileRec* __restrict__ tiles, uint32_t tile_cap) {
     __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    unsigned long long nc = counters[0];
+    const unsigned long long packed = counters[0];
+    unsigned long long nc = packed & kCandMask;
     const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
     unsigned long long evals = 0, bytes = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) block_stats[0] = nc;   // candidate count for the host (pinned memory)
@@ -244,8 +478,149 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) dedupe_table[i] = ~0ull;
     }
 
+    // ---- Tile refinement: the candidates of one template whose coarse cells are neighbours have level-0 windows kTileStep
+    // cells apart, so most of every feature's window is shared.  A tile (planned by k_coarse) covers up to kTileNx x kTileNy
+    // such candidates: R = 16 + kTileStep * (rows of candidates - 1) rows x S strips of the strip-major planes, lane = (strip q,
+    // row r), ONE aligned 16-byte load per lane and feature.  Class runs are summed in packed bytes and realigned once per run
+    // like everywhere else ({own strip, next strip's lane r} shifted by the run's byte phase) into u16 sums of tile columns
+    // [16 q, 16 q + 16); every member then takes the first strict maximum of its own 16 x 16 window of those sums — the same
+    // integers, the same tie-break (packed key) and the same float expression as the per-candidate path below.
+    if (tiles) {
+        const unsigned long long nt64 = packed >> kCandBits;
+        const uint32_t ntiles = nt64 < tile_cap ? (uint32_t)nt64 : tile_cap;
+        const LevelGeom lv = g.lv[0];
+        const int T = lv.T, Hd = lv.Hd, offset = T / 2 + (T % 2 - 1);
+        for (uint32_t ti = wave0; ti < ntiles; ti += nwaves) {
+            const TileRec t = tiles[ti];
+            const int work = __builtin_amdgcn_readfirstlane(t.work);
+            const uint32_t gxy = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.gxy);
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask);
+            const uint32_t slot_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.slot_base);
+            const int gx0 = (int16_t)(gxy & 0xFFFF), gy0 = (int16_t)(gxy >> 16);
+            const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
+            const TemplEntry e = entries[(size_t)pyr * g.levels];
+            const int nf = e.nf, nfp = e.nf_padded;
+            const uint32_t cols = (mask | (mask >> kTileNx)) & ((1u << kTileNx) - 1u);
+            const int S = cols > 1u ? 3 : 2;                                   // a second column of candidates needs a third strip
+            const int R = (mask >> kTileNx) ? 16 + kTileStep : 16;
+            int q = (lane >= R) + (lane >= 2 * R), r = lane - q * R;
+            const bool active = lane < R * S;
+            if (!active) { q = 0; r = 0; }                                     // idle lanes repeat lane 0's (valid) loads
+            const uint8_t* smp = sm_arena + (uint32_t)(q * Hd + r) * 16u;
+            const int nb_lane = (lane + R < 64 ? lane + R : lane) << 2;       // the lane holding the next strip of this row
+            uint32_t aE[4] = {0, 0, 0, 0}, aO[4] = {0, 0, 0, 0};              // u16x2 sums: aE[k] = cols 4k, 4k+2; aO[k] = cols 4k+1, 4k+3
+            const FeatStrip* fs = feat_strip + e.feat_start;
+            uint32_t r8[4] = {0, 0, 0, 0};
+            int cur = -1, cnt = 0;
+            auto flush = [&](int cls) {
+                uint32_t x[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x[k] = r8[k]; x[4 + k] = (uint32_t)__builtin_amdgcn_ds_bpermute(nb_lane, (int)r8[k]); r8[k] = 0; }
+                const int c0 = (cls + gx0) & 15;                               // byte phase of the tile's first column in its strip
+                const uint32_t sb = (uint32_t)(c0 & 3);
+                uint32_t o4[4];
+                switch (c0 >> 2) {                                             // wave-uniform
+                    case 0:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 1], x[k], sb);
+                        break;
+                    case 1:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 2], x[k + 1], sb);
+                        break;
+                    case 2:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 3], x[k + 2], sb);
+                        break;
+                    default:
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o4[k] = __builtin_amdgcn_alignbyte(x[k + 4], x[k + 3], sb);
+                        break;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) add_bytes(o4[k], aE[k], aO[k]);
+            };
+            if (nfp > 0) {
+                FeatStrip c[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
+                for (int f = 0; f < nfp; f += kFeatBatch) {
+                    const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
+                    FeatStrip cn[kFeatBatch];
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
+                    uint4 v[kFeatBatch];
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) {
+                        const uint32_t xa = (c[u].cell & 0xFFFF) + (uint32_t)gx0, ya = (c[u].cell >> 16) + (uint32_t)gy0;
+                        v[u] = ld_aligned16(smp + (c[u].sbase + ((xa >> 4) * (uint32_t)Hd + ya) * 16u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) {
+                        const int cls = (int)(c[u].cell & 15);
+                        if (cls != cur || cnt == 63) {
+                            if (cur >= 0) flush(cur);
+                            cur = cls; cnt = 0;
+                        }
+                        r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // <= 63 x 4 per byte
+                        ++cnt;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
+                }
+                if (cur >= 0) flush(cur);
+            }
+            // members, in slot order
+            uint32_t rest = mask;
+            int member = 0;
+            while (rest) {
+                const int bit = __ffs((int)rest) - 1;
+                rest &= rest - 1;
+                const int j = bit / kTileNx, i = bit - j * kTileNx;
+                const int rr = r - j * kTileStep;                              // row of this lane inside the member's window
+                uint32_t key = 0;
+                if (active && q < 2 && rr >= 0 && rr < 16) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int col = 16 * q + 4 * k - i * kTileStep;         // window column of the lane's 4-column group k
+                        if (col >= 0 && col < 16) {
+                            const uint32_t idx = (uint32_t)(rr * 16 + col);
+                            const uint32_t k0 = ((aE[k] & 0xFFFF) << 8) | (255u - idx), k1 = ((aO[k] & 0xFFFF) << 8) | (255u - (idx + 1));
+                            const uint32_t k2 = ((aE[k] >> 16) << 8) | (255u - (idx + 2)), k3 = ((aO[k] >> 16) << 8) | (255u - (idx + 3));
+                            const uint32_t ka = k0 > k1 ? k0 : k1, kb = k2 > k3 ? k2 : k3;
+                            const uint32_t kk = ka > kb ? ka : kb;
+                            key = kk > key ? kk : key;
+                        }
+                    }
+                }
+                const uint32_t k = wave_max_u32(key);
+                const int raw = (int)(k >> 8);
+                int br = -1, bc = -1;                                           // LL.cpp:1910-1911
+                float best = 0.f;
+                if (raw > 0) {
+                    const int idx = 255 - (int)(k & 0xFF);
+                    br = idx >> 4; bc = idx & 15;
+                    best = score_of(raw, nf);
+                }
+                const uint32_t slot = slot_base + (uint32_t)member;
+                ++member;
+                ++evals;
+                bytes += 256ull * nf;
+                if (lane == 0 && slot < cap) {
+                    Candidate m;
+                    m.x = (gx0 + i * kTileStep + bc) * T + offset;              // LL.cpp:1930-1931: x / T - 8 = the member's window origin
+                    m.y = (gy0 + j * kTileStep + br) * T + offset;
+                    m.score = best;
+                    m.work = best < threshold ? -1 : work;                      // LL.cpp:1935
+                    matches[slot] = m;
+                    matches_dev[slot] = m;
+                }
+            }
+        }
+    }
+
     for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
-        if (todo && !todo[ci]) continue;                     // refined by k_local_region already (wave-uniform)
+        if (todo && !todo[ci]) continue;                     // a tile member: refined above (wave-uniform)
         const Candidate cd = cands[ci];
         const int work = __builtin_amdgcn_readfirstlane(cd.work);
         const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
@@ -408,267 +783,12 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
                   float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
                   unsigned long long* block_stats, unsigned long long* dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* todo,
-                  int grid_blocks, hipStream_t s) {
+                  const TileRec* tiles, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
+    if (!(tiles && todo && tile_plan_possible(g))) { tiles = nullptr; todo = nullptr; }      // same decision as launch_coarse
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
                        feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
-                       dedupe_table, dedupe_cap_slots, todo);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Region refinement (two-level pyramids): the coarse candidates of ONE template sit a few cells apart, so their 16x16
-// windows overlap — on the bench frame their union has 3x fewer cells than their sum (tests/analysis/candidate_clusters.py).
-// One wave per template: its candidates (k_coarse's per-template list) are grouped into regions of <= 48 columns x 64 rows
-// around a seed; the similarity of the whole region is accumulated ONCE — lane = row, per feature the 16-byte rows of the
-// 3-4 strips the region touches, features of one alignment class summed in packed bytes and realigned once per class, like
-// the coarse pass — into u16 sums in LDS, and every candidate then takes the first strict maximum of its own window from
-// there.  The sums are the integers the per-candidate kernel computes, so the records are identical.  Candidates on the
-// slow path, templates with more than kRegionK candidates and deeper pyramids are left to k_local (todo stays 1).
-// STATUS: exact (the parity tests pass with LM_REGION=1) but OFF by default: 0.39 ms against k_local's 0.17 ms on the bench
-// frame.  Two versions were measured.  (1) one pass per region, lane = row, one load per feature and strip: half the cache
-// lines of k_local but 1.6x MORE load instructions, 0.38 ms.  (2) this one: every 64-lane load carries (region, row, strip)
-// slots of all regions of the template, ~2.5 loads per feature and template instead of k_local's 3.7: 0.39 ms.  So it is not
-// the vector L1 that bounds these kernels but their own overhead per template — wave 0 building the regions while three waves
-// wait, per-lane slot descriptors and address arithmetic, a per-lane byte realignment at the end of each of the ~16 class
-// runs, three barriers, and 183 VGPRs (2 waves per SIMD) — about 100 us per template and workgroup, where k_local's tight
-// per-candidate loop needs 11 us per candidate.  Closing that gap means making the setup as cheap as k_local's (regions and
-// slots prepared by a separate pass, uniform slot shapes so that addresses and realignment are wave-uniform again).
-// ---------------------------------------------------------------------------------------------
-constexpr int kSlotGroups = 4;        // 64-lane load groups per feature: up to 256 (region, row, strip) slots per template
-constexpr int kMaxRegions = 8;
-
-__global__ void __launch_bounds__(256)
-k_local_region(const uint8_t* __restrict__ sm_arena, FrameGeom g, const TemplEntry* __restrict__ entries, const FeatStrip* __restrict__ feat_strip,
-               const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap, float threshold,
-               Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap, uint32_t* __restrict__ tcount,
-               const uint32_t* __restrict__ tlist, uint8_t* __restrict__ todo, int num_work, unsigned long long* __restrict__ counters) {
-    // One workgroup per template.  Its candidates are grouped into regions (<= 48 columns x 64 rows around a seed); every
-    // (region, row, 16-column strip) is a SLOT = one lane of a load, so that a 64-lane load carries the rows of several regions at
-    // once: a region of NC 16-column chunks takes NC + 1 adjacent lanes per row (the strips a misaligned feature plane needs), rows
-    // never straddle a 64-lane group.  Per feature: one 16-byte load per slot; packed byte sums per alignment class; at the end of
-    // a class run every lane realigns {its strip, the next lane's strip} by the class's byte phase in ITS region and adds the 16
-    // bytes to its u16 column sums.  The four waves split the features (one LDS plane of sums each) and then the members.
-    __shared__ uint16_t s_sum[4][kSlotGroups * 64 * 16];
-    __shared__ int s_reg[kMaxRegions][8];                      // X0, Y0, Hr, NC, first slot, LDS offset of the sums
-    __shared__ int s_nreg, s_groups;
-    __shared__ unsigned char s_regof[64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const LevelGeom lv = g.lv[0];
-    const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
-    const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-    unsigned long long evals = 0, bytes = 0;
-    uint16_t* sum = s_sum[wv];
-
-    for (int work = blockIdx.x; work < num_work; work += gridDim.x) {
-        const uint32_t n = tcount[work];
-        __syncthreads();                                      // every wave has read the count (and is done with the previous template's LDS)
-        if (n == 0) continue;
-        if (threadIdx.x == 0) tcount[work] = 0;               // the list is consumed: empty for the slot's next frame
-        if (n > (uint32_t)kRegionK) continue;                 // more candidates than the list holds: all of them stay with k_local
-        const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
-        const TemplEntry e = entries[(size_t)pyr * g.levels];
-        const int nf = e.nf, nfp = e.nf_padded;
-        const int max_x = W - e.width - border, max_y = H - e.height - border;
-        // this lane's candidate (every wave holds the same list)
-        uint32_t ci = 0;
-        int gx = 0, gy = 0, px = 0, py = 0;
-        bool open = false;
-        if (lane < (int)n) {
-            ci = tlist[(size_t)work * kRegionK + lane];
-            const Candidate cd = cands[ci];
-            int x = cd.x * 2 + 1, y = cd.y * 2 + 1;             // LL.cpp:1871-1880
-            x = x > border ? x : border;  y = y > border ? y : border;
-            x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
-            px = x; py = y;
-            gx = x / T - 8; gy = y / T - 8;
-            open = ci < cap && e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 && ((e.max_x + gx * T) / T + 16 <= Wd) &&
-                   ((e.max_y + gy * T) / T + 16 <= Hd);          // the fast-path test of k_local
-        }
-        // ---- regions and their slots (wave 0) ----
-        if (wv == 0) {
-            int nreg = 0, pos = 0, lds = 0, regof = 255;
-            bool rem = open;
-            while (nreg < kMaxRegions) {
-                const unsigned long long pending = __ballot(rem);
-                if (!pending) break;
-                const int seed = __ffsll((long long)pending) - 1;
-                const int sgx = __shfl(gx, seed, 64), sgy = __shfl(gy, seed, 64);
-                const bool member = rem && gx >= sgx - 16 && gx <= sgx + 16 && gy >= sgy - 24 && gy <= sgy + 24;
-                int X0 = member ? gx : INT_MAX, X1 = member ? gx + 16 : INT_MIN, Y0 = member ? gy : INT_MAX, Y1 = member ? gy + 16 : INT_MIN;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
-                    Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
-                }
-                const int Wr = X1 - X0, Hr = Y1 - Y0;         // <= 48, <= 64 by construction of `member`
-                const int NC = (Wr + 15) >> 4, w = NC + 1, rpg = 64 / w;
-                const int off = pos & 63, rf = (64 - off) / w;
-                int end;
-                if (Hr <= rf) end = pos + Hr * w;
-                else { const int rest = Hr - rf - 1; end = ((pos >> 6) + 1 + rest / rpg) * 64 + (rest % rpg) * w + w; }
-                if (end > kSlotGroups * 64) break;            // no slots left: the remaining candidates stay with k_local
-                if (lane == 0) { s_reg[nreg][0] = X0; s_reg[nreg][1] = Y0; s_reg[nreg][2] = Hr; s_reg[nreg][3] = NC; s_reg[nreg][4] = pos; s_reg[nreg][5] = lds; }
-                if (member) { regof = nreg; rem = false; }
-                pos = end; lds += Hr * 16 * NC; ++nreg;
-            }
-            s_regof[lane] = (unsigned char)regof;
-            if (lane == 0) { s_nreg = nreg; s_groups = (pos + 63) >> 6; }
-        }
-        __syncthreads();
-        const int nreg = s_nreg, G = s_groups;
-        if (nreg == 0) continue;                               // uniform
-        // ---- this lane's slot in each load group ----
-        int dX0[kSlotGroups], dRow[kSlotGroups], dS[kSlotGroups], dLds[kSlotGroups];
-        bool dValid[kSlotGroups], dOwn[kSlotGroups];           // a slot exists / it owns 16 region columns (not the extra right-hand strip)
-#pragma unroll
-        for (int q = 0; q < kSlotGroups; ++q) { dX0[q] = 0; dRow[q] = 0; dS[q] = 0; dLds[q] = 0; dValid[q] = false; dOwn[q] = false; }
-        for (int r = 0; r < nreg; ++r) {
-            const int X0 = s_reg[r][0], Y0 = s_reg[r][1], Hr = s_reg[r][2], NC = s_reg[r][3], pos = s_reg[r][4], lds = s_reg[r][5];
-            const int w = NC + 1, rpg = 64 / w, off = pos & 63, g0 = pos >> 6, rf = (64 - off) / w;
-#pragma unroll
-            for (int q = 0; q < kSlotGroups; ++q) {
-                int row = -1, sidx = 0;
-                if (q == g0) {
-                    const int local = lane - off;
-                    if (local >= 0) { row = local / w; sidx = local - row * w; if (row >= rf) row = -1; }
-                } else if (q > g0) {
-                    const int j = lane / w;
-                    sidx = lane - j * w;
-                    if (j < rpg) row = rf + (q - g0 - 1) * rpg + j;
-                }
-                if (row >= 0 && row < Hr) {
-                    dX0[q] = X0; dRow[q] = Y0 + row; dS[q] = sidx; dValid[q] = true; dOwn[q] = sidx < NC;
-                    dLds[q] = lds + row * 16 * NC + 16 * sidx;
-                }
-            }
-        }
-        // ---- this wave's share of the features ----
-        uint32_t accE[kSlotGroups][4], accO[kSlotGroups][4], r8[kSlotGroups][4];
-#pragma unroll
-        for (int q = 0; q < kSlotGroups; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { accE[q][k] = 0; accO[q][k] = 0; r8[q][k] = 0; }
-        {
-            const FeatStrip* fs = feat_strip + e.feat_start;
-            int cur = -1, cnt = 0;
-            auto flush = [&](int cls) {
-#pragma unroll
-                for (int q = 0; q < kSlotGroups; ++q) {
-                    if (q < G) {                               // uniform
-                        const int c0 = (cls + dX0[q]) & 15;   // byte phase of this class in this lane's region
-                        const int dsel = c0 >> 2;
-                        const uint32_t sb = (uint32_t)(c0 & 3);
-                        uint32_t x[9];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { x[k] = r8[q][k]; x[4 + k] = (uint32_t)__shfl_down((int)r8[q][k], 1, 64); r8[q][k] = 0; }
-                        x[8] = 0;
-                        uint32_t y[5];
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) y[k] = dsel == 0 ? x[k] : dsel == 1 ? x[k + 1] : dsel == 2 ? x[k + 2] : x[k + 3];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) add_bytes(__builtin_amdgcn_alignbyte(y[k + 1], y[k], sb), accE[q][k], accO[q][k]);
-                    }
-                }
-            };
-            for (int f = 4 * wv; f < nfp; f += 16) {           // nf_padded is a multiple of kFeatBatch (8): batches of 4, dealt round-robin to the waves
-                FeatStrip c[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) c[u] = fs[f + u];                           // wave-uniform -> SMEM
-                uint4 v[4][kSlotGroups];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t lx = c[u].cell & 0xFFFF, ly = c[u].cell >> 16;
-#pragma unroll
-                    for (int q = 0; q < kSlotGroups; ++q) {
-                        v[u][q] = make_uint4(0, 0, 0, 0);
-                        if (q < G && dValid[q]) {
-                            const uint32_t pc = lx + (uint32_t)dX0[q];
-                            v[u][q] = ld_aligned16(sm_arena + c[u].sbase + ((((pc >> 4) + (uint32_t)dS[q]) * (uint32_t)Hd) + ly + (uint32_t)dRow[q]) * 16u);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cls = (int)(c[u].cell & 15);
-                    if (cls != cur || cnt == 63) {
-                        if (cur >= 0) flush(cur);
-                        cur = cls; cnt = 0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < kSlotGroups; ++q) { r8[q][0] += v[u][q].x; r8[q][1] += v[u][q].y; r8[q][2] += v[u][q].z; r8[q][3] += v[u][q].w; }
-                    ++cnt;
-                }
-            }
-            if (cur >= 0) flush(cur);
-        }
-        // this wave's partial sums to its LDS plane: 16 columns per owning slot
-#pragma unroll
-        for (int q = 0; q < kSlotGroups; ++q) {
-            if (q < G && dOwn[q]) {
-                uint16_t* o = sum + dLds[q];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    o[4 * k] = (uint16_t)(accE[q][k] & 0xFFFF); o[4 * k + 1] = (uint16_t)(accO[q][k] & 0xFFFF);
-                    o[4 * k + 2] = (uint16_t)(accE[q][k] >> 16); o[4 * k + 3] = (uint16_t)(accO[q][k] >> 16);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- the members, dealt to the waves: first strict maximum of the member's own window (LL.cpp:1910-1931) ----
-        const int myreg = s_regof[lane];
-        unsigned long long mm = __ballot(myreg != 255);
-        int turn = 0;
-        while (mm) {
-            const int m = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            if ((turn++ & 3) != wv) continue;
-            const int r = __shfl(myreg, m, 64);
-            const int X0 = s_reg[r][0], Y0 = s_reg[r][1], stride = 16 * s_reg[r][3], lds = s_reg[r][5];
-            const int wx = __shfl(gx, m, 64) - X0, wy = __shfl(gy, m, 64) - Y0;
-            uint32_t key = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = lane * 4 + k, rr = idx >> 4, cc = idx & 15;
-                const int at = lds + (wy + rr) * stride + wx + cc;
-                const uint32_t raw = (uint32_t)s_sum[0][at] + s_sum[1][at] + s_sum[2][at] + s_sum[3][at];
-                const uint32_t kk = (raw << 8) | (255u - (uint32_t)idx);
-                key = kk > key ? kk : key;
-            }
-            const uint32_t kbest = wave_max_u32(key);
-            const int raw = (int)(kbest >> 8);
-            int br = -1, bc = -1;
-            float best = 0.f;
-            if (raw > 0) {
-                const int idx = 255 - (int)(kbest & 0xFF);
-                br = idx >> 4; bc = idx & 15;
-                best = score_of(raw, nf);
-            }
-            const int mpx = __shfl(px, m, 64), mpy = __shfl(py, m, 64);
-            const uint32_t mci = (uint32_t)__shfl((int)ci, m, 64);
-            if (lane == 0) {
-                Candidate out;
-                out.x = (mpx / T - 8 + bc) * T + offset;       // LL.cpp:1930-1931
-                out.y = (mpy / T - 8 + br) * T + offset;
-                out.score = best;
-                out.work = best < threshold ? -1 : work;       // remove_if(MatchPredicate), LL.cpp:1935
-                matches[mci] = out;
-                matches_dev[mci] = out;
-                todo[mci] = 0;
-            }
-            ++evals;
-            bytes += 256ull * nf;
-        }
-    }
-    if (lane == 0 && evals) { atomicAdd(&counters[4], evals); atomicAdd(&counters[5], bytes); }
-}
-
-void launch_local_region(const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries, const FeatStrip* feat_strip,
-                         const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap, float threshold, Candidate* matches,
-                         Candidate* matches_dev, uint32_t cap, uint32_t* tcount, const uint32_t* tlist, uint8_t* todo, int num_work,
-                         unsigned long long* counters, int grid_blocks, hipStream_t s) {
-    if (grid_blocks <= 0 || num_work <= 0) return;
-    hipLaunchKernelGGL(k_local_region, dim3(grid_blocks), dim3(256), 0, s, sm_arena, g, entries, feat_strip, work_pyramids, cands, cand_cap,
-                       threshold, matches, matches_dev, cap, tcount, tlist, todo, num_work, counters);
+                       dedupe_table, dedupe_cap_slots, todo, tiles, tile_cap);
 }
 
 }  // namespace lm

@@ -237,7 +237,7 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
          const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid, ulonglong2* __restrict__ distinct_keys,
          unsigned long long* __restrict__ final_dev, unsigned long long* __restrict__ final_host) {
     __shared__ bool s_last;
-    const unsigned long long nc = counters[0];
+    const unsigned long long nc = counters[0] & kCandMask;                           // low bits: candidates; above: tiles (k_coarse)
     const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
     table_mask = dedupe_slots_for(n, table_mask + 1) - 1;                            // the slots k_local emptied for this frame
     const int lane = threadIdx.x & 63;
@@ -294,7 +294,7 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
         const unsigned long long nd = atomicAdd(&counters[1], 0ull), na = atomicAdd(&counters[2], 0ull), bad = atomicAdd(&counters[3], 0ull);
         final_dev[0] = nc; final_dev[1] = nd; final_dev[2] = na; final_dev[3] = bad;
         final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
-        final_host[4] = atomicAdd(&counters[4], 0ull); final_host[5] = atomicAdd(&counters[5], 0ull);   // region refinement: evaluations, bytes
+        final_host[4] = atomicAdd(&counters[0], 0ull) >> kCandBits;                                       // tiles planned by k_coarse
         for (int q = 0; q < 8; ++q) counters[q] = 0;
     }
 }

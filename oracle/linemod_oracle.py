@@ -721,11 +721,14 @@ def match_bank_c(bank: PackedBank, lms, sizes, T_at_level, threshold: float, nth
 # NMS (caller side; linemod_and_levelup_test.py:34-61) — numpy semantics, oracle for N1
 # --------------------------------------------------------------------------------------
 
-def nms_boxes(dets: np.ndarray, thresh: float) -> List[int]:
-    """Greedy IoU NMS on rows [x1,y1,x2,y2,score] with the driver's +1 pixel convention."""
+def nms_boxes(dets: np.ndarray, thresh: float, stable: bool = False) -> List[int]:
+    """Greedy IoU NMS on rows [x1,y1,x2,y2,score] with the driver's +1 pixel convention
+    (linemod_and_levelup_test.py:34-61).  The driver's `scores.argsort()[::-1]` leaves the order among EQUAL scores to numpy's
+    default (unstable, on x86 a SIMD) sort; stable=True fixes it the way the product documents it (ascending stable sort
+    reversed: among equal scores the later row first) for tests with tied scores."""
     x1, y1, x2, y2, scores = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
     areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = scores.argsort()[::-1]
+    order = (scores.argsort(kind="stable") if stable else scores.argsort())[::-1]
     keep = []
     while order.size > 0:
         i = order[0]

@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc}; TAG=${2:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
 i=0
 for grp in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \

@@ -1,0 +1,104 @@
+"""Planning study for the tile refinement (CPU only, oracle linear memories): per template, the coarse candidates form a
+bitmap on the coarse grid; a tile of R rows x S strips of the strip-major level-0 planes serves every candidate inside a
+(bw x bh) block of coarse cells at the cost of ONE 1 KB wave-load per feature, against 0.5 KB per candidate and feature
+in k_local.  Greedy cover (first hit in raster order = top-left corner of the next block)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, '6dpose_amd'), os.path.join(ROOT, 'oracle')]
+import numpy as np, synth, linemod_oracle as lo
+W, H, T, NF = 640, 480, [4, 8], (150, 75)
+rgb, dep = synth.make_frame(0, W, H)
+od = lo.OracleDetector(NF[0], T)
+pyr = od.quantize_pyramid(rgb, dep)
+quant = [(p[0], p[1]) for p in pyr]
+NT = int(os.environ.get("NT", "400"))
+feat, offs, wh = synth.make_planted_bank(1234, NT, quant, T, NF)
+lms, sizes = od.linear_memories(rgb, dep)
+Wt, Ht, Tt = W >> 1, H >> 1, 8
+Wd, Hd = Wt // Tt, Ht // Tt
+npos = Wd * Hd
+THR = float(os.environ.get("THR", "75"))
+maps = []
+for p in range(NT):
+    sim = np.zeros(npos, np.int32); nf_total = 0
+    for m in range(2):
+        e = 2 + m
+        a, b = offs[p * 4 + e], offs[p * 4 + e + 1]
+        nf_total += b - a
+        lm = lms[1][m]
+        for (fx, fy, lab) in feat[a:b]:
+            if not (0 <= fx < Wt and 0 <= fy < Ht):
+                continue
+            base = (int(lab) * Tt * Tt + (fy % Tt) * Tt + (fx % Tt)) * npos + (fy // Tt) * Wd + fx // Tt
+            sim += lm[base:base + npos]
+    w1, h1 = wh[p * 4 + 2]
+    wf, hf = (w1 - 1) // Tt + 1, (h1 - 1) // Tt + 1
+    tp = (Hd - hf) * Wd + (Wd - wf) + 1
+    score = sim.astype(np.float32) * np.float32(100.0) / np.float32(4 * nf_total)
+    hit = (score > THR) & (np.arange(npos) < tp)
+    # clamped candidates cannot share a tile (their window start is not 4*c - 7)
+    w0, h0 = wh[p * 4]
+    border = 32; max_x, max_y = W - w0 - border, H - h0 - border
+    rr, cc = np.divmod(np.arange(npos), Wd)
+    x = (cc * Tt + 3) * 2 + 1; y = (rr * Tt + 3) * 2 + 1
+    free = (x >= border) & (x <= max_x) & (y >= border) & (y <= max_y)
+    maps.append((hit.reshape(Hd, Wd), free.reshape(Hd, Wd)))
+
+def cover(bw, bh):
+    tiles = singles = served = clamped = 0
+    hist = {}
+    for hit, free in maps:
+        clamped += int((hit & ~free).sum())
+        m = (hit & free).copy()
+        while m.any():
+            r, c = np.unravel_index(np.argmax(m), m.shape)
+            blk = m[r:r + bh, c:c + bw]
+            n = int(blk.sum())
+            blk[:] = False
+            if n == 1: singles += 1
+            else: tiles += 1; served += n; hist[n] = hist.get(n, 0) + 1
+    return tiles, singles, served, clamped, hist
+
+tot = sum(int(h.sum()) for h, _ in maps)
+print("templates", NT, "thr", THR, "candidates", tot, "per template %.2f" % (tot / NT))
+for name, bw, bh in (("21 rows x 3 strips (5x2 cells)", 5, 2), ("16 rows x 4 strips (9x1)", 9, 1), ("32 rows x 2 strips (1x5)", 1, 5),
+                     ("hypothetical 32 rows x 3 strips = 1.5 KB (5x5)", 5, 5)):
+    tiles, singles, served, clamped, hist = cover(bw, bh)
+    unit = 1.5 if bh == 5 and bw == 5 else 1.0
+    cost = tiles * unit + (singles + clamped) * 0.5
+    print("%-50s tiles %5d (serving %5d) singles %5d clamped %4d -> KB/feature %.0f vs %.0f now: %.2fx   hist %s"
+          % (name, tiles, served, singles, clamped, cost, tot * 0.5, tot * 0.5 / cost, sorted(hist.items())))
+
+print("\n-- cost = active lanes (TCP accesses scale with the 16-byte slots actually loaded): R rows x S strips, bounding shape of the block")
+def cover_shaped(bw, bh, anchor="topleft"):
+    lanes = 0; n_tiles = 0; kinds = {}
+    for hit, free in maps:
+        lanes += 32 * int((hit & ~free).sum())
+        m = (hit & free).copy()
+        while m.any():
+            r, c = np.unravel_index(np.argmax(m), m.shape)
+            best = None
+            for dc in (range(0, bw) if anchor == "best" else (0,)):
+                c0 = max(0, c - dc)
+                blk = m[r:r + bh, c0:c0 + bw]
+                n = int(blk.sum())
+                if best is None or n > best[0]:
+                    best = (n, c0)
+            n, c0 = best
+            blk = m[r:r + bh, c0:c0 + bw]
+            ys, xs = np.nonzero(blk)
+            w, h = xs.max() - xs.min() + 1, ys.max() - ys.min() + 1
+            S = 2 if w == 1 else 3
+            R = 16 + 4 * (h - 1)
+            cost = R * S
+            if cost >= 32 * n:            # not worth a tile: singles
+                cost = 32 * n; key = "singles"
+            else:
+                key = "%dx%d" % (R, S); n_tiles += 1
+            kinds[key] = kinds.get(key, 0) + 1
+            lanes += cost
+            blk[:] = False
+    return lanes, n_tiles, kinds
+for name, bw, bh, anchor in (("5x2 greedy top-left", 5, 2, "topleft"), ("5x2 greedy best x shift", 5, 2, "best"), ("5x3 (24 rows x 3 strips = 72 lanes: two loads)", 5, 3, "best")):
+    lanes, n_tiles, kinds = cover_shaped(bw, bh, anchor)
+    print("%-50s lanes %7d vs %7d now: %.2fx  tiles %d  %s" % (name, lanes, tot * 32, tot * 32 / lanes, n_tiles, sorted(kinds.items())))

@@ -226,40 +226,59 @@ def test_match_edge_cases(lm):
         det.addClassPacked("hand", *bank)               # class already present
 
 
-def test_region_refinement_is_exact(lm):
-    """LM_REGION=1: the candidates of a template refined region by region (k_local_region: the union of their windows summed once)
-    give the records of the per-candidate kernel, pre-unique multiset and evaluation count included — on a planted bank (clusters
-    of neighbouring candidates), a random one (isolated candidates) and with oversized templates that stay on the slow path."""
+def test_tile_refinement_is_exact(lm):
+    """The default refinement groups the candidates of a template whose coarse cells are neighbours into tiles (planned by
+    k_coarse, the shared window region summed once per tile in k_local).  It must give the records of the per-candidate kernel
+    (LM_TILES=0, the round-1 path) AND of the oracle — pre-unique multiset, evaluation count and algorithmic bytes included — on
+    a planted bank (clusters of neighbouring candidates), a random one (isolated candidates), with templates planted against the
+    frame border (clamped windows stay singles), with oversized templates on the slow path, at low thresholds (dense tiles),
+    and with frames in flight."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
     rgb, dep = synth.make_frame(5, W, H)
     od = lo.OracleDetector(nfeat[0], T)
     pyr = od.quantize_pyramid(rgb, dep)
     banks = {"planted": synth.make_planted_bank(17, 300, [(p[0], p[1]) for p in pyr], T, nfeat), "random": synth.make_random_bank(18, 200, W, H, nfeat)}
-    plain = lm.Detector(nfeat[0], T, device=0)
-    os.environ["LM_REGION"] = "1"
+    tiled = lm.Detector(nfeat[0], T, device=0)
+    os.environ["LM_TILES"] = "0"
     try:
-        region = lm.Detector(nfeat[0], T, device=0)
+        plain = lm.Detector(nfeat[0], T, device=0)
     finally:
-        del os.environ["LM_REGION"]
-    for d in (plain, region):
+        del os.environ["LM_TILES"]
+    for d in (plain, tiled):
         for c, b in banks.items():
             d.addClassPacked(c, *b)
         d.setFrame([rgb, dep])
-    for thr, ids in ((75.0, ["planted"]), (60.0, ["random", "planted"]), (88.0, [])):
+    names = ["x", "y", "similarity", "class_index", "template_id"]
+    for thr, ids in ((75.0, ["planted"]), (60.0, ["random", "planted"]), (88.0, []), (45.0, ["planted"])):
         a = plain.matchResident(thr, ids)
-        b = region.matchResident(thr, ids)
+        b = tiled.matchResident(thr, ids)
         assert len(a) > 0 and a.tobytes() == b.tobytes(), (thr, ids, len(a), len(b))
-        ta, tb = plain.lastTimings(), region.lastTimings()
+        ta, tb = plain.lastTimings(), tiled.lastTimings()
+        assert ta["coarse_candidates"] == tb["coarse_candidates"]
         assert ta["local_evals"] == tb["local_evals"] and ta["matches_pre_unique"] == tb["matches_pre_unique"] and ta["local_bytes"] == tb["local_bytes"]
         ra = plain.matchResident(thr, ids, sort_unique=False)
-        rb = region.matchResident(thr, ids, sort_unique=False)
-        names = ["x", "y", "similarity", "class_index", "template_id"]
+        rb = tiled.matchResident(thr, ids, sort_unique=False)
         assert as_multiset(ra, names) == as_multiset(rb, names)
-    for k in range(6):                                          # pipelined, slots reused
-        region.submit(75.0, ["planted"])
+        if thr >= 60.0:                                           # ... and the oracle itself
+            order = ids if ids else sorted(banks)
+            raws = []
+            for ci, c in enumerate(order):
+                raw, _ = oracle_matches(od, rgb, dep, banks[c], T, thr, ci)
+                raws.append(raw)
+            same_records(b, lo.canonical_sort_unique(np.concatenate(raws)))
+    for k in range(7):                                          # pipelined, slots reused
+        tiled.submit(75.0, ["planted"])
         if k >= 2:
-            assert region.collect().tobytes() == plain.matchResident(75.0, ["planted"]).tobytes()
-    region.collect(); region.collect()
+            assert tiled.collect().tobytes() == plain.matchResident(75.0, ["planted"]).tobytes()
+    tiled.collect(); tiled.collect()
+    # a geometry the planner does not tile (coarse cells 16/5 fine cells apart) takes the per-candidate path unchanged
+    od58 = lo.OracleDetector(63, [5, 8])
+    p58 = od58.quantize_pyramid(rgb, dep)
+    b58 = synth.make_planted_bank(19, 120, [(p[0], p[1]) for p in p58], [5, 8], (63, 31))
+    d58 = lm.Detector(63, [5, 8], device=0)
+    d58.addClassPacked("o", *b58)
+    raw, _ = oracle_matches(od58, rgb, dep, b58, [5, 8], 70.0)
+    same_records(d58.matchArray([rgb, dep], 70.0, ["o"]), lo.canonical_sort_unique(raw))
 
 
 def test_sharded_equals_unsharded_on_one_device(lm):
@@ -940,6 +959,24 @@ def _pipeline_reference(mod, det, rgb, dep, wh, E, views, thr, top_k, iou, box=N
     return sel, poses, len(m)
 
 
+def _pipeline_oracle(od, rgb, dep, bank, T, wh, E, views, thr, top_k, iou, box=None):
+    """The same driver loop on the CPU ORACLE only (nothing of the product): match_oracle.c -> canonical sort/unique ->
+    numpy nms (the driver's own function) -> oracle poseRefine per kept match."""
+    raw, _ = oracle_matches(od, rgb, dep, bank, T, thr)
+    m = lo.canonical_sort_unique(raw)
+    dets = np.zeros((len(m), 5))
+    for i, r in enumerate(m):
+        w, h = wh[int(r["tid"]) * E] if box is None else box[int(r["tid"])]
+        dets[i] = (r["x"], r["y"], r["x"] + w, r["y"] + h, r["sim"])
+    keep = lo.nms_boxes(dets, iou, stable=True)[:top_k] if len(m) else []      # planted templates tie in score
+    sel = [m[i] for i in keep]
+    poses = []
+    for r in sel:
+        md, K, R, t = views[int(r["tid"])]
+        poses.append(lo.pose_refine(dep, md, K_CAM, K, R, t, int(r["x"]), int(r["y"]), scene_from_scene=True))
+    return sel, poses
+
+
 @pytest.mark.parametrize("dup", [False, True])
 def test_pipeline_equals_match_nms_pose_refine(lm, dup):
     """lm_pipeline_run on the device = Detector.match + nms + poseRefine of the reference driver, detection by
@@ -987,6 +1024,16 @@ def test_pipeline_equals_match_nms_pose_refine(lm, dup):
             else:
                 assert np.allclose(g["R"], p["R"], atol=1e-6, equal_nan=True) and np.allclose(g["t"], p["t"], atol=1e-3, equal_nan=True)
         assert tm["total_ms"] > 0 and tm["coarse_candidates"] > 0
+        # ... and against the ORACLE's own chain (no product call on the expected side): detections exact, poses to 1e-4
+        osel, oposes = _pipeline_oracle(od, rgb, dep, (feat, offs, wh), T, wh, E, views, thr, top_k, 0.5, box)
+        assert len(got) == len(osel)
+        for g, r, p in zip(got, osel, oposes):
+            assert (g["x"], g["y"], g["template_id"], g["similarity"]) == (int(r["x"]), int(r["y"]), int(r["tid"]), float(r["sim"]))
+            if p["residual"] == -1.0:
+                assert g["status"] == 1
+                continue
+            assert g["status"] == 0 and abs(g["residual"] - p["residual"]) < 1e-6
+            assert np.allclose(g["R"], p["R"], atol=1e-4) and np.allclose(np.ravel(g["t"]) / 1000.0, np.ravel(p["t"]) / 1000.0, atol=1e-4)
     pipe.close()
 
 
