@@ -95,10 +95,23 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     int prio[4] = {prio_greatest, prio_greatest, prio_least, 0};
     if (const char* pe = getenv("LM_STREAM_PRIO"))
         for (int i = 0; i < 4 && pe[i]; ++i) prio[i] = pe[i] == '1' ? prio_least : (pe[i] == '2' ? prio_greatest : 0);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio[0]) != hipSuccess ||
-        hipStreamCreateWithPriority(&d->cstream, hipStreamNonBlocking, prio[1]) != hipSuccess ||
-        hipStreamCreateWithPriority(&d->mstream, hipStreamNonBlocking, prio[2]) != hipSuccess ||
-        hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio[3]) != hipSuccess) {
+    // LM_CU_SPLIT=N (experiment): the front end and the coarse pass get CUs [0, N) to themselves, refinement and duplicate removal
+    // the rest (hipExtStreamCreateWithCUMask; no priorities on such streams)
+    int cu_split = 0;
+    if (const char* cs = getenv("LM_CU_SPLIT")) cu_split = atoi(cs);
+    bool streams_ok = hipSetDevice(device) == hipSuccess;
+    if (streams_ok && cu_split > 0 && cu_split < 256) {
+        uint32_t lo[8] = {0}, hi[8] = {0};
+        for (int i = 0; i < 256; ++i) (i < cu_split ? lo : hi)[i >> 5] |= 1u << (i & 31);
+        streams_ok = hipExtStreamCreateWithCUMask(&d->stream, 8, lo) == hipSuccess && hipExtStreamCreateWithCUMask(&d->cstream, 8, lo) == hipSuccess &&
+                     hipExtStreamCreateWithCUMask(&d->mstream, 8, hi) == hipSuccess && hipExtStreamCreateWithCUMask(&d->xchg.stream, 8, hi) == hipSuccess;
+    } else if (streams_ok) {
+        streams_ok = hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio[0]) == hipSuccess &&
+                     hipStreamCreateWithPriority(&d->cstream, hipStreamNonBlocking, prio[1]) == hipSuccess &&
+                     hipStreamCreateWithPriority(&d->mstream, hipStreamNonBlocking, prio[2]) == hipSuccess &&
+                     hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio[3]) == hipSuccess;
+    }
+    if (!streams_ok) {
         delete d;
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
@@ -1242,9 +1255,10 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     // Two streams: the front end of this frame (on `stream`, into this slot's linear-memory arenas) overlaps the
     // matching kernels of the previous frame (on `mstream`, reading the other slot's arenas).  The arenas of this
     // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
+    static const bool fe_share_in_pipe = getenv("LM_FE_FUSED_PIPE") && getenv("LM_FE_FUSED_PIPE")[0] == '1';   // experiment
     auto enqueue_fe = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[0], s));
-        int r = run_frontend(d, true, arena, false);
+        int r = run_frontend(d, true, arena, fe_share_in_pipe);
         if (r) return r;
         HIP_TRY(hipEventRecord(sl.ev[1], s));
         return LM_OK;

@@ -189,6 +189,7 @@ static __device__ __forceinline__ int grid_coord(double v, double mn, double inv
 __global__ void __launch_bounds__(256)
 k_icp_bbox(IcpBuffers B, int W, int H) {
     const int h = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.bar[h] = 0;       // the round counter of k_icp_persist
     if (B.st[h].status != 0) return;                              // slot without a detection (pipeline)
     const uint16_t* img = B.models + (size_t)B.in[h].model_slot * W * H;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
@@ -1004,9 +1005,14 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
 //       exact lexicographic minimum of (d, original index); 1, 2 or 4 lanes share a point's columns
 //       when the slice has fewer points than the workgroup has lanes;
 // and the slice's 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded) for the next prologue.
-static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
+// kPersist: called from the loop of k_icp_persist instead of once per launch — the slices' partial sums then travel through
+// agent-scope atomics (the workgroups of a hypothesis sit on different XCDs whose L2s are not coherent with each other) and
+// the fitness history lives in the workgroup (fit_hist / rmse_hist -> LDS) instead of IcpState.  Returns true when the
+// hypothesis is finished (converged, or evaluation max_iter done).
+template <bool kPersist>
+static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
                                                      unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist,
-                                                     const int max_iter, const double rel_tol) {
+                                                     const int max_iter, const double rel_tol, double* fit_hist, double* rmse_hist) {
     __shared__ double s_part[kSearchWG / 64][32];
     __shared__ double s_sum[32];
     __shared__ double s_U[12];
@@ -1028,7 +1034,15 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
             const int k = tid & 31, grp = tid >> 5;
             double a8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int gg = grp + 8 * u; a8[u] = gg < G ? part[(size_t)gg * 32 + k] : 0.0; }
+            for (int u = 0; u < 8; ++u) {
+                const int gg = grp + 8 * u;
+                a8[u] = 0.0;
+                if (gg < G) {
+                    if (kPersist) a8[u] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (size_t)gg * 32 + k),
+                                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    else a8[u] = part[(size_t)gg * 32 + k];
+                }
+            }
             double v = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += a8[u];
@@ -1047,10 +1061,10 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
             const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
             const double rmse = ncorr ? sqrt(s_sum[27] / (double)ncorr) : 0.0;
             bool stop = false;
-            if (it > 1 && fabs(S.fit_hist[it & 1] - fit) < rel_tol && fabs(S.rmse_hist[it & 1] - rmse) < rel_tol) stop = true;
+            if (it > 1 && fabs(fit_hist[it & 1] - fit) < rel_tol && fabs(rmse_hist[it & 1] - rmse) < rel_tol) stop = true;
             if (it - 1 == max_iter) stop = true;
+            if (kPersist || g == 0) { fit_hist[(it - 1) & 1] = fit; rmse_hist[(it - 1) & 1] = rmse; }
             if (g == 0) {
-                S.fit_hist[(it - 1) & 1] = fit; S.rmse_hist[(it - 1) & 1] = rmse;
                 S.fitness = fit; S.rmse = rmse; S.n_corr = ncorr;
                 if (stop) S.stop = 1;
             }
@@ -1083,13 +1097,13 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
             }
         }
         __syncthreads();
-        if (s_stop) return;
+        if (s_stop) return true;
     } else if (g == 0 && tid == 0) {
         for (int a = 0; a < 16; ++a) S.T[a] = (a % 5 == 0) ? 1.0 : 0.0;
         S.T[3] = S.init[0]; S.T[7] = S.init[1]; S.T[11] = S.init[2];
         S.iterations = 0;
     }
-    if (it > max_iter) return;                              // the last launch only finishes evaluation max_iter
+    if (it > max_iter) return true;                         // the last round only finishes evaluation max_iter
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
 
     const double* Src = B.src + (size_t)h * B.cap * 3;
@@ -1371,12 +1385,15 @@ static __device__ __forceinline__ void icp_eval_body(const IcpBuffers& B, IcpSta
     if (tid < 32) {
         double v = 0;
         for (int w = 0; w < kSearchWG / 64; ++w) v += s_part[w][tid];
-        B.partial[((((size_t)(it & 1) * B.count + h) * kIcpMaxSplit) + g) * 32 + tid] = v;
+        double* dst = B.partial + ((((size_t)(it & 1) * B.count + h) * kIcpMaxSplit) + g) * 32 + tid;
+        if (kPersist) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
     }
     if (g == 0 && tid == 0) {      // shader-cycle split of workgroup 0 (diagnostics): prologue, staging+transform, queue, search, sums
         const long long t4 = (long long)__builtin_amdgcn_s_memtime();
         S.clk[0] += t1 - t0; S.clk[1] += t2 - t1; S.clk[2] += (t3 - t2) - t_a2; S.clk[3] += t_a2; S.clk[4] += t4 - t3; S.clk[5] += 1;
     }
+    return false;
 }
 
 __global__ void __launch_bounds__(kSearchWG, 3)
@@ -1388,7 +1405,55 @@ k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) 
     const int h = blockIdx.y;
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
-    icp_eval_body(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol);
+    (void)icp_eval_body<false>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
+}
+
+// The same evaluations as ONE launch: grid (slices, hypotheses) as above, every workgroup loops over the ICP rounds of its
+// hypothesis and meets the other slices of that hypothesis at a counter in HBM between rounds (arrive: agent-scope release
+// add after the slice's partial sums are stored; wait: acquire loads until all G slices of the round are there).  A hypothesis
+// that has converged leaves — after 6.5 rounds on average on the pipeline's workload, where the launch-per-round scheme
+// always pays for max_iter + 2 = 32 launches of ~10 us even when every hypothesis has stopped.  Workgroups are dispatched in
+// linear order (slices of hypothesis 0 first), so the hypotheses whose slices are resident always include complete ones:
+// waiting slices cannot starve the ones they wait for.  A wait that exceeds kBarrierTimeout (another kernel holding the
+// GPU for that long) marks the hypothesis status 4; the host then repeats the run with one launch per round.
+constexpr long long kBarrierTimeout = 200ll * 100000;       // wall_clock64 ticks (100 MHz): 200 ms
+__global__ void __launch_bounds__(kSearchWG, 3)
+k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
+    __shared__ TgtRec s_tgt[kSlabPts];
+    __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
+    __shared__ int s_q[kLoopQueue];
+    __shared__ unsigned char s_cls[kLoopQueue];
+    __shared__ double s_hist[4];
+    __shared__ int s_abort;
+    const int h = blockIdx.y;
+    IcpState& S = B.st[h];
+    if (S.status != 0) return;                                  // the same for every slice of the hypothesis (set before this launch)
+    const unsigned int G = gridDim.x;
+    if (threadIdx.x == 0) s_abort = 0;
+    for (int it = 0; it <= max_iter + 1; ++it) {
+        if (it > 0) {                                           // evaluation it - 1 complete on every slice?
+            // The partial sums are agent-scope atomic stores and loads (they bypass the XCD-local caches), so the counter needs
+            // no release / acquire of its own — an agent-scope release is a write-back of the whole L2 (~30 us) — only that this
+            // slice's stores have completed: a wait on the memory counter before the workgroup barrier.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(&B.bar[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int want = G * (unsigned int)it;
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(&B.bar[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > kBarrierTimeout) { s_abort = 1; break; }
+                }
+            }
+            __syncthreads();
+            if (s_abort) {
+                if (threadIdx.x == 0) __hip_atomic_store(&S.status, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        if (icp_eval_body<true>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
+    }
 }
 
 // Pipeline glue (pipeline.cpp): turns the detections kept by the on-device NMS into ICP hypotheses without a
@@ -1428,7 +1493,7 @@ void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32
 }
 
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
-                         double rel_tol, int knn, hipStream_t s) {
+                         double rel_tol, int knn, bool persistent, hipStream_t s) {
     if (count <= 0) return;
     const int scene_mode = flags & 1;
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
@@ -1443,6 +1508,10 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     if (const char* e = getenv("LM_ICP_SPLITS")) splits = atoi(e);      // tuning knob (profiles/)
     if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
     if (splits < 1) splits = 1;
+    if (persistent && B.bar) {
+        hipLaunchKernelGGL(k_icp_persist, dim3(splits, count), dim3(kSearchWG), 0, s, B, max_dist, max_iter, rel_tol);
+        return;
+    }
     // evaluation `it` is finished (convergence test, solve, update) by the prologue of launch it + 1
     for (int it = 0; it <= max_iter + 1; ++it)
         hipLaunchKernelGGL(k_icp_eval, dim3(splits, count), dim3(kSearchWG), 0, s, B, it, max_dist, max_iter, rel_tol);

@@ -25,8 +25,11 @@ struct lm_icp {
     void* pinned = nullptr;        // staging for images
     size_t pinned_bytes = 0;
     IcpIn* h_in = nullptr;         // pinned
-    IcpState* h_st = nullptr;      // pinned
+    IcpState* h_st = nullptr;      // pinned: the states uploaded before / read after a run
+    IcpState* h_st2 = nullptr;     // pinned: read-back of lm_icp_run (h_st keeps the initial states for a repeated run)
     int h_cap = 0;
+    bool persist = false;          // LM_ICP_PERSIST=1: all ICP rounds in one launch (k_icp_persist: equal results; measured no faster than one launch
+                                   // per round — 1.79 vs 1.64 ms for 16 hypotheses — because a round's barrier costs what a launch costs); a barrier time-out turns it off
 };
 
 

@@ -28,7 +28,8 @@ struct IcpIn {               // one pose hypothesis (uploaded)
 
 struct IcpState {            // one pose hypothesis (device-written, downloaded after the run)
     int bbox[4];             // x0,y0,x1,y1 of modelDepth > 0 (uploaded as INT_MAX,INT_MAX,-1,-1)
-    int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys
+    int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys,
+                             // 4 k_icp_persist gave up waiting for its other slices (the host repeats the run with one launch per round)
     int n_model, n_scene;    // back-projected points
     int n_src, n_tgt;        // after voxel down-sampling
     int gx, gy, zq_max;      // search grid: columns in x and y, largest quantised depth
@@ -70,12 +71,13 @@ struct IcpBuffers {
     double* strip_sum;       // [count][kIcpStrips][8] centroid sums per strip
     double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
+    unsigned int* bar;       // [count] rounds x slices that have arrived (k_icp_persist), zeroed by k_icp_bbox
 };
 
 struct TopkSel;
 void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32_t* class_base, const float* view_K,
                      const int32_t* view_valid, int num_views, IcpIn* in, IcpState* st, int top_k, hipStream_t s);
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
-                         double rel_tol, int knn, hipStream_t s);
+                         double rel_tol, int knn, bool persistent /*one launch for all ICP rounds (k_icp_persist)*/, hipStream_t s);
 
 }  // namespace lm

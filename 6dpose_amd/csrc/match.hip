@@ -462,7 +462,14 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
         const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats,
         unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* __restrict__ todo,
-        const TileRec* __restrict__ tiles, uint32_t tile_cap) {
+        const TileRec* __restrict__ tiles, uint32_t tile_cap, int dbg) {
+    // What bounds it (profiles/r02_pmc_tiles.txt, r02_local_experiments.txt): the vector L1.  Per CU 139k cycles of accesses +
+    // 56k cycles stalled on pending misses of the 247k the kernel lasts (round 1: 345k + 37k of 363k) — every 128-byte line is
+    // used by exactly one load instruction, so a third of the accesses miss.  Tried and measured WORSE: four waves sharing an
+    // item through LDS (119 us: 104 VGPRs), 16 loads in flight per wave (123 us: 99 VGPRs) — occupancy matters more than the
+    // length of a wave's chain of load batches —, tiles and singles on different workgroups (117 us: any alternation in the
+    // workgroup index aliases with the round-robin over XCDs / shader engines) or on different waves of a workgroup (121 us).
+    // Tiles alone take 72 us, singles alone 58 us, an empty launch of this grid 11 us (LM_LOCAL_DBG = 1 / 2 / 3).
     __shared__ unsigned long long s_stats[4][2];
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -485,7 +492,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     // like everywhere else ({own strip, next strip's lane r} shifted by the run's byte phase) into u16 sums of tile columns
     // [16 q, 16 q + 16); every member then takes the first strict maximum of its own 16 x 16 window of those sums — the same
     // integers, the same tie-break (packed key) and the same float expression as the per-candidate path below.
-    if (tiles) {
+    if (tiles && !(dbg & 2)) {
         const unsigned long long nt64 = packed >> kCandBits;
         const uint32_t ntiles = nt64 < tile_cap ? (uint32_t)nt64 : tile_cap;
         const LevelGeom lv = g.lv[0];
@@ -619,7 +626,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         }
     }
 
-    for (uint32_t ci = wave0; ci < num_cands; ci += nwaves) {
+    for (uint32_t ci = wave0; ci < num_cands && !(dbg & 1); ci += nwaves) {
         if (todo && !todo[ci]) continue;                     // a tile member: refined above (wave-uniform)
         const Candidate cd = cands[ci];
         const int work = __builtin_amdgcn_readfirstlane(cd.work);
@@ -786,9 +793,10 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const TileRec* tiles, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
     if (!(tiles && todo && tile_plan_possible(g))) { tiles = nullptr; todo = nullptr; }      // same decision as launch_coarse
+    static const int dbg = getenv("LM_LOCAL_DBG") ? atoi(getenv("LM_LOCAL_DBG")) : 0;           // timing experiments (wrong results): 1 = tiles only, 2 = singles only
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
                        feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
-                       dedupe_table, dedupe_cap_slots, todo, tiles, tile_cap);
+                       dedupe_table, dedupe_cap_slots, todo, tiles, tile_cap, dbg);
 }
 
 }  // namespace lm

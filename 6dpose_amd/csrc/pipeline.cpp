@@ -262,7 +262,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         B.scene = d->cur_depth; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
         B.count = top_k;
         memcpy(B.sK, scene_K, sizeof(B.sK));
-        launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, s);
+        launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->persist, s);
         HIP_TRY(hipEventRecord(c->e1, s));
         HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)top_k * sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(p->h_sel, p->d_sel, (size_t)top_k * sizeof(TopkSel), hipMemcpyDeviceToHost, s));
@@ -272,6 +272,9 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         rc = lm_collect_frame(d, -1, nullptr, nullptr);          // retires the frame; 1 = candidate buffer overflow, rerun
         if (rc == 1) continue;
         if (rc) return rc;
+        bool timed_out = false;                                   // k_icp_persist gave up waiting for its other slices: one launch per round from now on
+        for (int i = 0; i < top_k; ++i) timed_out |= c->h_st[i].status == 4;
+        if (timed_out && c->persist) { c->persist = false; rc = 1; continue; }
         break;
     }
     if (rc == 1) return lm_set_error(LM_ERR_INVALID, "candidate buffer kept overflowing");

@@ -45,14 +45,15 @@ namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.bar, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
     c->d_in = nullptr; c->d_st = nullptr;
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_st) (void)hipHostFree(c->h_st);
-    c->h_in = nullptr; c->h_st = nullptr; c->h_cap = 0;
+    if (c->h_st2) (void)hipHostFree(c->h_st2);
+    c->h_in = nullptr; c->h_st = nullptr; c->h_st2 = nullptr; c->h_cap = 0;
     c->max_count = 0;
 }
 
@@ -93,10 +94,12 @@ int lm_icp_ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.cell_start16, (size_t)n * kIcpCells16 * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.keys, (size_t)n * 2 * cap2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&B.bar, (size_t)n * sizeof(unsigned int)));
     HIP_TRY(hipMalloc((void**)&c->d_in, (size_t)n * sizeof(IcpIn)));
     HIP_TRY(hipMalloc((void**)&c->d_st, (size_t)n * sizeof(IcpState)));
     HIP_TRY(hipHostMalloc((void**)&c->h_in, (size_t)n * sizeof(IcpIn), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_st, (size_t)n * sizeof(IcpState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_st2, (size_t)n * sizeof(IcpState), hipHostMallocDefault));
     c->h_cap = n;
     c->max_count = n;
     return LM_OK;
@@ -171,6 +174,7 @@ extern "C" int lm_icp_create(int device, lm_icp** out) {
     HIP_TRY(hipSetDevice(device));
     lm_icp* c = new lm_icp();
     c->device = device;
+    if (const char* e = getenv("LM_ICP_PERSIST")) c->persist = e[0] && e[0] != '0';
     if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->e0) != hipSuccess ||
         hipEventCreate(&c->e1) != hipSuccess) {
         delete c;
@@ -256,14 +260,22 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     B.scene = c->d_scene; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
     B.count = count;
     memcpy(B.sK, c->sK, sizeof(B.sK));
-    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
-    HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
-    HIP_TRY(hipEventRecord(c->e0, c->s));
-    launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->s);
-    HIP_TRY(hipEventRecord(c->e1, c->s));
-    HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
-    HIP_TRY(hipStreamSynchronize(c->s));
-    HIP_TRY(hipGetLastError());
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
+        HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
+        HIP_TRY(hipEventRecord(c->e0, c->s));
+        launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->persist, c->s);
+        HIP_TRY(hipEventRecord(c->e1, c->s));
+        HIP_TRY(hipMemcpyAsync(c->h_st2, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
+        HIP_TRY(hipStreamSynchronize(c->s));
+        HIP_TRY(hipGetLastError());
+        bool timed_out = false;
+        for (int i = 0; i < count; ++i) timed_out |= c->h_st2[i].status == 4;
+        if (!timed_out) break;
+        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected status 4");
+        c->persist = false;            // the persistent kernel waited too long for its other slices (GPU shared): one launch per round from now on
+    }
+    memcpy(c->h_st, c->h_st2, (size_t)count * sizeof(IcpState));
     c->last_count = count; c->last_flags = flags;
     if (device_ms) (void)hipEventElapsedTime(device_ms, c->e0, c->e1);
     for (int i = 0; i < count; ++i) {
