@@ -110,6 +110,46 @@ def test_precondition_errors_like_cv_assert(lm):
 # ---------------------------------------------------------------------------------------------
 # match: fixture banks (reference detect_test inputs) and synthetic banks
 # ---------------------------------------------------------------------------------------------
+def test_gpu_equals_the_reference_lines(lm):
+    """The GPU path against oracle/_ref = the reference's OWN match code (LL.cpp:1022-1658, 1694-1941 compiled unmodified against a
+    cv::Mat buffer shim, oracle/Makefile) on every reference fixture: frame 0000 and its half-occluded variant (test.cpp:95-96)
+    x banks 63 / 127 / 600 (test.cpp:111-123), thresholds 75 (test.cpp:128) and 55.  Linear memories byte for byte, the
+    pre-unique match list as a multiset, and the distinct (x, y, similarity) of Detector::match's own output.  Where the prebuilt
+    library did not travel, the committed digest tests/golden/ref_expected.json (written from it) is used instead."""
+    import json
+    import ll_ref
+    import ref_cases as rc
+    exp = json.load(open(os.path.join(GOLDEN, "ref_expected.json")))
+    for frame in ("", "_half"):
+        for bank in ("63", "127", "600"):
+            case = rc.fixture_case(frame, bank)
+            q, T = rc.quantized_of(case), case["T"]
+            det = lm.Detector(case["nfeat"], T, device=0)
+            det.readClasses(["06_template"], os.path.join(GOLDEN, "bank" + bank + "_%s.yaml.gz"))
+            det.setFrame([case["rgb"], case["dep"]])
+            det.matchResident(75.0, ["06_template"])
+            for l in range(2):
+                for m in range(2):
+                    lm_gpu = det.readStage(l, 2 + m)[:8 * q[l][m].size]
+                    assert rc.sha(lm_gpu) == exp[case["name"]]["lm"][l][m]
+                    if ll_ref.available():
+                        assert np.array_equal(lm_gpu, ll_ref.build_linear_memories(q[l][m], T[l]))
+            for thr in rc.FIXTURE_THRESHOLDS:
+                e = exp[case["name"]]["match"][rc.record_key(thr, ["06_template"])]
+                pre = det.matchResident(thr, ["06_template"], sort_unique=False)
+                fin = det.matchResident(thr, ["06_template"])
+                assert len(pre) == e["pre_unique_n"]
+                distinct = set(zip(fin["x"].tolist(), fin["y"].tolist(), fin["similarity"].tolist()))
+                assert len(distinct) == e["final_distinct_n"]
+                if ll_ref.available():
+                    rpre = ll_ref.match(q, T, case["banks"], thr, ["06_template"], pre_unique=True)
+                    assert as_multiset(pre, ["x", "y", "similarity", "template_id"]) == as_multiset(rpre, ["x", "y", "sim", "tid"])
+                    rfin = ll_ref.match(q, T, case["banks"], thr, ["06_template"])
+                    assert distinct == set(zip(rfin["x"].tolist(), rfin["y"].tolist(), rfin["sim"].tolist()))
+                    if len(rfin):
+                        assert (int(fin[0]["x"]), int(fin[0]["y"]), float(fin[0]["similarity"])) == (int(rfin[0]["x"]), int(rfin[0]["y"]), float(rfin[0]["sim"]))
+
+
 @pytest.mark.parametrize("bank,nfeat", [("127", 127), ("63", 63)])
 def test_match_fixture_banks(lm, bank, nfeat):
     rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
