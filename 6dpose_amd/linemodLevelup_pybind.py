@@ -824,7 +824,11 @@ class Pipeline:
         _check(self._lib.lm_pipeline_set_views_rendered(self._h, mesh._h, class_id.encode(), int(first_template), n, _ptr(Ks), _ptr(Rs), _ptr(ts),
                                                         float(clip_near), float(clip_far), None if wh is None else _ptr(wh)))
 
-    def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5):
+    def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5,
+            norms_thresh: Optional[float] = None):
+        """One frame of the driver loop on the device.  norms_thresh (mm): additionally the translation NMS the ROS node applies
+        to the refined poses (linemod_ros/detect.py:128, `nms_norms(ts, ts_scores, 40.0)` with score = -residual): the refined
+        detections are returned in its keep order, the suppressed ones dropped (those without a pose are left out, as there)."""
         ids = [c.encode() for c in class_ids]
         arr = (ctypes.c_char_p * len(ids))(*ids) if ids else None
         sK = np.ascontiguousarray(np.asarray(scene_K, np.float32).reshape(9))
@@ -842,6 +846,11 @@ class Pipeline:
                         "R": np.array(o.pose.R).reshape(3, 3), "t": np.array(o.pose.t), "residual": float(o.pose.residual),
                         "rmse": float(o.pose.inlier_rmse), "iterations": int(o.pose.iterations),
                         "n_source": int(o.pose.n_source), "n_target": int(o.pose.n_target)})
+        if norms_thresh is not None:
+            posed = [r for r in res if r["status"] == 0]
+            keep = nms_norms(np.array([r["t"] for r in posed], np.float64).reshape(-1, 3), np.array([-r["residual"] for r in posed], np.float64),
+                             float(norms_thresh)) if posed else []
+            res = [posed[i] for i in keep]
         return res, tm.as_dict()
 
 

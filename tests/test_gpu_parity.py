@@ -1064,6 +1064,15 @@ def test_pipeline_equals_match_nms_pose_refine(lm, dup):
             else:
                 assert np.allclose(g["R"], p["R"], atol=1e-6, equal_nan=True) and np.allclose(g["t"], p["t"], atol=1e-3, equal_nan=True)
         assert tm["total_ms"] > 0 and tm["coarse_candidates"] > 0
+        # the ROS node's translation NMS on top (linemod_ros/detect.py:128): same survivors as numpy nms_norms on the results
+        posed = [g for g in got if g["status"] == 0]
+        if len(posed) > 1:
+            keep = lo.nms_norms(np.array([g["t"] for g in posed]).reshape(-1, 3), np.array([-g["residual"] for g in posed]), 40.0)
+            det.setFrame([rgb, dep])
+            got_n, _ = pipe.run(thr, ["obj"], K_CAM, top_k=top_k, nms_iou=0.5, norms_thresh=40.0)
+            if len(set(g["residual"] for g in posed)) == len(posed):      # tied residuals: numpy's argsort decides the order
+                assert [(g["x"], g["y"], g["template_id"]) for g in got_n] == [(posed[i]["x"], posed[i]["y"], posed[i]["template_id"]) for i in keep]
+            assert 1 <= len(got_n) <= len(posed)
         # ... and against the ORACLE's own chain (no product call on the expected side): detections exact, poses to 1e-4
         osel, oposes = _pipeline_oracle(od, rgb, dep, (feat, offs, wh), T, wh, E, views, thr, top_k, 0.5, box)
         assert len(got) == len(osel)
