@@ -11,8 +11,12 @@ module.  The product (`6dpose_amd/`) never does; it fails loudly without its HIP
 Parity status
   * quantisation + template extraction (addTemplate): PINNED by the reference golden
     (tests/test_oracle_golden.py reproduces the YAML element-for-element).
-  * match(): the reference holds no expected match output -> pinned only through
-    the stage hashes of SURVEY Appendix C.2 and the restated match list recorded there.
+  * match(): the reference holds no expected match output, but its match code itself runs here:
+    oracle/_ref = LL.cpp:1022-1658 + 1694-1941 compiled unmodified from /root/reference against a cv::Mat buffer
+    shim (oracle/Makefile, ref_harness.cpp, ll_ref.py).  PINNED: tests/test_ref_pin.py compares match_oracle.c with
+    it record by record (linear memories, pre-unique match lists in the reference's order) on every reference
+    fixture and six synthetic geometries; tests/golden/ref_expected.json holds the digests.
+  * nms_boxes / nms_norms ARE the reference (plain numpy of its drivers); nms_boxes_cv restates OpenCV: UNPINNED.
   * poseRefine/ICP: PARITY UNPINNED.  The arithmetic lives in Open3D (un-vendored, version
     unpinned, absent here).  `icp_*` below restates Open3D 0.8/0.9's published algorithm
      with deterministic tie rules shared with the GPU path.

@@ -3,6 +3,9 @@
  * linemodLevelup::Detector::match, restated in plain C with the same SSE2/SSSE3 operations the
  * reference uses.  Citations "LL.cpp:N" are to /root/reference/linemodLevelup/linemodLevelup.cpp.
  *
+ * Pinned to the reference's own lines: tests/test_ref_pin.py compares every function here with oracle/_ref (the
+ * cited LL.cpp ranges compiled unmodified against a cv::Mat buffer shim) on all reference fixtures.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Built by oracle/Makefile (or linemod_oracle.build_c) with the reference's flags: -O3 -Wall, no
  * -march (linemodLevelup/CMakeLists.txt:8).
