@@ -128,6 +128,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
+    if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) d->num_cus = prop.multiProcessorCount;
@@ -1430,7 +1431,58 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         return LM_OK;
     }
     // sort_unique = 0: every record alive (the raw pre-unique multiset); 1 / 2: the records without exact duplicates
-    // (k_dedupe) — what std::unique would leave of them anyway — canonically sorted + uniqued (1) or as they are (2)
+    // (k_dedupe) — what std::unique would leave of them anyway — canonically sorted + uniqued (1) or as they are (2);
+    // 3: the reference's own output, permutation and surviving duplicates included (below)
+    if (sort_unique == 1 && d->reference_order) sort_unique = 3;
+    if (sort_unique == 3) {
+        // Detector::match ends with std::sort under an order that ignores x, y and std::unique under an equality that ignores
+        // template_id (LL.cpp:1771-1776, LL.h:234-246): what comes out depends on the order the records went in and on
+        // libstdc++'s introsort.  Both are reproducible: the reference appends class by class (caller's order), template by
+        // template, candidates in raster order of the coarse grid (LL.cpp:1753-1769, 1835-1852; remove_if keeps the order) — the
+        // coarse position of every slot is in the candidate buffer — and std::sort is the same template of the same libstdc++
+        // this library is built with, so the same comparisons on the same sequence give the same permutation.
+        const int slot_index = (int)((d->n_collected - 1) % lm_detector::kSlots);
+        std::vector<Candidate> coarse((size_t)ncand);
+        if (ncand) HIP_TRY(hipMemcpy(coarse.data(), d->d_cands.p + (size_t)d->cand_cap * slot_index, (size_t)ncand * sizeof(Candidate), hipMemcpyDeviceToHost));
+        const std::vector<int32_t>& wcls = *sl.work_cls;
+        const std::vector<int32_t>& wtid = *sl.work_tid;
+        struct Rec { int32_t cls, tid, cy, cx; lm_match m; };
+        std::vector<Rec> recs;
+        recs.reserve((size_t)nm);
+        for (uint64_t i = 0; i < ncand; ++i) {
+            const Candidate& c = hm[i];
+            if (c.work < 0) continue;
+            Rec r;
+            r.cls = wcls[c.work]; r.tid = wtid[c.work]; r.cy = coarse[i].y; r.cx = coarse[i].x;
+            r.m.x = c.x; r.m.y = c.y; r.m.similarity = c.score; r.m.class_index = r.cls; r.m.template_id = r.tid;
+            recs.push_back(r);
+        }
+        std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {      // a total order: emission order of the reference
+            if (a.cls != b.cls) return a.cls < b.cls;
+            if (a.tid != b.tid) return a.tid < b.tid;
+            if (a.cy != b.cy) return a.cy < b.cy;
+            return a.cx < b.cx;
+        });
+        const auto t3 = std::chrono::steady_clock::now();
+        std::vector<lm_match> v(recs.size());
+        for (size_t i = 0; i < recs.size(); ++i) v[i] = recs[i].m;
+        std::sort(v.begin(), v.end(), [](const lm_match& a, const lm_match& b) {  // Match::operator< (LL.h:234-241)
+            if (a.similarity != b.similarity) return a.similarity > b.similarity;
+            return a.template_id < b.template_id;
+        });
+        v.erase(std::unique(v.begin(), v.end(), match_eq), v.end());               // Match::operator== (LL.h:243-246)
+        const auto t4 = std::chrono::steady_clock::now();
+        lm_match* res = (lm_match*)malloc(std::max<size_t>(1, v.size()) * sizeof(lm_match));
+        if (!res) return lm_set_error(LM_ERR_INVALID, "out of host memory");
+        if (!v.empty()) memcpy(res, v.data(), v.size() * sizeof(lm_match));
+        auto msf = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<float, std::milli>(b - a).count();
+        };
+        tm.host_submit_ms = msf(sl.t0, sl.t1); tm.host_wait_ms = msf(sl.t1, t2); tm.host_collect_ms = msf(t2, t3); tm.host_merge_ms = msf(t3, t4);
+        d->timings = tm;
+        *out = res; *n_out = v.size();
+        return LM_OK;
+    }
     const bool use_distinct = sort_unique != 0 && sl.num_work > 0;
     const uint64_t nd = use_distinct ? sl.h_counters[1] : 0;
     if (use_distinct && (nd > ncand || nd > nm || nm > ncand))
@@ -1469,6 +1521,12 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
 }
 
 extern "C" int lm_detector_max_in_flight(void) { return lm_detector::kSlots; }
+
+extern "C" int lm_detector_set_reference_order(lm_detector* d, int on) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    d->reference_order = on != 0;
+    return LM_OK;
+}
 
 extern "C" int lm_detector_submit(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");

@@ -112,6 +112,7 @@ struct lm_detector {
     DevBuf<TileRec> d_tiles;                        // per result slot: the tiles k_coarse planned (cand_cap / 2 records each)
     DevBuf<uint8_t> d_todo;                         // per result slot: 1 = candidate that no tile serves (refined on its own)
     bool use_tiles = true;                          // LM_TILES=0: every candidate on its own (the round-1 refinement)
+    bool reference_order = false;                   // lm_detector_set_reference_order / LM_REFERENCE_ORDER=1: match() returns the reference's own permutation (sort_unique 3)
     DevBuf<ulonglong2> d_distinct_keys;             // the distinct records as 128-bit sort keys, per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
     DevBuf<unsigned long long> d_counters;          // working counters per result slot: zero between frames (k_dedupe's last block resets them)

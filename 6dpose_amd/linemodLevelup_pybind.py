@@ -160,6 +160,7 @@ def load_library():
     lib.lm_detector_submit_frame.argtypes = [P, P, P, I, I, F, ctypes.POINTER(S), I]
     lib.lm_detector_ingest_buffer.argtypes = [P, I, I, ctypes.POINTER(P), ctypes.POINTER(P)]
     lib.lm_detector_max_in_flight.restype = I
+    lib.lm_detector_set_reference_order.argtypes = [P, I]
     lib.lm_exchange_max_capacity.restype = I
     lib.lm_detector_exchange_stream.argtypes = [P]
     lib.lm_detector_exchange_stream.restype = P
@@ -385,6 +386,12 @@ class Detector:
         return out
 
     # ---- matching -------------------------------------------------------------------------------
+    def setReferenceOrder(self, on: bool = True) -> None:
+        """match() / collect() return the list exactly as the reference's Detector::match does — the permutation libstdc++'s
+        std::sort leaves and the duplicates std::unique then keeps (LL.cpp:1771-1776) — instead of the canonical order
+        (lm_detector_set_reference_order).  Single GPU; costs a host-side sort of all pre-unique records."""
+        _check(self._lib.lm_detector_set_reference_order(self._h, 1 if on else 0))
+
     def setShard(self, rank: int, world: int) -> None:
         """This process searches slice `rank` of `world` of the selected template pyramids."""
         _check(self._lib.lm_detector_set_shard(self._h, rank, world))

@@ -193,6 +193,15 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
  * lm_detector_match_resident == submit + collect. */
 int lm_detector_submit(lm_detector *d, float threshold, const char *const *class_ids, int num_class_ids);
 int lm_detector_collect(lm_detector *d, int sort_unique, lm_match **out, size_t *n);
+/* sort_unique = 3 (collect, match_resident), or lm_detector_set_reference_order(d, 1) for every sort_unique = 1 call of this
+ * detector (lm_detector_match included; LM_REFERENCE_ORDER=1 sets it at creation): the list exactly as the reference's
+ * Detector::match returns it — its std::sort (Match::operator<, which ignores x, y) and std::unique (operator==, which ignores
+ * template_id) replayed on the pre-unique records in the order the reference appends them (LL.cpp:1753-1776), with the same
+ * libstdc++ introsort.  Unlike the canonical order (the default) this keeps the duplicates the reference keeps: on fixture
+ * bank 63 at threshold 55 it returns the reference's 560 entries, the canonical order 366 (the same 358 distinct positions).
+ * Host-side cost: one extra device-to-host copy of the candidate buffer and a sort of all pre-unique records; single GPU only
+ * (a sharded match merges canonically). */
+int lm_detector_set_reference_order(lm_detector *d, int on);
 /* Live-stream ingest (the per-frame call of linemod_ros/detect.py:83-138 and of the dataset loop
  * linemod_and_levelup_test.py:314-327, which hand a NEW host frame to every Detector.match): lm_detector_submit_frame =
  * "upload this host frame + lm_detector_submit" without blocking.  The frame is staged in a ring of pinned buffers (one per

@@ -148,6 +148,33 @@ def test_gpu_equals_the_reference_lines(lm):
                     assert distinct == set(zip(rfin["x"].tolist(), rfin["y"].tolist(), rfin["sim"].tolist()))
                     if len(rfin):
                         assert (int(fin[0]["x"]), int(fin[0]["y"]), float(fin[0]["similarity"])) == (int(rfin[0]["x"]), int(rfin[0]["y"]), float(rfin[0]["sim"]))
+                    # reference-order mode: Detector::match's own list, entry by entry — the permutation libstdc++'s std::sort
+                    # leaves and the duplicates std::unique keeps included (560 entries on bank 63 at threshold 55, not 366)
+                    det.setReferenceOrder(True)
+                    exact = det.matchResident(thr, ["06_template"])
+                    det.setReferenceOrder(False)
+                    assert len(exact) == e["final_n"] == len(rfin)
+                    for a, b in (("x", "x"), ("y", "y"), ("similarity", "sim"), ("template_id", "tid")):
+                        assert np.array_equal(exact[a], rfin[b]), (case["name"], thr, a)
+    # two classes in the caller's order, an unknown class in between, 8-bit and 16-bit paths, tiles on: still entry by entry
+    if ll_ref.available():
+        for i in (0, 1):
+            case = rc.synth_case(i)
+            q, T = rc.quantized_of(case), case["T"]
+            det = lm.Detector(case["nfeat"], T, device=0)
+            for name, b in case["banks"].items():
+                det.addClassPacked(name, b.feat, b.tmpl_off, b.tmpl_wh)
+            det.setReferenceOrder(True)
+            names = sorted(case["banks"])
+            for req in case["requests"]:
+                thr = case["thresholds"][0]
+                got = det.matchArray([case["rgb"], case["dep"]], thr, req)
+                rfin = ll_ref.match(q, T, case["banks"], thr, req)
+                order = list(req) if req else names
+                assert len(got) == len(rfin) > 0
+                assert [order[k] for k in got["class_index"].tolist()] == [names[k] for k in rfin["cls"].tolist()]
+                for a, b in (("x", "x"), ("y", "y"), ("similarity", "sim"), ("template_id", "tid")):
+                    assert np.array_equal(got[a], rfin[b]), (case["name"], req, a)
 
 
 @pytest.mark.parametrize("bank,nfeat", [("127", 127), ("63", 63)])
