@@ -16,7 +16,7 @@ distinct noisy frames and every step stamps its number into the frame it submits
 frames parked in HBM (round 1's headline) is reported under `extras.resident_replay`.
 
 Workload (N=1): BASELINE configs[1] — 1 object x 2000 template pyramids, Detector(150,[4,8])
-(150+150 features at level 0, 75+75 at level 1), threshold 75, planted synthetic bank (6dpose_amd/
+(150+150 features at level 0, 75+75 at level 1), threshold 75, planted synthetic bank (tests/
 synth.py).  N>1, --scaling weak (default): configs[3] shape — N objects x 2000 templates, one object
 per rank; --scaling strong: a fixed bank of 8 objects x 2000 templates (configs[3], 16k) split over
 the N ranks (whole objects per rank when N divides 8, contiguous template ranges otherwise).  Each
@@ -48,6 +48,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "6dpose_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))           # synth.py: the synthetic frames and banks of the workload
 
 W, H = 640, 480
 T_LEVELS = [4, 8]

@@ -4,7 +4,7 @@ against the packed binary bank (writeBank / readBank, csrc/bank_file.cpp), at 2k
 import json, os, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "6dpose_amd")]
+sys.path[:0] = [os.path.join(ROOT, "6dpose_amd"), os.path.join(ROOT, "tests")]
 import linemodLevelup_pybind as lm, synth
 
 def timed(f):

@@ -6,7 +6,7 @@ python profiles/cfg4_full_bank.py [objects=30] [templates_per_object=3000]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "6dpose_amd")]
+sys.path[:0] = [os.path.join(ROOT, "6dpose_amd"), os.path.join(ROOT, "tests")]
 import linemodLevelup_pybind as lm, synth
 W, H, T, NF = 1280, 960, [4, 8], (150, 75)
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 30

@@ -6,7 +6,7 @@ Also times the host path (gather through host memory is not emulated: only the m
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "6dpose_amd")]
+sys.path[:0] = [os.path.join(ROOT, "6dpose_amd"), os.path.join(ROOT, "tests")]
 import torch
 import linemodLevelup_pybind as lm, synth
 W, H, T, NF, NT, WORLD, CAP, THR = 640, 480, [4, 8], (150, 75), 2000, 8, 4096, 75.0

@@ -3,7 +3,7 @@ by one (staging copy, canonical sort), at 3 and 4 frames in flight.  GPU box: py
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "6dpose_amd")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "6dpose_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import bench, linemodLevelup_pybind as lm, synth
 W, H = bench.W, bench.H
 det = lm.Detector(bench.NFEAT[0], bench.T_LEVELS, device=0)

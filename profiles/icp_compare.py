@@ -3,7 +3,7 @@ LM_ICP_PERSIST=0 gives the launch-per-round variant.  GPU box: python profiles/i
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "6dpose_amd")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "6dpose_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import bench, linemodLevelup_pybind as lm, synth
 W, H = bench.W, bench.H
 out = {"persist": os.environ.get("LM_ICP_PERSIST", "1"), "icp": bench.icp_bench(0)}

@@ -3,7 +3,7 @@ and rates (the bit-exact check of this size against the CPU oracle is tests/test
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "6dpose_amd")]
+sys.path[:0] = [os.path.join(ROOT, "6dpose_amd"), os.path.join(ROOT, "tests")]
 import linemodLevelup_pybind as lm, synth
 W, H, T, NF, N = 1280, 960, [4, 8], (150, 75), int(sys.argv[1]) if len(sys.argv) > 1 else 11250
 rgb, dep = synth.make_frame(0, W, H)

@@ -3,7 +3,7 @@ linear memories).  On the bench workload (frame 0, planted bank): ~7
 overlap so much that their union has 3x fewer cells than their sum."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [os.path.join(ROOT, '6dpose_amd'), os.path.join(ROOT, 'oracle')]
+sys.path[:0] = [os.path.join(ROOT, '6dpose_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]
 import numpy as np, synth, linemod_oracle as lo
 W, H, T, NF = 640, 480, [4, 8], (150, 75)
 rgb, dep = synth.make_frame(0, W, H)

@@ -4,7 +4,7 @@ bitmap on the coarse grid; a tile of R rows x S strips of the strip-major level-
 in k_local.  Greedy cover (first hit in raster order = top-left corner of the next block)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [os.path.join(ROOT, '6dpose_amd'), os.path.join(ROOT, 'oracle')]
+sys.path[:0] = [os.path.join(ROOT, '6dpose_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]
 import numpy as np, synth, linemod_oracle as lo
 W, H, T, NF = 640, 480, [4, 8], (150, 75)
 rgb, dep = synth.make_frame(0, W, H)
@@ -102,3 +102,33 @@ def cover_shaped(bw, bh, anchor="topleft"):
 for name, bw, bh, anchor in (("5x2 greedy top-left", 5, 2, "topleft"), ("5x2 greedy best x shift", 5, 2, "best"), ("5x3 (24 rows x 3 strips = 72 lanes: two loads)", 5, 3, "best")):
     lanes, n_tiles, kinds = cover_shaped(bw, bh, anchor)
     print("%-50s lanes %7d vs %7d now: %.2fx  tiles %d  %s" % (name, lanes, tot * 32, tot * 32 / lanes, n_tiles, sorted(kinds.items())))
+
+print("\n-- the clamped candidates (LL.cpp:1871-1880): window origins after clamping")
+import collections
+tot_cl = dup_saved = runs_members = n_runs = lone = 0
+for p, (hit, free) in enumerate(maps):
+    w0, h0 = wh[p * 4]
+    border = 32; max_x, max_y = W - w0 - border, H - h0 - border
+    ys, xs = np.nonzero(hit & ~free)
+    if len(ys) == 0:
+        continue
+    org = collections.Counter()
+    for r, c in zip(ys, xs):
+        x = (c * Tt + 3) * 2 + 1; y = (r * Tt + 3) * 2 + 1
+        x = min(max(x, border), max_x); y = min(max(y, border), max_y)
+        org[(x // 4 - 8, y // 4 - 8)] += 1
+    tot_cl += len(ys)
+    dup_saved += len(ys) - len(org)
+    pts = set(org)
+    used = set()
+    for (gx, gy) in sorted(pts):
+        if (gx, gy) in used: continue
+        # vertical run (same gx, gy + 4k) or horizontal run (same gy, gx + 4k), up to 5
+        v = [(gx, gy + 4 * k) for k in range(5) if (gx, gy + 4 * k) in pts and (gx, gy + 4 * k) not in used]
+        h = [(gx + 4 * k, gy) for k in range(5) if (gx + 4 * k, gy) in pts and (gx + 4 * k, gy) not in used]
+        best = v if len(v) >= len(h) else h
+        if len(best) >= 2:
+            n_runs += 1; runs_members += len(best); used.update(best)
+        else:
+            lone += 1; used.add((gx, gy))
+print("clamped", tot_cl, "identical windows saved", dup_saved, "distinct", tot_cl - dup_saved, "in runs of >= 2:", runs_members, "runs", n_runs, "left alone", lone)

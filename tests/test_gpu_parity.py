@@ -1119,7 +1119,7 @@ def test_pipeline_equals_match_nms_pose_refine(lm, dup):
 _SHARD_WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 root, port, rank, world, backend = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-sys.path[:0] = [os.path.join(root, "6dpose_amd"), os.path.join(root, "oracle")]
+sys.path[:0] = [os.path.join(root, "6dpose_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")]
 import linemodLevelup_pybind as lm, sharded, synth, linemod_oracle as lo
 kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
 dist.init_process_group(backend, init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world, **kw)
