@@ -47,6 +47,22 @@ static __device__ __forceinline__ float score_of(int raw, int nfeat) {
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ uint4 ld_aligned16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// The gathers of the three fast paths go through buffer loads: `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` takes the
+// arena as a resource in SGPRs, ONE 32-bit per-lane offset (constant for the whole item) and the feature's wave-uniform byte
+// offset in an SGPR.  As global loads the compiler kept a 64-bit VGPR address per load in flight — 16 VGPRs for a batch of 8 and
+// two VALU adds per load — which is what put k_local at 67 and k_coarse at 96 VGPRs (occupancy 7 / 5 waves per SIMD); the
+// kernels' speed follows their occupancy (profiles/r02_local_experiments.txt).
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+static __device__ __forceinline__ BufRsrc make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* no range check: 2^32 - 1 bytes */, 0x00020000 /* gfx9: raw dwords */);
+}
+static __device__ __forceinline__ uint4 ld_buf16(BufRsrc r, uint32_t lane_off, uint32_t uniform_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uniform_off, 0);
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    return u;
+}
+
 // widen 4 packed bytes of `v` into two packed u16x2 accumulators: e gets bytes 0,2 ; o gets bytes 1,3
 static __device__ __forceinline__ void add_bytes(uint32_t v, uint32_t& e, uint32_t& o) {
     e += v & 0x00FF00FFu;
@@ -115,7 +131,9 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
          const int32_t* __restrict__ work_pyramids, int num_work, int wpt, float threshold, Candidate* __restrict__ cands, uint32_t cap,
          unsigned long long* __restrict__ counters, TilePlanGeom plan, TileRec* __restrict__ tiles, uint8_t* __restrict__ todo) {
     extern __shared__ uint32_t s_dyn[];
-    const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler must know it: the
+                                                                                         // template's entry and feature offsets then come through SMEM into SGPRs
     const int group = (int)(blockDim.x >> 6) / wpt;
     const int tslot = wave_in_block / wpt, wave = wave_in_block - tslot * wpt, nwaves = wpt;
     const int work_raw = blockIdx.x * group + tslot;
@@ -148,7 +166,7 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
         const int j0 = (chunk0 + lane) * 16;                   // first position owned by this lane
         uint32_t even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0};
         if (chunk0 * 16 < tp && nfp > 0) {                     // wave-uniform
-            const uint8_t* base = lm_arena + j0;
+            const BufRsrc arena = make_rsrc(lm_arena);
             uint32_t r8[4] = {0, 0, 0, 0};                      // packed-u8 sums of the current class run
             int cur = -1, cnt = 0;
             auto flush = [&](int cls) {                         // realign the run: bytes [cls, cls+16) of {own, next lane}
@@ -189,7 +207,7 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
                 for (int u = 0; u < kFeatBatch; ++u) on[u] = fo[fn + u];
                 uint4 v[kFeatBatch];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_aligned16(base + (o[u] & ~15));
+                for (int u = 0; u < kFeatBatch; ++u) v[u] = ld_buf16(arena, (uint32_t)j0, (uint32_t)(o[u] & ~15));
 #pragma unroll
                 for (int u = 0; u < kFeatBatch; ++u) {
                     const int cls = o[u] & 15;
@@ -428,10 +446,32 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
         static const int dbg = getenv("LM_COARSE_DBG") ? atoi(getenv("LM_COARSE_DBG")) : 0;
         static const int max_group = getenv("LM_COARSE_GROUP") ? atoi(getenv("LM_COARSE_GROUP")) : 8;
         plan.dbg = dbg;
-        // templates per workgroup: as many as 16 waves and 64 KB of LDS hold, at most 8
+        // Templates per workgroup (<= 8, <= 16 waves, <= 64 KB of LDS): the count that keeps the most waves resident on a CU — the pass
+        // is bound by its chains of dependent load batches, so resident waves are what it runs on (VGA: 6 templates = 12 waves, two
+        // workgroups per CU; 1280x960: 2 templates = 10 waves, two per CU, where 3 templates = 15 waves left room for only one) —
+        // and among equals the largest (fewer atomics on the frame's counter).
         const size_t per = coarse_plan_lds_bytes(lv.Wd, lv.Hd);
-        group = std::min(std::max(1, max_group), std::min(16 / waves, (int)((64 * 1024 - 256) / per)));
-        if (group < 1) group = 1;
+        const int gmax = std::max(1, std::min(std::max(1, max_group), std::min(16 / waves, (int)((64 * 1024 - 256) / per))));
+        static int cached_key = -1, cached_group = 1;
+        const int key = (lv.Wd << 16) ^ lv.Hd ^ (gmax << 28);
+        if (key != cached_key) {
+            int best_waves = -1;
+            for (int gtry = 1; gtry <= gmax; ++gtry) {
+                int nb = 0;
+                const size_t l = per * gtry + (4 * (size_t)gtry + 4) * sizeof(uint32_t);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_coarse, gtry * waves * 64, l) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+                const int resident = nb * gtry * waves;
+                if (resident >= best_waves) { best_waves = resident; cached_group = gtry; }
+            }
+            cached_key = key;
+        }
+        group = cached_group;
+        static int num_cus = 0;
+        if (!num_cus) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cus <= 0) num_cus = 256;
+        }
+        if ((num_work + gmax - 1) / gmax <= num_cus) group = gmax;   // a small bank is resident whatever the grouping: fewest atomics
         lds = per * group + (4 * (size_t)group + 4) * sizeof(uint32_t);
     }
     hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group), dim3(group * waves * 64), lds, s, lm_arena, lv, level, g.levels, entries,
@@ -513,7 +553,8 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             int q = (lane >= R) + (lane >= 2 * R), r = lane - q * R;
             const bool active = lane < R * S;
             if (!active) { q = 0; r = 0; }                                     // idle lanes repeat lane 0's (valid) loads
-            const uint8_t* smp = sm_arena + (uint32_t)(q * Hd + r) * 16u;
+            const BufRsrc strips = make_rsrc(sm_arena);
+            const uint32_t lane_off = (uint32_t)(q * Hd + r) * 16u;
             const int nb_lane = (lane + R < 64 ? lane + R : lane) << 2;       // the lane holding the next strip of this row
             uint32_t aE[4] = {0, 0, 0, 0}, aO[4] = {0, 0, 0, 0};              // u16x2 sums: aE[k] = cols 4k, 4k+2; aO[k] = cols 4k+1, 4k+3
             const FeatStrip* fs = feat_strip + e.feat_start;
@@ -560,7 +601,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) {
                         const uint32_t xa = (c[u].cell & 0xFFFF) + (uint32_t)gx0, ya = (c[u].cell >> 16) + (uint32_t)gy0;
-                        v[u] = ld_aligned16(smp + (c[u].sbase + ((xa >> 4) * (uint32_t)Hd + ya) * 16u));
+                        v[u] = ld_buf16(strips, lane_off, c[u].sbase + ((xa >> 4) * (uint32_t)Hd + ya) * 16u);
                     }
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) {
@@ -656,7 +697,8 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             if (all_in) {
                 const int half = lane >> 5, l5 = lane & 31, r = l5 >> 1, h = l5 & 1;
                 const uint32_t HS = (uint32_t)Hd * 16u;
-                const uint8_t* smp = sm_arena + (h * HS + r * 16);
+                const BufRsrc strips = make_rsrc(sm_arena);
+                const uint32_t lane_off = h * HS + (uint32_t)r * 16u;
                 uint32_t w[4] = {0, 0, 0, 0};                   // u16x2: cols (0,2) (1,3) (4,6) (5,7) of this lane's 8 columns
                 if (nfp > 0) {
                     const FeatStrip* fs = feat_strip + e.feat_start;
@@ -702,7 +744,7 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
                             const uint32_t xb = (c[2 * k + 1].cell & 0xFFFF) + gx, yb = (c[2 * k + 1].cell >> 16) + gy;
                             const uint32_t ba = c[2 * k].sbase + ((xa >> 4) * Hd + ya) * 16u;
                             const uint32_t bb = c[2 * k + 1].sbase + ((xb >> 4) * Hd + yb) * 16u;
-                            v[k] = ld_aligned16(smp + (half ? bb : ba));
+                            v[k] = ld_buf16(strips, lane_off + (half ? bb : ba), 0u);
                         }
 #pragma unroll
                         for (int k = 0; k < kFeatBatch / 2; ++k) {
