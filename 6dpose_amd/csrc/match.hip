@@ -224,23 +224,21 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
             if (cur >= 0) flush(cur);
         }
         // Threshold scan (LL.cpp:1835-1852).
-        uint32_t hit_mask = 0;
-        float sc[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = j0 + k;
+        auto raw_at = [&](int k) -> int {                        // the lane's k-th position sum (positions >= template_positions stay 0)
             const uint32_t pk = (k & 1) ? odd[k >> 2] : even[k >> 2];
             const int rawk = (int)((k & 2) ? (pk >> 16) : (pk & 0xFFFF));
-            const int r = j < tp ? rawk : 0;                  // positions >= template_positions stay 0
-            sc[k] = score_of(r, nf);
-            if (live && lane < kChunksPerWave && j < npos && sc[k] > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
-        }
+            return j0 + k < tp ? rawk : 0;
+        };
+        uint32_t hit_mask = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (live && lane < kChunksPerWave && j0 + k < npos && score_of(raw_at(k), nf) > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
         if (plan.enabled) {
             // the hits of the whole template are collected in LDS; slots, tiles and records follow once all of them are known
             if (hit_mask) {
                 atomicOr(const_cast<uint32_t*>(&s_hit[j0 >> 5]), hit_mask << (j0 & 31));
 #pragma unroll
-                for (int k = 0; k < 16; ++k) if (hit_mask & (1u << k)) s_score[j0 + k] = sc[k];
+                for (int k = 0; k < 16; ++k) if (hit_mask & (1u << k)) s_score[j0 + k] = score_of(raw_at(k), nf);
             }
             continue;
         }
@@ -260,7 +258,7 @@ k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int leve
                         const int j = j0 + k;
                         const int cy = j / Wd, cx = j - cy * Wd;
                         Candidate c;
-                        c.x = cx * T + offset; c.y = cy * T + offset; c.score = sc[k]; c.work = work;
+                        c.x = cx * T + offset; c.y = cy * T + offset; c.score = score_of(raw_at(k), nf); c.work = work;
                         cands[slot] = c;
                     }
                     ++slot;
@@ -444,34 +442,13 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
         plan.W0 = g.lv[0].W; plan.H0 = g.lv[0].H; plan.T0 = g.lv[0].T; plan.Wd0 = g.lv[0].Wd; plan.Hd0 = g.lv[0].Hd;
         plan.tile_cap = tile_cap;
         static const int dbg = getenv("LM_COARSE_DBG") ? atoi(getenv("LM_COARSE_DBG")) : 0;
-        static const int max_group = getenv("LM_COARSE_GROUP") ? atoi(getenv("LM_COARSE_GROUP")) : 8;
+        static const int max_group = getenv("LM_COARSE_GROUP") ? atoi(getenv("LM_COARSE_GROUP")) : 4;
         plan.dbg = dbg;
-        // Templates per workgroup (<= 8, <= 16 waves, <= 64 KB of LDS): the count that keeps the most waves resident on a CU — the pass
-        // is bound by its chains of dependent load batches, so resident waves are what it runs on (VGA: 6 templates = 12 waves, two
-        // workgroups per CU; 1280x960: 2 templates = 10 waves, two per CU, where 3 templates = 15 waves left room for only one) —
-        // and among equals the largest (fewer atomics on the frame's counter).
+        // Templates per workgroup: up to 4 (<= 16 waves, <= 64 KB of LDS).  More templates mean fewer atomics on the frame's counter,
+        // but workgroups of 7-8 templates (14-16 waves) leave room for one workgroup per CU only: 16k templates at VGA 162 us with
+        // 2-6 per workgroup, 300 us with 7-8; 2k templates 45 us with 2-8, 57 us with 1 (profiles/r02_coarse_group_sweep.txt).
         const size_t per = coarse_plan_lds_bytes(lv.Wd, lv.Hd);
-        const int gmax = std::max(1, std::min(std::max(1, max_group), std::min(16 / waves, (int)((64 * 1024 - 256) / per))));
-        static int cached_key = -1, cached_group = 1;
-        const int key = (lv.Wd << 16) ^ lv.Hd ^ (gmax << 28);
-        if (key != cached_key) {
-            int best_waves = -1;
-            for (int gtry = 1; gtry <= gmax; ++gtry) {
-                int nb = 0;
-                const size_t l = per * gtry + (4 * (size_t)gtry + 4) * sizeof(uint32_t);
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_coarse, gtry * waves * 64, l) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
-                const int resident = nb * gtry * waves;
-                if (resident >= best_waves) { best_waves = resident; cached_group = gtry; }
-            }
-            cached_key = key;
-        }
-        group = cached_group;
-        static int num_cus = 0;
-        if (!num_cus) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cus <= 0) num_cus = 256;
-        }
-        if ((num_work + gmax - 1) / gmax <= num_cus) group = gmax;   // a small bank is resident whatever the grouping: fewest atomics
+        group = std::max(1, std::min(std::min(4, std::max(1, max_group)), std::min(16 / waves, (int)((64 * 1024 - 256) / per))));
         lds = per * group + (4 * (size_t)group + 4) * sizeof(uint32_t);
     }
     hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group), dim3(group * waves * 64), lds, s, lm_arena, lv, level, g.levels, entries,
