@@ -72,7 +72,8 @@ struct lm_detector {
     const uint8_t* cur_rgb = nullptr;           // what the front end reads: frame_rgb / frame_depth, or — for a frame that came in through
     const uint16_t* cur_depth = nullptr;        // lm_detector_submit_frame — the ingest ring's device buffers (no device-to-device copy)
     DevBuf<uint8_t> nrm_raw;                    // normals before the median (level 0)
-    static constexpr int kSlots = 4;            // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight)
+    static constexpr int kSlots = 8;            // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight): every one owns
+                                                // its arenas, candidate / record buffers and pinned result memory (~25 MB at VGA)
     DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
                                                 // while the matching kernels of frame k read the other
     int last_arena = 0;                         // set written by the most recent front end (lm_detector_read_stage)

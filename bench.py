@@ -9,7 +9,7 @@ linemod_ros/detect.py:83-138) on a NEW host frame: the frame is handed over in h
 (lm_detector_submit_frame: pinned staging ring, H2D on a copy stream), then front end (quantise,
 spread, response, linearise) + coarse similarity over all templates + 16x16 refinement of every
 candidate + download, canonical sort and unique of the match records (+, for N>1, the all-gather of
-the per-rank records over RCCL and the merge on the device).  Up to four frames are in flight, so
+the per-rank records over RCCL and the merge on the device).  Four to six frames are in flight, so
 the upload of frame k+1 overlaps the matching of frame k — SURVEY §8(d): "t_frame = one match call
 with the bank resident, frame H2D included".  No frame is replayed from HBM: the host holds a pool of
 distinct noisy frames and every step stamps its number into the frame it submits.  The rate with the
@@ -58,7 +58,10 @@ STRONG_OBJECTS = 8            # --scaling strong: configs[3], 8 objects x 2000 t
 THRESHOLD = 75.0
 N_FRAMES = 16                 # distinct host frames in the pool the stream cycles through
 N_PARKED = 4                  # frames parked in HBM for the resident legs (roofline, extras)
-PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "4"))   # frames in flight (= lm_detector_max_in_flight()): upload + front end of k+3 | coarse of k+2 | refinement of k+1 | host collects k
+PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "0"))   # frames in flight (<= lm_detector_max_in_flight() = 8): upload, front end, coarse pass, refinement, duplicate removal of
+                                                              # neighbouring frames side by side while the host collects the oldest.  Steady state: 0.216 ms/frame at 3, 0.187 at
+                                                              # 4, 0.178 at 6, 0.177 at 8; the timed region starts and ends with an empty pipeline, and filling / draining a deeper
+                                                              # one costs more, so the default (0) is 4 for runs of fewer than 100 steps and 6 above
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0         # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 LDS_PEAK_GBS = 150000.0       # ibid. "LDS": ~150 TB/s aggregate for ds_read_b64/b128
@@ -108,6 +111,9 @@ def main():
     ap.add_argument("--exchange", choices=["auto", "host", "device"], default="auto",
                     help="multi-GPU exchange of the match records: on the device (sharded.DeviceExchange; auto = when world > 1) or through the host")
     args = ap.parse_args()
+    global PIPELINE_DEPTH
+    if PIPELINE_DEPTH <= 0:
+        PIPELINE_DEPTH = 4 if args.steps < 100 else 6
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 

@@ -187,7 +187,7 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
                                int sort_unique, lm_match **out, size_t *n);
 /* Pipelined stream mode: lm_detector_submit enqueues front end + matching of the current
  * frame and returns; lm_detector_collect waits for the OLDEST submitted frame and returns its matches.
- * Up to lm_detector_max_in_flight() (four) frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
+ * Up to lm_detector_max_in_flight() (eight) frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
  * streams while the host sorts frame k:
  *   select_frame(k+2); submit(); collect() -> frame k; ...
  * lm_detector_match_resident == submit + collect. */

@@ -534,7 +534,7 @@ def test_pipelined_submit_collect_equals_synchronous(lm):
 
 def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
     """SURVEY §8f N4 proper: a NEW host frame per step (linemod_ros/detect.py:83-138, linemod_and_levelup_test.py:314-327)
-    through lm_detector_submit_frame — pinned ring + copy stream, up to four frames in flight, every frame different —
+    through lm_detector_submit_frame — pinned ring + copy stream, up to lm_detector_max_in_flight() frames in flight, every frame different —
     returns, frame by frame, exactly what the oracle and the synchronous Detector.match return; also through the zero-copy
     ring buffers, the matchStream generator, mixed with parked-frame submits, and across a frame-size change."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
