@@ -338,6 +338,18 @@ def test_tile_refinement_is_exact(lm):
         if k >= 2:
             assert tiled.collect().tobytes() == plain.matchResident(75.0, ["planted"]).tobytes()
     tiled.collect(); tiled.collect()
+    # other tileable geometries: T = {2, 4} and {8, 16} (coarse cells again 4 fine cells apart), a small and a non-square frame
+    for (W2, H2, T2, nf2, thr2) in ((320, 240, [2, 4], (64, 32), 65.0), (640, 480, [8, 16], (64, 32), 60.0), (384, 272, [4, 8], (96, 48), 65.0)):
+        rgb2, dep2 = synth.make_frame(23, W2, H2, 24)
+        od2 = lo.OracleDetector(nf2[0], T2)
+        p2 = od2.quantize_pyramid(rgb2, dep2)
+        b2 = synth.make_planted_bank(29, 150, [(p[0], p[1]) for p in p2], T2, nf2)
+        d2 = lm.Detector(nf2[0], T2, device=0)
+        d2.addClassPacked("o", *b2)
+        raw2, st2 = oracle_matches(od2, rgb2, dep2, b2, T2, thr2)
+        assert st2["coarse_candidates"] > 150
+        same_records(d2.matchArray([rgb2, dep2], thr2, ["o"]), lo.canonical_sort_unique(raw2))
+        assert d2.lastTimings()["coarse_candidates"] == st2["coarse_candidates"]
     # a geometry the planner does not tile (coarse cells 16/5 fine cells apart) takes the per-candidate path unchanged
     od58 = lo.OracleDetector(63, [5, 8])
     p58 = od58.quantize_pyramid(rgb, dep)
