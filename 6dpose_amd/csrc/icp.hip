@@ -1017,7 +1017,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     __shared__ double s_sum[32];
     __shared__ double s_U[12];
     __shared__ double s_A[6][6], s_b[6], s_x[6];
-    __shared__ int s_nq, s_stop;
+    __shared__ int s_stop;
     __shared__ int s_cnt[kClasses], s_cur[kClasses];
     __shared__ double s_xmm[kSearchWG / 64][2];
     __shared__ double s_red8[8][32];
@@ -1121,9 +1121,6 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     const double r2 = max_dist * max_dist;
     const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
     const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
-    // lanes per queued point: spread the columns of a search over idle lanes
-    const int lpp_shift = (i_hi - i_lo) * 4 <= kSearchWG ? 2 : (i_hi - i_lo) * 2 <= kSearchWG ? 1 : 0;
-    const int lpp = 1 << lpp_shift, sub = tid & (lpp - 1);
 
     // pcd.Transform: the initial guess at evaluation 0, the update afterwards
     double xmn = 1e300, xmx = -1e300;
@@ -1232,7 +1229,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
                     const int nxc = grid_coord(px + rad, minx, inv, gx) - grid_coord(px - rad, minx, inv, gx) + 1;
                     const int nyc = grid_coord(py + rad, miny, inv, gy) - grid_coord(py - rad, miny, inv, gy) + 1;
                     const int ncol = nxc * nyc;
-                    cls = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 6 ? 3 : ncol <= 9 ? 4 : ncol <= 16 ? 5 : ncol <= 25 ? 6 : 7;
+                    cls = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;   // lanes = 2^cls, one column each
                 }
             }
             if (i < end) s_cls[i - base] = (unsigned char)cls;
@@ -1246,7 +1243,6 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         if (tid == 0) {
             int run = 0;
             for (int c = 0; c < kClasses; ++c) { s_cur[c] = run; run += s_cnt[c]; }
-            s_nq = run;
         }
         __syncthreads();
         for (int i0 = base; i0 < end; i0 += kSearchWG) {
@@ -1264,11 +1260,17 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             }
         }
         __syncthreads();
-        const int nq = s_nq;
         const long long ta = (long long)__builtin_amdgcn_s_memtime();
-        for (int q0 = 0; q0 < nq; q0 += kSearchWG >> lpp_shift) {
+        // The queue is ordered by cost class; a class is walked with as many lanes per point as its searches have groups of
+        // four columns (1 .. 16: a lane takes four columns per trip), so that the lanes of a wave finish together — a search of
+        // 1.5 x max_dist for a point without correspondence overlaps dozens of columns and would otherwise hold 63 lanes up.
+        for (int cq = 0, qa = 0; cq < kClasses; ++cq) {
+        const int qb = s_cur[cq];                              // end of the class (its start + its count, after the scatter)
+        const int lpp_shift = cq < 6 ? cq : 6;
+        const int lpp = 1 << lpp_shift, sub = tid & (lpp - 1);
+        for (int q0 = qa; q0 < qb; q0 += kSearchWG >> lpp_shift) {
             const int q = q0 + (tid >> lpp_shift);
-            const bool active = q < nq;
+            const bool active = q < qb;
             const int i = active ? s_q[q] : i_lo;
             const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
             const int pj = prev[i];
@@ -1292,49 +1294,37 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
                 const int zlo = zq_of(pz - rad, minz, inv_z, zq_max), zhi = zq_of(pz + rad, minz, inv_z, zq_max);
                 const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
                 const float inv_nxc = 1.0f / (float)nxc;
-                for (int r0 = sub * 4; r0 < ncol; r0 += 4 * lpp) {
-                    int ca4[4], cb4[4];                           // four columns per trip: their bounds load independently
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ca4[u] = 0; cb4[u] = 0;
-                        const int r = r0 + u;
-                        if (r < ncol) {
-                            const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
-                            const int c = (xa + (r - yy * nxc)) * gy + ya + yy;
-                            ca4[u] = cell_at(c); cb4[u] = cell_at(c + 1);
-                        }
+                for (int r = sub; r < ncol; r += lpp) {            // one column per lane and trip
+                    const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
+                    const int c = (xa + (r - yy * nxc)) * gy + ya + yy;
+                    int a = cell_at(c);
+                    const int b = cell_at(c + 1);
+                    if (b - a > 8) {                              // long run: first point at depth step >= zlo by bisection (the run is depth-ordered)
+                        int hi = b;
+                        while (a < hi) { const int mid = (a + hi) >> 1; if (tgt_zq(mid) < zlo) a = mid + 1; else hi = mid; }
                     }
+                    // four candidates per trip (independent LDS reads in flight); indices past the run are
+                    // clamped to its last point, which only re-tests a candidate; past depth step zhi the run is done
+                    for (int j0 = a; j0 < b; j0 += 4) {
+                        double d4[4];
+                        int j4[4];
+                        bool more = true;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int a = ca4[u];
-                        const int b = cb4[u];
-                        if (b - a > 8) {                          // long run: first point at depth step >= zlo by bisection (the run is depth-ordered)
-                            int hi = b;
-                            while (a < hi) { const int mid = (a + hi) >> 1; if (tgt_zq(mid) < zlo) a = mid + 1; else hi = mid; }
+                        for (int v = 0; v < 4; ++v) {
+                            j4[v] = j0 + v < b ? j0 + v : b - 1;
+                            double qx, qy, qz;
+                            tgt_xyz(j4[v], qx, qy, qz);
+                            d4[v] = sqdist(px, py, pz, qx, qy, qz);
+                            if (tgt_zq(j4[v]) > zhi) more = false;
                         }
-                        // four candidates per trip (independent LDS reads in flight); indices past the run are
-                        // clamped to its last point, which only re-tests a candidate; past depth step zhi the run is done
-                        for (int j0 = a; j0 < b; j0 += 4) {
-                            double d4[4];
-                            int j4[4];
-                            bool more = true;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                j4[v] = j0 + v < b ? j0 + v : b - 1;
-                                double qx, qy, qz;
-                                tgt_xyz(j4[v], qx, qy, qz);
-                                d4[v] = sqdist(px, py, pz, qx, qy, qz);
-                                if (tgt_zq(j4[v]) > zhi) more = false;
-                            }
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                const int j = j4[v];
-                                const double d = d4[v];
-                                if (d < bd) { bd = d; bo = tgt_orig(j); bp = j; }
-                                else if (d == bd && bp >= 0 && bp != j) { const int o = tgt_orig(j); if (o < bo) { bo = o; bp = j; } }
-                            }
-                            if (!more) break;
+                        for (int v = 0; v < 4; ++v) {
+                            const int j = j4[v];
+                            const double d = d4[v];
+                            if (d < bd) { bd = d; bo = tgt_orig(j); bp = j; }
+                            else if (d == bd && bp >= 0 && bp != j) { const int o = tgt_orig(j); if (o < bo) { bo = o; bp = j; } }
                         }
+                        if (!more) break;
                     }
                 }
             }
@@ -1348,6 +1338,8 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
                 prev[i] = bp;
                 if (bp < 0) lb[i] = sqrt(bd);                 // every target closer than sqrt(bound2) was visited
             }
+        }
+        qa = qb;
         }
         __syncthreads();
         t_a2 += (long long)__builtin_amdgcn_s_memtime() - ta;
@@ -1386,6 +1378,10 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         double v = 0;
         for (int w = 0; w < kSearchWG / 64; ++w) v += s_part[w][tid];
         double* dst = B.partial + ((((size_t)(it & 1) * B.count + h) * kIcpMaxSplit) + g) * 32 + tid;
+        if (tid >= 29) {   // diagnostics in the padding: shader cycles of this slice's evaluation (total, search, prologue)
+            const long long tn = (long long)__builtin_amdgcn_s_memtime();
+            v = tid == 29 ? (double)(tn - t0) : tid == 30 ? (double)t_a2 : (double)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7]);
+        }
         if (kPersist) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = v;
     }

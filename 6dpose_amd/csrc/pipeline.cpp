@@ -314,3 +314,8 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
     }
     return LM_OK;
 }
+
+extern "C" int64_t lm_pipeline_read_icp_debug(lm_pipeline* p, int hypothesis, int kind, double* dst, int64_t capacity) {
+    if (!p) return lm_set_error(LM_ERR_INVALID, "null argument");
+    return lm_icp_read_debug(p->icp, hypothesis, kind, dst, capacity);
+}

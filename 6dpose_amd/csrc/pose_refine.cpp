@@ -336,6 +336,14 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             n = (int64_t)tmp.size();
             break;
         }
+        case 4: {   // the slices' partial sums of the last two evaluations, [2][kIcpMaxSplit][32] (slots 29..31: shader cycles of the slice)
+            n = 2 * kIcpMaxSplit * 32; tmp.resize((size_t)n);
+            for (int par = 0; par < 2; ++par)
+                if (hipMemcpy(tmp.data() + (size_t)par * kIcpMaxSplit * 32, c->B.partial + (((size_t)par * c->last_count + hypothesis) * kIcpMaxSplit) * 32,
+                              (size_t)kIcpMaxSplit * 32 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                    return lm_set_error(LM_ERR_HIP, "read-back failed");
+            break;
+        }
         default: return lm_set_error(LM_ERR_INVALID, "unknown debug kind %d", kind);
     }
     if (dst && capacity > 0) memcpy(dst, tmp.data(), (size_t)std::min<int64_t>(n, capacity) * sizeof(double));

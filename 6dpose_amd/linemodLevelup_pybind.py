@@ -785,7 +785,7 @@ class IcpContext:
         out = np.zeros(int(n), np.float64)
         if n:
             self._lib.lm_icp_read_debug(self._h, int(hypothesis), int(kind), _ptr(out), int(n))
-        return out if kind == 3 else out.reshape(-1, 3)
+        return out if kind >= 3 else out.reshape(-1, 3)
 
 
 class Pipeline:
@@ -830,6 +830,19 @@ class Pipeline:
         wh = None if box_wh is None else np.ascontiguousarray(np.asarray(box_wh, np.int32).reshape(n, 2))
         _check(self._lib.lm_pipeline_set_views_rendered(self._h, mesh._h, class_id.encode(), int(first_template), n, _ptr(Ks), _ptr(Rs), _ptr(ts),
                                                         float(clip_near), float(clip_far), None if wh is None else _ptr(wh)))
+
+    def read_icp_debug(self, hypothesis: int, kind: int):
+        """IcpContext.read_debug for the hypotheses of the last run()."""
+        f = self._lib.lm_pipeline_read_icp_debug
+        f.restype = ctypes.c_int64
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+        n = f(self._h, int(hypothesis), int(kind), None, 0)
+        if n < 0:
+            _check(int(n))
+        out = np.zeros(int(n), np.float64)
+        if n:
+            f(self._h, int(hypothesis), int(kind), _ptr(out), int(n))
+        return out if kind >= 3 else out.reshape(-1, 3)
 
     def run(self, threshold: float, class_ids: Sequence[str], scene_K, top_k: int = 16, nms_iou: float = 0.5,
             norms_thresh: Optional[float] = None):

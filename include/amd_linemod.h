@@ -296,7 +296,8 @@ int lm_icp_run(lm_icp *c, int count, const int32_t *model_slots, const float *mo
                const int32_t *detect_xy /*[count][2]*/, int flags, lm_pose_result *results, float *device_ms);
 /* Test/diagnostic read-back of the last run's device intermediates of one hypothesis.  kind: 0 source
  * cloud, 1 target cloud, 2 target normals (xyz triples, voxel order), 3 {init_guess t[3], T[16],
- * n_model, n_scene, grid_x, grid_y, cell, iterations, 4 phase cycle counts of the iteration kernel}.  Copies min(capacity, size) doubles, returns the size. */
+ * n_model, n_scene, grid_x, grid_y, cell, iterations, 4 phase cycle counts of the iteration kernel}, 4 the slices' partial sums of
+ * the last two evaluations [2][64][32].  Copies min(capacity, size) doubles, returns the size. */
 int64_t lm_icp_read_debug(lm_icp *c, int hypothesis, int kind, double *dst, int64_t capacity);
 
 /* ---- per-frame pipeline --------------------------------------------------------
@@ -329,6 +330,8 @@ int lm_pipeline_set_views(lm_pipeline *p, const char *class_id, int first_templa
                           const uint16_t *const *depth_ren, const float *Ks, const float *Rs, const float *ts,
                           const int32_t *box_wh);
 /* Runs on the detector's resident frame (lm_detector_set_frame / select_frame).  out: top_k entries; *n_out kept. */
+/* lm_icp_read_debug on the pipeline's own ICP context (the hypotheses of the last lm_pipeline_run). */
+int64_t lm_pipeline_read_icp_debug(lm_pipeline *p, int hypothesis, int kind, double *dst, int64_t capacity);
 int lm_pipeline_run(lm_pipeline *p, float threshold, const char *const *class_ids, int num_class_ids, const float *scene_K,
                     int top_k, double nms_iou, int flags, lm_detection *out, int *n_out, lm_pipeline_timings *tm);
 
