@@ -565,304 +565,292 @@ k_icp_grid(IcpBuffers B, int flags) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_icp_knn: open3d EstimateNormals(KDTreeSearchParamKNN(30)), neighbour search part.  One wave per
-// target point.  The columns within ring R of the point's column, cut to depths pz -+ R*cell, hold every point
-// closer than R*cell, so once >= k candidates are closer than that, the k nearest of them are the k nearest
-// of the cloud.  Candidates sit one per lane-slot in registers; the k-th smallest squared distance is
-// found by bisection on its bit pattern (a ballot + popcount per step, no sorting), ties at the
-// threshold go to the lower original index, and the cumulants of the selected points are wave-reduced.
-// Rings with more than 384 candidates take the generic path: k selection passes over the runs.
+// k_icp_knn: open3d EstimateNormals(KDTreeSearchParamKNN(30)), neighbour search part.  The columns within ring R of a point's
+// column hold every point closer than R*cell, so once >= k candidates are closer than that, the k nearest of them are the
+// k nearest of the cloud.  A workgroup owns a contiguous range of sorted positions (= an x slab of the grid) and stages the
+// columns its base rings reach in LDS (grown rings read HBM where they leave it).
+// EIGHT LANES per point, eight points per wave.  (A wave per point — candidates across 64 lanes, ballots for the selection —
+// was bound by instruction issue, ~4000 wave instructions per point; a lane per point needs ~400 but leaves the chip
+// underfilled at the pipeline's sizes — 128k points are 2000 waves, two per SIMD, each a 300k-cycle serial walk — and stalls
+// whole waves on the isolated points whose rings grow to thousands of candidates.  Eight lanes keep the instruction count
+// of the lane-per-point version, give 16k waves, and share a grown ring eight ways.)
+// Nothing is stored per candidate: every pass walks the ring again and recomputes the squared distances (the oracle's
+// expression); the lanes of a point take the candidates four at a time, round robin, and add up their counts (DPP) —
+//   pass 1   the candidates closer than the guarantee radius g and than three fractions of it (grows the ring when < k);
+//   pass 2   counts below four thresholds interpolated inside the bracket pass 1 left (the distances of a surface patch are
+//            close to uniform in d^2);
+//   pass 3+  every lane keeps the 4 smallest DISTINCT distances of the bracket it sees, with multiplicities (equal distances
+//            are common in a cloud that comes off a pixel grid); the lanes' lists are merged smallest first until the
+//            running count reaches k, or the bracket moves past what was collected;
+//   ties at the k-th distance go to the lower original index (one pass per tie taken, rare);
+//   last     the cumulants of the selected points and the distance to the nearest other point.
 // ---------------------------------------------------------------------------------------------
-constexpr int kKnnWG = 512;        // 8 waves: 8 target points in flight per workgroup
-constexpr int kKnnCache = 384;     // candidates per point held in registers (6 per lane)
-constexpr int kKnnSlots = kKnnCache / 64;
-constexpr int kLoopLdsPts = 1536;  // target points of a workgroup's x slab staged in LDS by k_icp_knn (32-byte records, 48 KiB: two workgroups per CU)
+constexpr int kKnnWG = 512;
+constexpr int kKnnLanes = 8;       // lanes per point
+constexpr int kKnnSlabPts = 2048;  // target points staged per workgroup (32-byte records, 64 KiB: two workgroups per CU)
+constexpr int kKnnRuns = 16;       // x columns of a ring kept as separate runs (R <= 7; wider rings take whole x columns)
+constexpr int kKnnHard = 512;      // points per round of a workgroup, any of which may be handed to a whole wave
+constexpr int kKnnFew = 4;         // distinct distances a lane sorts in registers in a collecting pass
 
-template <int N, int OFF>
-static __device__ __forceinline__ void reduce_halve16(double (&v)[16], int lane) {
-    const bool hi = (lane & OFF) != 0;
+// reductions over the 8 lanes of a point (xor 1, xor 2, mirror within the half row): every lane ends with the result
+template <int CTRL> static __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> static __device__ __forceinline__ double dpp_mov(double v) {
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+}
+static __device__ __forceinline__ int sum8(int v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v; }
+static __device__ __forceinline__ double sum8(double v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v; }
+static __device__ __forceinline__ double min8(double v) {
+    v = fmin(v, dpp_mov<0xB1>(v)); v = fmin(v, dpp_mov<0x4E>(v)); v = fmin(v, dpp_mov<0x141>(v)); return v;
+}
+static __device__ __forceinline__ int min8(int v) { v = min(v, dpp_mov<0xB1>(v)); v = min(v, dpp_mov<0x4E>(v)); v = min(v, dpp_mov<0x141>(v)); return v; }
+
+// f(j, d): this lane's share of the candidates of the ring — nx runs [runs[i].x, runs[i].y) of sorted positions (the columns
+// ya..yb of one x are contiguous; the runs of a point sit in LDS) — with their squared distances to p: four consecutive
+// candidates per trip, the lanes of the point side by side.  A run inside the staged slab [p0, p0 + np) comes from LDS.
+template <int L, bool kFromLds, typename F>
+static __device__ __forceinline__ void knn_scan_run(const int a, const int b, const int sub, const TgtRec* s_rel /*s_tgt - p0*/,
+                                                    const double* __restrict__ T, const double px, const double py, const double pz, F&& f) {
+    for (int j0 = a + 4 * sub; j0 < b; j0 += 4 * L) {
+        double d4[4], q4[4][3];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const double send = hi ? v[k] : v[k + N];
-        const double keep = hi ? v[k + N] : v[k];
-        v[k] = keep + shfl_xor_d(send, OFF);
+        for (int v = 0; v < 4; ++v) {
+            const int j = j0 + v < b ? j0 + v : b - 1;
+            if (kFromLds) { const TgtRec& r = s_rel[j]; q4[v][0] = r.x; q4[v][1] = r.y; q4[v][2] = r.z; }
+            else { q4[v][0] = T[3 * (size_t)j]; q4[v][1] = T[3 * (size_t)j + 1]; q4[v][2] = T[3 * (size_t)j + 2]; }
+            d4[v] = sqdist(px, py, pz, q4[v][0], q4[v][1], q4[v][2]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (j0 + v < b) f(j0 + v, d4[v], q4[v][0], q4[v][1], q4[v][2]);
+    }
+}
+// (two loops, not one loop with a choice of pointer inside: a pointer that may be LDS or HBM makes every load a FLAT load,
+// which costs an LDS read the latency of a trip to memory)
+template <int L, typename F>
+static __device__ __forceinline__ void knn_scan(const int2* runs, const int nx, const int sub, const TgtRec* s_tgt, const int p0, const int np,
+                                                const double* __restrict__ T, const double px, const double py, const double pz, F&& f) {
+    for (int xi = 0; xi < nx; ++xi) {
+        const int2 ab = runs[xi];
+        if (ab.x >= p0 && ab.y <= p0 + np) knn_scan_run<L, true>(ab.x, ab.y, sub, s_tgt - p0, T, px, py, pz, f);
+        else knn_scan_run<L, false>(ab.x, ab.y, sub, s_tgt - p0, T, px, py, pz, f);
     }
 }
 
-static __device__ __forceinline__ void knn_body(const IcpBuffers& B, const IcpState& S, const int h, const int knn, TgtRec* s_tgt,
-                                                int* s_list) {
-    const int nt = S.n_tgt;
-    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
-    const int* orig = B.tgt_orig + (size_t)h * B.cap;
-    const int* cs = B.cell_start + (size_t)h * kIcpCells;
-    double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max;
-    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, cell = S.cell, inv_z = S.inv_z;
-    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = knn < nt ? knn : nt;
-    int R0 = (int)ceil(0.009 / cell);
-    if (R0 < 1) R0 = 1;
-    // this workgroup's points: a contiguous range of sorted positions = an x slab of the grid; the cells within
-    // R0 + 1 rings of it are staged in LDS (larger rings, rare, read HBM)
-    const int q0 = (int)((long long)nt * blockIdx.x / gridDim.x), q1 = (int)((long long)nt * (blockIdx.x + 1) / gridDim.x);
-    if (q0 >= q1) return;
-    const int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
-    const int xhi = min(grid_coord(T[3 * (size_t)(q1 - 1)], minx, inv, gx) + (R0 + 1), gx - 1);
-    const int p0 = cs[xlo * gy], p1 = cs[(xhi + 1) * gy];
-    const int np = p1 - p0;
-    const bool kLds = np <= kLoopLdsPts;
-    if (kLds) {                                                  // 16-byte copies of the prepared records
-        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap + p0);
-        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
-        for (int j = threadIdx.x; j < np * 2; j += kKnnWG) dst[j] = src[j];
-        __syncthreads();
-    }
-    auto tgt_xyz = [&](int j, double& x, double& y, double& z) {
-        if (kLds && (unsigned)(j - p0) < (unsigned)np) { const TgtRec& r = s_tgt[j - p0]; x = r.x; y = r.y; z = r.z; }
-        else { x = T[3 * (size_t)j]; y = T[3 * (size_t)j + 1]; z = T[3 * (size_t)j + 2]; }
-    };
-    auto tgt_orig = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].orig : orig[j]; };
-    auto tgt_zq = [&](int j) { return (kLds && (unsigned)(j - p0) < (unsigned)np) ? s_tgt[j - p0].zq : rec[j].zq; };
-    int* list = s_list + wave * kKnnCache;
+// One point, L lanes (8: the lane group of the main loop; 64: a whole wave, for the points whose ring has to grow).
+template <int L> struct Red;
+template <> struct Red<8> {
+    static __device__ __forceinline__ int sum(int v) { return sum8(v); }
+    static __device__ __forceinline__ double sum(double v) { return sum8(v); }
+    static __device__ __forceinline__ int mn(int v) { return min8(v); }
+    static __device__ __forceinline__ double mn(double v) { return min8(v); }
+};
+template <> struct Red<64> {
+    static __device__ __forceinline__ int sum(int v) { v = sum8(v); for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64); return v; }
+    static __device__ __forceinline__ double sum(double v) { v = sum8(v); for (int o = 8; o < 64; o <<= 1) v += shfl_xor_d(v, o); return v; }
+    static __device__ __forceinline__ int mn(int v) { v = min8(v); for (int o = 8; o < 64; o <<= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
+    static __device__ __forceinline__ double mn(double v) { v = min8(v); for (int o = 8; o < 64; o <<= 1) v = fmin(v, shfl_xor_d(v, o)); return v; }
+};
 
-    for (int pos = q0 + wave; pos < q1; pos += kKnnWG / 64) {
-        double px, py, pz;
-        tgt_xyz(pos, px, py, pz);
-        const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
-        int R = R0, M = 0, xa = 0, xb = 0, ya = 0, yb = 0;
-        double dreg[kKnnSlots];
-        int preg[kKnnSlots];
-        for (;;) {
-            xa = max(cx - R, 0); xb = min(cx + R, gx - 1); ya = max(cy - R, 0); yb = min(cy + R, gy - 1);
-            const double gw = (double)R * cell * (1.0 + 1e-9) + 1e-12;      // every point closer than R*cell has its depth in pz -+ gw
-            const int zlo = zq_of(pz - gw, minz, inv_z, zq_max), zhi = zq_of(pz + gw, minz, inv_z, zq_max);
-            const bool all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1 && zlo == 0 && zhi == zq_max;
-            const double g = (double)R * cell * (1.0 - 1e-9), g2 = g * g;   // margin >> the rounding of grid_coord
-            const int nx = xb - xa + 1, nruns = nx * (yb - ya + 1);
-            M = 0;
-            for (int r0 = 0; r0 < nruns; r0 += 64) {                // one (x, y) column per lane: its depth range by bisection
-                const int r = r0 + lane;
-                int a = 0, len = 0;
-                if (r < nruns) {
-                    const int y = ya + r / nx, x = xa + r % nx;
-                    const int c = x * gy + y;
-                    const int ca = cs[c], cb = cs[c + 1];
-                    int lo = ca, hi = cb;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tgt_zq(mid) < zlo) lo = mid + 1; else hi = mid; }
-                    a = lo;
-                    hi = cb;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tgt_zq(mid) <= zhi) lo = mid + 1; else hi = mid; }
-                    len = lo - a;
-                }
-                int incl = len;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
-                }
-                const int off = M + incl - len;
-                for (int t = 0; t < len; ++t)
-                    if (off + t < kKnnCache) list[off + t] = a + t;
-                M += __shfl(incl, 63, 64);
-            }
-            int inside = 0;
-            if (M <= kKnnCache) {
-#pragma unroll
-                for (int s = 0; s < kKnnSlots; ++s) {
-                    const int m = lane + 64 * s;
-                    dreg[s] = __longlong_as_double(0x7FF0000000000000ll);   // +inf: never selected
-                    preg[s] = -1;
-                    if (s * 64 < M) {
-                        if (m < M) {
-                            const int j = list[m];
-                            double qx, qy, qz;
-                            tgt_xyz(j, qx, qy, qz);
-                            dreg[s] = sqdist(px, py, pz, qx, qy, qz);
-                            preg[s] = j;
-                        }
-                        inside += __popcll(__ballot(dreg[s] < g2));
-                    }
-                }
-            } else {
-                // too many candidates for the registers: one coalesced scan (columns (x, ya..yb) are one contiguous run, a
-                // superset of the ring) in which every lane keeps the kKnnSlots smallest distances it has seen, sorted
-#pragma unroll
-                for (int s = 0; s < kKnnSlots; ++s) { dreg[s] = __longlong_as_double(0x7FF0000000000000ll); preg[s] = -1; }
-                for (int x = xa; x <= xb; ++x) {
-                    const int a = cs[x * gy + ya], b = cs[x * gy + yb + 1];
-                    for (int j0 = a; j0 < b; j0 += 64) {
-                        const int j = j0 + lane;
-                        bool in = false;
-                        if (j < b) {
-                            double qx, qy, qz;
-                            tgt_xyz(j, qx, qy, qz);
-                            double d = sqdist(px, py, pz, qx, qy, qz);
-                            in = d < g2;
-                            if (d < dreg[kKnnSlots - 1]) {
-                                int jj = j;
-#pragma unroll
-                                for (int s = 0; s < kKnnSlots; ++s)
-                                    if (d < dreg[s]) { const double td = dreg[s]; const int tj = preg[s]; dreg[s] = d; preg[s] = jj; d = td; jj = tj; }
-                            }
-                        }
-                        inside += __popcll(__ballot(in));
-                    }
-                }
-            }
-            if (inside >= k || all) break;
-            R += R > 1 ? R >> 1 : 1;                               // isolated points: grow geometrically, not ring by ring
-        }
-        double sum[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sum[q] = 0.0;
-        double sep2 = 1e300;
-        int taken = 0;
-        const int nslots = M <= kKnnCache ? (M + 63) >> 6 : kKnnSlots;
-        bool exact = true;
-        unsigned long long v = 0;
-        {
-            // k-th smallest squared distance by bisection on the (non-negative) bit pattern.  Invariant: `below` patterns are < v,
-            // `upto` are < v + 2^(bit+1), below < k <= upto; when one pattern is left in between it is the k-th smallest and the
-            // remaining bits need not be walked (typically after ~25 of the 63 steps)
-            int below = 0, upto = 0;
-#pragma unroll
-            for (int s = 0; s < kKnnSlots; ++s)
-                if (s < nslots) upto += __popcll(__ballot(dreg[s] == dreg[s]));          // every pattern is below 2^63 (no NaN in the cache)
-            for (int bit = 62; bit >= 0; --bit) {
-                const unsigned long long t = v | (1ull << bit);
-                int c = 0;
-#pragma unroll
-                for (int s = 0; s < kKnnSlots; ++s)
-                    if (s < nslots) c += __popcll(__ballot((unsigned long long)__double_as_longlong(dreg[s]) < t));
-                if (c < k) { v = t; below = c; } else upto = c;
-                if (upto - below == 1 && upto >= k) {
-                    const unsigned long long top = bit == 0 ? v + 1 : (c < k ? v + (1ull << bit) : t);   // exclusive end of the interval
-                    unsigned long long mine = ~0ull;
-#pragma unroll
-                    for (int s = 0; s < kKnnSlots; ++s)
-                        if (s < nslots) {
-                            const unsigned long long u = (unsigned long long)__double_as_longlong(dreg[s]);
-                            if (u >= v && u < top && u < mine) mine = u;
-                        }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(mine >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)mine, o, 64);
-                        mine = other < mine ? other : mine;
-                    }
-                    v = mine;
-                    break;
-                }
-            }
-            // lanes that kept only their smallest: a lane whose largest kept distance does not exceed the k-th smallest may
-            // have dropped a neighbour -> the per-lane lists are not proof enough, take the pass-by-pass path
-            if (M > kKnnCache && __ballot(!((unsigned long long)__double_as_longlong(dreg[kKnnSlots - 1]) > v))) exact = false;
-        }
-        if (exact) {
-            const double dk = __longlong_as_double((long long)v);
-            int less = 0, eq = 0;
-#pragma unroll
-            for (int s = 0; s < kKnnSlots; ++s)
-                if (s < nslots) { less += __popcll(__ballot(dreg[s] < dk)); eq += __popcll(__ballot(dreg[s] == dk)); }
-            int need = k - less;                                      // how many of the `eq` ties are taken
-            bool sel[kKnnSlots];
-#pragma unroll
-            for (int s = 0; s < kKnnSlots; ++s) sel[s] = s < nslots && dreg[s] < dk;
-            if (eq <= need) {
-#pragma unroll
-                for (int s = 0; s < kKnnSlots; ++s) sel[s] = sel[s] || (s < nslots && dreg[s] == dk);
-            } else {                                                   // ties: lower original index first
-                int last_o = -1;
-                for (int n = 0; n < need; ++n) {
-                    int bo = INT_MAX;
-#pragma unroll
-                    for (int s = 0; s < kKnnSlots; ++s)
-                        if (s < nslots && dreg[s] == dk && preg[s] >= 0) { const int o = tgt_orig(preg[s]); if (o > last_o && o < bo) bo = o; }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) bo = min(bo, __shfl_xor(bo, o, 64));
-#pragma unroll
-                    for (int s = 0; s < kKnnSlots; ++s)
-                        if (s < nslots && dreg[s] == dk && preg[s] >= 0 && tgt_orig(preg[s]) == bo) sel[s] = true;
-                    last_o = bo;
-                }
-            }
-            double nearest = 1e300;
-#pragma unroll
-            for (int s = 0; s < kKnnSlots; ++s) {
-                if (s < nslots) {
-                    if (sel[s]) {
-                        double qx, qy, qz;
-                        tgt_xyz(preg[s], qx, qy, qz);
-                        sum[0] += qx; sum[1] += qy; sum[2] += qz;
-                        sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
-                        sum[9] += 1.0;
-                    }
-                    if (preg[s] >= 0 && preg[s] != pos) nearest = fmin(nearest, dreg[s]);
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) nearest = fmin(nearest, shfl_xor_d(nearest, o));
-            sep2 = nearest;
-            reduce_halve16<8, 32>(sum, lane);
-            reduce_halve16<4, 16>(sum, lane);
-            reduce_halve16<2, 8>(sum, lane);
-            reduce_halve16<1, 4>(sum, lane);
-            double tot = sum[0] + shfl_xor_d(sum[0], 2);
-            tot += shfl_xor_d(tot, 1);
-            const int q = lane >> 2;                                   // lane l holds the wave total of value l >> 2
-            if ((lane & 3) == 0 && q < 10) cov[(size_t)pos * kIcpCovStride + q] = tot;
-            if (lane == 0) cov[(size_t)pos * kIcpCovStride + 10] = sep2;
+template <int L>
+static __device__ __forceinline__ bool knn_point(const int pos, const int sub, int2* runs, const int k, const int R0, const int Rmax, const TgtRec* s_tgt, const int p0,
+                                                 const int np, const double* __restrict__ T, const int* __restrict__ orig, const int* __restrict__ cs,
+                                                 double* __restrict__ cov, const int gx, const int gy, const double minx, const double miny,
+                                                 const double inv, const double cell) {
+    const double kInfD = __longlong_as_double(0x7FF0000000000000ll);
+    const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
+    const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
+    int R = R0, nx, c0, c1, c2, c3, M;
+        double g2;
+    bool all;
+    for (;;) {
+        const int xa = max(cx - R, 0), xb = min(cx + R, gx - 1), ya = max(cy - R, 0), yb = min(cy + R, gy - 1);
+        all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1;
+        nx = xb - xa + 1;
+        if (nx > kKnnRuns) {                                   // a ring that wide (tiny cloud): whole x columns, which are one run
+            nx = 1;
+            if (sub == 0) runs[0] = make_int2(cs[xa * gy], cs[(xb + 1) * gy]);
         } else {
-            // generic path: k passes over the runs, each taking the next candidate in (distance, index) order
-            double prev_d = -1.0;
-            int prev_o = -1;
-            for (int pass = 0; pass < k; ++pass) {
-                double bd = 1e300;
-                int bo = INT_MAX, bp = -1;
-                for (int x = xa; x <= xb; ++x) {
-                    const int a = cs[x * gy + ya], b = cs[x * gy + yb + 1];
-                    for (int j = a + lane; j < b; j += 64) {
-                        double qx, qy, qz;
-                        tgt_xyz(j, qx, qy, qz);
-                        const double d = sqdist(px, py, pz, qx, qy, qz);
-                        const int o = tgt_orig(j);
-                        const bool after = d > prev_d || (d == prev_d && o > prev_o);
-                        if (after && (d < bd || (d == bd && o < bo))) { bd = d; bo = o; bp = j; }
-                    }
-                }
+            for (int xi = sub; xi < nx; xi += L) runs[xi] = make_int2(cs[(xa + xi) * gy + ya], cs[(xa + xi) * gy + yb + 1]);
+        }
+        const double g = (double)R * cell * (1.0 - 1e-9);     // margin >> the rounding of grid_coord
+        g2 = g * g;
+        // pass 1: how many candidates are closer than g, g/sqrt(2), g/2, g/sqrt(8)
+        const double h1 = g2 * 0.5, h2 = g2 * 0.25, h3 = g2 * 0.125;
+        c0 = 0; c1 = 0; c2 = 0; c3 = 0; M = 0;
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
+            ++M; c0 += d < g2 ? 1 : 0; c1 += d < h1 ? 1 : 0; c2 += d < h2 ? 1 : 0; c3 += d < h3 ? 1 : 0;
+        });
+        c0 = Red<L>::sum(c0); c1 = Red<L>::sum(c1); c2 = Red<L>::sum(c2); c3 = Red<L>::sum(c3); M = Red<L>::sum(M);
+        if (c0 >= k || all) break;
+        if (R >= Rmax) return false;                            // the ring has to grow further: the caller hands the point to a whole wave
+        R += R > 1 ? R >> 1 : 1;                               // isolated points: grow geometrically, not ring by ring
+    }
+    // bracket: `cl` distances are < lo, `ch` are < hi, cl < k <= ch.  Selected in the end: d < v, and of the candidates at
+    // d == v none (ties 0), all (1) or those up to original index last_o (2).
+    double lo = 0.0, hi = c0 >= k ? g2 : kInfD;
+    int cl = 0, ch = c0 >= k ? c0 : M;
+    if (c0 >= k) {
+        const double h1 = g2 * 0.5, h2 = g2 * 0.25, h3 = g2 * 0.125;
+        if (c1 >= k) { hi = h1; ch = c1; } else if (c1 > cl) { lo = h1; cl = c1; }
+        if (c2 >= k) { hi = h2; ch = c2; } else if (c2 > cl) { lo = h2; cl = c2; }
+        if (c3 >= k) { hi = h3; ch = c3; } else if (c3 > cl) { lo = h3; cl = c3; }
+    }
+    double v = hi;
+    int ties = ch == k ? 0 : -1, last_o = -1;
+    if (ties < 0 && hi < kInfD) {
+        // pass 2: four thresholds around where the k-th smallest should be if the count is linear in between
+        const double w = hi - lo, f0 = ((double)(k - cl) + 0.5) / (double)(ch - cl + 1), df = 1.5 / (double)(ch - cl + 1);
+        double t[4] = {lo + w * (f0 - 3.0 * df), lo + w * (f0 - df), lo + w * (f0 + df), lo + w * (f0 + 3.0 * df)};
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double od = shfl_xor_d(bd, off);
-                    const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
-                    if (od < bd || (od == bd && oo < bo)) { bd = od; bo = oo; bp = op; }
-                }
-                if (bp < 0) break;
-                if (bp != pos && bd < sep2) sep2 = bd;
-                prev_d = bd; prev_o = bo;
-                double qx, qy, qz;
-                tgt_xyz(bp, qx, qy, qz);
-                sum[0] += qx; sum[1] += qy; sum[2] += qz;
-                sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
-                ++taken;
-            }
-            if (lane == 0) {
+        for (int q = 0; q < 4; ++q) t[q] = t[q] > lo ? (t[q] < hi ? t[q] : hi) : lo;
+        int n4[4] = {0, 0, 0, 0};
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) cov[(size_t)pos * kIcpCovStride + q] = sum[q];
-                cov[(size_t)pos * kIcpCovStride + 9] = (double)taken;
-                cov[(size_t)pos * kIcpCovStride + 10] = sep2;
+            for (int q = 0; q < 4; ++q) n4[q] += d < t[q] ? 1 : 0;
+        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                          // ascending thresholds: the last one below k raises lo, the first one at or above k lowers hi
+            const int n = Red<L>::sum(n4[q]);
+            if (n < k) { if (n >= cl && t[q] > lo) { lo = t[q]; cl = n; } }
+            else if (t[q] < hi) { hi = t[q]; ch = n; }
+        }
+        if (ch == k) { ties = 0; v = hi; }
+    }
+    while (ties < 0) {
+        // the kKnnFew smallest distinct distances in [lo, hi) this lane sees, with their multiplicities
+        double sv[kKnnFew];
+        int sc[kKnnFew];
+#pragma unroll
+        for (int q = 0; q < kKnnFew; ++q) { sv[q] = kInfD; sc[q] = 0; }
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
+            if (d >= lo && d < hi) {
+                double x = d;
+                int xc = 1;
+#pragma unroll
+                for (int q = 0; q < kKnnFew; ++q) {
+                    if (x == sv[q]) { sc[q] += xc; xc = 0; x = kInfD; }
+                    else if (x < sv[q]) { const double tt = sv[q]; const int tc = sc[q]; sv[q] = x; sc[q] = xc; x = tt; xc = tc; }
+                }
             }
+        });
+        // merge the 8 lists smallest value first.  A lane whose list ran empty after being full may have dropped larger
+        // values: nothing above the smallest such "last kept" value can be trusted (limit)
+        double limit = Red<L>::mn(sc[kKnnFew - 1] > 0 ? sv[kKnnFew - 1] : kInfD);
+        int cum = cl, less = -1, eq = 0;
+        for (int it = 0; it < kKnnFew * L && less < 0; ++it) {
+            const double head = Red<L>::mn(sv[0]);
+            if (!(head < kInfD) || head > limit) break;
+            const int mult = Red<L>::sum(sv[0] == head ? sc[0] : 0);
+            if (cum + mult >= k) { v = head; less = cum; eq = mult; break; }
+            cum += mult;
+            if (sv[0] == head) {                                // pop
+#pragma unroll
+                for (int q = 0; q + 1 < kKnnFew; ++q) { sv[q] = sv[q + 1]; sc[q] = sc[q + 1]; }
+                sv[kKnnFew - 1] = kInfD; sc[kKnnFew - 1] = 0;
+            }
+            if (head == limit) break;                           // everything up to the limit is counted; beyond it lists are incomplete
+        }
+        if (less < 0) {                                          // the k-th is above what was collected: go on from there
+            // every distance <= the last merged value is counted in cum; restart just above it
+            const double top = limit < kInfD ? limit : hi;       // (limit == inf: all lists complete, so cum == ch >= k cannot happen here)
+            lo = __longlong_as_double(__double_as_longlong(top) + 1ll); cl = cum;
+            continue;
+        }
+        if (less + eq == k) { ties = 1; break; }
+        ties = 2;                                                // k - less of the eq candidates at v, by original index
+        for (int n = less; n < k; ++n) {
+            int bo = INT_MAX;
+            const int lo_o = last_o;
+            knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int j, double d, double, double, double) {
+                if (d == v) { const int o = orig[j]; if (o > lo_o && o < bo) bo = o; }
+            });
+            last_o = Red<L>::mn(bo);
         }
     }
+    double sum[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sum[q] = 0.0;
+    double sep2 = 1e300;
+    int taken = 0;
+    knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int j, double d, double qx, double qy, double qz) {
+        if (j != pos && d < sep2) sep2 = d;
+        bool sel = d < v;
+        if (ties && d == v) sel = ties == 1 || orig[j] <= last_o;
+        if (sel) {
+            sum[0] += qx; sum[1] += qy; sum[2] += qz;
+            sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
+            ++taken;
+        }
+    });
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sum[q] = Red<L>::sum(sum[q]);
+    taken = Red<L>::sum(taken);
+    sep2 = Red<L>::mn(sep2);
+    if (sub == 0) {
+        double* c = cov + (size_t)pos * kIcpCovStride;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] = sum[q];
+        c[9] = (double)taken;
+        c[10] = sep2;
+    }
+    return true;
 }
 
 __global__ void __launch_bounds__(kKnnWG)
 k_icp_knn(IcpBuffers B, int knn) {
-    __shared__ TgtRec s_tgt[kLoopLdsPts];
-    __shared__ int s_list[(kKnnWG / 64) * kKnnCache];
+    __shared__ TgtRec s_tgt[kKnnSlabPts];
+    __shared__ int2 s_runs[kKnnWG / kKnnLanes][kKnnRuns];
+    __shared__ int s_hard[kKnnHard];
+    __shared__ int s_nhard;
     const int h = blockIdx.y;
     const IcpState& S = B.st[h];
     if (S.status != 0 || S.n_tgt == 0) return;
-    knn_body(B, S, h, knn, s_tgt, s_list);
+    const int nt = S.n_tgt;
+    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
+    const int* orig = B.tgt_orig + (size_t)h * B.cap;
+    const int* cs = B.cell_start + (size_t)h * kIcpCells;
+    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
+    double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    const int gx = S.gx, gy = S.gy;
+    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell, cell = S.cell;
+    const int k = knn < nt ? knn : nt;
+    int R0 = (int)ceil(0.009 / cell);
+    if (R0 < 1) R0 = 1;
+    const int q0 = (int)((long long)nt * blockIdx.x / gridDim.x), q1 = (int)((long long)nt * (blockIdx.x + 1) / gridDim.x);
+    if (q0 >= q1) return;
+    // the slab: the columns the rings R0 + 1 of this workgroup's points reach (R0 if that is too much for the LDS)
+    int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
+    int xhi = min(grid_coord(T[3 * (size_t)(q1 - 1)], minx, inv, gx) + (R0 + 1), gx - 1);
+    if (cs[(xhi + 1) * gy] - cs[xlo * gy] > kKnnSlabPts) { xlo = min(xlo + 1, xhi); xhi = max(xhi - 1, xlo); }
+    const int p0 = cs[xlo * gy];
+    int np = cs[(xhi + 1) * gy] - p0;
+    if (np > kKnnSlabPts) np = 0;                                 // slab too large for LDS: every ring reads HBM
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rec + p0);
+        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
+        for (int j = threadIdx.x; j < np * 2; j += kKnnWG) dst[j] = src[j];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & (kKnnLanes - 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = q0; base < q1; base += kKnnHard) {
+        const int end = base + kKnnHard < q1 ? base + kKnnHard : q1;
+        if (threadIdx.x == 0) s_nhard = 0;
+        __syncthreads();
+        // every lane group takes a point per trip; groups past the end idle (their lanes stay together: the DPP exchanges only
+        // ever pair lanes of one group)
+        for (int pos = base + threadIdx.x / kKnnLanes; pos < end; pos += kKnnWG / kKnnLanes) {
+            const bool done = knn_point<kKnnLanes>(pos, sub, s_runs[threadIdx.x / kKnnLanes], k, R0, R0 + 1, s_tgt, p0, np, T, orig, cs, cov, gx, gy, minx, miny,
+                                                          inv, cell);
+            if (!done && sub == 0) s_hard[atomicAdd(&s_nhard, 1)] = pos;
+        }
+        __syncthreads();
+        // the points whose base ring held fewer than k candidates inside the guarantee radius (isolated points, flying pixels:
+        // 2-15 % of a scene cloud, rings of hundreds to thousands of candidates): a wave each
+        const int nhard = s_nhard;
+        for (int i = wave; i < nhard; i += kKnnWG / 64)
+            (void)knn_point<64>(s_hard[i], lane, s_runs[wave * (64 / kKnnLanes)], k, R0 + 1 + ((R0 + 1) >> 1), INT_MAX, s_tgt, p0, np, T, orig, cs, cov, gx, gy, minx, miny, inv, cell);
+        __syncthreads();
+    }
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----

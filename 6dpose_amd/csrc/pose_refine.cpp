@@ -336,6 +336,12 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             n = (int64_t)tmp.size();
             break;
         }
+        case 5: {   // cumulants of the k nearest neighbours per sorted target position [n_tgt][kIcpCovStride]
+            n = (int64_t)st.n_tgt * kIcpCovStride; tmp.resize((size_t)n);
+            if (n && hipMemcpy(tmp.data(), c->B.cov + off * kIcpCovStride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                return lm_set_error(LM_ERR_HIP, "read-back failed");
+            break;
+        }
         case 4: {   // the slices' partial sums of the last two evaluations, [2][kIcpMaxSplit][32] (slots 29..31: shader cycles of the slice)
             n = 2 * kIcpMaxSplit * 32; tmp.resize((size_t)n);
             for (int par = 0; par < 2; ++par)
