@@ -609,18 +609,20 @@ static __device__ __forceinline__ int min8(int v) { v = min(v, dpp_mov<0xB1>(v))
 // candidates per trip, the lanes of the point side by side.  A run inside the staged slab [p0, p0 + np) comes from LDS.
 template <int L, bool kFromLds, typename F>
 static __device__ __forceinline__ void knn_scan_run(const int a, const int b, const int sub, const TgtRec* s_rel /*s_tgt - p0*/,
-                                                    const double* __restrict__ T, const double px, const double py, const double pz, F&& f) {
-    for (int j0 = a + 4 * sub; j0 < b; j0 += 4 * L) {
-        double d4[4], q4[4][3];
+                                                    const TgtRec* __restrict__ g_rec, const double px, const double py, const double pz, F&& f) {
+    constexpr int U = kFromLds ? 4 : 8;                            // candidates per lane and trip (HBM: more bytes in flight)
+    for (int j0 = a + U * sub; j0 < b; j0 += U * L) {
+        double d4[U], q4[U][3];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < U; ++v) {
             const int j = j0 + v < b ? j0 + v : b - 1;
             if (kFromLds) { const TgtRec& r = s_rel[j]; q4[v][0] = r.x; q4[v][1] = r.y; q4[v][2] = r.z; }
-            else { q4[v][0] = T[3 * (size_t)j]; q4[v][1] = T[3 * (size_t)j + 1]; q4[v][2] = T[3 * (size_t)j + 2]; }
-            d4[v] = sqdist(px, py, pz, q4[v][0], q4[v][1], q4[v][2]);
+            else { const double2 xy = *reinterpret_cast<const double2*>(&g_rec[j].x); q4[v][0] = xy.x; q4[v][1] = xy.y; q4[v][2] = g_rec[j].z; }
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < U; ++v) d4[v] = sqdist(px, py, pz, q4[v][0], q4[v][1], q4[v][2]);
+#pragma unroll
+        for (int v = 0; v < U; ++v)
             if (j0 + v < b) f(j0 + v, d4[v], q4[v][0], q4[v][1], q4[v][2]);
     }
 }
@@ -628,7 +630,7 @@ static __device__ __forceinline__ void knn_scan_run(const int a, const int b, co
 // which costs an LDS read the latency of a trip to memory)
 template <int L, typename F>
 static __device__ __forceinline__ void knn_scan(const int2* runs, const int nx, const int sub, const TgtRec* s_tgt, const int p0, const int np,
-                                                const double* __restrict__ T, const double px, const double py, const double pz, F&& f) {
+                                                const TgtRec* __restrict__ T, const double px, const double py, const double pz, F&& f) {
     for (int xi = 0; xi < nx; ++xi) {
         const int2 ab = runs[xi];
         if (ab.x >= p0 && ab.y <= p0 + np) knn_scan_run<L, true>(ab.x, ab.y, sub, s_tgt - p0, T, px, py, pz, f);
@@ -653,8 +655,8 @@ template <> struct Red<64> {
 
 template <int L>
 static __device__ __forceinline__ bool knn_point(const int pos, const int sub, int2* runs, const int k, const int R0, const int Rmax, const TgtRec* s_tgt, const int p0,
-                                                 const int np, const double* __restrict__ T, const int* __restrict__ orig, const int* __restrict__ cs,
-                                                 double* __restrict__ cov, const int gx, const int gy, const double minx, const double miny,
+                                                 const int np, const double* __restrict__ T, const TgtRec* __restrict__ rec, const int* __restrict__ orig,
+                                                 const int* __restrict__ cs, double* __restrict__ cov, const int gx, const int gy, const double minx, const double miny,
                                                  const double inv, const double cell) {
     const double kInfD = __longlong_as_double(0x7FF0000000000000ll);
     const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
@@ -677,13 +679,15 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         // pass 1: how many candidates are closer than g, g/sqrt(2), g/2, g/sqrt(8)
         const double h1 = g2 * 0.5, h2 = g2 * 0.25, h3 = g2 * 0.125;
         c0 = 0; c1 = 0; c2 = 0; c3 = 0; M = 0;
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
             ++M; c0 += d < g2 ? 1 : 0; c1 += d < h1 ? 1 : 0; c2 += d < h2 ? 1 : 0; c3 += d < h3 ? 1 : 0;
         });
         c0 = Red<L>::sum(c0); c1 = Red<L>::sum(c1); c2 = Red<L>::sum(c2); c3 = Red<L>::sum(c3); M = Red<L>::sum(M);
         if (c0 >= k || all) break;
         if (R >= Rmax) return false;                            // the ring has to grow further: the caller hands the point to a whole wave
-        R += R > 1 ? R >> 1 : 1;                               // isolated points: grow geometrically, not ring by ring
+        // isolated points: grow geometrically, not ring by ring; a whole wave doubles, and past 8 rings (a point ~5 cm from
+        // anything: a depth outlier) takes the whole cloud, which is one contiguous run
+        R = L == 64 ? (R >= 8 ? (gx > gy ? gx : gy) : 2 * R) : R + (R > 1 ? R >> 1 : 1);
     }
     // bracket: `cl` distances are < lo, `ch` are < hi, cl < k <= ch.  Selected in the end: d < v, and of the candidates at
     // d == v none (ties 0), all (1) or those up to original index last_o (2).
@@ -704,7 +708,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) t[q] = t[q] > lo ? (t[q] < hi ? t[q] : hi) : lo;
         int n4[4] = {0, 0, 0, 0};
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) n4[q] += d < t[q] ? 1 : 0;
         });
@@ -722,7 +726,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         int sc[kKnnFew];
 #pragma unroll
         for (int q = 0; q < kKnnFew; ++q) { sv[q] = kInfD; sc[q] = 0; }
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
             if (d >= lo && d < hi) {
                 double x = d;
                 int xc = 1;
@@ -761,7 +765,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         for (int n = less; n < k; ++n) {
             int bo = INT_MAX;
             const int lo_o = last_o;
-            knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int j, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, double d, double, double, double) {
                 if (d == v) { const int o = orig[j]; if (o > lo_o && o < bo) bo = o; }
             });
             last_o = Red<L>::mn(bo);
@@ -772,7 +776,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
     for (int q = 0; q < 9; ++q) sum[q] = 0.0;
     double sep2 = 1e300;
     int taken = 0;
-    knn_scan<L>(runs, nx, sub, s_tgt, p0, np, T, px, py, pz, [&](int j, double d, double qx, double qy, double qz) {
+    knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, double d, double qx, double qy, double qz) {
         if (j != pos && d < sep2) sep2 = d;
         bool sel = d < v;
         if (ties && d == v) sel = ties == 1 || orig[j] <= last_o;
@@ -839,7 +843,7 @@ k_icp_knn(IcpBuffers B, int knn) {
         // every lane group takes a point per trip; groups past the end idle (their lanes stay together: the DPP exchanges only
         // ever pair lanes of one group)
         for (int pos = base + threadIdx.x / kKnnLanes; pos < end; pos += kKnnWG / kKnnLanes) {
-            const bool done = knn_point<kKnnLanes>(pos, sub, s_runs[threadIdx.x / kKnnLanes], k, R0, R0 + 1, s_tgt, p0, np, T, orig, cs, cov, gx, gy, minx, miny,
+            const bool done = knn_point<kKnnLanes>(pos, sub, s_runs[threadIdx.x / kKnnLanes], k, R0, R0 + 1, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny,
                                                           inv, cell);
             if (!done && sub == 0) s_hard[atomicAdd(&s_nhard, 1)] = pos;
         }
@@ -848,7 +852,7 @@ k_icp_knn(IcpBuffers B, int knn) {
         // 2-15 % of a scene cloud, rings of hundreds to thousands of candidates): a wave each
         const int nhard = s_nhard;
         for (int i = wave; i < nhard; i += kKnnWG / 64)
-            (void)knn_point<64>(s_hard[i], lane, s_runs[wave * (64 / kKnnLanes)], k, R0 + 1 + ((R0 + 1) >> 1), INT_MAX, s_tgt, p0, np, T, orig, cs, cov, gx, gy, minx, miny, inv, cell);
+            (void)knn_point<64>(s_hard[i], lane, s_runs[wave * (64 / kKnnLanes)], k, R0 + 1 + ((R0 + 1) >> 1), INT_MAX, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny, inv, cell);
         __syncthreads();
     }
 }

@@ -26,12 +26,6 @@ if os.environ.get("PIPE_DIAG"):
             print("   worst slice %d: cycles %.0f search %.0f max over lanes: (candidates, columns*1000+queued) %s points %d..%d | median slice classes %s" % (worst, tot[worst], sea[worst], divmod(int(wall[worst]), 1000000), 0, 0, sorted(int(w) for w in wall[act])[len(wall[act]) // 2]), file=sys.stderr)
             print("hyp %2d iters %2d n_model %5d n_scene %5d grid %dx%d | slices %d: cycles min %.0f median %.0f max %.0f, search median %.0f max %.0f, wall us max %.1f | not in LDS %d, largest slab %d | corr/slice max %.0f" % (
                 hyp, st[24], st[19], st[20], st[21], st[22], act.sum(), tot[act].min(), np.median(tot[act]), tot[act].max(), np.median(sea[act]), sea[act].max(), wall[act].max() / 100, st[31], st[32], d[0, act, 28].max()), file=sys.stderr)
-        for hyp in range(16):
-            c = self.read_icp_debug(hyp, 5).reshape(-1, 12)
-            if not len(c): continue
-            x = c[:, 11]; cyc = np.floor(x / 1e8); rem = x - cyc * 1e8; M = np.floor(rem / 1000); rem2 = rem - M * 1000; grow = np.floor(rem2 / 100); coll = rem2 - grow * 100
-            print("knn hyp %2d n_tgt %5d: cycles/point median %6.0f p90 %7.0f max %8.0f sum %.3g | M median %4.0f p90 %5.0f max %6.0f | grown rings %4d (max +%d) | collect passes mean %.2f max %d" % (
-                hyp, len(c), np.median(cyc), np.percentile(cyc, 90), cyc.max(), cyc.sum(), np.median(M), np.percentile(M, 90), M.max(), (grow > 0).sum(), grow.max(), coll.mean(), coll.max()), file=sys.stderr)
         _close(self)
     lm.Pipeline.close = close_with_dump
 print(json.dumps(bench.pipeline_bench(det, frames, bank, ["obj00"], steps=steps)))
