@@ -168,6 +168,83 @@ static __device__ __forceinline__ void bitonic_sort_hybrid(unsigned long long* g
     }
 }
 
+// Stable LSD radix sort by one workgroup of 1024 threads: n <= kSortLds 16-bit indices ordered by their 32-bit keys (the keys
+// stay put in LDS, the indices move), 8 bits per pass.  Every wave owns a contiguous chunk of the list; inside a round of 64
+// the lanes with the same digit find each other with 8 ballots (rank = lanes before me with my digit), the per-wave digit
+// counts are prefix-summed digit-major / wave-minor, and the second walk scatters.  3 passes for the 24-bit voxel index of
+// a 0.6 m cloud, 4 for the grid key — against ~105 barrier-separated compare-exchange steps of the bitonic network.
+// Lists of up to 2 x kSortLds points keep their keys in HBM (u32, read through L2) and have the whole buffer for indices:
+// keys | idx | idx | counts = 64 | 32 | 32 | 16 KiB for n <= 16384, idx | idx | counts = 64 | 64 | 16 KiB for n <= 32768.
+constexpr int kRadixBig = 2 * kSortLds;
+constexpr int kRadixLdsBytes = 2 * kRadixBig * 2 + 16 * 256 * 4;   // 144 KiB
+struct RadixView { unsigned short* idx[2]; unsigned int (*hist)[256]; unsigned int* key_lds; };
+static __device__ __forceinline__ RadixView radix_view(unsigned char* raw, const bool big) {
+    RadixView v;
+    v.key_lds = reinterpret_cast<unsigned int*>(raw);
+    v.idx[0] = reinterpret_cast<unsigned short*>(raw + (big ? 0 : kSortLds * 4));
+    v.idx[1] = v.idx[0] + (big ? kRadixBig : kSortLds);
+    v.hist = reinterpret_cast<unsigned int (*)[256]>(raw + 2 * kRadixBig * 2);
+    return v;
+}
+
+template <typename KeyF>
+static __device__ __forceinline__ const unsigned short* wg_radix_sort(const RadixView& m, const int n, const int bits, int* s_wave /*[32]*/, KeyF&& key_of) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = ((n + 1023) >> 10) << 6;                         // chunk of a wave: a multiple of 64, 16 chunks cover n
+    for (int i = tid; i < n; i += kWG) m.idx[0][i] = (unsigned short)i;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        const unsigned short* in = m.idx[cur];
+        unsigned short* out = m.idx[cur ^ 1];
+        for (int d = lane; d < 256; d += 64) m.hist[wave][d] = 0;
+        __syncthreads();                                             // (the indices of the previous pass are written)
+        for (int walk = 0; walk < 2; ++walk) {
+            for (int r = 0; r < C; r += 64) {
+                const int i = wave * C + r + lane;
+                const bool active = i < n;
+                const unsigned int id = active ? in[i] : 0;
+                const unsigned int d = active ? (key_of(id) >> shift) & 255u : 0;
+                unsigned long long peers = __ballot(active);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const unsigned long long bb = __ballot(active && ((d >> b) & 1u));
+                    peers &= ((d >> b) & 1u) ? bb : ~bb;
+                }
+                const int cnt = __popcll(peers), rank = __popcll(peers & ((1ull << lane) - 1ull));
+                if (walk == 0) {
+                    if (active && rank == 0) m.hist[wave][d] += cnt;
+                } else {
+                    unsigned int base = 0;
+                    if (active) base = m.hist[wave][d];
+                    if (active) out[base + rank] = (unsigned short)id;
+                    if (active && rank == 0) m.hist[wave][d] = base + cnt;
+                }
+            }
+            if (walk == 0) {
+                // exclusive prefix over (digit, wave): thread t owns digit t / 4, waves 4 (t % 4) .. + 3
+                __syncthreads();
+                const int d = tid >> 2, w0 = (tid & 3) * 4;
+                unsigned int c[4], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { c[q] = m.hist[w0 + q][d]; sum += c[q]; }
+                unsigned int incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                if (lane == 63) s_wave[wave] = (int)incl;
+                __syncthreads();
+                unsigned int base = incl - sum;
+                for (int w = 0; w < wave; ++w) base += (unsigned int)s_wave[w];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { m.hist[w0 + q][d] = base; base += c[q]; }
+                __syncthreads();
+            }
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    return m.idx[cur];
+}
+
 static __device__ __forceinline__ int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -373,7 +450,8 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWG)
 k_icp_voxel(IcpBuffers B, int flags, double voxel) {
-    __shared__ unsigned long long s_keys[kSortLds];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRadixLdsBytes];   // radix layout, or 128 KiB of 64-bit keys (bitonic)
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw);
     __shared__ int s_wave[32];
     __shared__ double s_part[16 * 6];
     __shared__ double s_mm[6];
@@ -409,19 +487,34 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
     }
     const int npad = next_pow2(n < 2 ? 2 : n);
     const bool in_lds = npad <= kSortLds;
+    const bool radix = n <= kRadixBig && bx + by + bz <= 32;       // voxel index in 32 bits: stable radix sort of the point indices
+    const bool big = n > kSortLds;                                 // ... whose keys then stay in HBM
+    const RadixView s_rx = radix_view(s_raw, big);
     unsigned long long* gk = B.keys + ((size_t)h * 2 + which) * B.cap2;
-    for (int i = tid; i < npad; i += kWG) {
+    unsigned int* gk32 = reinterpret_cast<unsigned int*>(gk);
+    for (int i = tid; i < (radix ? n : npad); i += kWG) {
         unsigned long long key = ~0ull;
         if (i < n) {
             const unsigned long long ix = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i] - mnx, voxel));
             const unsigned long long iy = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 1] - mny, voxel));
             const unsigned long long iz = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 2] - mnz, voxel));
-            key = ((((ix << by) | iy) << bz | iz) << bi) | (unsigned long long)i;
+            key = (((ix << by) | iy) << bz | iz);
+            if (!radix) key = (key << bi) | (unsigned long long)i;
         }
-        if (in_lds) s_keys[i] = key; else gk[i] = key;
+        if (radix) { if (big) gk32[i] = (unsigned int)key; else s_rx.key_lds[i] = (unsigned int)key; }
+        else if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort_hybrid(gk, npad, s_keys);
+    const unsigned short* order = nullptr;
+    if (radix && big) order = wg_radix_sort(s_rx, n, bx + by + bz, s_wave, [&](unsigned int id) { return gk32[id]; });
+    else if (radix) order = wg_radix_sort(s_rx, n, bx + by + bz, s_wave, [&](unsigned int id) { return s_rx.key_lds[id]; });
+    else if (in_lds) bitonic_sort(s_keys, npad);
+    else bitonic_sort_hybrid(gk, npad, s_keys);
+    // sorted position -> (voxel index << bi) | point index, whichever way the list was sorted
+    auto key_at = [&](int i) -> unsigned long long {
+        if (radix) { const unsigned int id = order[i]; return ((unsigned long long)(big ? gk32[id] : s_rx.key_lds[id]) << bi) | id; }
+        return in_lds ? s_keys[i] : gk[i];
+    };
     const unsigned long long imask = (1ull << bi) - 1ull;
     int nout = 0;
     for (int base = 0; base < n; base += kWG) {
@@ -429,9 +522,9 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         bool head = false;
         unsigned long long vox = 0;
         if (i < n) {
-            const unsigned long long k = in_lds ? s_keys[i] : gk[i];
+            const unsigned long long k = key_at(i);
             vox = k >> bi;
-            head = i == 0 || ((in_lds ? s_keys[i - 1] : gk[i - 1]) >> bi) != vox;
+            head = i == 0 || (key_at(i - 1) >> bi) != vox;
         }
         int tot;
         const int pos = nout + block_scan_flag(head, s_wave, tot);
@@ -440,7 +533,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
             double sx = 0, sy = 0, sz = 0;
             int cnt = 0, j = i;
             for (;;) {
-                const unsigned long long k = in_lds ? s_keys[j] : gk[j];
+                const unsigned long long k = key_at(j);
                 if ((k >> bi) != vox) break;
                 const size_t idx = (size_t)(k & imask);
                 sx += pts[3 * idx]; sy += pts[3 * idx + 1]; sz += pts[3 * idx + 2];
@@ -474,7 +567,9 @@ static __device__ __forceinline__ int zq_of(double z, double minz, double inv_z,
 
 __global__ void __launch_bounds__(kWG)
 k_icp_grid(IcpBuffers B, int flags) {
-    __shared__ unsigned long long s_keys[kSortLds];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRadixLdsBytes];   // radix layout, or 128 KiB of 64-bit keys (bitonic)
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw);
+    __shared__ int s_wave[32];
     __shared__ double s_part[16 * 6];
     __shared__ double s_mm[6];
     const int h = blockIdx.x, tid = threadIdx.x;
@@ -519,25 +614,42 @@ k_icp_grid(IcpBuffers B, int flags) {
     const int gx = grid_coord(s_mm[3], minx, inv, kIcpGrid) + 1, gy = grid_coord(s_mm[4], miny, inv, kIcpGrid) + 1;
     const int zq_max = zq_of(s_mm[5], minz, inv_z, (1 << kZBits) - 1);
     const int npad = next_pow2(nt < 2 ? 2 : nt);
-    const bool in_lds = npad <= kSortLds;
+    const bool radix = nt <= kRadixBig;                            // (column, depth step) is 32 bits: stable radix sort of the point indices
+    const bool big = nt > kSortLds;                                // ... whose keys then stay in HBM
+    const RadixView s_rx = radix_view(s_raw, big);
+    const int cell_bits = bits_for((long long)gx * gy - 1), z_bits = bits_for(zq_max);
     unsigned long long* gk = B.keys + (size_t)h * 2 * B.cap2;
-    for (int i = tid; i < npad; i += kWG) {
+    unsigned int* gk32 = reinterpret_cast<unsigned int*>(gk);
+    for (int i = tid; i < (radix ? nt : npad); i += kWG) {
         unsigned long long key = ~0ull;
         if (i < nt) {
             const int cx = grid_coord(T[3 * (size_t)i], minx, inv, gx), cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy);
             const int zq = zq_of(T[3 * (size_t)i + 2], minz, inv_z, zq_max);
-            key = ((((unsigned long long)(cx * gy + cy) << kZBits) | (unsigned long long)zq) << kIdxBits) | (unsigned long long)i;
+            if (radix) key = ((unsigned long long)(cx * gy + cy) << z_bits) | (unsigned long long)zq;
+            else key = ((((unsigned long long)(cx * gy + cy) << kZBits) | (unsigned long long)zq) << kIdxBits) | (unsigned long long)i;
         }
-        if (in_lds) s_keys[i] = key; else gk[i] = key;
+        if (radix) { if (big) gk32[i] = (unsigned int)key; else s_rx.key_lds[i] = (unsigned int)key; }
+        else gk[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort(s_keys, npad); else bitonic_sort_hybrid(gk, npad, s_keys);
+    const unsigned short* order = nullptr;
+    if (radix && big) order = wg_radix_sort(s_rx, nt, cell_bits + z_bits, s_wave, [&](unsigned int id) { return gk32[id]; });
+    else if (radix) order = wg_radix_sort(s_rx, nt, cell_bits + z_bits, s_wave, [&](unsigned int id) { return s_rx.key_lds[id]; });
+    else bitonic_sort_hybrid(gk, npad, s_keys);
+    // sorted position -> ((column << kZBits | depth step) << kIdxBits) | point index, whichever way the list was sorted
+    auto key_at = [&](int i) -> unsigned long long {
+        if (radix) {
+            const unsigned int id = order[i], k32 = big ? gk32[id] : s_rx.key_lds[id];
+            return ((((unsigned long long)(k32 >> z_bits) << kZBits) | (unsigned long long)(k32 & ((1u << z_bits) - 1u))) << kIdxBits) | id;
+        }
+        return gk[i];
+    };
     double* Ts = B.tgt_sorted + (size_t)h * B.cap * 3;
     int* orig = B.tgt_orig + (size_t)h * B.cap;
     TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
     unsigned short* cs16 = B.cell_start16 + (size_t)h * kIcpCells16;
     for (int p = tid; p < nt; p += kWG) {
-        const unsigned long long k = in_lds ? s_keys[p] : gk[p];
+        const unsigned long long k = key_at(p);
         const size_t i = (size_t)(k & ((1ull << kIdxBits) - 1ull));
         Ts[3 * (size_t)p] = T[3 * i]; Ts[3 * (size_t)p + 1] = T[3 * i + 1]; Ts[3 * (size_t)p + 2] = T[3 * i + 2];
         orig[p] = (int)i;
@@ -552,7 +664,7 @@ k_icp_grid(IcpBuffers B, int flags) {
         int lo = 0, hi = nt;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            const unsigned long long k = in_lds ? s_keys[mid] : gk[mid];
+            const unsigned long long k = key_at(mid);
             if (k < want) lo = mid + 1; else hi = mid;
         }
         cs[c] = lo;
@@ -1490,7 +1602,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_knn, dim3(count <= 32 ? 64 : 32, count), dim3(kKnnWG), 0, s, B, knn);
-    hipLaunchKernelGGL(k_icp_normals, dim3(8, count), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
     int splits = 768 / count;
     if (const char* e = getenv("LM_ICP_SPLITS")) splits = atoi(e);      // tuning knob (profiles/)

@@ -964,13 +964,16 @@ def test_icp_device_intermediates_match_oracle(lm):
         ctx.close()
 
 
-def test_icp_large_clouds_take_the_global_sort_path(lm):
-    """> 16k points per cloud: the voxel / grid sorts leave LDS for the HBM scratch.  The down-sampled cloud must
-    still equal the oracle's, and registering the cloud to itself (verbatim mode, LL.cpp:109) is the identity."""
+@pytest.mark.parametrize("half_w,half_h", [(110, 100), (80, 75)])
+def test_icp_large_clouds_take_the_global_sort_path(lm, half_w, half_h):
+    """> 16k points per cloud: the voxel / grid sorts keep their keys in HBM (radix sort, up to 32k points: the 159 x 149 =
+    23.7k-pixel case) or leave LDS altogether (bitonic network through the HBM scratch: 219 x 199 = 43.6k pixels).  The
+    down-sampled cloud must still equal the oracle's, and registering the cloud to itself (verbatim mode, LL.cpp:109) is
+    the identity."""
     import linemodLevelup_pybind as mod
     H, W = 480, 640
     yy, xx = np.mgrid[0:H, 0:W]
-    inside = (np.abs(xx - W // 2) < 110) & (np.abs(yy - H // 2) < 100)                    # 219 x 199 = 43.6k pixels
+    inside = (np.abs(xx - W // 2) < half_w) & (np.abs(yy - H // 2) < half_h)
     md = np.where(inside, 2000 + ((xx - W // 2) * 0.5).astype(np.int64) + ((yy % 7) == 0) * 3, 0).astype(np.uint16)
     ys, xs = np.nonzero(md)
     dx, dy = int(xs.min()), int(ys.min())
