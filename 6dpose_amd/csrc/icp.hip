@@ -517,6 +517,48 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
     };
     const unsigned long long imask = (1ull << bi) - 1ull;
     int nout = 0;
+    if (radix) {
+        // the points of 1024 sorted positions are gathered into LDS side by side (the index buffer the sort left free), then
+        // the first thread of every voxel adds its points up in input order — out of LDS, not one dependent HBM gather each
+        unsigned short* spare = order == s_rx.idx[0] ? s_rx.idx[1] : s_rx.idx[0];
+        double* st = reinterpret_cast<double*>(spare);                       // [kWG][3]
+        unsigned int* sv = reinterpret_cast<unsigned int*>(st + 3 * kWG);    // [kWG] voxel index per position
+        auto vox_of = [&](int i) -> unsigned int { const unsigned int id = order[i]; return big ? gk32[id] : s_rx.key_lds[id]; };
+        for (int base = 0; base < n; base += kWG) {
+            const int i = base + tid;
+            unsigned int v = 0;
+            if (i < n) {
+                const unsigned int id = order[i];
+                v = big ? gk32[id] : s_rx.key_lds[id];
+                st[3 * tid] = pts[3 * (size_t)id]; st[3 * tid + 1] = pts[3 * (size_t)id + 1]; st[3 * tid + 2] = pts[3 * (size_t)id + 2];
+                sv[tid] = v;
+            }
+            __syncthreads();
+            const bool head = i < n && (i == 0 || (tid > 0 ? sv[tid - 1] : vox_of(i - 1)) != v);
+            int tot;
+            const int pos = nout + block_scan_flag(head, s_wave, tot);
+            nout += tot;
+            if (head) {
+                double sx = 0, sy = 0, sz = 0;
+                int cnt = 0;
+                for (int j = i; j < n; ++j) {
+                    const int t = j - base;
+                    if (t < kWG) {
+                        if (sv[t] != v) break;
+                        sx += st[3 * t]; sy += st[3 * t + 1]; sz += st[3 * t + 2];
+                    } else {                                             // the voxel runs on into the next 1024 positions
+                        if (vox_of(j) != v) break;
+                        const size_t idx = order[j];
+                        sx += pts[3 * idx]; sy += pts[3 * idx + 1]; sz += pts[3 * idx + 2];
+                    }
+                    ++cnt;
+                }
+                const double c = (double)cnt;
+                out[3 * (size_t)pos] = sx / c; out[3 * (size_t)pos + 1] = sy / c; out[3 * (size_t)pos + 2] = sz / c;
+            }
+            __syncthreads();
+        }
+    } else
     for (int base = 0; base < n; base += kWG) {
         const int i = base + tid;
         bool head = false;
