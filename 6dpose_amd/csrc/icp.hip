@@ -744,6 +744,7 @@ constexpr int kKnnLanes = 8;       // lanes per point
 constexpr int kKnnSlabPts = 2048;  // target points staged per workgroup (32-byte records, 64 KiB: two workgroups per CU)
 constexpr int kKnnRuns = 16;       // x columns of a ring kept as separate runs (R <= 7; wider rings take whole x columns)
 constexpr int kKnnHard = 512;      // points per round of a workgroup, any of which may be handed to a whole wave
+constexpr int kKnnFarMax = 256;    // points per hypothesis k_icp_knn_far takes (more than that stay with their wave)
 constexpr int kKnnFew = 4;         // distinct distances a lane sorts in registers in a collecting pass
 
 // reductions over the 8 lanes of a point (xor 1, xor 2, mirror within the half row): every lane ends with the result
@@ -807,6 +808,29 @@ template <> struct Red<64> {
     static __device__ __forceinline__ double mn(double v) { v = min8(v); for (int o = 8; o < 64; o <<= 1) v = fmin(v, shfl_xor_d(v, o)); return v; }
 };
 
+// a whole workgroup of 512 threads per point (k_icp_knn_far): wave reduction, then the 8 waves meet in LDS.  Every thread of
+// the workgroup must make the same calls (the point's state is the same in all of them, so the control flow is).
+template <> struct Red<512> {
+    template <typename V, typename Op> static __device__ __forceinline__ V all(V v, Op op) {
+        __shared__ V s_v[8];
+        v = op(v, dpp_mov<0xB1>(v)); v = op(v, dpp_mov<0x4E>(v)); v = op(v, dpp_mov<0x141>(v));
+        for (int o = 8; o < 64; o <<= 1) v = op(v, shfl_any(v, o));
+        __syncthreads();                                             // (the previous reduction has been read)
+        if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6] = v;
+        __syncthreads();
+        V r = s_v[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) r = op(r, s_v[w]);
+        return r;
+    }
+    static __device__ __forceinline__ int shfl_any(int v, int o) { return __shfl_xor(v, o, 64); }
+    static __device__ __forceinline__ double shfl_any(double v, int o) { return shfl_xor_d(v, o); }
+    static __device__ __forceinline__ int sum(int v) { return all(v, [](int a, int b) { return a + b; }); }
+    static __device__ __forceinline__ double sum(double v) { return all(v, [](double a, double b) { return a + b; }); }
+    static __device__ __forceinline__ int mn(int v) { return all(v, [](int a, int b) { return a < b ? a : b; }); }
+    static __device__ __forceinline__ double mn(double v) { return all(v, [](double a, double b) { return fmin(a, b); }); }
+};
+
 template <int L>
 static __device__ __forceinline__ bool knn_point(const int pos, const int sub, int2* runs, const int k, const int R0, const int Rmax, const TgtRec* s_tgt, const int p0,
                                                  const int np, const double* __restrict__ T, const TgtRec* __restrict__ rec, const int* __restrict__ orig,
@@ -828,6 +852,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         } else {
             for (int xi = sub; xi < nx; xi += L) runs[xi] = make_int2(cs[(xa + xi) * gy + ya], cs[(xa + xi) * gy + yb + 1]);
         }
+        if (L > 64) __syncthreads();                               // (within a wave the LDS operations are in order)
         const double g = (double)R * cell * (1.0 - 1e-9);     // margin >> the rounding of grid_coord
         g2 = g * g;
         // pass 1: how many candidates are closer than g, g/sqrt(2), g/2, g/sqrt(8)
@@ -839,9 +864,8 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         c0 = Red<L>::sum(c0); c1 = Red<L>::sum(c1); c2 = Red<L>::sum(c2); c3 = Red<L>::sum(c3); M = Red<L>::sum(M);
         if (c0 >= k || all) break;
         if (R >= Rmax) return false;                            // the ring has to grow further: the caller hands the point to a whole wave
-        // isolated points: grow geometrically, not ring by ring; a whole wave doubles, and past 8 rings (a point ~5 cm from
-        // anything: a depth outlier) takes the whole cloud, which is one contiguous run
-        R = L == 64 ? (R >= 8 ? (gx > gy ? gx : gy) : 2 * R) : R + (R > 1 ? R >> 1 : 1);
+        // isolated points: grow geometrically, not ring by ring (a whole wave doubles)
+        R = L == 64 ? 2 * R : R + (R > 1 ? R >> 1 : 1);
     }
     // bracket: `cl` distances are < lo, `ch` are < hi, cl < k <= ch.  Selected in the end: d < v, and of the candidates at
     // d == v none (ties 0), all (1) or those up to original index last_o (2).
@@ -969,6 +993,7 @@ k_icp_knn(IcpBuffers B, int knn) {
     const int* cs = B.cell_start + (size_t)h * kIcpCells;
     const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
     double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    int* far_list = reinterpret_cast<int*>(B.keys + (size_t)h * 2 * B.cap2);   // the sort scratch is free by now
     const int gx = S.gx, gy = S.gy;
     const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell, cell = S.cell;
     const int k = knn < nt ? knn : nt;
@@ -980,6 +1005,7 @@ k_icp_knn(IcpBuffers B, int knn) {
     int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
     int xhi = min(grid_coord(T[3 * (size_t)(q1 - 1)], minx, inv, gx) + (R0 + 1), gx - 1);
     if (cs[(xhi + 1) * gy] - cs[xlo * gy] > kKnnSlabPts) { xlo = min(xlo + 1, xhi); xhi = max(xhi - 1, xlo); }
+    if (nt <= kKnnSlabPts) { xlo = 0; xhi = gx - 1; }             // a small cloud is staged whole: grown rings stay in LDS too
     const int p0 = cs[xlo * gy];
     int np = cs[(xhi + 1) * gy] - p0;
     if (np > kKnnSlabPts) np = 0;                                 // slab too large for LDS: every ring reads HBM
@@ -1005,10 +1031,38 @@ k_icp_knn(IcpBuffers B, int knn) {
         // the points whose base ring held fewer than k candidates inside the guarantee radius (isolated points, flying pixels:
         // 2-15 % of a scene cloud, rings of hundreds to thousands of candidates): a wave each
         const int nhard = s_nhard;
-        for (int i = wave; i < nhard; i += kKnnWG / 64)
-            (void)knn_point<64>(s_hard[i], lane, s_runs[wave * (64 / kKnnLanes)], k, R0 + 1 + ((R0 + 1) >> 1), INT_MAX, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny, inv, cell);
+        for (int i = wave; i < nhard; i += kKnnWG / 64) {
+            const int pos = s_hard[i];
+            int2* runs = s_runs[wave * (64 / kKnnLanes)];
+            if (knn_point<64>(pos, lane, runs, k, R0 + 1 + ((R0 + 1) >> 1), 8, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny, inv, cell)) continue;
+            // more than 8 rings from its k-th neighbour (a depth outlier, or a blob of fewer than k points away from the rest):
+            // such a point needs the whole cloud — left to k_icp_knn_far, a workgroup each
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&B.st[h].n_far, 1);
+            slot = __shfl(slot, 0, 64);
+            if (slot < kKnnFarMax) { if (lane == 0) far_list[slot] = pos; }
+            else (void)knn_point<64>(pos, lane, runs, k, gx > gy ? gx : gy, INT_MAX, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny, inv, cell);
+        }
         __syncthreads();
     }
+}
+
+// The points k_icp_knn could not finish within 8 rings: a workgroup each, the whole cloud as one coalesced run (one wave
+// streaming 12k records four times over took ~1 M cycles, and a blob of such points sits in ONE workgroup of k_icp_knn).
+__global__ void __launch_bounds__(512)
+k_icp_knn_far(IcpBuffers B, int knn) {
+    __shared__ int2 s_runs[kKnnRuns];
+    const int h = blockIdx.y;
+    const IcpState& S = B.st[h];
+    if (S.status != 0 || S.n_tgt == 0) return;
+    const int nfar = S.n_far < kKnnFarMax ? S.n_far : kKnnFarMax;
+    if ((int)blockIdx.x >= nfar) return;
+    const int nt = S.n_tgt;
+    const int pos = reinterpret_cast<const int*>(B.keys + (size_t)h * 2 * B.cap2)[blockIdx.x];
+    const int big = S.gx > S.gy ? S.gx : S.gy;
+    (void)knn_point<512>(pos, (int)threadIdx.x, s_runs, knn < nt ? knn : nt, big, INT_MAX, nullptr, 0, 0, B.tgt_sorted + (size_t)h * B.cap * 3,
+                         B.tgt_rec + (size_t)h * B.cap, B.tgt_orig + (size_t)h * B.cap, B.cell_start + (size_t)h * kIcpCells,
+                         B.cov + (size_t)h * B.cap * kIcpCovStride, S.gx, S.gy, S.gminx, S.gminy, S.inv_cell, S.cell);
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----
@@ -1644,6 +1698,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_knn, dim3(count <= 32 ? 64 : 32, count), dim3(kKnnWG), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
     int splits = 768 / count;

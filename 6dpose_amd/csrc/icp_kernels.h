@@ -39,7 +39,7 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     double T[16];            // final transformation_ (row-major)
     double fitness, rmse;    // fitness_, inlier_rmse_
     int stop;                // RegistrationICP finished (converged or max_iteration)
-    int pad2;
+    int n_far;               // target points k_icp_knn left to k_icp_knn_far (their k nearest are more than 8 rings away)
     double fit_hist[2], rmse_hist[2];   // fitness / rmse of the last two evaluations, slot = evaluation parity
     long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };

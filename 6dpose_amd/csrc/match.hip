@@ -45,7 +45,6 @@ static __device__ __forceinline__ float score_of(int raw, int nfeat) {
 // argument, README.md:67-69) and realigns ONCE per class run (v_alignbyte + one neighbour exchange)
 // into the u16 position accumulators.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ uint4 ld_aligned16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
 // The gathers of the three fast paths go through buffer loads: `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` takes the
 // arena as a resource in SGPRs, ONE 32-bit per-lane offset (constant for the whole item) and the feature's wave-uniform byte
