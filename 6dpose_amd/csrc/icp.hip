@@ -1131,6 +1131,7 @@ k_icp_normals(IcpBuffers B) {
 // the pipeline (16 hypotheses x 16 slices = 256 workgroups = one per CU); the stream order of the
 // launches is the only synchronisation, converged hypotheses return at once.
 constexpr int kSearchWG = 256;      // workgroup of k_icp_search
+constexpr int kIcpFineFrom = 6;     // evaluations from this one on run on kIcpMaxSplit slices per hypothesis
 constexpr double kFarMargin = 1.5;  // search radius (x max_dist) of a source point that has no correspondence
 constexpr int kClasses = 8;         // search-cost classes of the queue (by overlapped grid columns)
 constexpr int kLoopQueue = 1024;    // source points per round whose correspondence needs a grid search
@@ -1210,7 +1211,7 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
 // the fitness history lives in the workgroup (fit_hist / rmse_hist -> LDS) instead of IcpState.  Returns true when the
 // hypothesis is finished (converged, or evaluation max_iter done).
 template <bool kPersist>
-static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, TgtRec* s_tgt,
+static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, const int Gprev, TgtRec* s_tgt,
                                                      unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist,
                                                      const int max_iter, const double rel_tol, double* fit_hist, double* rmse_hist) {
     __shared__ double s_part[kSearchWG / 64][32];
@@ -1237,7 +1238,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             for (int u = 0; u < 8; ++u) {
                 const int gg = grp + 8 * u;
                 a8[u] = 0.0;
-                if (gg < G) {
+                if (gg < Gprev) {
                     if (kPersist) a8[u] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (size_t)gg * 32 + k),
                                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     else a8[u] = part[(size_t)gg * 32 + k];
@@ -1593,7 +1594,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
 }
 
 __global__ void __launch_bounds__(kSearchWG, 3)
-k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) {
+k_icp_eval(IcpBuffers B, int it, int prev_slices, double max_dist, int max_iter, double rel_tol) {
     __shared__ TgtRec s_tgt[kSlabPts];
     __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
     __shared__ int s_q[kLoopQueue];
@@ -1601,7 +1602,7 @@ k_icp_eval(IcpBuffers B, int it, double max_dist, int max_iter, double rel_tol) 
     const int h = blockIdx.y;
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
-    (void)icp_eval_body<false>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
+    (void)icp_eval_body<false>(B, S, h, it, prev_slices, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
 }
 
 // The same evaluations as ONE launch: grid (slices, hypotheses) as above, every workgroup loops over the ICP rounds of its
@@ -1648,7 +1649,7 @@ k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
                 return;
             }
         }
-        if (icp_eval_body<true>(B, S, h, it, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
+        if (icp_eval_body<true>(B, S, h, it, (int)gridDim.x, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
     }
 }
 
@@ -1710,8 +1711,14 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
         return;
     }
     // evaluation `it` is finished (convergence test, solve, update) by the prologue of launch it + 1
-    for (int it = 0; it <= max_iter + 1; ++it)
-        hipLaunchKernelGGL(k_icp_eval, dim3(splits, count), dim3(kSearchWG), 0, s, B, it, max_dist, max_iter, rel_tol);
+    // the first evaluations have every hypothesis at work (768 workgroups = three per CU); by the sixth most have converged
+    // and the ones that go on for all 30 are cut finer (their latency is what is left): 64 slices each
+    int prev = splits;
+    for (int it = 0; it <= max_iter + 1; ++it) {
+        const int cur = it < kIcpFineFrom || getenv("LM_ICP_SPLITS") ? splits : kIcpMaxSplit;
+        hipLaunchKernelGGL(k_icp_eval, dim3(cur, count), dim3(kSearchWG), 0, s, B, it, prev, max_dist, max_iter, rel_tol);
+        prev = cur;
+    }
 }
 
 }  // namespace lm
