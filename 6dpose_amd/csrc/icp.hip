@@ -6,10 +6,10 @@
 // One stream of launches per batch of hypotheses, no host round trip in between:
 //   k_icp_bbox     bounding box of modelDepth > 0                                   (LL.cpp:43-50)
 //   k_icp_points   dilated mask, back-projection, raster-order compaction, centroids (LL.cpp:52-104)
-//   k_icp_voxel    VoxelDownSample: 64-bit (voxel, index) keys, bitonic sort in LDS, segment means
-//   k_icp_grid     bins the target cloud into <= 64 x 64 xy columns (cell >= 5 mm), sorted by cell
-//   k_icp_knn      one wave per target point: ring search over the columns, the k nearest in
-//                  (distance, index) order, cumulants accumulated in that order;
+//   k_icp_voxel    VoxelDownSample: stable radix sort of the point indices by voxel, segment means
+//   k_icp_grid     bins the target cloud into <= 64 x 64 xy columns (cell >= 5 mm), sorted by (column, depth step)
+//   k_icp_knn      eight lanes per target point: ring search over the columns, the k nearest selected by counting
+//                  passes (ties by index), cumulants; whole waves / k_icp_knn_far for the points whose ring grows
 //   k_icp_normals  covariance + Jacobi eigenvector, one thread per point
 //   k_icp_eval     once per ICP evaluation (<= 31 + 1): exact nearest neighbours through the
 //                  grid (search radius = distance to the previous correspondence), 29 double sums by a
