@@ -376,6 +376,16 @@ def main():
                                   "one_candidate_per_template": sparse_threshold_run(det, frames, classes, args.templates),
                                   "icp": icp_bench(local_rank),
                                   "pipeline": pipeline_bench(det, frames, banks[cls0], classes)})
+            pl = out["extras"]["pipeline"]
+            out["extras"]["roofline_icp"] = {
+                "bound": "latency of a chain of dependent launches (f64 VALU + LDS reads inside one): max_iteration + 2 = 32 "
+                         "k_icp_eval launches in stream order, each as long as its slowest slice",
+                "evaluation_launches": 32,
+                "us_per_launch_if_all_of_icp_ms_were_evaluations": pl["icp_ms"] * 1e3 / 32.0,
+                "measured_split": "profiles/r02_icp_experiments.txt + profiles/r02_kernel_stats_v4.txt: of 2.64 ms, 32 evaluations 1.75 ms (55 us each; "
+                                  "the slowest slice 35-40 us of searching), kNN 0.38, voxel + grid sorts 0.35, normals 0.06, points + bbox 0.07",
+                "f64_flops_note": "a point-to-plane evaluation is ~200 f64 operations per source point: 16 x 7k points = 22 MFLOP per launch, "
+                                  "0.4 TFLOP/s of the 78 TFLOP/s f64 vector peak - the chain is nowhere near an arithmetic bound"}
         traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
         if os.path.exists(traffic):
             try:
@@ -489,8 +499,8 @@ def pcie_inclusive(det, frames, classes, n_templates, steps=20):
 
 
 def icp_bench(device, hypotheses=16, reps=5):
-    """BASELINE configs[2]: poseRefine on the top-16 hypotheses of a frame, one ICP launch (one workgroup
-    per hypothesis, <=30 point-to-plane iterations each).  Reports ICP iterations/sec."""
+    """BASELINE configs[2]: poseRefine on the top-16 hypotheses of a frame (cloud preparation, kNN normals and <= 30
+    point-to-plane iterations each, one stream of launches for the batch).  Reports ICP iterations/sec."""
     import linemodLevelup_pybind as lm
     import synth
     K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
