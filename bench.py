@@ -273,7 +273,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    primed = {"live": False, "resident": False}
+
     def timed(nsteps, warmup, resident=False):
+        # one-time set-up, before the W warm-up steps: every slot of the result ring (lm_detector kSlots = 8) creates its pinned
+        # staging buffer and instantiates its hipGraph the first time a frame lands in it - with W < 8 that would happen inside
+        # the timed region (3 slots x ~0.5 ms at the driver's --steps 20 --warmup 5)
+        key = "resident" if resident else "live"
+        if not primed[key]:
+            run(8, resident)
+            primed[key] = True
         run(warmup, resident)
         fence()
         for q in host_t:
@@ -347,6 +356,9 @@ def main():
                        "ranks_observed": (dist.get_world_size() if use_dist else 1), "backend": (backend if use_dist else None),
                        "exchange": exchange_mode, "exchange_capacity": (ex.capacity if ex is not None else None),
                        "pipeline_depth": PIPELINE_DEPTH,
+                       "setup_before_warmup": "8 frames through the ingest ring (each of the library's 8 result slots allocates its pinned staging "
+                                              "buffer and instantiates its hipGraph on first use); the timed region starts and ends with an empty pipeline, "
+                                              "so at K = 20 it carries one frame latency (~0.45 ms) of fill and drain",
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
             "stages_ms": {k: mean[k] for k in ("h2d_ms", "frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
