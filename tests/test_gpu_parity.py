@@ -964,6 +964,42 @@ def test_icp_device_intermediates_match_oracle(lm):
         ctx.close()
 
 
+def test_icp_normals_of_a_cloud_with_depth_outliers(lm):
+    """The kNN normals of a target cloud that carries what a depth sensor leaves behind: flying pixels a few centimetres off
+    the surface (their ring has to grow: whole waves), single pixels and a blob of fewer than 30 points decimetres away (their
+    30 nearest neighbours are the far side of the cloud: k_icp_knn_far, the whole cloud per point).  Neighbour sets are exact,
+    so the normals agree with the oracle's brute force to 1e-9 (up to sign), and so does the registration."""
+    import linemodLevelup_pybind as mod
+    md = synth.synth_model_depth(33)
+    sd = _perturbed_scene(md, K_CAM.astype(np.float64), 1.5, (2.0, 1.0, -3.0), 33)
+    ys, xs = np.nonzero(md)
+    dx, dy = int(xs.min()), int(ys.min())
+    rng = np.random.default_rng(5)
+    sd = sd.copy()
+    inside = np.argwhere(sd > 0)
+    pick = inside[rng.choice(len(inside), 40, replace=False)]
+    for (y, x), off in zip(pick[:20], rng.integers(15, 60, 20)):          # flying pixels
+        sd[y, x] = sd[y, x] + off
+    for (y, x), off in zip(pick[20:28], (150, -120, 300, 420, -200, 250, 600, -90)):   # lone far pixels
+        sd[y, x] = max(1, int(sd[y, x]) + off)
+    y0, x0 = pick[30]
+    sd[y0:y0 + 3, x0:x0 + 4] = np.where(sd[y0:y0 + 3, x0:x0 + 4] > 0, sd[y0:y0 + 3, x0:x0 + 4] + 800, 0)   # a blob of <= 12 points 0.8 m behind
+    R, t = np.eye(3, dtype=np.float32), np.array([0, 0, 1000], np.float32)
+    ctx = mod.IcpContext(device=0, scene_from_scene=True)
+    ctx.set_scene(sd, K_CAM)
+    ctx.set_models([md])
+    res, ms = ctx.run(K_CAM.reshape(1, 9), R.reshape(1, 9), t.reshape(1, 3), [(dx, dy)])
+    ref = lo.pose_refine(sd, md, K_CAM, K_CAM, R, t, dx, dy, scene_from_scene=True)
+    tgt, nrm = ctx.read_debug(0, 1), ctx.read_debug(0, 2)
+    assert tgt.shape == ref["tgt"].shape and np.abs(tgt - ref["tgt"]).max() < 1e-12
+    assert (tgt[:, 2].max() - np.median(tgt[:, 2])) > 0.5                  # the far blob is in the cloud
+    cosang = np.abs((nrm * ref["normals"]).sum(1))
+    assert cosang.min() > 1 - 1e-9, (cosang.min(), int(np.argmin(cosang)))
+    assert res[0]["iterations"] == ref["iterations"] and abs(res[0]["residual"] - ref["residual"]) < 1e-6
+    assert np.abs(res[0]["R"] - ref["R"]).max() < 1e-4 and np.abs(res[0]["t"] - ref["t"]).max() / 1000.0 < 1e-4
+    ctx.close()
+
+
 @pytest.mark.parametrize("half_w,half_h", [(110, 100), (80, 75)])
 def test_icp_large_clouds_take_the_global_sort_path(lm, half_w, half_h):
     """> 16k points per cloud: the voxel / grid sorts keep their keys in HBM (radix sort, up to 32k points: the 159 x 149 =
