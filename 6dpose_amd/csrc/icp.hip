@@ -1465,14 +1465,29 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         // The queue is ordered by cost class; a class is walked with as many lanes per point as its searches have groups of
         // four columns (1 .. 16: a lane takes four columns per trip), so that the lanes of a wave finish together — a search of
         // 1.5 x max_dist for a point without correspondence overlaps dozens of columns and would otherwise hold 63 lanes up.
-        for (int cq = 0, qa = 0; cq < kClasses; ++cq) {
-        const int qb = s_cur[cq];                              // end of the class (its start + its count, after the scatter)
-        const int lpp_shift = cq < 6 ? cq : 6;
-        const int lpp = 1 << lpp_shift, sub = tid & (lpp - 1);
-        for (int q0 = qa; q0 < qb; q0 += kSearchWG >> lpp_shift) {
-            const int q = q0 + (tid >> lpp_shift);
-            const bool active = q < qb;
-            const int i = active ? s_q[q] : i_lo;
+        // All classes in one sweep of the workgroup's lanes: the points are laid out over the lanes widest class first (so that a
+        // point's 2^shift lanes are aligned and never straddle a wave), lane t finds its class in the table of lane offsets.
+        // Walking the classes one after the other cost a latency-bound pass per non-empty class (five or six per evaluation).
+        int lane_end[kClasses], q_start[kClasses], total_lanes = 0;
+#pragma unroll
+        for (int c = kClasses - 1; c >= 0; --c) {
+            const int cnt = s_cnt[c];
+            q_start[c] = s_cur[c] - cnt;                       // s_cur[c] = end of the class in the queue, after the scatter
+            total_lanes += cnt << (c < 6 ? c : 6);
+            lane_end[c] = total_lanes;
+        }
+        for (int t0 = 0; t0 < total_lanes; t0 += kSearchWG) {
+            const int t = t0 + tid;
+            const bool active = t < total_lanes;
+            int cq = 0, lane0 = lane_end[1], qs = q_start[0];
+#pragma unroll
+            for (int c = kClasses - 1; c >= 1; --c) {
+                const int first = c == kClasses - 1 ? 0 : lane_end[c + 1];
+                if (t >= first && t < lane_end[c]) { cq = c; lane0 = first; qs = q_start[c]; }
+            }
+            const int lpp_shift = cq < 6 ? cq : 6, lpp = 1 << lpp_shift;
+            const int sub = (t - lane0) & (lpp - 1);
+            const int i = active ? s_q[qs + ((t - lane0) >> lpp_shift)] : i_lo;
             const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
             const int pj = prev[i];
             // a point without correspondence searches 1.5 x max_dist once: the distance it finds (or the search
@@ -1529,18 +1544,17 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
                     }
                 }
             }
-            for (int off = 1; off < lpp; off <<= 1) {         // combine the lanes that shared the point
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {          // combine the lanes that shared the point (every lane makes every exchange)
                 const double od = shfl_xor_d(bd, off);
                 const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
-                if (op >= 0 && (od < bd || (od == bd && oo < bo))) { bd = od; bo = oo; bp = op; }
+                if (off < lpp && op >= 0 && (od < bd || (od == bd && oo < bo))) { bd = od; bo = oo; bp = op; }
             }
             if (active && sub == 0) {
                 if (bp >= 0 && !(bd < r2)) bp = -1;          // seen, but not a correspondence (d^2 < max_dist^2 required)
                 prev[i] = bp;
                 if (bp < 0) lb[i] = sqrt(bd);                 // every target closer than sqrt(bound2) was visited
             }
-        }
-        qa = qb;
         }
         __syncthreads();
         t_a2 += (long long)__builtin_amdgcn_s_memtime() - ta;
