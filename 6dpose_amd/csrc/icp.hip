@@ -1130,7 +1130,7 @@ k_icp_normals(IcpBuffers B) {
 // source points.  Splitting a hypothesis over G workgroups is what fills the chip at the batch sizes of
 // the pipeline (16 hypotheses x 16 slices = 256 workgroups = one per CU); the stream order of the
 // launches is the only synchronisation, converged hypotheses return at once.
-constexpr int kSearchWG = 256;      // workgroup of k_icp_search
+constexpr int kSearchWG = 256;      // workgroup of k_icp_eval
 constexpr int kIcpFineFrom = 6;     // evaluations from this one on run on kIcpMaxSplit slices per hypothesis
 constexpr double kFarMargin = 1.5;  // search radius (x max_dist) of a source point that has no correspondence
 constexpr int kClasses = 8;         // search-cost classes of the queue (by overlapped grid columns)
@@ -1203,8 +1203,8 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
 //       The other points are queued in LDS, ordered by the number of grid columns their search cube
 //       overlaps, so that the searches a wave runs in lock-step cost about the same;
 //   A2  queued points search the cells overlapping the cube of half-width sqrt(min(d_prev, r^2)):
-//       exact lexicographic minimum of (d, original index); 1, 2 or 4 lanes share a point's columns
-//       when the slice has fewer points than the workgroup has lanes;
+//       exact lexicographic minimum of (d, original index); a point of class c (<= 2^c columns) has 2^c lanes, one column
+//       each, and all classes are walked in one sweep of the workgroup's lanes;
 // and the slice's 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded) for the next prologue.
 // kPersist: called from the loop of k_icp_persist instead of once per launch — the slices' partial sums then travel through
 // agent-scope atomics (the workgroups of a hypothesis sit on different XCDs whose L2s are not coherent with each other) and
@@ -1462,10 +1462,9 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         }
         __syncthreads();
         const long long ta = (long long)__builtin_amdgcn_s_memtime();
-        // The queue is ordered by cost class; a class is walked with as many lanes per point as its searches have groups of
-        // four columns (1 .. 16: a lane takes four columns per trip), so that the lanes of a wave finish together — a search of
-        // 1.5 x max_dist for a point without correspondence overlaps dozens of columns and would otherwise hold 63 lanes up.
-        // All classes in one sweep of the workgroup's lanes: the points are laid out over the lanes widest class first (so that a
+        // The queue is ordered by cost class; a point of class c gets 2^c lanes, one grid column each, so that the lanes of a
+        // wave finish together — a search of 1.5 x max_dist for a point without correspondence overlaps dozens of columns and
+        // would otherwise hold 63 lanes up.  All classes in one sweep of the workgroup's lanes: the points are laid out over the lanes widest class first (so that a
         // point's 2^shift lanes are aligned and never straddle a wave), lane t finds its class in the table of lane offsets.
         // Walking the classes one after the other cost a latency-bound pass per non-empty class (five or six per evaluation).
         int lane_end[kClasses], q_start[kClasses], total_lanes = 0;
