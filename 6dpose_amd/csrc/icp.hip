@@ -1211,7 +1211,7 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
 // the fitness history lives in the workgroup (fit_hist / rmse_hist -> LDS) instead of IcpState.  Returns true when the
 // hypothesis is finished (converged, or evaluation max_iter done).
 template <bool kPersist>
-static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, const int Gprev, TgtRec* s_tgt,
+static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, const int Gprev, const int max_shift, TgtRec* s_tgt,
                                                      unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist,
                                                      const int max_iter, const double rel_tol, double* fit_hist, double* rmse_hist) {
     __shared__ double s_part[kSearchWG / 64][32];
@@ -1472,7 +1472,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         for (int c = kClasses - 1; c >= 0; --c) {
             const int cnt = s_cnt[c];
             q_start[c] = s_cur[c] - cnt;                       // s_cur[c] = end of the class in the queue, after the scatter
-            total_lanes += cnt << (c < 6 ? c : 6);
+            total_lanes += cnt << (c < max_shift ? c : max_shift);
             lane_end[c] = total_lanes;
         }
         for (int t0 = 0; t0 < total_lanes; t0 += kSearchWG) {
@@ -1484,7 +1484,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
                 const int first = c == kClasses - 1 ? 0 : lane_end[c + 1];
                 if (t >= first && t < lane_end[c]) { cq = c; lane0 = first; qs = q_start[c]; }
             }
-            const int lpp_shift = cq < 6 ? cq : 6, lpp = 1 << lpp_shift;
+            const int lpp_shift = cq < max_shift ? cq : max_shift, lpp = 1 << lpp_shift;
             const int sub = (t - lane0) & (lpp - 1);
             const int i = active ? s_q[qs + ((t - lane0) >> lpp_shift)] : i_lo;
             const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
@@ -1607,7 +1607,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
 }
 
 __global__ void __launch_bounds__(kSearchWG, 3)
-k_icp_eval(IcpBuffers B, int it, int prev_slices, double max_dist, int max_iter, double rel_tol) {
+k_icp_eval(IcpBuffers B, int it, int prev_slices, int max_shift, double max_dist, int max_iter, double rel_tol) {
     __shared__ TgtRec s_tgt[kSlabPts];
     __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
     __shared__ int s_q[kLoopQueue];
@@ -1615,7 +1615,7 @@ k_icp_eval(IcpBuffers B, int it, int prev_slices, double max_dist, int max_iter,
     const int h = blockIdx.y;
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
-    (void)icp_eval_body<false>(B, S, h, it, prev_slices, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
+    (void)icp_eval_body<false>(B, S, h, it, prev_slices, max_shift, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
 }
 
 // The same evaluations as ONE launch: grid (slices, hypotheses) as above, every workgroup loops over the ICP rounds of its
@@ -1662,7 +1662,7 @@ k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
                 return;
             }
         }
-        if (icp_eval_body<true>(B, S, h, it, (int)gridDim.x, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
+        if (icp_eval_body<true>(B, S, h, it, (int)gridDim.x, 6, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
     }
 }
 
@@ -1729,7 +1729,11 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     int prev = splits;
     for (int it = 0; it <= max_iter + 1; ++it) {
         const int cur = it < kIcpFineFrom || getenv("LM_ICP_SPLITS") ? splits : kIcpMaxSplit;
-        hipLaunchKernelGGL(k_icp_eval, dim3(cur, count), dim3(kSearchWG), 0, s, B, it, prev, max_dist, max_iter, rel_tol);
+        // lanes per searching point: at most 8 while every point searches (the first evaluations: more lanes only multiply the
+        // set-up), 16 afterwards (few searches left: their latency is what counts) — measured, profiles/r02_icp_experiments.txt
+        static const int early = getenv("LM_ICP_MAXSHIFT") ? atoi(getenv("LM_ICP_MAXSHIFT")) : 3;
+        static const int late = getenv("LM_ICP_MAXSHIFT_LATE") ? atoi(getenv("LM_ICP_MAXSHIFT_LATE")) : 4;
+        hipLaunchKernelGGL(k_icp_eval, dim3(cur, count), dim3(kSearchWG), 0, s, B, it, prev, it < kIcpFineFrom ? early : late, max_dist, max_iter, rel_tol);
         prev = cur;
     }
 }
