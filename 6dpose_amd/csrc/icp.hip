@@ -999,7 +999,10 @@ k_icp_knn(IcpBuffers B, int knn) {
     const int k = knn < nt ? knn : nt;
     int R0 = (int)ceil(0.009 / cell);
     if (R0 < 1) R0 = 1;
-    const int q0 = (int)((long long)nt * blockIdx.x / gridDim.x), q1 = (int)((long long)nt * (blockIdx.x + 1) / gridDim.x);
+    // workgroups at work on this cloud: ~96 points each (a small cloud on all of the grid's workgroups would stage itself 64 times)
+    const int want = (nt + 95) / 96, nb = want < 16 ? 16 : want > (int)gridDim.x ? (int)gridDim.x : want;
+    if ((int)blockIdx.x >= nb) return;
+    const int q0 = (int)((long long)nt * blockIdx.x / nb), q1 = (int)((long long)nt * (blockIdx.x + 1) / nb);
     if (q0 >= q1) return;
     // the slab: the columns the rings R0 + 1 of this workgroup's points reach (R0 if that is too much for the LDS)
     int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
@@ -1711,7 +1714,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
-    hipLaunchKernelGGL(k_icp_knn, dim3(count <= 32 ? 64 : 32, count), dim3(kKnnWG), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn, dim3(getenv("LM_KNN_BLOCKS") ? atoi(getenv("LM_KNN_BLOCKS")) : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
