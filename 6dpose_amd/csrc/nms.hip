@@ -48,38 +48,74 @@ static __device__ __forceinline__ bool visit_before(const NmsKey& a, const NmsKe
     if (a.sim != b.sim) return a.sim > b.sim;
     return canon_before(b, a);
 }
-static __device__ __forceinline__ NmsKey shfl_key(const NmsKey& k, int off) {
-    NmsKey o;
-    o.sim = (uint32_t)__shfl_xor((int)k.sim, off, 64); o.tid = __shfl_xor(k.tid, off, 64); o.cls = __shfl_xor(k.cls, off, 64);
-    o.y = __shfl_xor(k.y, off, 64); o.x = __shfl_xor(k.x, off, 64); o.slot = __shfl_xor(k.slot, off, 64);
+// The two orders as 128-bit unsigned integers (compared hi word first, larger = preferred), so that a selection exchanges four
+// dwords per step instead of six fields and a chain of comparisons:
+//   visit order  (higher similarity, then the LATER canonical entry): (sim, tid, cls | y, x, slot), all ascending = preferred
+//   canonical    (similarity desc, template_id, class, y, x, slot asc): the same with the similarity inverted; the LATEST
+//                entry before R is the largest such key below R's.
+struct Key128 { unsigned long long hi, lo; };
+static __device__ __forceinline__ Key128 pack_key(const NmsKey& k, bool canonical) {
+    Key128 p;
+    const uint32_t sim = canonical ? ~k.sim : k.sim;
+    p.hi = ((unsigned long long)sim << 32) | ((unsigned long long)(uint32_t)k.tid << 8) | (unsigned long long)(uint32_t)k.cls;
+    p.lo = ((unsigned long long)(uint32_t)(k.y + 32768) << 48) | ((unsigned long long)(uint32_t)(k.x + 32768) << 32) | (unsigned long long)(uint32_t)k.slot;
+    return p;
+}
+static __device__ __forceinline__ bool key_less(const Key128& a, const Key128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+static __device__ __forceinline__ NmsKey unpack_key(const Key128& p, bool canonical) {
+    NmsKey k;
+    const uint32_t sim = (uint32_t)(p.hi >> 32);
+    k.sim = canonical ? ~sim : sim;
+    k.tid = (int32_t)((p.hi >> 8) & 0xFFFFFF); k.cls = (int32_t)(p.hi & 0xFF);
+    k.y = (int32_t)((p.lo >> 48) & 0xFFFF) - 32768; k.x = (int32_t)((p.lo >> 32) & 0xFFFF) - 32768; k.slot = (int32_t)(uint32_t)p.lo;
+    return k;
+}
+static __device__ __forceinline__ Key128 shfl_key128(const Key128& k, int off) {
+    Key128 o;
+    o.hi = ((unsigned long long)(uint32_t)__shfl_xor((int)(k.hi >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k.hi, off, 64);
+    o.lo = ((unsigned long long)(uint32_t)__shfl_xor((int)(k.lo >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k.lo, off, 64);
     return o;
 }
 
-// Workgroup-wide selection of the key that `better` prefers; slot < 0 = none.  Result broadcast to every thread.
-template <typename Better>
-static __device__ __forceinline__ NmsKey block_select(NmsKey k, NmsKey* s_keys, Better better) {
+// Workgroup-wide maximum of the packed keys (`valid` = this thread has one); slot < 0 in the result = none.  Wave reduction,
+// the 16 wave results reduced again by the first wave, result broadcast through LDS.
+static __device__ __forceinline__ NmsKey block_select_max(const NmsKey& mine, const bool canonical, Key128* s_keys /*[kNmsWG / 64 + 1]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Key128 k = pack_key(mine, canonical);
+    bool have = mine.slot >= 0;
+    if (!have) { k.hi = 0; k.lo = 0; }
+    // a valid key is never all-zero in lo (slot >= 0 but y + 32768 >= 0 ... ) — validity travels as an extra flag in bit 31 of lo's slot field
+    k.lo = have ? (k.lo | 0x80000000ull) : 0ull;                     // slots are < 2^31: the flag makes every valid key larger than "none"
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const NmsKey o = shfl_key(k, off);
-        if (o.slot >= 0 && (k.slot < 0 || better(o, k))) k = o;
+        const Key128 o = shfl_key128(k, off);
+        if (key_less(k, o)) k = o;
     }
     __syncthreads();
     if (lane == 0) s_keys[wave] = k;
     __syncthreads();
-    NmsKey best = s_keys[0];
-    for (int w = 1; w < kNmsWG / 64; ++w) {
-        const NmsKey o = s_keys[w];
-        if (o.slot >= 0 && (best.slot < 0 || better(o, best))) best = o;
+    if (wave == 0) {
+        Key128 w = lane < kNmsWG / 64 ? s_keys[lane] : Key128{0, 0};
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const Key128 o = shfl_key128(w, off);
+            if (key_less(w, o)) w = o;
+        }
+        if (lane == 0) s_keys[kNmsWG / 64] = w;
     }
-    return best;
+    __syncthreads();
+    Key128 best = s_keys[kNmsWG / 64];
+    NmsKey r;
+    if (!(best.lo & 0x80000000ull)) { r.slot = -1; r.sim = 0; r.tid = r.cls = r.x = r.y = 0; return r; }
+    best.lo &= ~0x80000000ull;
+    return unpack_key(best, canonical);
 }
 
 constexpr int kNmsLds = 8192;      // distinct records held in LDS (128 KiB); more than that stay in the HBM scratch
 
 // Greedy loop over m distinct records (rec in LDS or HBM).
 template <typename RecPtr>
-static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const int top_k, const double thresh, NmsKey* s_keys,
+static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const int top_k, const double thresh, Key128* s_keys,
                                                  TopkSel* __restrict__ sel) {
     const int tid = threadIdx.x;
     int kept = 0;
@@ -92,7 +128,7 @@ static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const 
             const NmsKey k = key_of(r, i);
             if (mine.slot < 0 || visit_before(k, mine)) mine = k;
         }
-        const NmsKey R = block_select(mine, s_keys, [](const NmsKey& a, const NmsKey& b) { return visit_before(a, b); });
+        const NmsKey R = block_select_max(mine, false, s_keys);
         if (R.slot < 0) break;
         // (2) std::unique: R disappears iff its canonical predecessor (over ALL entries of the frame) equals it in (x, y, similarity, class)
         NmsKey pm; pm.slot = -1; pm.sim = 0; pm.tid = pm.cls = pm.x = pm.y = 0;
@@ -100,7 +136,7 @@ static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const 
             const NmsKey k = key_of(rec[i], i);
             if (canon_before(k, R) && (pm.slot < 0 || canon_before(pm, k))) pm = k;
         }
-        const NmsKey P = block_select(pm, s_keys, [](const NmsKey& a, const NmsKey& b) { return canon_before(b, a); });
+        const NmsKey P = block_select_max(pm, true, s_keys);
         const bool dup = P.slot >= 0 && P.sim == R.sim && P.cls == R.cls && P.x == R.x && P.y == R.y;
         const int4 rr = rec[R.slot];
         __syncthreads();
@@ -148,7 +184,7 @@ k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __re
            int num_views, int top_k, double thresh, int4* __restrict__ rec,
            unsigned long long* __restrict__ table, uint32_t table_mask, TopkSel* __restrict__ sel, int32_t* __restrict__ nsel_status) {
     __shared__ int4 s_rec[kNmsLds];
-    __shared__ NmsKey s_keys[kNmsWG / 64];
+    __shared__ Key128 s_keys[kNmsWG / 64 + 1];
     __shared__ int s_bad, s_m;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long nc = counters[0];
