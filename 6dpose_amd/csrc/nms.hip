@@ -174,25 +174,24 @@ static __device__ __forceinline__ int nms_rounds(RecPtr rec, const int m, const 
     return kept;
 }
 
-// Pack + exact-duplicate removal + greedy loop.  Several coarse candidates of one template often refine to the
-// same position: those records are identical in every output field, std::unique removes all but one, so they are
-// dropped up front with an open-addressing hash on (x, y, template, class) (`table`: 64-bit slots preset to ~0).
-__global__ void __launch_bounds__(kNmsWG)
-k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __restrict__ counters, uint32_t cap,
+// Pack + exact-duplicate removal (k_nms_pack, the whole chip), then the greedy loop (k_topk_nms, one workgroup).  Several coarse
+// candidates of one template often refine to the same position: those records are identical in every output field, std::unique
+// removes all but one, so they are dropped up front with an open-addressing hash on (x, y, template, class) (`table`: 64-bit
+// slots preset to ~0).  A record is a chain of five dependent HBM reads and an HBM atomic: one workgroup walking 10k of them
+// 1024 at a time took ~55 us; spread over the chip the chain is paid once.  The distinct records land in `rec` in whatever order
+// the atomics resolve — the order does not matter: no two of them are equal in (x, y, template, class), so no comparison of
+// the greedy loop ever gets as far as the slot.  ctr[0] = number of records - 1, ctr[1] = "bad field" marker (both preset to ~0).
+__global__ void __launch_bounds__(256)
+k_nms_pack(const Candidate* __restrict__ matches, const unsigned long long* __restrict__ counters, uint32_t cap,
            const int32_t* __restrict__ work_pyramids, const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid,
            const TemplEntry* __restrict__ entries, int levels, const int32_t* __restrict__ class_base, const int32_t* __restrict__ view_wh,
-           int num_views, int top_k, double thresh, int4* __restrict__ rec,
-           unsigned long long* __restrict__ table, uint32_t table_mask, TopkSel* __restrict__ sel, int32_t* __restrict__ nsel_status) {
-    __shared__ int4 s_rec[kNmsLds];
-    __shared__ Key128 s_keys[kNmsWG / 64 + 1];
-    __shared__ int s_bad, s_m;
-    const int tid = threadIdx.x, lane = tid & 63;
+           int num_views, int4* __restrict__ rec, unsigned long long* __restrict__ table, uint32_t table_mask, uint32_t* __restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
     const unsigned long long nc = counters[0];
     const int n = (int)(nc < cap ? nc : cap);
-    if (tid == 0) { s_bad = 0; s_m = 0; }
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += kNmsWG) {
-        const int i = i0 + tid;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int i = i0 + threadIdx.x;
         bool keep = false;
         int4 r = make_int4(0, 0, 0, 0);
         if (i < n) {
@@ -208,7 +207,7 @@ k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __re
                 }
                 if (t < 0 || t >= (1 << 24) || cl < 0 || cl >= 128 || c.x < -32768 || c.x > 32767 || c.y < -32768 || c.y > 32767 ||
                     bw < 0 || bw > 65535 || bh < 0 || bh > 65535 || c.score < 0.f || !(c.score == c.score)) {
-                    s_bad = 1;
+                    ctr[1] = 0;
                 } else {
                     r.x = (c.x & 0xFFFF) | (c.y << 16);
                     r.y = (bw & 0xFFFF) | (bh << 16);
@@ -226,24 +225,30 @@ k_topk_nms(const Candidate* __restrict__ matches, const unsigned long long* __re
                 }
             }
         }
-        const unsigned long long mask = __ballot(keep);                            // one LDS atomic per wave reserves the slots
+        const unsigned long long mask = __ballot(keep);                            // one HBM atomic per wave reserves the slots
         if (mask) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_m, __popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (keep) {
-                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < kNmsLds) s_rec[pos] = r;
-                rec[pos] = r;
-            }
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctr[0], (uint32_t)__popcll(mask)) + 1u;   // the counter starts at ~0
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (keep) rec[base + __popcll(mask & ((1ull << lane) - 1ull))] = r;
         }
     }
-    __syncthreads();
-    if (s_bad) {
+}
+
+__global__ void __launch_bounds__(kNmsWG)
+k_topk_nms(int top_k, double thresh, int4* __restrict__ rec, const uint32_t* __restrict__ ctr, TopkSel* __restrict__ sel,
+           int32_t* __restrict__ nsel_status) {
+    __shared__ int4 s_rec[kNmsLds];
+    __shared__ Key128 s_keys[kNmsWG / 64 + 1];
+    const int tid = threadIdx.x;
+    if (ctr[1] == 0) {                                                             // a field does not fit the packed record
         if (tid == 0) { nsel_status[0] = 0; nsel_status[1] = 1; }
         return;
     }
-    const int m = s_m;
+    const int m = (int)(ctr[0] + 1u);
+    if (m <= kNmsLds)
+        for (int i = tid; i < m; i += kNmsWG) s_rec[i] = rec[i];
+    __syncthreads();
     const int kept = m <= kNmsLds ? nms_rounds(s_rec, m, top_k, thresh, s_keys, sel) : nms_rounds(rec, m, top_k, thresh, s_keys, sel);
     if (tid == 0) { nsel_status[0] = kept; nsel_status[1] = 0; }
 }
@@ -252,13 +257,16 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
                      const int32_t* work_cls, const int32_t* work_tid, const TemplEntry* entries, int levels,
                      const int32_t* class_base, const int32_t* view_wh, int num_views, int top_k,
                      double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s) {
-    // scratch: cap int4 records, then the hash table (power of two >= 2 * cap 64-bit slots)
+    // scratch: cap int4 records, then the hash table (power of two >= 2 * cap 64-bit slots), then the two counters — one
+    // memset presets table and counters to ~0
     size_t tsz = 1;
     while (tsz < 2 * (size_t)cap) tsz <<= 1;
     unsigned long long* table = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + (size_t)cap * 16);
-    (void)hipMemsetAsync(table, 0xFF, tsz * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_topk_nms, dim3(1), dim3(kNmsWG), 0, s, matches_dev, counters, cap, work_pyramids, work_cls, work_tid, entries,
-                       levels, class_base, view_wh, num_views, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), sel, nsel_status);
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(table + tsz);
+    (void)hipMemsetAsync(table, 0xFF, tsz * sizeof(unsigned long long) + 16, s);
+    hipLaunchKernelGGL(k_nms_pack, dim3(64), dim3(256), 0, s, matches_dev, counters, cap, work_pyramids, work_cls, work_tid, entries, levels, class_base,
+                       view_wh, num_views, reinterpret_cast<int4*>(scratch), table, (uint32_t)(tsz - 1), ctr);
+    hipLaunchKernelGGL(k_topk_nms, dim3(1), dim3(kNmsWG), 0, s, top_k, iou_thresh, reinterpret_cast<int4*>(scratch), ctr, sel, nsel_status);
 }
 
 // Records identical in every field — several coarse candidates of one template refined to the same position — are
@@ -351,7 +359,7 @@ size_t dedupe_table_slots(uint32_t cap) {
 size_t topk_nms_scratch_bytes(uint32_t cap) {
     size_t tsz = 1;
     while (tsz < 2 * (size_t)cap) tsz <<= 1;
-    return (size_t)cap * 16 + tsz * sizeof(unsigned long long);
+    return (size_t)cap * 16 + tsz * sizeof(unsigned long long) + 16;
 }
 
 }  // namespace lm
