@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc_icp}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/profiles/icp_only.py 16"
+CMD=${LM_PMC_CMD:-"python $ROOT/profiles/pipeline_only.py 3"}
 i=0
 for grp in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
