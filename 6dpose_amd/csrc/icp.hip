@@ -766,11 +766,13 @@ template <int L, bool kFromLds, typename F>
 static __device__ __forceinline__ void knn_scan_run(const int a, const int b, const int sub, const TgtRec* s_rel /*s_tgt - p0*/,
                                                     const TgtRec* __restrict__ g_rec, const double px, const double py, const double pz, F&& f) {
     constexpr int U = kFromLds ? 4 : 8;                            // candidates per lane and trip (HBM: more bytes in flight)
-    for (int j0 = a + U * sub; j0 < b; j0 += U * L) {
+    // candidate v of a trip: j0 + v * L + sub — the lanes of a point read consecutive records (LDS: all banks once per group of
+    // eight; HBM: coalesced), U per lane
+    for (int j0 = a + sub; j0 < b; j0 += U * L) {
         double d4[U], q4[U][3];
 #pragma unroll
         for (int v = 0; v < U; ++v) {
-            const int j = j0 + v < b ? j0 + v : b - 1;
+            const int j = j0 + v * L < b ? j0 + v * L : b - 1;
             if (kFromLds) { const TgtRec& r = s_rel[j]; q4[v][0] = r.x; q4[v][1] = r.y; q4[v][2] = r.z; }
             else { const double2 xy = *reinterpret_cast<const double2*>(&g_rec[j].x); q4[v][0] = xy.x; q4[v][1] = xy.y; q4[v][2] = g_rec[j].z; }
         }
@@ -778,7 +780,7 @@ static __device__ __forceinline__ void knn_scan_run(const int a, const int b, co
         for (int v = 0; v < U; ++v) d4[v] = sqdist(px, py, pz, q4[v][0], q4[v][1], q4[v][2]);
 #pragma unroll
         for (int v = 0; v < U; ++v)
-            if (j0 + v < b) f(j0 + v, d4[v], q4[v][0], q4[v][1], q4[v][2]);
+            if (j0 + v * L < b) f(j0 + v * L, d4[v], q4[v][0], q4[v][1], q4[v][2]);
     }
 }
 // (two loops, not one loop with a choice of pointer inside: a pointer that may be LDS or HBM makes every load a FLAT load,
