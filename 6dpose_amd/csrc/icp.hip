@@ -1137,7 +1137,7 @@ k_icp_normals(IcpBuffers B) {
 // launches is the only synchronisation, converged hypotheses return at once.
 constexpr int kSearchWG = 256;      // workgroup of k_icp_eval
 constexpr int kIcpFineFrom = 6;     // evaluations from this one on run on kIcpMaxSplit slices per hypothesis
-constexpr double kFarMargin = 1.5;  // search radius (x max_dist) of a source point that has no correspondence
+constexpr double kFarMargin = 1.2;  // search radius (x max_dist) of a source point that has no correspondence (1.5: 49 columns per search instead of 36; profiles/r02_icp_experiments.txt)
 constexpr int kClasses = 8;         // search-cost classes of the queue (by overlapped grid columns)
 constexpr int kLoopQueue = 1024;    // source points per round whose correspondence needs a grid search
 constexpr int kSlabPts = 1024;      // target points of a slice's x slab staged in LDS (32-byte records)
@@ -1355,7 +1355,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             const int pj = prev[i];
             // how far this point's search will reach (the same tests as the queue below): nothing when its previous
             // correspondence is certified or it is provably out of range, the distance to the previous correspondence, or
-            // 1.5 max_dist for a point without one
+            // kFarMargin x max_dist for a point without one
             double reach = 0.0;
             if (pj < 0) {
                 const double nlb = lb[i] - (sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12);
@@ -1371,7 +1371,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     }
     // the x slab of the grid this slice's searches can reach: a contiguous range of cells [c0, c1] and of sorted target
     // points [p0, p1), staged in LDS when it fits (sized by the actual search radii: once most points keep their
-    // correspondence the slab is a few columns, not the 1.5 max_dist margin on either side)
+    // correspondence the slab is a few columns, not the kFarMargin x max_dist margin on either side)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { xmn = fmin(xmn, shfl_xor_d(xmn, o)); xmx = fmax(xmx, shfl_xor_d(xmx, o)); }
     if (lane == 0) { s_xmm[wave][0] = xmn; s_xmm[wave][1] = xmx; }
@@ -1468,7 +1468,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         __syncthreads();
         const long long ta = (long long)__builtin_amdgcn_s_memtime();
         // The queue is ordered by cost class; a point of class c gets 2^c lanes, one grid column each, so that the lanes of a
-        // wave finish together — a search of 1.5 x max_dist for a point without correspondence overlaps dozens of columns and
+        // wave finish together — a search of kFarMargin x max_dist for a point without correspondence overlaps dozens of columns and
         // would otherwise hold 63 lanes up.  All classes in one sweep of the workgroup's lanes: the points are laid out over the lanes widest class first (so that a
         // point's 2^shift lanes are aligned and never straddle a wave), lane t finds its class in the table of lane offsets.
         // Walking the classes one after the other cost a latency-bound pass per non-empty class (five or six per evaluation).
@@ -1494,7 +1494,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             const int i = active ? s_q[qs + ((t - lane0) >> lpp_shift)] : i_lo;
             const double px = P[3 * (size_t)i], py = P[3 * (size_t)i + 1], pz = P[3 * (size_t)i + 2];
             const int pj = prev[i];
-            // a point without correspondence searches 1.5 x max_dist once: the distance it finds (or the search
+            // a point without correspondence searches kFarMargin x max_dist once: the distance it finds (or the search
             // radius) minus its later motion is the lower bound that keeps it out of the queue (A1)
             const double bound2 = pj >= 0 ? r2 : far2;
             double bd = bound2;
