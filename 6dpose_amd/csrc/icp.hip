@@ -594,7 +594,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
 
 // ---------------------------------------------------------------------------------------------
 // k_icp_grid: the target cloud binned into xy columns (cell edge >= 5 mm, <= 64 x 64 columns) and, inside
-// a column, ordered by quantised depth (>= 0.1 mm steps): points sorted by (x column, y column, z step,
+// a column, ordered by quantised depth (>= 1 mm steps): points sorted by (x column, y column, z step,
 // original index).  A search visits one run per column and finds the depth range it needs by bisection,
 // so the table stays a few thousand entries however deep the cloud is (a scene cloud carries background
 // far behind the object); an x slab of columns is one contiguous range of cells and of points (what a
@@ -647,7 +647,7 @@ k_icp_grid(IcpBuffers B, int flags) {
     double cell = ext / (double)kIcpGrid;
     if (!(cell > kCellMin)) cell = kCellMin;                       // also catches NaN
     double zres = extz / (double)((1 << kZBits) - 1);
-    if (!(zres > 1e-4)) zres = 1e-4;
+    if (!(zres > 1e-3)) zres = 1e-3;                               // 1 mm steps: a metre of depth is 10 bits, so the sort key (column, step) is 3 radix passes, not 4
     const double inv = 1.0 / cell, inv_z = 1.0 / zres;
     if (!(ext < 1e30) || !(extz < 1e30)) {                         // non-finite coordinates
         if (tid == 0) { S.status = 3; S.n_tgt = 0; S.gx = 1; S.gy = 1; S.zq_max = 0; cs[0] = 0; cs[1] = 0; }
