@@ -1143,33 +1143,45 @@ constexpr int kLoopQueue = 1024;    // source points per round whose corresponde
 constexpr int kSlabPts = 1024;      // target points of a slice's x slab staged in LDS (32-byte records)
 constexpr int kSlabCells = 4096;    // cells of that slab (16-bit starts)
 
-// Gaussian elimination with partial pivoting, A x = b (6x6), on LDS arrays (one thread; keeps the
-// dynamically indexed rows out of scratch).  Returns false if singular / non-finite.
-static __device__ __forceinline__ bool solve6(double (*A)[6], double* b, double* x) {
+// Gaussian elimination with partial pivoting, [A | b] (6 x 7), in registers: every loop is unrolled, a row exchange is a chain of
+// conditional swaps (no dynamic indexing, so nothing goes to scratch), one reciprocal per pivot.  Returns false if singular /
+// non-finite.  (On LDS arrays — the first version — the ~250 dependent LDS accesses of the elimination were most of the
+// evaluation's 6 us prologue, which every slice of every hypothesis pays before it can transform a point.)
+static __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6]) {
+    double inv[6];
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
         int piv = c;
-        double best = fabs(A[c][c]);
+        double best = fabs(M[c][c]);
+#pragma unroll
         for (int r = c + 1; r < 6; ++r)
-            if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+            if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); piv = r; }
         if (!(best > 0.0)) return false;
-        if (piv != c) {
-            for (int k = 0; k < 6; ++k) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-            double t = b[c]; b[c] = b[piv]; b[piv] = t;
-        }
+#pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-            double f = A[r][c] / A[c][c];
-            for (int k = c; k < 6; ++k) A[r][k] -= f * A[c][k];
-            b[r] -= f * b[c];
+            const bool sw = piv == r;
+#pragma unroll
+            for (int q = c; q < 7; ++q) { const double a = M[c][q], b = M[r][q]; M[c][q] = sw ? b : a; M[r][q] = sw ? a : b; }
+        }
+        inv[c] = 1.0 / M[c][c];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = M[r][c] * inv[c];
+#pragma unroll
+            for (int q = c + 1; q < 7; ++q) M[r][q] -= f * M[c][q];
         }
     }
+#pragma unroll
     for (int r = 5; r >= 0; --r) {
-        double s = b[r];
-        for (int k = r + 1; k < 6; ++k) s -= A[r][k] * x[k];
-        x[r] = s / A[r][r];
+        double s = M[r][6];
+#pragma unroll
+        for (int q = r + 1; q < 6; ++q) s -= M[r][q] * x[q];
+        x[r] = s * inv[r];
     }
-    for (int r = 0; r < 6; ++r)
-        if (!isfinite(x[r])) return false;
-    return true;
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ok = ok && isfinite(x[r]);
+    return ok;
 }
 
 // Sum of 32 per-lane values over the wave with 32 shuffles instead of 6 x 32: every step halves the
@@ -1222,7 +1234,6 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     __shared__ double s_part[kSearchWG / 64][32];
     __shared__ double s_sum[32];
     __shared__ double s_U[12];
-    __shared__ double s_A[6][6], s_b[6], s_x[6];
     __shared__ int s_stop;
     __shared__ int s_cnt[kClasses], s_cur[kClasses];
     __shared__ double s_xmm[kSearchWG / 64][2];
@@ -1276,14 +1287,21 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             }
             s_stop = stop ? 1 : 0;
             if (!stop) {
-                double (*A)[6] = s_A;
-                double *b = s_b, *x = s_x;
-                int k = 0;
-                for (int a = 0; a < 6; ++a)
-                    for (int c = a; c < 6; ++c) { A[a][c] = s_sum[k]; A[c][a] = s_sum[k]; ++k; }
-                for (int a = 0; a < 6; ++a) b[a] = -s_sum[21 + a];
+                double M[6][7], x[6];
+                {
+                    double up[21];
+#pragma unroll
+                    for (int q = 0; q < 21; ++q) up[q] = s_sum[q];
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int c = a; c < 6; ++c) { M[a][c] = up[k]; M[c][a] = up[k]; ++k; }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) M[a][6] = -s_sum[21 + a];
+                }
                 double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-                if (ncorr >= 6 && solve6(A, b, x)) {
+                if (ncorr >= 6 && solve6(M, x)) {
                     double sx, cx, sy, cy, sz, cz;
                     sincos(x[0], &sx, &cx); sincos(x[1], &sy, &cy); sincos(x[2], &sz, &cz);
                     // Rz(x2) * Ry(x1) * Rx(x0)
