@@ -1244,6 +1244,34 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     const int ns = S.n_src, nt = S.n_tgt;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
 
+    const double* Src = B.src + (size_t)h * B.cap * 3;
+    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
+    const double* N = B.normals + (size_t)h * B.cap * 3;
+    const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    const int* orig = B.tgt_orig + (size_t)h * B.cap;
+    const int* cs = B.cell_start + (size_t)h * kIcpCells;
+    double* P = B.work + (size_t)h * B.cap * 3;
+    int* prev = B.prev_nn + (size_t)h * B.cap;
+    double* lb = B.nn_lb + (size_t)h * B.cap;
+    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max;
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
+    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
+    const double r2 = max_dist * max_dist;
+    const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
+    const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
+
+    // this thread's (first) point and what the transform needs of its correspondence, requested before the prologue waits for
+    // the slices' partial sums and the solve: the loads ride out that wait instead of starting after it
+    const int i_pf = i_lo + tid;
+    const bool pf = it > 0 && i_pf < i_hi;
+    double pfx = 0, pfy = 0, pfz = 0, pflb = 0, pftx = 0, pfty = 0, pftz = 0, pfsep = 0;
+    int pfj = -1;
+    if (pf) {
+        pfx = P[3 * (size_t)i_pf]; pfy = P[3 * (size_t)i_pf + 1]; pfz = P[3 * (size_t)i_pf + 2];
+        pfj = prev[i_pf]; pflb = lb[i_pf];
+        if (pfj >= 0) { pftx = T[3 * (size_t)pfj]; pfty = T[3 * (size_t)pfj + 1]; pftz = T[3 * (size_t)pfj + 2]; pfsep = cov[(size_t)pfj * kIcpCovStride + 10]; }
+    }
+
     // ---- prologue: finish evaluation it - 1 ----
     if (it > 0) {
         const double* part = B.partial + (((size_t)((it - 1) & 1) * B.count + h) * kIcpMaxSplit) * 32;
@@ -1330,22 +1358,6 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
     if (it > max_iter) return true;                         // the last round only finishes evaluation max_iter
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
 
-    const double* Src = B.src + (size_t)h * B.cap * 3;
-    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
-    const double* N = B.normals + (size_t)h * B.cap * 3;
-    const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-    const int* orig = B.tgt_orig + (size_t)h * B.cap;
-    const int* cs = B.cell_start + (size_t)h * kIcpCells;
-    double* P = B.work + (size_t)h * B.cap * 3;
-    int* prev = B.prev_nn + (size_t)h * B.cap;
-    double* lb = B.nn_lb + (size_t)h * B.cap;
-    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max;
-    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
-    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
-    const double r2 = max_dist * max_dist;
-    const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
-    const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);
-
     // pcd.Transform: the initial guess at evaluation 0, the update afterwards
     double xmn = 1e300, xmx = -1e300;
     if (it == 0) {
@@ -1364,27 +1376,33 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
         double U[12];
 #pragma unroll
         for (int a = 0; a < 12; ++a) U[a] = s_U[a];
-        for (int i = i_lo + tid; i < i_hi; i += kSearchWG) {
-            const double x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+        auto move_point = [&](const int i, const double x, const double y, const double z, const int pj, const double lbi, const double tx,
+                              const double ty, const double tz, const double sep) {
             const double nx = U[0] * x + U[1] * y + U[2] * z + U[3];
             const double ny = U[4] * x + U[5] * y + U[6] * z + U[7];
             const double nz = U[8] * x + U[9] * y + U[10] * z + U[11];
             P[3 * (size_t)i] = nx; P[3 * (size_t)i + 1] = ny; P[3 * (size_t)i + 2] = nz;
-            const int pj = prev[i];
             // how far this point's search will reach (the same tests as the queue below): nothing when its previous
             // correspondence is certified or it is provably out of range, the distance to the previous correspondence, or
             // kFarMargin x max_dist for a point without one
             double reach = 0.0;
             if (pj < 0) {
-                const double nlb = lb[i] - (sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12);
+                const double nlb = lbi - (sqrt(sqdist(nx, ny, nz, x, y, z)) * (1.0 + 1e-9) + 1e-12);
                 lb[i] = nlb;
                 if (!(nlb > lb_need)) reach = far;
             } else {
-                const double d = sqdist(nx, ny, nz, T[3 * (size_t)pj], T[3 * (size_t)pj + 1], T[3 * (size_t)pj + 2]);
-                if (!(d < r2 && 4.0 * d * (1.0 + 1e-9) < cov[(size_t)pj * kIcpCovStride + 10])) reach = sqrt(d < r2 ? d : r2);
+                const double d = sqdist(nx, ny, nz, tx, ty, tz);
+                if (!(d < r2 && 4.0 * d * (1.0 + 1e-9) < sep)) reach = sqrt(d < r2 ? d : r2);
             }
             reach = reach * (1.0 + 1e-6) + 1e-9;
             xmn = fmin(xmn, nx - reach); xmx = fmax(xmx, nx + reach);
+        };
+        if (pf) move_point(i_pf, pfx, pfy, pfz, pfj, pflb, pftx, pfty, pftz, pfsep);
+        for (int i = i_pf + kSearchWG; i < i_hi; i += kSearchWG) {
+            const int pj = prev[i];
+            double tx = 0, ty = 0, tz = 0, sep = 0;
+            if (pj >= 0) { tx = T[3 * (size_t)pj]; ty = T[3 * (size_t)pj + 1]; tz = T[3 * (size_t)pj + 2]; sep = cov[(size_t)pj * kIcpCovStride + 10]; }
+            move_point(i, P[3 * (size_t)i], P[3 * (size_t)i + 1], P[3 * (size_t)i + 2], pj, lb[i], tx, ty, tz, sep);
         }
     }
     // the x slab of the grid this slice's searches can reach: a contiguous range of cells [c0, c1] and of sorted target

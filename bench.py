@@ -394,8 +394,8 @@ def main():
                          "k_icp_eval launches in stream order, each as long as its slowest slice",
                 "evaluation_launches": 32,
                 "us_per_launch_if_all_of_icp_ms_were_evaluations": pl["icp_ms"] * 1e3 / 32.0,
-                "measured_split": "profiles/r02_icp_experiments.txt + profiles/r02_kernel_stats_v5.txt: of 2.03 ms, 32 evaluations 1.25 ms (39 us each; "
-                                  "the slowest slice 15-25 us), kNN 0.28, voxel + grid sorts 0.35, normals 0.06, points + bbox 0.07",
+                "measured_split": "profiles/r02_icp_experiments.txt + profiles/r02_kernel_stats_v5.txt: of 1.88 ms, 32 evaluations 1.15 ms (36 us each; "
+                                  "the slowest slice 15-25 us), kNN 0.28, voxel + grid sorts 0.33, normals 0.06, points + bbox 0.07",
                 "f64_flops_note": "a point-to-plane evaluation is ~200 f64 operations per source point: 16 x 7k points = 22 MFLOP per launch, "
                                   "0.4 TFLOP/s of the 78 TFLOP/s f64 vector peak - the chain is nowhere near an arithmetic bound"}
         traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
