@@ -19,13 +19,14 @@ if os.environ.get("PIPE_DIAG"):
         for hyp in range(16):
             st = self.read_icp_debug(hyp, 3)
             d = self.read_icp_debug(hyp, 4).reshape(2, 64, 32)
-            tot, sea, wall = d[0, :, 29], d[0, :, 30], d[0, :, 31]
+            par = int(os.environ.get('PIPE_DIAG_PARITY', '0'))
+            tot, sea, wall = d[par, :, 29], d[par, :, 30], d[par, :, 31]
             act = tot > 0
             if not act.any(): continue
             worst = int(np.argmax(tot))
             print("   worst slice %d: cycles %.0f search %.0f max over lanes: (candidates, columns*1000+queued) %s points %d..%d | median slice classes %s" % (worst, tot[worst], sea[worst], divmod(int(wall[worst]), 1000000), 0, 0, sorted(int(w) for w in wall[act])[len(wall[act]) // 2]), file=sys.stderr)
             print("hyp %2d iters %2d n_model %5d n_scene %5d grid %dx%d | slices %d: cycles min %.0f median %.0f max %.0f, search median %.0f max %.0f, wall us max %.1f | not in LDS %d, largest slab %d | corr/slice max %.0f" % (
-                hyp, st[24], st[19], st[20], st[21], st[22], act.sum(), tot[act].min(), np.median(tot[act]), tot[act].max(), np.median(sea[act]), sea[act].max(), wall[act].max() / 100, st[31], st[32], d[0, act, 28].max()), file=sys.stderr)
+                hyp, st[24], st[19], st[20], st[21], st[22], act.sum(), tot[act].min(), np.median(tot[act]), tot[act].max(), np.median(sea[act]), sea[act].max(), wall[act].max() / 100, st[31], st[32], d[par, act, 28].max()), file=sys.stderr)
         _close(self)
     lm.Pipeline.close = close_with_dump
 print(json.dumps(bench.pipeline_bench(det, frames, bank, ["obj00"], steps=steps)))
