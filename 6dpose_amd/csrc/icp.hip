@@ -1746,6 +1746,7 @@ void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, bool persistent, hipStream_t s) {
     if (count <= 0) return;
+    if (const char* e = getenv("LM_ICP_MAXITER_DIAG")) max_iter = atoi(e);   // diagnostics only (profiles/): stop after a few evaluations
     const int scene_mode = flags & 1;
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
     hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
