@@ -1076,7 +1076,8 @@ static __device__ void smallest_eigvec(double a00, double a01, double a02, doubl
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 12; ++sweep) {
         double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        if (off == 0.0) break;
+        // (the sweeps converge quadratically: 1e-4, 1e-8, 1e-16, 1e-32 of the diagonal ... waiting for an exact zero was four more sweeps)
+        if (off <= 1e-30 * (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]))) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 double apq = A[p][q];
