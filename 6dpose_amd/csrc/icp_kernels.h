@@ -13,7 +13,7 @@ namespace lm {
 constexpr int kIcpGrid = 64;                      // NN search grid: at most 64 x 64 ...
 constexpr int kIcpCells = kIcpGrid * kIcpGrid + 1; // ... columns in x and y (+1 end marker)
 constexpr int kIcpCells16 = 4104;                 // kIcpCells rounded up to a multiple of 8 (16-byte copies of the u16 table)
-constexpr int kIcpStrips = 16;                    // row strips of the bounding box in k_icp_points
+constexpr int kIcpStrips = 48;                    // row strips of the bounding box in k_icp_points
 constexpr int kIcpMaxSplit = 64;                  // workgroups (source slices) per hypothesis in k_icp_search
 constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
 
