@@ -46,6 +46,7 @@ struct lm_pipeline {
     int32_t* h_nsel = nullptr;                    // pinned
     int32_t* h_class_base = nullptr;              // pinned
     int h_cap = 0, h_class_cap = 0;
+    std::vector<int32_t> class_base_on_device;    // what d_class_base holds (re-uploaded only when it changes)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 };
 
@@ -210,6 +211,7 @@ static int ensure_run_buffers(lm_pipeline* p, int top_k, int num_classes) {
         if (p->d_class_base) (void)hipFree(p->d_class_base);
         if (p->h_class_base) (void)hipHostFree(p->h_class_base);
         p->d_class_base = nullptr; p->h_class_base = nullptr;
+        p->class_base_on_device.clear();
         p->class_cap = std::max(num_classes, 8);
         HIP_TRY(hipMalloc((void**)&p->d_class_base, (size_t)p->class_cap * sizeof(int32_t)));
         HIP_TRY(hipHostMalloc((void**)&p->h_class_base, (size_t)p->class_cap * sizeof(int32_t), hipHostMallocDefault));
@@ -249,13 +251,16 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
             auto it = p->views.find(order[i]);
             p->h_class_base[i] = it == p->views.end() ? -1 : it->second.base;
         }
-        if (!order.empty())
+        if (!order.empty() && (p->class_base_on_device.size() != order.size() ||
+                               memcmp(p->class_base_on_device.data(), p->h_class_base, order.size() * sizeof(int32_t)) != 0)) {
+            // the stream order keeps earlier frames' kernels ahead of this copy; the pinned source is stable until the next change
             HIP_TRY(hipMemcpyAsync(p->d_class_base, p->h_class_base, order.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            p->class_base_on_device.assign(p->h_class_base, p->h_class_base + order.size());
+        }
         HIP_TRY(hipEventRecord(p->e1, s));
         const int slot = (int)((d->n_submitted - 1) % lm_detector::kSlots);          // the frame just submitted
         launch_topk_nms(d->d_matches_dev.p + (size_t)d->cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->cand_cap, d->d_work.p, d->d_work_cls.p, d->d_work_tid.p, d->d_entries.p,
                         d->pyramid_levels, p->d_class_base, p->d_view_wh, p->num_views, top_k, nms_iou, p->d_scratch, p->d_sel, p->d_nsel, s);
-        HIP_TRY(hipMemsetAsync(c->d_st, 0, (size_t)top_k * sizeof(IcpState), s));
         launch_icp_bind(p->d_sel, p->d_nsel, p->d_class_base, p->d_view_K, p->d_view_valid, p->num_views, c->d_in, c->d_st, top_k, s);
         HIP_TRY(hipEventRecord(p->e2, s));
         IcpBuffers B = c->B;
