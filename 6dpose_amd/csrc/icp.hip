@@ -177,56 +177,61 @@ static __device__ __forceinline__ void bitonic_sort_hybrid(unsigned long long* g
 // keys | idx | idx | counts = 64 | 32 | 32 | 16 KiB for n <= 16384, idx | idx | counts = 64 | 64 | 16 KiB for n <= 32768.
 constexpr int kRadixBig = 2 * kSortLds;
 constexpr int kRadixLdsBytes = 2 * kRadixBig * 2 + 16 * 256 * 4;   // 144 KiB
-struct RadixView { unsigned short* idx[2]; unsigned int (*hist)[256]; unsigned int* key_lds; };
+struct RadixView { unsigned short* idx[2]; unsigned short* hist; unsigned int* key_lds; };   // hist: [16 waves][2^digit bits] 16-bit counts / positions
 static __device__ __forceinline__ RadixView radix_view(unsigned char* raw, const bool big) {
     RadixView v;
     v.key_lds = reinterpret_cast<unsigned int*>(raw);
     v.idx[0] = reinterpret_cast<unsigned short*>(raw + (big ? 0 : kSortLds * 4));
     v.idx[1] = v.idx[0] + (big ? kRadixBig : kSortLds);
-    v.hist = reinterpret_cast<unsigned int (*)[256]>(raw + 2 * kRadixBig * 2);
+    v.hist = reinterpret_cast<unsigned short*>(raw + 2 * kRadixBig * 2);
     return v;
 }
 
-template <typename KeyF>
-static __device__ __forceinline__ const unsigned short* wg_radix_sort(const RadixView& m, const int n, const int bits, int* s_wave /*[32]*/, KeyF&& key_of) {
+// One pass structure for 8- and 9-bit digits (DB): 9 bits when that saves a pass (a 25-bit voxel index: 3 passes instead of 4, a
+// ninth ballot per round of 64 keys); the counts of a wave's chunk (<= 2048 keys) and the positions (< 32768) fit 16 bits, so
+// 16 waves x 512 digits still are 16 KiB.
+template <int DB, typename KeyF>
+static __device__ __forceinline__ const unsigned short* wg_radix_passes(const RadixView& m, const int n, const int bits, int* s_wave /*[32]*/, KeyF&& key_of) {
+    constexpr int ND = 1 << DB, E = ND / 64;                      // digits; (digit, wave) entries a thread owns in the prefix
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = ((n + 1023) >> 10) << 6;                         // chunk of a wave: a multiple of 64, 16 chunks cover n
+    unsigned short* hist = m.hist;
     for (int i = tid; i < n; i += kWG) m.idx[0][i] = (unsigned short)i;
     int cur = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = 0; shift < bits; shift += DB) {
         const unsigned short* in = m.idx[cur];
         unsigned short* out = m.idx[cur ^ 1];
-        for (int d = lane; d < 256; d += 64) m.hist[wave][d] = 0;
+        for (int d = lane; d < ND; d += 64) hist[wave * ND + d] = 0;
         __syncthreads();                                             // (the indices of the previous pass are written)
         for (int walk = 0; walk < 2; ++walk) {
             for (int r = 0; r < C; r += 64) {
                 const int i = wave * C + r + lane;
                 const bool active = i < n;
                 const unsigned int id = active ? in[i] : 0;
-                const unsigned int d = active ? (key_of(id) >> shift) & 255u : 0;
+                const unsigned int d = active ? (key_of(id) >> shift) & (unsigned int)(ND - 1) : 0;
                 unsigned long long peers = __ballot(active);
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
+                for (int b = 0; b < DB; ++b) {
                     const unsigned long long bb = __ballot(active && ((d >> b) & 1u));
                     peers &= ((d >> b) & 1u) ? bb : ~bb;
                 }
                 const int cnt = __popcll(peers), rank = __popcll(peers & ((1ull << lane) - 1ull));
                 if (walk == 0) {
-                    if (active && rank == 0) m.hist[wave][d] += cnt;
+                    if (active && rank == 0) hist[wave * ND + d] = (unsigned short)(hist[wave * ND + d] + cnt);
                 } else {
                     unsigned int base = 0;
-                    if (active) base = m.hist[wave][d];
+                    if (active) base = hist[wave * ND + d];
                     if (active) out[base + rank] = (unsigned short)id;
-                    if (active && rank == 0) m.hist[wave][d] = base + cnt;
+                    if (active && rank == 0) hist[wave * ND + d] = (unsigned short)(base + cnt);
                 }
             }
             if (walk == 0) {
-                // exclusive prefix over (digit, wave): thread t owns digit t / 4, waves 4 (t % 4) .. + 3
+                // exclusive prefix over (digit, wave), digit-major: thread t owns the E consecutive entries from t * E
                 __syncthreads();
-                const int d = tid >> 2, w0 = (tid & 3) * 4;
-                unsigned int c[4], sum = 0;
+                const int d = (tid * E) >> 4, w0 = (tid * E) & 15;
+                unsigned int c[E], sum = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { c[q] = m.hist[w0 + q][d]; sum += c[q]; }
+                for (int q = 0; q < E; ++q) { c[q] = hist[(w0 + q) * ND + d]; sum += c[q]; }
                 unsigned int incl = sum;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -235,7 +240,7 @@ static __device__ __forceinline__ const unsigned short* wg_radix_sort(const Radi
                 unsigned int base = incl - sum;
                 for (int w = 0; w < wave; ++w) base += (unsigned int)s_wave[w];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { m.hist[w0 + q][d] = base; base += c[q]; }
+                for (int q = 0; q < E; ++q) { hist[(w0 + q) * ND + d] = (unsigned short)base; base += c[q]; }
                 __syncthreads();
             }
         }
@@ -243,6 +248,10 @@ static __device__ __forceinline__ const unsigned short* wg_radix_sort(const Radi
     }
     __syncthreads();
     return m.idx[cur];
+}
+template <typename KeyF>
+static __device__ __forceinline__ const unsigned short* wg_radix_sort(const RadixView& m, const int n, const int bits, int* s_wave /*[32]*/, KeyF&& key_of) {
+    return (bits + 8) / 9 < (bits + 7) / 8 ? wg_radix_passes<9>(m, n, bits, s_wave, key_of) : wg_radix_passes<8>(m, n, bits, s_wave, key_of);
 }
 
 static __device__ __forceinline__ int next_pow2(int n) {
