@@ -297,7 +297,8 @@ int lm_icp_run(lm_icp *c, int count, const int32_t *model_slots, const float *mo
 /* Test/diagnostic read-back of the last run's device intermediates of one hypothesis.  kind: 0 source
  * cloud, 1 target cloud, 2 target normals (xyz triples, voxel order), 3 {init_guess t[3], T[16],
  * n_model, n_scene, grid_x, grid_y, cell, iterations, 4 phase cycle counts of the iteration kernel}, 4 the slices' partial sums of
- * the last two evaluations [2][64][32].  Copies min(capacity, size) doubles, returns the size. */
+ * the last two evaluations [2][64][32] (slots 29-31 of a slice: its shader cycles, search cycles, queued points), 5 the cumulants of the
+ * k nearest neighbours per sorted target position [n_target][12].  Copies min(capacity, size) doubles, returns the size. */
 int64_t lm_icp_read_debug(lm_icp *c, int hypothesis, int kind, double *dst, int64_t capacity);
 
 /* ---- per-frame pipeline --------------------------------------------------------
