@@ -982,9 +982,11 @@ extern "C" int lm_nms_boxes(const double* boxes, const double* scores, int n, do
 }
 
 // Translation NMS over refined poses (linemod_ros/detect.py:41-51, `nms_norms(ts, ts_scores, 40.0)` at :128): visit by
-// score descending (scores.argsort()[::-1]: among equal scores the higher index first, as in lm_nms_boxes), keep, drop every
-// later pose whose translation is within `thresh` of it (kept iff ||t_i - t_j|| > thresh, double precision, numpy's
-// sqrt(dx*dx + dy*dy + dz*dz)).
+// score descending, keep, drop every later pose whose translation is within `thresh` of it (kept iff ||t_i - t_j|| > thresh,
+// double precision, numpy's sqrt(dx*dx + dy*dy + dz*dz)).  Visiting order among EQUAL scores: the higher index first — what
+// `scores.argsort()[::-1]` gives for n <= 16 (numpy's default argsort is an introsort: insertion sort, hence stable, up to 16
+// elements; beyond that numpy's tie order is an implementation detail and this function's rule is this library's definition, not a
+// reference-exact one).
 extern "C" int lm_nms_norms(const double* ts, const double* scores, int n, double thresh, int32_t* keep) {
     if (n <= 0 || !ts || !scores || !keep) return 0;
     std::vector<int> order((size_t)n);
@@ -1177,7 +1179,7 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
         // than items gives every wave at most one item and lets the hardware's workgroup dispatch do the balancing — 171 us (3 per CU,
         // items dealt round-robin, slowest wave 2 tiles + 1 single) -> 122 (8) -> 103 (16 and more), profiles/r02_sweep_local_blocks.txt.
         d->local_blocks = d->num_cus * (d->use_tiles ? 16 : 3);
-        if (const char* lb = getenv("LM_LOCAL_BLOCKS")) { int v = atoi(lb); if (v > 0) d->local_blocks = v; }
+        if (knobs().local_blocks > 0) d->local_blocks = knobs().local_blocks;
     }
     if (!sl.h_counters)
         HIP_TRY(hipHostMalloc((void**)&sl.h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
@@ -1246,6 +1248,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
+    sl.cand_cap = d->cand_cap; sl.cands = cands;
 
     Candidate* d_matches = nullptr;
     unsigned long long* d_hcounters = nullptr;
@@ -1256,7 +1259,7 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     // Two streams: the front end of this frame (on `stream`, into this slot's linear-memory arenas) overlaps the
     // matching kernels of the previous frame (on `mstream`, reading the other slot's arenas).  The arenas of this
     // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
-    static const bool fe_share_in_pipe = getenv("LM_FE_FUSED_PIPE") && getenv("LM_FE_FUSED_PIPE")[0] == '1';   // experiment
+    const bool fe_share_in_pipe = knobs().fe_fused_pipe;   // experiment
     auto enqueue_fe = [&]() -> int {
         HIP_TRY(hipEventRecord(sl.ev[0], s));
         int r = run_frontend(d, true, arena, fe_share_in_pipe);
@@ -1389,8 +1392,9 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     HIP_TRY(hipGetLastError());
     const uint64_t ncand = sl.h_counters[0];
     if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
-    if (ncand > d->cand_cap || ncand > sl.match_cap) {   // never drop silently: grow, caller reruns the frame
+    if (ncand > sl.cand_cap || ncand > sl.match_cap) {   // never drop silently: grow, caller reruns the frame
         d->cand_cap = std::max<uint32_t>(d->cand_cap, (uint32_t)(ncand + ncand / 4 + 1024));
+        d->ingest.used[(d->n_collected - 1) % lm_detector::kSlots] = false;
         return 1;
     }
     lm_timings tm{};
@@ -1441,9 +1445,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         // template, candidates in raster order of the coarse grid (LL.cpp:1753-1769, 1835-1852; remove_if keeps the order) — the
         // coarse position of every slot is in the candidate buffer — and std::sort is the same template of the same libstdc++
         // this library is built with, so the same comparisons on the same sequence give the same permutation.
-        const int slot_index = (int)((d->n_collected - 1) % lm_detector::kSlots);
-        std::vector<Candidate> coarse((size_t)ncand);
-        if (ncand) HIP_TRY(hipMemcpy(coarse.data(), d->d_cands.p + (size_t)d->cand_cap * slot_index, (size_t)ncand * sizeof(Candidate), hipMemcpyDeviceToHost));
+        std::vector<Candidate> coarse((size_t)ncand);                            // from the buffer the frame was submitted with: d->cand_cap may have grown since
+        if (ncand) HIP_TRY(hipMemcpy(coarse.data(), sl.cands, (size_t)ncand * sizeof(Candidate), hipMemcpyDeviceToHost));
         const std::vector<int32_t>& wcls = *sl.work_cls;
         const std::vector<int32_t>& wtid = *sl.work_tid;
         struct Rec { int32_t cls, tid, cy, cx; lm_match m; };

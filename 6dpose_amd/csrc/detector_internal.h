@@ -7,6 +7,7 @@
 
 #include "../../include/amd_linemod.h"
 #include "host_templates.h"
+#include "knobs.h"
 #include "lm_kernels.h"
 
 int lm_set_error(int code, const char* fmt, ...);
@@ -137,6 +138,8 @@ struct lm_detector {
         bool pending = false;
         float threshold = 0.f, h2d_ms = 0.f;
         int num_work = 0;
+        uint32_t cand_cap = 0;                      // the candidate capacity / buffer this frame was submitted with (d->cand_cap may grow before it is collected)
+        const Candidate* cands = nullptr;
         int64_t coarse_bytes = 0;
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "icp_kernels.h"
+#include "knobs.h"
 #include "lm_kernels.h"
 
 namespace lm {
@@ -1676,7 +1677,7 @@ k_icp_eval(IcpBuffers B, int it, int prev_slices, int max_shift, double max_dist
 // always pays for max_iter + 2 = 32 launches of ~10 us even when every hypothesis has stopped.  Workgroups are dispatched in
 // linear order (slices of hypothesis 0 first), so the hypotheses whose slices are resident always include complete ones:
 // waiting slices cannot starve the ones they wait for.  A wait that exceeds kBarrierTimeout (another kernel holding the
-// GPU for that long) marks the hypothesis status 4; the host then repeats the run with one launch per round.
+// GPU for that long) marks the hypothesis kIcpPersistTimeout; the host then repeats the run with one launch per round.
 constexpr long long kBarrierTimeout = 200ll * 100000;       // wall_clock64 ticks (100 MHz): 200 ms
 __global__ void __launch_bounds__(kSearchWG, 3)
 k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
@@ -1709,7 +1710,7 @@ k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
             }
             __syncthreads();
             if (s_abort) {
-                if (threadIdx.x == 0) __hip_atomic_store(&S.status, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) __hip_atomic_store(&S.status, (int)kIcpPersistTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
         }
@@ -1728,12 +1729,12 @@ __global__ void k_icp_bind(const TopkSel* __restrict__ sel, const int32_t* __res
     IcpIn I;
     for (int k = 0; k < 9; ++k) I.mK[k] = 0.f;
     I.dx = 0; I.dy = 0; I.model_slot = 0; I.pad = 0;
-    int status = 4;                                              // no detection for this slot
+    int status = kIcpNoDetection;                                // no detection for this slot
     if (nsel_status[1] == 0 && h < nsel_status[0]) {
         const TopkSel s = sel[h];
         const int base = class_base[s.class_index];
         const int v = base + s.template_id;
-        status = 5;                                              // the matched template has no rendered view
+        status = kIcpNoView;                                     // the matched template has no rendered view
         if (base >= 0 && v >= 0 && v < num_views && view_valid[v]) {
             status = 0;
             for (int k = 0; k < 9; ++k) I.mK[k] = view_K[(size_t)v * 9 + k];
@@ -1757,19 +1758,22 @@ void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, bool persistent, hipStream_t s) {
     if (count <= 0) return;
-    if (const char* e = getenv("LM_ICP_MAXITER_DIAG")) max_iter = atoi(e);   // diagnostics only (profiles/): stop after a few evaluations
+    const Knobs& kn = knobs();
+#ifdef LM_DIAG
+    if (kn.icp_maxiter_diag >= 0) max_iter = kn.icp_maxiter_diag;            // diagnostics only (profiles/): stop after a few evaluations
+#endif
     const int scene_mode = flags & 1;
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
     hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
-    hipLaunchKernelGGL(k_icp_knn, dim3(getenv("LM_KNN_BLOCKS") ? atoi(getenv("LM_KNN_BLOCKS")) : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
     int splits = 768 / count;
-    if (const char* e = getenv("LM_ICP_SPLITS")) splits = atoi(e);      // tuning knob (profiles/)
+    if (kn.icp_splits > 0) splits = kn.icp_splits;                     // tuning knob (profiles/)
     if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
     if (splits < 1) splits = 1;
     if (persistent && B.bar) {
@@ -1781,11 +1785,10 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     // and the ones that go on for all 30 are cut finer (their latency is what is left): 64 slices each
     int prev = splits;
     for (int it = 0; it <= max_iter + 1; ++it) {
-        const int cur = it < kIcpFineFrom || getenv("LM_ICP_SPLITS") ? splits : kIcpMaxSplit;
+        const int cur = it < kIcpFineFrom || kn.icp_splits > 0 ? splits : kIcpMaxSplit;
         // lanes per searching point: at most 8 while every point searches (the first evaluations: more lanes only multiply the
         // set-up), 16 afterwards (few searches left: their latency is what counts) — measured, profiles/r02_icp_experiments.txt
-        static const int early = getenv("LM_ICP_MAXSHIFT") ? atoi(getenv("LM_ICP_MAXSHIFT")) : 3;
-        static const int late = getenv("LM_ICP_MAXSHIFT_LATE") ? atoi(getenv("LM_ICP_MAXSHIFT_LATE")) : 4;
+        const int early = kn.icp_maxshift, late = kn.icp_maxshift_late;
         hipLaunchKernelGGL(k_icp_eval, dim3(cur, count), dim3(kSearchWG), 0, s, B, it, prev, it < kIcpFineFrom ? early : late, max_dist, max_iter, rel_tol);
         prev = cur;
     }

@@ -26,10 +26,19 @@ struct IcpIn {               // one pose hypothesis (uploaded)
     int pad;
 };
 
+enum IcpStatus {             // IcpState::status; every value has ONE meaning (the host tests them by name)
+    kIcpOk = 0,
+    kIcpOutOfFrame = 1,      // window leaves the frame (LL.cpp:52-55): residual = -1
+    kIcpEmptyModel = 2,      // empty model depth
+    kIcpTooLarge = 3,        // cloud too large for 64-bit voxel keys
+    kIcpNoDetection = 4,     // pipeline: hypothesis slot without a detection (k_icp_bind)
+    kIcpNoView = 5,          // pipeline: the matched template has no rendered view (k_icp_bind)
+    kIcpPersistTimeout = 6,  // k_icp_persist gave up waiting for its other slices (the host repeats the run with one launch per round)
+};
+
 struct IcpState {            // one pose hypothesis (device-written, downloaded after the run)
     int bbox[4];             // x0,y0,x1,y1 of modelDepth > 0 (uploaded as INT_MAX,INT_MAX,-1,-1)
-    int status;              // 0 ok, 1 window leaves the frame (LL.cpp:52-55), 2 empty model depth, 3 cloud too large for 64-bit voxel keys,
-                             // 4 k_icp_persist gave up waiting for its other slices (the host repeats the run with one launch per round)
+    int status;              // IcpStatus below
     int n_model, n_scene;    // back-projected points
     int n_src, n_tgt;        // after voxel down-sampling
     int gx, gy, zq_max;      // search grid: columns in x and y, largest quantised depth

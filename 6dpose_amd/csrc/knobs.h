@@ -1,0 +1,48 @@
+// Tuning knobs of the library, read from the environment ONCE (first use = creation of the first detector / ICP context), never
+// on a launch path.  Every knob here leaves the results unchanged.  The knobs of the timing experiments under profiles/ that
+// produce WRONG results (skipping a phase of a kernel, stopping ICP early) exist only in a build with -DLM_DIAG
+// (`make DIAG=1`); the default library does not read them.
+#pragma once
+#include <stdlib.h>
+
+namespace lm {
+
+struct Knobs {
+    int coarse_group = 4;          // LM_COARSE_GROUP: templates per workgroup of k_coarse (<= 4)
+    int local_blocks = 0;          // LM_LOCAL_BLOCKS: grid of k_local (0 = default per CU count)
+    int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default)
+    int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default)
+    int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
+    int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
+    int icp_maxshift_late = 4;
+    bool fe_fused_pipe = false;    // LM_FE_FUSED_PIPE=1: shared front-end launches also with frames in flight (measured slower)
+#ifdef LM_DIAG
+    int coarse_dbg = 0;            // LM_COARSE_DBG: 1 = no tile grouping, 2 = no global atomic (wrong results)
+    int local_dbg = 0;             // LM_LOCAL_DBG: 1 = tiles only, 2 = singles only (wrong results)
+    int icp_maxiter_diag = -1;     // LM_ICP_MAXITER_DIAG: stop ICP after this many evaluations (wrong results)
+#endif
+};
+
+inline const Knobs& knobs() {
+    static const Knobs k = [] {
+        Knobs v;
+        auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; };
+        v.coarse_group = geti("LM_COARSE_GROUP", v.coarse_group);
+        v.local_blocks = geti("LM_LOCAL_BLOCKS", 0);
+        v.frame_batch = geti("LM_FRAME_BATCH", 0);
+        v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
+        v.icp_splits = geti("LM_ICP_SPLITS", 0);
+        v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
+        v.icp_maxshift_late = geti("LM_ICP_MAXSHIFT_LATE", v.icp_maxshift_late);
+        v.fe_fused_pipe = geti("LM_FE_FUSED_PIPE", 0) == 1;
+#ifdef LM_DIAG
+        v.coarse_dbg = geti("LM_COARSE_DBG", 0);
+        v.local_dbg = geti("LM_LOCAL_DBG", 0);
+        v.icp_maxiter_diag = geti("LM_ICP_MAXITER_DIAG", -1);
+#endif
+        return v;
+    }();
+    return k;
+}
+
+}  // namespace lm

@@ -15,10 +15,9 @@
 //             offset stays exact).  At the top level, features outside the image (LL.cpp:1330) are
 //             already redirected to the zero tail.  feat_xy[] = int16 x | int16 y << 16 is only
 //             read on the slow path of the refinement (bounds test of LL.cpp:1394).
-#include <stdlib.h>
-
 #include <algorithm>
 
+#include "knobs.h"
 #include "lm_kernels.h"
 
 namespace lm {
@@ -440,9 +439,10 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
         plan.enabled = 1;
         plan.W0 = g.lv[0].W; plan.H0 = g.lv[0].H; plan.T0 = g.lv[0].T; plan.Wd0 = g.lv[0].Wd; plan.Hd0 = g.lv[0].Hd;
         plan.tile_cap = tile_cap;
-        static const int dbg = getenv("LM_COARSE_DBG") ? atoi(getenv("LM_COARSE_DBG")) : 0;
-        static const int max_group = getenv("LM_COARSE_GROUP") ? atoi(getenv("LM_COARSE_GROUP")) : 4;
-        plan.dbg = dbg;
+        const int max_group = knobs().coarse_group;
+#ifdef LM_DIAG
+        plan.dbg = knobs().coarse_dbg;
+#endif
         // Templates per workgroup: up to 4 (<= 16 waves, <= 64 KB of LDS).  More templates mean fewer atomics on the frame's counter,
         // but workgroups of 7-8 templates (14-16 waves) leave room for one workgroup per CU only: 16k templates at VGA 162 us with
         // 2-6 per workgroup, 300 us with 7-8; 2k templates 45 us with 2-8, 57 us with 1 (profiles/r02_coarse_group_sweep.txt).
@@ -811,7 +811,10 @@ void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameG
                   const TileRec* tiles, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0) return;
     if (!(tiles && todo && tile_plan_possible(g))) { tiles = nullptr; todo = nullptr; }      // same decision as launch_coarse
-    static const int dbg = getenv("LM_LOCAL_DBG") ? atoi(getenv("LM_LOCAL_DBG")) : 0;           // timing experiments (wrong results): 1 = tiles only, 2 = singles only
+    int dbg = 0;
+#ifdef LM_DIAG
+    dbg = knobs().local_dbg;                                    // timing experiments (wrong results): 1 = tiles only, 2 = singles only
+#endif
     hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
                        feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
                        dedupe_table, dedupe_cap_slots, todo, tiles, tile_cap, dbg);

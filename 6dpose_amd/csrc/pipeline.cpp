@@ -239,7 +239,8 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
     lm_icp* c = p->icp;
     int rc;
     if ((rc = lm_icp_ensure_arenas(c, top_k))) return rc;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    int overflows = 0;
+    for (;;) {                                                    // one pass normally; again after a candidate-buffer overflow (<= 3) or the one persist time-out
         HIP_TRY(hipEventRecord(p->e0, d->stream));
         if ((rc = lm_submit_frame(d, threshold, class_ids, num_class_ids))) return rc;
         // class position (caller's class_ids order, or sorted order) -> first view slot
@@ -275,14 +276,17 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
         rc = lm_collect_frame(d, -1, nullptr, nullptr);          // retires the frame; 1 = candidate buffer overflow, rerun
-        if (rc == 1) continue;
+        if (rc == 1) {
+            if (++overflows >= 3) return lm_set_error(LM_ERR_INVALID, "candidate buffer kept overflowing");
+            continue;
+        }
         if (rc) return rc;
         bool timed_out = false;                                   // k_icp_persist gave up waiting for its other slices: one launch per round from now on
-        for (int i = 0; i < top_k; ++i) timed_out |= c->h_st[i].status == 4;
-        if (timed_out && c->persist) { c->persist = false; rc = 1; continue; }
-        break;
+        for (int i = 0; i < top_k; ++i) timed_out |= c->h_st[i].status == kIcpPersistTimeout;
+        if (!timed_out) break;
+        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected persist time-out status");
+        c->persist = false;                                       // its own retry, not counted as an overflow
     }
-    if (rc == 1) return lm_set_error(LM_ERR_INVALID, "candidate buffer kept overflowing");
     if (p->h_nsel[1] != 0)
         return lm_set_error(LM_ERR_INVALID, "on-device NMS: a match field exceeds the packed record (template id >= 2^24, class position >= 128 or |x|,|y| >= 32768)");
     c->last_count = top_k; c->last_flags = flags;

@@ -270,9 +270,9 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
         HIP_TRY(hipStreamSynchronize(c->s));
         HIP_TRY(hipGetLastError());
         bool timed_out = false;
-        for (int i = 0; i < count; ++i) timed_out |= c->h_st2[i].status == 4;
+        for (int i = 0; i < count; ++i) timed_out |= c->h_st2[i].status == kIcpPersistTimeout;
         if (!timed_out) break;
-        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected status 4");
+        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected persist time-out status");
         c->persist = false;            // the persistent kernel waited too long for its other slices (GPU shared): one launch per round from now on
     }
     memcpy(c->h_st, c->h_st2, (size_t)count * sizeof(IcpState));

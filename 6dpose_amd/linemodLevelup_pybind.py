@@ -848,7 +848,10 @@ class Pipeline:
             norms_thresh: Optional[float] = None):
         """One frame of the driver loop on the device.  norms_thresh (mm): additionally the translation NMS the ROS node applies
         to the refined poses (linemod_ros/detect.py:128, `nms_norms(ts, ts_scores, 40.0)` with score = -residual): the refined
-        detections are returned in its keep order, the suppressed ones dropped (those without a pose are left out, as there)."""
+        detections are returned in its keep order, the suppressed ones dropped.  Deliberate difference: a detection whose
+        refinement failed (status != 0: window outside the frame, LL.cpp:52-55, or no rendered view) is left out here, whereas the
+        node's shared `poseRefine` object would hand `nms_norms` residual -1 (score +1, ranked first) together with the STALE R / t of
+        the previous detection — a reference defect this does not reproduce.  Tie order among equal scores: see lm_nms_norms."""
         ids = [c.encode() for c in class_ids]
         arr = (ctypes.c_char_p * len(ids))(*ids) if ids else None
         sK = np.ascontiguousarray(np.asarray(scene_K, np.float32).reshape(9))
