@@ -107,6 +107,7 @@ def main():
                     help="N>1: weak = one object x --templates per GPU (configs[1] scaled up); strong = a fixed bank of 8 objects x "
                          "--templates (configs[3]) split over the GPUs.  N=1 --scaling strong runs that 16k bank on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the GPU-vs-oracle comparison of frames 0 and 1 before timing (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extras legs (resident replay, ICP, pipeline, thresholds, 16k bank)")
     ap.add_argument("--exchange", choices=["auto", "host", "device"], default="auto",
                     help="multi-GPU exchange of the match records: on the device (sharded.DeviceExchange; auto = when world > 1) or through the host")
@@ -189,6 +190,13 @@ def main():
         exchange_mode = "device" if ok else "host (device exchange failed its check)"
         if not ok:
             ex = None
+
+    # Parity gate ("parity gate before any timing counts"): the GPU's Detector.match of pool frames 0 and 1
+    # against the CPU oracle (quantisation in numpy, match loops = the SSE C port pinned to the reference's lines) - bit-exact
+    # (x, y, similarity, template_id) in the canonical order, or the bench aborts without a number.
+    parity = None
+    if world == 1 and not strong and not args.no_parity_gate:
+        parity = parity_gate(det, frames, banks[classes[0]], classes, args.templates)
 
     host_t = {"submit": 0.0, "collect": 0.0, "gather": 0.0, "merge": 0.0}
     keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "h2d_ms", "total_ms", "coarse_candidates", "local_evals",
@@ -347,6 +355,7 @@ def main():
             "value": value, "unit": "templates*Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
+            "parity_checked": bool(parity and parity["ok"]), "parity": parity,
             "config": {"workload": workload,
                        "frame_source": "host memory, a new frame per step through lm_detector_submit_frame (pinned ring + copy stream); "
                                        "H2D inside the timed region; pool of %d distinct noisy frames, step number stamped in" % N_FRAMES,
@@ -387,7 +396,12 @@ def main():
                                   "pcie_inclusive": pcie_inclusive(det, frames, classes, args.templates),
                                   "one_candidate_per_template": sparse_threshold_run(det, frames, classes, args.templates),
                                   "icp": icp_bench(local_rank),
+                                  "real_fixture": real_fixture_leg(local_rank),
                                   "pipeline": pipeline_bench(det, frames, banks[cls0], classes)})
+            if not args.no_cpu_baseline:
+                out["extras"]["icp"]["cpu_baseline"] = icp_cpu_baseline()
+                cb = out["extras"]["icp"]["cpu_baseline"]
+                out["extras"]["icp"]["speedup_vs_cpu_numpy"] = (out["extras"]["icp"]["icp_iters_per_sec_device"] / cb["icp_iters_per_sec"]) if cb["icp_iters_per_sec"] else None
             pl = out["extras"]["pipeline"]
             out["extras"]["roofline_icp"] = {
                 "bound": "latency of a chain of dependent launches (f64 VALU + LDS reads inside one): max_iteration + 2 = 32 "
@@ -420,6 +434,46 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def oracle_matches(od, lo, pb, rgb, dep, threshold):
+    """Detector.match of the CPU oracle for one frame: numpy quantisation + the C port of the match loops + canonical merge.
+    Returns (records, seconds of quantisation, seconds of linear memories + match loops)."""
+    t0 = time.perf_counter()
+    pyr = od.quantize_pyramid(rgb, dep)
+    t1 = time.perf_counter()
+    lms = [[lo.build_linear_memories(p[0], od.T_at_level[l]), lo.build_linear_memories(p[1], od.T_at_level[l])] for l, p in enumerate(pyr)]
+    sizes = [(p[0].shape[1], p[0].shape[0]) for p in pyr]
+    raw, st = lo.match_bank_c(pb, lms, sizes, od.T_at_level, threshold, 1)
+    t2 = time.perf_counter()
+    return lo.canonical_sort_unique(raw), raw, st, pyr, t1 - t0, t2 - t1
+
+
+def same_records(got, want):
+    return (len(got) == len(want) and np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"]) and
+            np.array_equal(got["template_id"], want["tid"]) and np.array_equal(got["similarity"], want["sim"]))
+
+
+def parity_gate(det, frames, bank, classes, n_templates, n_frames=2):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    od = lo.OracleDetector(NFEAT[0], T_LEVELS)
+    pb = lo.PackedBank(n_templates, 2, *bank)
+    out = {"ok": True, "frames": [], "oracle": "oracle/linemod_oracle.py quantisation + oracle/match_oracle.c (SSE port pinned to the reference's own "
+                                               "lines, tests/test_ref_pin.py) + canonical merge; compared: x, y, similarity bits, template_id, in order"}
+    for k in range(n_frames):
+        rgb, dep = frames[k]
+        want, _, st, _, _, _ = oracle_matches(od, lo, pb, rgb, dep, THRESHOLD)
+        got = det.matchArray([rgb, dep], THRESHOLD, classes)
+        tm = det.lastTimings()
+        ok = same_records(got, want) and int(tm["coarse_candidates"]) == int(st["coarse_candidates"])
+        out["frames"].append({"frame": k, "matches": int(len(want)), "gpu_matches": int(len(got)), "coarse_candidates": int(st["coarse_candidates"]),
+                              "gpu_coarse_candidates": int(tm["coarse_candidates"]), "equal": bool(ok)})
+        out["ok"] = out["ok"] and ok
+    if not out["ok"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED - GPU matches differ from the CPU oracle: %s\n" % json.dumps(out["frames"]))
+        sys.exit(3)
+    return out
 
 
 def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=4, depth=3):
@@ -617,26 +671,51 @@ def pipeline_bench(det, frames, bank, classes, top_k=16, steps=20):
     return out
 
 
+def host_cpu_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
 def cpu_baseline(frames, bank, n_templates, n_timed=10, n_warm=2):
-    """The oracle's C (SSE2/SSSE3) port of the matching step, single thread like the reference, on the host cores of this
-    box: spread/response/linearise + coarse + local for the same bank, median over `n_timed` frames of the stream after
-    `n_warm` warm-up frames.  Quantisation (numpy in the oracle) is NOT timed, which can only flatter the CPU."""
+    """The CPU side of the same matching step, single thread like the reference, on the host cores of this box, over `n_timed`
+    frames of the stream after `n_warm` warm-up frames.  Two implementations are timed on identical inputs:
+      * "reference" (the `value` when oracle/_ref is present): the reference's OWN Detector::match (LL.cpp:1702-1777 minus the
+        quantisers: spread, computeResponseMaps, linearize, matchClass, std::sort + std::unique), compiled from /root/reference
+        by oracle/Makefile with the reference's flags (-O3, SSE2) - oracle/_ref/libll_ref_sse2.so;
+      * "port": oracle/match_oracle.c, the restatement of the same loops (pinned to the former record by record).
+    The quantisation (numpy in the oracle, OpenCV in the reference) is timed separately and reported as `incl_quantisation`:
+    numpy is slower than OpenCV would be, so the quantisation-exclusive figure is the one that cannot flatter the GPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import linemod_oracle as lo
+    import ll_ref
     od = lo.OracleDetector(NFEAT[0], T_LEVELS)
     feat, offs, wh = bank
     pb = lo.PackedBank(n_templates, 2, feat, offs, wh)
-    times, cands = [], 0
+    have_ref = ll_ref.available("sse2")
+    times, qtimes, rtimes, cands = [], [], [], 0
     use = frames[:n_warm + n_timed]
+    ref_equal = None
     for i, (rgb, dep) in enumerate(use):
-        pyr = od.quantize_pyramid(rgb, dep)
-        t0 = time.perf_counter()
-        lms = [[lo.build_linear_memories(p[0], T_LEVELS[l]), lo.build_linear_memories(p[1], T_LEVELS[l])] for l, p in enumerate(pyr)]
-        sizes = [(p[0].shape[1], p[0].shape[0]) for p in pyr]
-        m, st = lo.match_bank_c(pb, lms, sizes, T_LEVELS, THRESHOLD, 1)
+        _, raw, st, pyr, tq, tmatch = oracle_matches(od, lo, pb, rgb, dep, THRESHOLD)
+        quant = [(p[0], p[1]) for p in pyr]
+        if have_ref:
+            t0 = time.perf_counter()
+            rr = ll_ref.match(quant, T_LEVELS, {"obj": pb}, THRESHOLD, ["obj"], pre_unique=True)
+            tr = time.perf_counter() - t0
+            if i == 0:   # same pre-unique records, in the reference's own emission order
+                ref_equal = bool(len(rr) == len(raw) and all(np.array_equal(rr[a], raw[b]) for a, b in (("x", "x"), ("y", "y"), ("sim", "sim"), ("tid", "tid"))))
         if i >= n_warm:
-            times.append(time.perf_counter() - t0)
+            times.append(tmatch); qtimes.append(tq)
             cands += st["coarse_candidates"]
+            if have_ref:
+                rtimes.append(tr)
+    lms = [[lo.build_linear_memories(p[0], T_LEVELS[l]), lo.build_linear_memories(p[1], T_LEVELS[l])] for l, p in enumerate(pyr)]
+    sizes = [(p[0].shape[1], p[0].shape[0]) for p in pyr]
     ncores = os.cpu_count() or 1
     mt = []
     for _ in range(3):
@@ -644,23 +723,130 @@ def cpu_baseline(frames, bank, n_templates, n_timed=10, n_warm=2):
         lo.match_bank_c(pb, lms, sizes, T_LEVELS, THRESHOLD, ncores)
         mt.append(time.perf_counter() - t0)
     t_mt = float(np.median(mt))
-    sec = float(np.median(times))
-    cpu = ""
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                cpu = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": n_templates * (W * H / 1e6) / sec, "unit": "templates*Mpx/s", "cores": 1, "kind": "port",
-            "sample": "%d frames (after %d warm-up frames) x %d templates (same bank and stream as the GPU run), SSE C port of LL.cpp:1026-1941 "
-                      "(pinned record by record to the reference's own lines, oracle/_ref), linear memories + coarse + local timed, numpy "
-                      "quantisation excluded; median %.3f s/frame (min %.3f, max %.3f), %.1f coarse candidates/template"
-                      % (len(times), n_warm, n_templates, sec, min(times), max(times), cands / len(times) / n_templates),
-            "host_cpu": cpu, "host_cores": ncores,
-            "all_cores_variant": {"threads": ncores, "value": n_templates * (W * H / 1e6) / t_mt,
-                                  "note": "templates split across pthreads, match loops only (not what the reference does); median of 3"}}
+    sec_port, sec_q = float(np.median(times)), float(np.median(qtimes))
+    rate = lambda sec: n_templates * (W * H / 1e6) / sec
+    port = {"value": rate(sec_port), "unit": "templates*Mpx/s", "cores": 1, "seconds_per_frame": sec_port,
+            "what": "oracle/match_oracle.c (SSE2/SSSE3 C port of LL.cpp:1026-1941), linear memories + coarse + local, median of %d frames" % len(times)}
+    out = dict(port, kind="port")
+    if have_ref:
+        sec_ref = float(np.median(rtimes))
+        out = {"value": rate(sec_ref), "unit": "templates*Mpx/s", "cores": 1, "kind": "reference", "seconds_per_frame": sec_ref,
+               "reference_lines": {"value": rate(sec_ref), "seconds_per_frame": sec_ref, "min": min(rtimes), "max": max(rtimes),
+                                   "library": "oracle/_ref/libll_ref_sse2.so = LL.cpp:1022-1658, 1694-1941 cut from the reference checkout at build time, "
+                                              "-O3 (the reference's flags: SSE2 paths), Detector::match from the quantised maps on",
+                                   "equals_port_records": ref_equal},
+               "port": port}
+    out.update({
+        "sample": "%d frames (after %d warm-up frames) x %d templates (same bank and stream as the GPU run); single thread; "
+                  "median %.3f s/frame; %.1f coarse candidates/template; quantisation excluded from `value`"
+                  % (len(times), n_warm, n_templates, out["seconds_per_frame"], cands / len(times) / n_templates),
+        "incl_quantisation": {"value": rate(out["seconds_per_frame"] + sec_q), "seconds_per_frame": out["seconds_per_frame"] + sec_q,
+                              "quantisation_seconds": sec_q,
+                              "note": "quantisation = the oracle's numpy restatement of the OpenCV calls (LL.cpp:350-505, 729-880), NOT the reference's "
+                                      "OpenCV: an upper bound on the CPU time of a frame"},
+        "host_cpu": host_cpu_name(), "host_cores": ncores,
+        "all_cores_variant": {"threads": ncores, "value": rate(t_mt),
+                              "note": "port, templates split across pthreads, match loops only (not what the reference does); median of 3"}})
+    return out
+
+
+def icp_cpu_baseline(hypotheses=4):
+    """CPU side of extras.icp: the oracle's pose_refine (numpy restatement of LL.cpp:27-155 + Open3D's VoxelDownSample /
+    EstimateNormals(KNN 30) / RegistrationICP point-to-plane, brute-force neighbours) on the first `hypotheses` of the same 16
+    hypotheses, single thread.  The reference times this call at linemod_and_levelup_test.py:362-376.  Labelled numpy: Open3D's
+    KD-tree + OpenMP would be faster, so a second figure replaces the neighbour searches of the ICP loop by scipy's cKDTree."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    import synth
+    from scipy.spatial import cKDTree
+    K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
+    rng = np.random.default_rng(7)
+    scene_model = synth.synth_model_depth(100)
+    scene = np.where(scene_model > 0, scene_model + 4, 0).astype(np.uint16)
+    scene = np.where(scene > 0, scene + rng.integers(-1, 2, scene.shape), 0).astype(np.uint16)
+    R, t = np.eye(3, dtype=np.float32), np.array([0, 0, 1000], np.float32)
+    its, sec, its_kd, sec_kd = 0, 0.0, 0, 0.0
+    for h in range(16):
+        md = synth.synth_model_depth(100 + (h % 4))
+        ys, xs = np.nonzero(md)
+        xy = (int(xs.min()) + int(rng.integers(-2, 3)), int(ys.min()) + int(rng.integers(-2, 3)))   # same draws as icp_bench
+        if h >= hypotheses:
+            continue
+        t0 = time.perf_counter()
+        r = lo.pose_refine(scene, md, K, K, R, t, xy[0], xy[1], scene_from_scene=True)
+        sec += time.perf_counter() - t0
+        its += r["iterations"]
+        # the ICP loop alone with KD-tree neighbour searches (same clouds, normals and update rule)
+        src, tgt, nrm, T = r["src"], r["tgt"], r["normals"], np.array(r["init_guess"])
+        t0 = time.perf_counter()
+        tree = cKDTree(tgt)
+        pts = src @ T[:3, :3].T + T[:3, 3]
+        prev = None
+        for _ in range(lo.ICP_MAX_ITER + 1):
+            d, j = tree.query(pts, k=1, distance_upper_bound=lo.ICP_MAX_DIST)
+            ok = np.isfinite(d)
+            n = int(ok.sum())
+            cur = (n / len(pts), float(np.sqrt((d[ok] ** 2).sum() / n)) if n else 0.0)
+            if prev is not None:
+                its_kd += 1
+                if abs(prev[0] - cur[0]) < lo.ICP_REL and abs(prev[1] - cur[1]) < lo.ICP_REL:
+                    break
+            prev = cur
+            upd = np.eye(4)
+            if n >= 6:
+                p, q, nt = pts[ok], tgt[j[ok]], nrm[j[ok]]
+                rres = ((p - q) * nt).sum(1)
+                J = np.concatenate([np.cross(p, nt), nt], 1)
+                try:
+                    x = np.linalg.solve(J.T @ J, -(J.T @ rres))
+                    if np.all(np.isfinite(x)):
+                        upd = lo._rot_xyz(x)
+                except np.linalg.LinAlgError:
+                    pass
+            pts = pts @ upd[:3, :3].T + upd[:3, 3]
+        sec_kd += time.perf_counter() - t0
+    return {"kind": "port", "cores": 1, "hypotheses": hypotheses, "iterations_total": its, "seconds": sec,
+            "icp_iters_per_sec": its / sec if sec > 0 else 0.0,
+            "what": "oracle pose_refine (numpy, brute-force neighbours), whole call: clouds + voxel grid + normals + ICP; parity unpinned (Open3D absent)",
+            "kdtree_icp_loop_only": {"iterations_total": its_kd, "seconds": sec_kd, "icp_iters_per_sec": its_kd / sec_kd if sec_kd > 0 else 0.0,
+                                     "what": "the ICP evaluations alone (clouds, normals given) with scipy cKDTree searches + numpy normal equations: "
+                                             "the kind of loop Open3D runs (KD-tree), one thread; not bit-compared"}}
+
+
+def real_fixture_leg(device, steps=40, target=2000):
+    """the reference's own detect_test (linemodLevelup/test.cpp:111-130) - fixture frame 0000 read as BGR,
+    Detector(127, {5, 8}), bank `127` (89 template pyramids at 1000 mm), threshold 75 - with the bank tiled to ~2k pyramids
+    (copies under new template ids) so that it is the configs[1] size.  Parity-checked against the CPU oracle (all pyramids),
+    then the same live-stream loop as the headline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    import linemodLevelup_pybind as lm
+    from helpers import GOLDEN, load_bgr, load_u16
+    rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
+    od = lo.OracleDetector(127, [5, 8])
+    od.readClasses(["06_template"], os.path.join(GOLDEN, "bank127_%s.yaml.gz"))
+    pyrs = od.class_templates["06_template"]
+    reps = max(1, (target + len(pyrs) - 1) // len(pyrs))
+    pb = lo.pack_bank(pyrs * reps, 2)
+    det = lm.Detector(127, [5, 8], device=device)
+    det.addClassPacked("06_template", pb.feat, pb.tmpl_off, pb.tmpl_wh)
+    classes = ["06_template"]
+    od2 = lo.OracleDetector(127, [5, 8])
+    want, _, st, _, _, tmatch = oracle_matches(od2, lo, pb, rgb, dep, THRESHOLD)
+    got = det.matchArray([rgb, dep], THRESHOLD, classes)
+    equal = same_records(got, want)
+    frames = [(rgb.copy(), dep.copy()) for _ in range(4)]
+    dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps, depth=PIPELINE_DEPTH or 4)
+    n = pb.num_pyramids
+    return {"workload": "test.cpp:111-130 detect_test: fixture frame 0000 (BGR) x bank 127 tiled x%d = %d template pyramids, Detector(127,{5,8}), "
+                        "threshold 75, 640x480" % (reps, n),
+            "templates": n, "ms_per_frame": dt * 1e3, "value": n * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
+            "coarse_candidates": tm.get("coarse_candidates"), "matches_pre_unique": tm.get("matches_pre_unique"), "matches_final": int(len(got)),
+            "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "frontend_ms": tm.get("frontend_ms"),
+            "equals_oracle": bool(equal), "top_match": ({"x": int(got[0]["x"]), "y": int(got[0]["y"]), "similarity": float(got[0]["similarity"]),
+                                                        "template_id": int(got[0]["template_id"])} if len(got) else None),
+            "cpu_port_seconds_per_frame": tmatch,
+            "note": "T = {5, 8} is the geometry of every reference fixture bank; GT bbox origin of the object is (331, 130) (test.cpp:86)"}
 
 
 if __name__ == "__main__":

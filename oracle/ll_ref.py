@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE, NOT product code: ctypes loader for oracle/_ref (the reference's own match
 lines — LL.cpp:1022-1658, 1694-1941 — compiled from /root/reference against the buffer shim, see
-oracle/Makefile and oracle/ref_harness.cpp).  Only tests/ and tests/golden/make_ref_fixtures.py
-import this module.  `available()` is False where oracle/_ref was never built."""
+oracle/Makefile and oracle/ref_harness.cpp).  Only tests/, tests/golden/make_ref_fixtures.py
+and bench.py's `cpu_baseline` leg (which TIMES it as the CPU baseline, kind "reference") import this module.  `available()` is False where oracle/_ref was never built."""
 import ctypes
 import os
 from typing import Dict, List, Sequence

@@ -1,16 +1,17 @@
 """GPU tests of the rasteriser against its numpy restatement (oracle/render_oracle.py) and of the
-device-side render_train / depth_ren paths against the host round trip."""
+device-side render_train / depth_ren paths against the host round trip AND the oracle's addTemplate."""
 import os
 import struct
 
 import numpy as np
 import pytest
 
-import linemod_oracle as lo  # noqa: F401  (keeps the oracle path on sys.path like the other GPU tests)
+import linemod_oracle as lo
 import render_oracle as ro
 
 pytestmark = pytest.mark.gpu
 
+ORACLE_VIEWS = 4          # views per configuration that also go through the numpy oracle's addTemplate
 K_CAM = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32).reshape(3, 3)
 
 
@@ -147,6 +148,21 @@ def test_rendered_training_equals_the_host_round_trip(lm, nfeat, T, views, dist,
     for t in [t for t in want_ids if t >= 0]:
         for a, b in zip(det_a.getTemplates("obj", t), det_b.getTemplates("obj", t)):
             assert (a.width, a.height, a.pyramid_level) == (b.width, b.height, b.pyramid_level) and np.array_equal(a.features, b.features)
+    # ... and the ORACLE's addTemplate (oracle/linemod_oracle.py: the restatement that reproduces the reference golden
+    # writeClasses/06_template.yaml) on the same rendered images gives the same templates: the device selection meets the oracle
+    # directly, not only the product's own host path.  The first views of every configuration (numpy: ~1 s per view).
+    od = lo.OracleDetector(nfeat, T)
+    for i in range(min(len(Rs), ORACLE_VIEWS)):
+        mask = (depth[i] > 0).astype(np.uint8) * 255
+        oid = od.addTemplate([rgb[i], depth[i]], "obj", mask)
+        assert (oid >= 0) == (want_ids[i] >= 0), (i, oid, want_ids[i])
+        if oid < 0:
+            continue
+        got, want = det_a.getTemplates("obj", want_ids[i]), od.class_templates["obj"][oid]
+        assert len(got) == len(want) == 2 * len(T)
+        for a, b in zip(got, want):
+            assert (a.width, a.height, a.pyramid_level) == (b.width, b.height, b.pyramid_level), i
+            assert np.array_equal(a.features, np.asarray(b.features, np.int32).reshape(-1, 3)), i
     if dist < 2000:                                                                        # the forced host selection gives the same bank
         os.environ["LM_TRAIN_HOST"] = "1"
         try:
