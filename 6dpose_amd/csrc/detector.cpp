@@ -125,8 +125,9 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     }
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
-    if (const char* ng = getenv("LM_NO_GRAPH")) d->use_graph = !(ng[0] && ng[0] != '0');
     if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
+    if (knobs().frame_batch > 0) d->batch_max = std::min(knobs().frame_batch, kMaxBatch);
+    if (knobs().batch_queue > 0) d->keep_queued = knobs().batch_queue;
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
@@ -166,8 +167,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
-        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
-        if (sl.graph) (void)hipGraphDestroy(sl.graph);
         if (sl.fe_done) (void)hipEventDestroy(sl.fe_done);
         if (sl.local_done) (void)hipEventDestroy(sl.local_done);
         if (sl.coarse_done) (void)hipEventDestroy(sl.coarse_done);
@@ -317,10 +316,8 @@ static int run_frontend(lm_detector* d, bool build_lm, int arena = 0, bool share
     // ~3 us kernels could overlap.  Instead the jobs that do not depend on each other can share a LAUNCH (k_fe_stage): per
     // level {colour chain, normals + median or their nearest-neighbour pyramid, pyrDown to the next level}, then the linear
     // memories of all levels — 7 -> 3 launches at two levels.  That is what a LONE frame and the training views get (launch
-    // latency is their critical path: synchronous match 0.409 -> 0.390 ms).  With frames in flight the front end is off the
-    // critical path and the shared launches are a loss (0.227 -> 0.250 ms/frame, whatever the stream priorities: the bursts of
-    // mixed-body workgroups slow the refinement running beside them more than seven spaced launches do), so the captured
-    // per-slot graph keeps one launch per job.
+    // latency is their critical path: synchronous match 0.409 -> 0.390 ms).  The matching path (run_frontend_batch) uses the same
+    // shared launches for all frames of a batch; this function serves addTemplate (build_lm = false).
     hipStream_t s = d->stream;
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
@@ -1171,18 +1168,8 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
 }
 
 static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t match_cap) {
-    if (!d->local_blocks) {
-        // Grid of the refinement kernel.  Per-candidate path (LM_TILES=0): 3 workgroups (12 waves) per CU — alone it is as fast as
-        // with every wave slot taken (it is bound by the vector L1, not by latency), and the free slots let the coarse pass of the next
-        // frame and the front end run beside it (pipelined: 0.244 -> 0.222 ms/frame; 2 per CU is slower, 4 crowds the others out).  With tiles the
-        // work items are fewer and larger (a tile = two singles' worth of loads; ~5k items per 2k templates): a grid with more waves
-        // than items gives every wave at most one item and lets the hardware's workgroup dispatch do the balancing — 171 us (3 per CU,
-        // items dealt round-robin, slowest wave 2 tiles + 1 single) -> 122 (8) -> 103 (16 and more), profiles/r02_sweep_local_blocks.txt.
-        d->local_blocks = d->num_cus * (d->use_tiles ? 16 : 3);
-        if (knobs().local_blocks > 0) d->local_blocks = knobs().local_blocks;
-    }
     if (!sl.h_counters)
-        HIP_TRY(hipHostMalloc((void**)&sl.h_counters, (8 + 2 * (size_t)d->local_blocks) * sizeof(unsigned long long), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     if (match_cap > sl.match_cap) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
         sl.h_matches = nullptr; sl.match_cap = 0;
@@ -1195,239 +1182,336 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
     return LM_OK;
 }
 
-// Enqueue the whole device pipeline of the current frame into a free result slot (asynchronous).
-int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
-    if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame / select_frame first");
+static int sync_all_streams(lm_detector* d) {
+    HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
+    if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
+    return LM_OK;
+}
+
+// Grid of the refinement kernel for a batch of nb frames.  Per-candidate path (LM_TILES=0): 3 workgroups (12 waves) per CU — alone it
+// is as fast as with every wave slot taken (it is bound by the vector L1, not by latency), and the free slots let the coarse pass of
+// the next frame and the front end run beside it.  With tiles the work items are fewer and larger (a tile = two singles' worth of
+// loads; ~5k items per 2k templates): a grid with more waves than items gives every wave at most one item and lets the hardware's
+// workgroup dispatch do the balancing — 171 us (3 per CU, items dealt round-robin, slowest wave 2 tiles + 1 single) -> 122 (8) ->
+// 103 (16 and more), profiles/r02_sweep_local_blocks.txt.  A batch has nb times the items: the grid grows with it.
+static int local_grid(lm_detector* d, int nb) {
+    if (knobs().local_blocks > 0) return knobs().local_blocks;
+    return d->num_cus * (d->use_tiles ? 16 : 3) * std::max(1, std::min(nb, 4));
+}
+
+// Front end of a batch: the same three stages a lone frame takes (k_fe_stage: {colour chain, normals + median or their
+// nearest-neighbour pyramid, pyrDown to the next level} per level, then the linear memories of every level), every stage ONE launch
+// that carries the jobs of all frames of the batch.  Frame b keeps its intermediates in level_bufs(b, l) and writes the arenas of its
+// own result slot.  7 launches per frame (round 2's per-slot graph) -> 3 per batch.
+static int run_frontend_batch(lm_detector* d, int first, int nb) {
+    hipStream_t s = d->stream;
+    const int L = d->pyramid_levels;
+    const float thr_sq = d->weak_threshold * d->weak_threshold;
+    int rc;
+    for (int b = 1; b < nb; ++b) {                       // intermediates of the batch's further frames (frame 0: setup_geometry)
+        for (int l = 0; l < L; ++l) {
+            LevelBufs& B = d->level_bufs(b, l);
+            B.W = d->lvl[l].W; B.H = d->lvl[l].H;
+            const size_t n = (size_t)B.W * B.H;
+            if (l > 0 && (rc = B.rgb.ensure(n * 3))) return rc;
+            if ((rc = B.mag.ensure(n))) return rc;
+            if ((rc = B.ang.ensure(n))) return rc;
+            if ((rc = B.nrm.ensure(n))) return rc;
+        }
+        if ((rc = d->nrm_raw_x[b - 1].ensure((size_t)d->fW * d->fH))) return rc;
+    }
+    FeStage st{};
+    auto flush = [&]() { if (st.njobs) launch_fe_stage(st, s); st.njobs = 0; };
+    auto room = [&](int jobs) { if (st.njobs + jobs > kFeMaxJobs) flush(); };
+    for (int l = 0; l < L; ++l) {
+        st.njobs = 0;
+        for (int b = 0; b < nb; ++b) {
+            const lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
+            LevelBufs& B = d->level_bufs(b, l);
+            const uint8_t* src = l == 0 ? sl.in_rgb : B.rgb.p;
+            room(3);
+            fe_job_colour(st.job[st.njobs++], src, B.mag.p, B.ang.p, B.W, B.H, thr_sq);                                          // LL.cpp:367-504
+            if (l == 0) fe_job_normals(st.job[st.njobs++], sl.in_depth, b == 0 ? d->nrm_raw.p : d->nrm_raw_x[b - 1].p, B.nrm.p, B.W, B.H,
+                                       d->distance_threshold, d->difference_threshold);                                          // LL.cpp:729-819
+            else fe_job_nn_down2(st.job[st.njobs++], d->level_bufs(b, l - 1).nrm.p, B.nrm.p, d->level_bufs(b, l - 1).W, d->level_bufs(b, l - 1).H);   // LL.cpp:857-880
+            if (l + 1 < L) fe_job_pyrdown(st.job[st.njobs++], src, d->level_bufs(b, l + 1).rgb.p, B.W, B.H);                     // LL.cpp:557-581
+        }
+        flush();
+    }
+    for (int b = 0; b < nb; ++b) {
+        const int arena = (first + b) % lm_detector::kSlots;
+        const lm_detector::Slot& sl = d->slot[arena];
+        for (int l = 0; l < L; ++l) {
+            LevelBufs& B = d->level_bufs(b, l);
+            const LevelGeom& lv = d->geom.lv[l];
+            const bool strips = l < L - 1;
+            const uint8_t* quant[2] = {B.ang.p, B.nrm.p};
+            const uint8_t* mask[2] = {sl.have_mask[0] ? d->lvl[l].mask[0].p : nullptr, sl.have_mask[1] ? d->lvl[l].mask[1].p : nullptr};
+            uint8_t* lmp[2] = {d->lm_arena[arena].p + lv.lm_off[0], d->lm_arena[arena].p + lv.lm_off[1]};
+            uint8_t* smp[2] = {strips ? d->sm_arena[arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[arena].p + lv.sm_off[1] : nullptr};
+            room(1);
+            fe_job_build_lm(st.job[st.njobs++], quant, mask, lmp, smp, B.W, B.H, lv.T);
+        }
+    }
+    flush();
+    d->last_arena = first;                               // read_stage: the maps of level_bufs(0, .) belong to the batch's first frame
+    HIP_TRY(hipGetLastError());
+    return LM_OK;
+}
+
+// Device pointers of result slot `si` (everything a frame in flight owns).
+static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, FrameSlot* out) {
+    lm_detector::Slot& sl = d->slot[si];
+    const uint32_t cc = d->buf_cand_cap;
+    FrameSlot F{};
+    F.lm_arena = d->lm_arena[si].p; F.sm_arena = d->sm_arena[si].p;
+    F.cands = d->d_cands.p + (size_t)cc * si;
+    F.tiles = tiled ? d->d_tiles.p + (size_t)tile_cap * si : nullptr;
+    F.todo = tiled ? d->d_todo.p + (size_t)cc * si : nullptr;
+    F.counters = d->d_counters.p + (size_t)kCounterWords * si;
+    F.matches_dev = d->d_matches_dev.p + (size_t)cc * si;
+    F.dedupe_table = d->d_hash.p + dedupe_table_slots(cc) * (size_t)si;
+    F.distinct_keys = d->d_distinct_keys.p + (size_t)cc * si;
+    F.final_dev = d->d_final.p + 8 * (size_t)si;
+    HIP_TRY(hipHostGetDevicePointer((void**)&F.matches, sl.h_matches, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&F.distinct, sl.h_distinct, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&F.final_host, sl.h_counters, 0));
+    *out = F;
+    return LM_OK;
+}
+
+// Takes the next result slot for a frame (resident frame or ingest ring entry `ring`) and queues it behind the frames that wait for
+// their batch; nothing is launched here.  The frames of a batch share threshold, work list and buffers, so a change of any of them
+// launches what is waiting first.
+static int slot_begin(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids, const uint8_t* rgb, const uint16_t* depth,
+                      const bool have_mask[2], int ring) {
     if (d->n_submitted - d->n_collected >= (uint64_t)lm_detector::kSlots)
         return lm_set_error(LM_ERR_INVALID, "%d frames already in flight: call lm_detector_collect first", lm_detector::kSlots);
     HIP_TRY(hipSetDevice(d->device));
-    lm_detector::Slot& sl = d->slot[d->n_submitted % lm_detector::kSlots];
     int rc;
     if (d->bank_dirty || d->bank_geom_W != d->fW || d->bank_geom_H != d->fH) {
         if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "bank or frame geometry changed with a frame in flight");
         if ((rc = upload_bank(d))) return rc;
     }
+    {   // the same selection as the frames waiting for their batch?  (build_work replaces the device-resident work list otherwise)
+        std::vector<std::string> key;
+        if (class_ids && num_class_ids > 0)
+            for (int i = 0; i < num_class_ids; ++i) key.push_back(class_ids[i] ? class_ids[i] : "");
+        const bool same = d->work_valid && key == d->work_key && d->work_key_rank == d->shard_rank && d->work_key_world == d->shard_world;
+        if (d->pend_n && (!same || threshold != d->pend_threshold) && (rc = lm_launch_pending(d))) return rc;
+    }
     if ((rc = build_work(d, class_ids, num_class_ids))) return rc;
     const int num_work = (int)d->work_pyr.size();
-    if (d->d_cands.cap < (size_t)d->cand_cap * lm_detector::kSlots || d->d_hash.cap < dedupe_table_slots(d->cand_cap) * lm_detector::kSlots || d->d_matches_dev.cap < (size_t)d->cand_cap * lm_detector::kSlots ||
-        d->d_distinct_keys.cap < (size_t)d->cand_cap * lm_detector::kSlots) {
-        // buffers are about to be replaced (first use, or the candidate capacity was raised): frames still in flight keep
-        // using the old ones until they are done
-        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
-        if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
+    const int K = lm_detector::kSlots;
+    if (d->buf_cand_cap < d->cand_cap) {
+        // first use, or the candidate capacity was raised after an overflow: the per-slot buffers are replaced.  Frames waiting for
+        // their batch are launched, frames in flight finish on the old buffers first.
+        if ((rc = lm_launch_pending(d))) return rc;
+        if ((rc = sync_all_streams(d))) return rc;
+        const uint32_t cc = d->cand_cap;
+        if ((rc = d->d_cands.ensure((size_t)cc * K))) return rc;            // per result slot: coarse(k+1) runs beside local(k)
+        if ((rc = d->d_matches_dev.ensure((size_t)cc * K))) return rc;
+        if ((rc = d->d_hash.ensure(dedupe_table_slots(cc) * K))) return rc;   // one table per result slot
+        if ((rc = d->d_distinct_keys.ensure((size_t)cc * K))) return rc;
+        d->buf_cand_cap = cc;
     }
     if (!d->d_counters.p) {                                                          // per result slot; zero from here on (see k_dedupe)
-        if ((rc = d->d_counters.ensure(8 * lm_detector::kSlots))) return rc;
-        if ((rc = d->d_final.ensure(8 * lm_detector::kSlots))) return rc;
-        HIP_TRY(hipMemset(d->d_counters.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d->d_final.p, 0, 8 * lm_detector::kSlots * sizeof(unsigned long long)));
+        if ((rc = d->d_counters.ensure((size_t)kCounterWords * K))) return rc;
+        if ((rc = d->d_final.ensure(8 * (size_t)K))) return rc;
+        HIP_TRY(hipMemset(d->d_counters.p, 0, (size_t)kCounterWords * K * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d->d_final.p, 0, 8 * (size_t)K * sizeof(unsigned long long)));
     }
-    if ((rc = d->d_cands.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;   // per result slot: coarse(k+1) runs beside local(k)
-    if ((rc = d->d_matches_dev.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
-    if ((rc = d->d_hash.ensure(dedupe_table_slots(d->cand_cap) * lm_detector::kSlots))) return rc;   // one table per result slot
-    if ((rc = d->d_distinct_keys.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
     // tile refinement (match.hip): two-level pyramids with a tileable geometry; the buffers exist per result slot
     const bool tiled = d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
-    const uint32_t tile_cap = d->cand_cap / 2;      // a tile has at least two members
-    if (tiled && (d->d_tiles.cap < (size_t)tile_cap * lm_detector::kSlots || d->d_todo.cap < (size_t)d->cand_cap * lm_detector::kSlots)) {
-        HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
-        if ((rc = d->d_tiles.ensure((size_t)tile_cap * lm_detector::kSlots))) return rc;
-        if ((rc = d->d_todo.ensure((size_t)d->cand_cap * lm_detector::kSlots))) return rc;
+    const uint32_t tile_cap = d->buf_cand_cap / 2;      // a tile has at least two members
+    if (tiled && (d->d_tiles.cap < (size_t)tile_cap * K || d->d_todo.cap < (size_t)d->buf_cand_cap * K)) {
+        if ((rc = lm_launch_pending(d))) return rc;
+        if ((rc = sync_all_streams(d))) return rc;
+        if ((rc = d->d_tiles.ensure((size_t)tile_cap * K))) return rc;
+        if ((rc = d->d_todo.ensure((size_t)d->buf_cand_cap * K))) return rc;
     }
-    if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->cand_cap)))) return rc;
-    hipStream_t s = d->stream, ms = d->mstream;
-    const int arena = (int)(d->n_submitted % lm_detector::kSlots);
-    unsigned long long* counters = d->d_counters.p + 8 * (size_t)arena;
-    unsigned long long* final_dev = d->d_final.p + 8 * (size_t)arena;
-    Candidate* cands = d->d_cands.p + (size_t)d->cand_cap * arena;
-    TileRec* tiles = tiled ? d->d_tiles.p + (size_t)tile_cap * arena : nullptr;
-    uint8_t* todo = tiled ? d->d_todo.p + (size_t)d->cand_cap * arena : nullptr;
-    unsigned long long* hash = d->d_hash.p + dedupe_table_slots(d->cand_cap) * (size_t)arena;
-    Candidate* matches_dev = d->d_matches_dev.p + (size_t)d->cand_cap * arena;
-    ulonglong2* distinct_keys = d->d_distinct_keys.p + (size_t)d->cand_cap * arena;
+    const int si = (int)(d->n_submitted % K);
+    lm_detector::Slot& sl = d->slot[si];
+    if ((rc = ensure_slot_buffers(d, sl, std::max<uint32_t>(sl.match_cap, d->buf_cand_cap)))) return rc;
     sl.t0 = std::chrono::steady_clock::now();
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
-    sl.cand_cap = d->cand_cap; sl.cands = cands;
+    sl.cand_cap = d->buf_cand_cap; sl.cands = d->d_cands.p + (size_t)d->buf_cand_cap * si;
+    sl.in_rgb = rgb; sl.in_depth = depth; sl.have_mask[0] = have_mask[0]; sl.have_mask[1] = have_mask[1]; sl.ring = ring;
+    sl.launched = false; sl.pending = true; sl.leader = -1; sl.batch_n = 0;
+    if (d->pend_n == 0) { d->pend_first = si; d->pend_threshold = threshold; }
+    ++d->pend_n;
+    ++d->n_submitted;
+    return LM_OK;
+}
 
-    Candidate* d_matches = nullptr;
-    unsigned long long* d_hcounters = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void**)&d_hcounters, sl.h_counters, 0));
-    HIP_TRY(hipHostGetDevicePointer((void**)&d_matches, sl.h_matches, 0));
-    Candidate* d_distinct = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void**)&d_distinct, sl.h_distinct, 0));
-    // Two streams: the front end of this frame (on `stream`, into this slot's linear-memory arenas) overlaps the
-    // matching kernels of the previous frame (on `mstream`, reading the other slot's arenas).  The arenas of this
-    // slot are free: its previous frame was collected before this submit (at most kSlots frames are in flight).
-    const bool fe_share_in_pipe = knobs().fe_fused_pipe;   // experiment
-    auto enqueue_fe = [&]() -> int {
-        HIP_TRY(hipEventRecord(sl.ev[0], s));
-        int r = run_frontend(d, true, arena, fe_share_in_pipe);
-        if (r) return r;
-        HIP_TRY(hipEventRecord(sl.ev[1], s));
-        return LM_OK;
-    };
+// Enqueue the whole device pipeline of the frames waiting in slots [pend_first, pend_first + pend_n): ONE front end, coarse pass,
+// refinement and duplicate removal for all of them (asynchronous).
+int lm_launch_pending(lm_detector* d) {
+    const int nb = d->pend_n, first = d->pend_first;
+    if (nb <= 0) return LM_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    d->pend_n = 0;
+    lm_detector::Slot& lead = d->slot[first];
+    const int num_work = lead.num_work;
+    const float threshold = lead.threshold;
+    const bool tiled = d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
+    const uint32_t tile_cap = d->buf_cand_cap / 2;
+    FrameBatch fb{};
+    fb.nb = nb;
+    int rc;
+    for (int b = 0; b < nb; ++b)
+        if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
+    hipStream_t s = d->stream, ms = d->mstream;
+    // the frames' uploads (copy stream) before the front end
+    for (int b = 0; b < nb; ++b) {
+        const int ring = d->slot[(first + b) % lm_detector::kSlots].ring;
+        if (ring >= 0) HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0));
+    }
+    HIP_TRY(hipEventRecord(lead.ev[0], s));
+    if ((rc = run_frontend_batch(d, first, nb))) return rc;
+    HIP_TRY(hipEventRecord(lead.ev[1], s));
+    HIP_TRY(hipEventRecord(lead.fe_done, s));
+    for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
+        const lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
+        if (sl.ring < 0 && d->ingest.stream)
+            for (int r = 0; r < lm_detector::kSlots; ++r)
+                if (d->ingest.d_rgb[r].p && sl.in_rgb == d->ingest.d_rgb[r].p) d->ingest.reader[r] = lead.fe_done;
+    }
+    const uint32_t cap = std::min<uint32_t>(lead.match_cap, d->buf_cand_cap);
     auto enqueue_coarse = [&](hipStream_t st) -> int {
-        HIP_TRY(hipEventRecord(sl.ev[2], st));
-        // the counters are zero on entry (reset by the slot's previous k_dedupe)
-        launch_coarse(d->lm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, cands,
-                      d->cand_cap, counters, tiles, tile_cap, todo, st);
-        HIP_TRY(hipEventRecord(sl.ev[3], st));
+        HIP_TRY(hipEventRecord(lead.ev[2], st));
+        // the counters are zero on entry (reset by the slots' previous k_dedupe)
+        launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
+        HIP_TRY(hipEventRecord(lead.ev[3], st));
         return LM_OK;
     };
     auto enqueue_match = [&]() -> int {
-        HIP_TRY(hipEventRecord(sl.ev[5], ms));
-        // persistent refinement grid; the candidate count is read on the device (no host round trip) and, like the per-block
-        // statistics and the results, stored straight into this slot's pinned host memory; it also empties the hash table
-        // k_dedupe uses
-        // tiles first (the candidates of a template that share most of their windows, accumulated once per tile), then the
-        // candidates no tile serves — both phases of the one persistent kernel
-        launch_local(d->lm_arena[arena].p, d->sm_arena[arena].p, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p,
-                     d->d_work.p, cands, num_work > 0 ? d->cand_cap : 0, threshold, d_matches, matches_dev,
-                     std::min<uint32_t>(sl.match_cap, d->cand_cap), counters, d_hcounters, hash, (uint32_t)dedupe_table_slots(d->cand_cap), todo,
-                     tiles, tile_cap, d->local_blocks, ms);
-        HIP_TRY(hipEventRecord(sl.ev[4], ms));
+        HIP_TRY(hipEventRecord(lead.ev[5], ms));
+        // persistent refinement grid over the tiles and then the remaining candidates of every frame of the batch; the counts are
+        // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
+        // the hash tables k_dedupe uses
+        if (num_work > 0)
+            launch_local(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
+                         (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, local_grid(d, nb), ms);
+        HIP_TRY(hipEventRecord(lead.ev[4], ms));
         return LM_OK;
     };
-    // exact duplicates out (they never survive std::unique): distinct records + counts to this slot's pinned memory
+    // exact duplicates out (they never survive std::unique): distinct records + counts to the slots' pinned memory
     auto enqueue_dedupe = [&](hipStream_t st) -> int {
         if (num_work > 0)
-            launch_dedupe(matches_dev, counters, d->cand_cap, hash, dedupe_table_slots(d->cand_cap), d_distinct, d->d_work_cls.p, d->d_work_tid.p,
-                          distinct_keys, final_dev, d_hcounters, d->num_cus * 2, st);
+            launch_dedupe(fb, d->buf_cand_cap, dedupe_table_slots(d->buf_cand_cap), d->d_work_cls.p, d->d_work_tid.p, d->num_cus * 2, st);
         else
-            HIP_TRY(hipMemsetAsync(final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
+            for (int b = 0; b < nb; ++b) HIP_TRY(hipMemsetAsync(fb.f[b].final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
         return LM_OK;
     };
-    auto capture = [&](hipStream_t st, hipGraph_t& g, hipGraphExec_t& ex, auto&& fn) -> bool {
-        if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
-        if (g) { (void)hipGraphDestroy(g); g = nullptr; }
-        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            int r = fn();
-            hipError_t ee = hipStreamEndCapture(st, &g);
-            ok = (r == LM_OK) && ee == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (!ok) {
-            (void)hipGetLastError();
-            if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
-            if (g) { (void)hipGraphDestroy(g); g = nullptr; }
-        }
-        return ok;
-    };
-    if (d->use_graph) {
-        uint32_t thr_bits;
-        memcpy(&thr_bits, &threshold, 4);
-        const uint64_t key[8] = {thr_bits, (uint64_t)num_work, (uint64_t)(uintptr_t)d->d_work.p, d->cand_cap, sl.match_cap,
-                                 ((uint64_t)d->fW << 32) | (uint32_t)d->fH, (uint64_t)d->have_mask[0] | ((uint64_t)d->have_mask[1] << 1),
-                                 (uint64_t)(uintptr_t)d->d_feat_off.p ^ ((uint64_t)(uintptr_t)d_matches << 1) ^ (uint64_t)(uintptr_t)cands ^
-                                     ((uint64_t)(uintptr_t)matches_dev << 2) ^ ((uint64_t)(uintptr_t)d->lm_arena[arena].p << 3) ^
-                                     ((uint64_t)(uintptr_t)hash << 4) ^ ((uint64_t)(uintptr_t)d_distinct << 5) ^ ((uint64_t)(uintptr_t)distinct_keys << 6) ^ ((uint64_t)(uintptr_t)d->d_work_cls.p << 7) ^ ((uint64_t)(uintptr_t)d->d_work_tid.p << 8) ^ ((uint64_t)(uintptr_t)final_dev << 9) ^ ((uint64_t)(uintptr_t)counters << 10) ^
-                                     ((uint64_t)(uintptr_t)d->cur_rgb << 11) ^ ((uint64_t)(uintptr_t)d->cur_depth << 12) ^ ((uint64_t)(uintptr_t)tiles << 13)};
-        if (!sl.exec || memcmp(key, sl.key, sizeof(key)) != 0) {
-            const bool ok = capture(s, sl.graph, sl.exec, enqueue_fe);      // the front end: seven small kernels, one launch
-            if (ok) memcpy(sl.key, key, sizeof(key));
-            else {   // capture unavailable: fall back to plain launches for good
-                if (sl.exec) { (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
-                if (sl.graph) { (void)hipGraphDestroy(sl.graph); sl.graph = nullptr; }
-                d->use_graph = false;
-            }
-        }
-    }
-    if (d->n_submitted == d->n_collected) {   // a lone frame: three shared launches, not the graph of seven (see run_frontend)
-        HIP_TRY(hipEventRecord(sl.ev[0], s));
-        if ((rc = run_frontend(d, true, arena, true))) return rc;
-        HIP_TRY(hipEventRecord(sl.ev[1], s));
-    } else if (d->use_graph && sl.exec) {
-        HIP_TRY(hipGraphLaunch(sl.exec, s));
-        d->last_arena = arena;
-    } else if ((rc = enqueue_fe())) return rc;
-    // events recorded by graph nodes keep their previous state until the node runs: cross-stream ordering and the
-    // host wait use eagerly recorded events
-    HIP_TRY(hipEventRecord(sl.fe_done, s));
-    // The three matching kernels (plain launches: a graph of so few nodes gains nothing).  Dependent kernels on one queue start
-    // ~15 us apart, and neither the coarse pass of frame k+1 nor the duplicate removal of frame k needs anything the refinement of
-    // the neighbouring frame touches (per-slot candidates, counters, records, hash table).  So with a frame already in flight each
-    // stage has its own stream — coarse(k+1) and dedupe(k) run beside local(k) / local(k+1) — while a lone frame (synchronous call,
-    // on-device pipeline) keeps all three on the matching stream: no extra cross-stream hops on the latency path.
-    if (d->n_submitted != d->n_collected) {
-        HIP_TRY(hipStreamWaitEvent(d->cstream, sl.fe_done, 0));
+    // Dependent kernels on one queue start a few us apart, and neither the coarse pass of batch k+1 nor the duplicate removal of batch
+    // k needs anything the refinement of the neighbouring batch touches (per-slot candidates, counters, records, hash tables).  So
+    // with work already in flight each stage has its own stream — coarse(k+1) and dedupe(k) run beside local(k) / local(k+1) —
+    // while a lone launch (synchronous call, on-device pipeline, the first batch of a stream) keeps all three on the matching
+    // stream: no extra cross-stream hops on the latency path.  Cross-stream ordering and the host wait use eagerly recorded events.
+    if (d->n_launched != d->n_collected) {
+        HIP_TRY(hipStreamWaitEvent(d->cstream, lead.fe_done, 0));
         if ((rc = enqueue_coarse(d->cstream))) return rc;
-        HIP_TRY(hipEventRecord(sl.coarse_done, d->cstream));
-        HIP_TRY(hipStreamWaitEvent(ms, sl.coarse_done, 0));
+        HIP_TRY(hipEventRecord(lead.coarse_done, d->cstream));
+        HIP_TRY(hipStreamWaitEvent(ms, lead.coarse_done, 0));
         if ((rc = enqueue_match())) return rc;
-        HIP_TRY(hipEventRecord(sl.local_done, ms));
-        HIP_TRY(hipStreamWaitEvent(d->xchg.stream, sl.local_done, 0));
+        HIP_TRY(hipEventRecord(lead.local_done, ms));
+        HIP_TRY(hipStreamWaitEvent(d->xchg.stream, lead.local_done, 0));
         if ((rc = enqueue_dedupe(d->xchg.stream))) return rc;
-        HIP_TRY(hipEventRecord(sl.done, d->xchg.stream));
+        HIP_TRY(hipEventRecord(lead.done, d->xchg.stream));
     } else {
-        HIP_TRY(hipStreamWaitEvent(ms, sl.fe_done, 0));
+        HIP_TRY(hipStreamWaitEvent(ms, lead.fe_done, 0));
         if ((rc = enqueue_coarse(ms))) return rc;
         if ((rc = enqueue_match())) return rc;
         if ((rc = enqueue_dedupe(ms))) return rc;
-        HIP_TRY(hipEventRecord(sl.done, ms));
+        HIP_TRY(hipEventRecord(lead.done, ms));
     }
-    sl.t1 = std::chrono::steady_clock::now();
-    sl.pending = true;
-    ++d->n_submitted;
+    const auto now = std::chrono::steady_clock::now();
+    for (int b = 0; b < nb; ++b) {
+        lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
+        sl.launched = true; sl.leader = first; sl.batch_n = nb; sl.t1 = now;
+    }
+    d->queued.emplace_back(d->n_launched, first);
+    d->n_launched += (uint64_t)nb;
     return LM_OK;
+}
+
+// Batches launched and not yet finished on the GPU (an event query per finished batch, none in the steady state of a full queue).
+static int batches_queued(lm_detector* d) {
+    while (!d->queued.empty() && hipEventQuery(d->slot[d->queued.front().second].done) == hipSuccess) d->queued.erase(d->queued.begin());
+    (void)hipGetLastError();                                  // hipErrorNotReady is not an error
+    return (int)d->queued.size();
+}
+
+// The detector's current frame (lm_detector_set_frame / select_frame, or the frame a previous submit_frame left current) as a
+// batch of one, launched at once.
+int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids) {
+    if (!d->frame_valid) return lm_set_error(LM_ERR_INVALID, "no frame resident: call lm_detector_set_frame / select_frame first");
+    int rc;
+    if ((rc = lm_launch_pending(d))) return rc;               // frames waiting for their batch go first (results come back in order)
+    if ((rc = slot_begin(d, threshold, class_ids, num_class_ids, d->cur_rgb, d->cur_depth, d->have_mask, -1))) return rc;
+    return lm_launch_pending(d);
 }
 
 // Wait for the oldest frame in flight and turn its records into lm_match.  Returns 1 when a buffer
 // overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
     if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
-    lm_detector::Slot& sl = d->slot[d->n_collected % lm_detector::kSlots];
+    const int slot_index = (int)(d->n_collected % lm_detector::kSlots);
+    lm_detector::Slot& sl = d->slot[slot_index];
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(sl.done));
+    if (!sl.launched) {                                 // still waiting for its batch to fill: launch what is there
+        int rc = lm_launch_pending(d);
+        if (rc) return rc;
+    }
+    lm_detector::Slot& lead = d->slot[sl.leader];       // the events are those of the batch's first slot
+    HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
     sl.pending = false;
-    {
-        const int slot_index = (int)(d->n_collected % lm_detector::kSlots);
-        if (d->xchg.state[slot_index] != 0) {          // exchange work of this frame may still read the slot's buffers
-            HIP_TRY(hipStreamSynchronize(d->xchg.stream));
-            d->xchg.state[slot_index] = 0;
-        }
+    while (!d->queued.empty() && d->queued.front().first <= d->n_collected) d->queued.erase(d->queued.begin());   // this frame's batch and everything before it are done
+    if (d->xchg.state[slot_index] != 0) {               // exchange work of this frame may still read the slot's buffers
+        HIP_TRY(hipStreamSynchronize(d->xchg.stream));
+        d->xchg.state[slot_index] = 0;
     }
     ++d->n_collected;
     HIP_TRY(hipGetLastError());
-    const uint64_t ncand = sl.h_counters[0];
+    // published by the last block of the frame's k_dedupe: candidates, distinct, alive, key overflow, tiles, evaluations, bytes
+    const unsigned long long* hc = sl.h_counters;
+    const uint64_t ncand = sl.num_work > 0 ? hc[0] : 0;
     if (ncand > 0xFFFFFFF0ull) return lm_set_error(LM_ERR_INVALID, "too many coarse candidates (%llu)", (unsigned long long)ncand);
     if (ncand > sl.cand_cap || ncand > sl.match_cap) {   // never drop silently: grow, caller reruns the frame
         d->cand_cap = std::max<uint32_t>(d->cand_cap, (uint32_t)(ncand + ncand / 4 + 1024));
-        d->ingest.used[(d->n_collected - 1) % lm_detector::kSlots] = false;
+        d->ingest.used[slot_index] = false;
         return 1;
     }
     lm_timings tm{};
     tm.h2d_ms = sl.h2d_ms; tm.templates = sl.num_work; tm.coarse_bytes = sl.coarse_bytes;
-    {
-        const int r = (int)((d->n_collected - 1) % lm_detector::kSlots);
-        if (d->ingest.used[r]) {   // streamed frame: its H2D ran on the copy stream
-            d->ingest.used[r] = false;
-            float h = 0.f;
-            if (hipEventElapsedTime(&h, d->ingest.t0[r], d->ingest.t1[r]) == hipSuccess) tm.h2d_ms = h;
-        }
+    if (d->ingest.used[slot_index]) {   // streamed frame: its H2D ran on the copy stream
+        d->ingest.used[slot_index] = false;
+        float h = 0.f;
+        if (hipEventElapsedTime(&h, d->ingest.t0[slot_index], d->ingest.t1[slot_index]) == hipSuccess) tm.h2d_ms = h;
     }
-    uint64_t evals = 0, lbytes = 0, nm = 0;
-    for (int b = 0; b < d->local_blocks; ++b) { evals += sl.h_counters[8 + 2 * b]; lbytes += sl.h_counters[8 + 2 * b + 1]; }
+    const uint64_t evals = sl.num_work > 0 ? hc[5] : 0, lbytes = sl.num_work > 0 ? hc[6] : 0;
+    uint64_t nm = 0;
     const Candidate* hm = sl.h_matches;
-    if (sort_unique == 0 || sl.num_work == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
-    else nm = sl.h_counters[2];                        // counted on the device by k_dedupe: no pass over the raw records
+    if (sl.num_work == 0) nm = 0;
+    else if (sort_unique == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
+    else nm = hc[2];                                   // counted on the device by k_dedupe: no pass over the raw records
     tm.coarse_candidates = (int64_t)ncand;
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;
     tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
-    if (hipEventElapsedTime(&tm.frontend_ms, sl.ev[0], sl.ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&tm.coarse_ms, sl.ev[2], sl.ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, sl.ev[5], sl.ev[4]) != hipSuccess ||
-        hipEventElapsedTime(&tm.total_ms, sl.ev[0], sl.ev[4]) != hipSuccess) {
+    tm.batch_frames = sl.batch_n;
+    if (hipEventElapsedTime(&tm.frontend_ms, lead.ev[0], lead.ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, lead.ev[2], lead.ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, lead.ev[5], lead.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.total_ms, lead.ev[0], lead.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
-        if (d->use_graph && d->graph_events_ok) {   // event nodes of a graph are not timeable here: time with plain launches
-            d->graph_events_ok = false;
-            d->use_graph = false;
-        }
         tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;
     }
+    // the stage times are those of the LAUNCHES, which serve batch_frames frames: per frame = time / batch_frames
     if (sort_unique < 0) {                            // pipeline mode: the records stay on the device
         d->timings = tm;
         if (out) *out = nullptr;
@@ -1487,7 +1571,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         return LM_OK;
     }
     const bool use_distinct = sort_unique != 0 && sl.num_work > 0;
-    const uint64_t nd = use_distinct ? sl.h_counters[1] : 0;
+    const uint64_t nd = use_distinct ? hc[1] : 0;
     if (use_distinct && (nd > ncand || nd > nm || nm > ncand))
         return lm_set_error(LM_ERR_HIP, "duplicate removal out of step with the refinement (%llu distinct of %llu alive, %llu candidates)",
                             (unsigned long long)nd, (unsigned long long)nm, (unsigned long long)ncand);
@@ -1601,19 +1685,50 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     uint8_t* st = (uint8_t*)g.pinned[r];
     if (rgb != st) memcpy(st, rgb, n * 3);                        // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
     if ((const uint8_t*)depth != st + n * 3) memcpy(st + n * 3, depth, n * 2);
+    if (g.reader[r]) {                                            // a resident re-match of the entry's previous frame may still read it (another slot's front end)
+        HIP_TRY(hipStreamWaitEvent(g.stream, g.reader[r], 0));
+        g.reader[r] = nullptr;
+    }
     HIP_TRY(hipEventRecord(g.t0[r], g.stream));
     HIP_TRY(hipMemcpyAsync(g.d_rgb[r].p, st, n * 3, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(g.d_depth[r].p, st + n * 3, n * 2, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipEventRecord(g.t1[r], g.stream));
-    HIP_TRY(hipStreamWaitEvent(d->stream, g.t1[r], 0));           // the front end starts when the frame has arrived
+    HIP_TRY(hipEventRecord(g.t1[r], g.stream));                   // the batch's front end waits for it (lm_launch_pending)
     d->cur_rgb = g.d_rgb[r].p; d->cur_depth = g.d_depth[r].p;
     d->have_mask[0] = d->have_mask[1] = false;
     d->last_h2d_ms = 0.f;
     d->frame_valid = true;
     const uint64_t before = d->n_submitted;
-    rc = lm_submit_frame(d, threshold, class_ids, num_class_ids);
-    if (rc == LM_OK && d->n_submitted == before + 1) g.used[r] = true;
-    return rc;
+    rc = slot_begin(d, threshold, class_ids, num_class_ids, g.d_rgb[r].p, g.d_depth[r].p, d->have_mask, r);
+    if (rc) return rc;
+    if (d->n_submitted == before + 1) g.used[r] = true;
+    // Launched at once while the GPU has fewer than keep_queued batches queued (it must never wait for a batch to fill: the first
+    // frames of a stream go out alone), otherwise when batch_max frames are waiting; lm_detector_flush / lm_detector_collect launch a
+    // partial batch.  So the batches are as large as the GPU's backlog allows and no larger.
+    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || batches_queued(d) < d->keep_queued) return lm_launch_pending(d);
+    return LM_OK;
+}
+
+extern "C" int lm_detector_flush(lm_detector* d) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    return lm_launch_pending(d);
+}
+
+extern "C" int lm_detector_set_batch(lm_detector* d, int frames) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    if (frames < 1 || frames > kMaxBatch) return lm_set_error(LM_ERR_INVALID, "frames per launch must be in [1, %d]", kMaxBatch);
+    int rc = lm_launch_pending(d);
+    if (rc) return rc;
+    d->batch_max = frames;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_get_batch(const lm_detector* d) { return d ? d->batch_max : 0; }
+
+extern "C" int lm_detector_set_batch_queue(lm_detector* d, int batches) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    if (batches < 0 || batches > lm_detector::kSlots) return lm_set_error(LM_ERR_INVALID, "batches queued on the GPU must be in [0, %d]", lm_detector::kSlots);
+    d->keep_queued = batches;
+    return LM_OK;
 }
 
 extern "C" int lm_detector_collect(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {

@@ -73,13 +73,16 @@ struct lm_detector {
     const uint8_t* cur_rgb = nullptr;           // what the front end reads: frame_rgb / frame_depth, or — for a frame that came in through
     const uint16_t* cur_depth = nullptr;        // lm_detector_submit_frame — the ingest ring's device buffers (no device-to-device copy)
     DevBuf<uint8_t> nrm_raw;                    // normals before the median (level 0)
-    static constexpr int kSlots = 8;            // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight): every one owns
-                                                // its arenas, candidate / record buffers and pinned result memory (~25 MB at VGA)
+    static constexpr int kSlots = 16;           // frames in flight (lm_detector_submit / collect; lm_detector_max_in_flight): every one owns
+                                                // its arenas, candidate / record buffers and pinned result memory (~35 MB at VGA)
     DevBuf<uint8_t> lm_arena[kSlots], sm_arena[kSlots];   // linear memories per result slot: the front end of frame k+1 writes one set
                                                 // while the matching kernels of frame k read the other
     int last_arena = 0;                         // set written by the most recent front end (lm_detector_read_stage)
 
-    LevelBufs lvl[kMaxLevels];
+    LevelBufs lvl[kMaxLevels];                  // front-end intermediates of frame 0 of a batch (and of addTemplate, read_stage)
+    LevelBufs lvl_x[kMaxBatch - 1][kMaxLevels]; // ... of frames 1.. of a batch (allocated on first use)
+    DevBuf<uint8_t> nrm_raw_x[kMaxBatch - 1];
+    LevelBufs& level_bufs(int b, int l) { return b == 0 ? lvl[l] : lvl_x[b - 1][l]; }
     FrameGeom geom{};
     size_t lm_block_bytes[kMaxLevels] = {};
     std::vector<DevBuf<uint8_t>> slot_rgb;      // frames parked in HBM (lm_detector_store_frame)
@@ -117,9 +120,10 @@ struct lm_detector {
     bool reference_order = false;                   // lm_detector_set_reference_order / LM_REFERENCE_ORDER=1: match() returns the reference's own permutation (sort_unique 3)
     DevBuf<ulonglong2> d_distinct_keys;             // the distinct records as 128-bit sort keys, per result slot (multi-GPU exchange)
     DevBuf<int32_t> d_work_cls, d_work_tid;         // class position / template id per work item
-    DevBuf<unsigned long long> d_counters;          // working counters per result slot: zero between frames (k_dedupe's last block resets them)
+    DevBuf<unsigned long long> d_counters;          // kCounterWords working counters per result slot: zero between frames (k_dedupe's last block resets them)
     DevBuf<unsigned long long> d_final;             // per result slot: [0] candidates, [1] distinct, [2] alive, [3] key overflow of the finished frame
-    uint32_t cand_cap = 1u << 18;
+    uint32_t cand_cap = 1u << 18;                   // candidate capacity wanted (raised when a frame overflowed)
+    uint32_t buf_cand_cap = 0;                      // ... the per-slot device buffers are laid out for (frames in flight use this one)
     // Result slots: the refinement kernel of a later frame writes into one pinned buffer while the host
     // collects an earlier frame from another (lm_detector_submit / lm_detector_collect).
     struct Slot {
@@ -127,11 +131,16 @@ struct lm_detector {
         Candidate* h_distinct = nullptr;            // pinned: the same without exact duplicates (k_dedupe), unordered
         uint32_t match_cap = 0;
         unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [1] distinct records, [2] records alive, [8..] 2 words of statistics per refinement block
-        hipGraph_t graph = nullptr;                 // front end (on `stream`), captured once per configuration
-        hipGraphExec_t exec = nullptr;
-        uint64_t key[8] = {};
-        hipEvent_t ev[6] = {};                      // stage timing (recorded inside the graphs): front end 0-1, coarse 2-3 (on `stream`), refinement 5-4 (on `mstream`)
-        hipEvent_t done = nullptr;                  // recorded eagerly after the launch: the only event the host waits on
+        // A BATCH of consecutive slots is launched together (one front end / coarse / refinement / duplicate-removal launch for all
+        // its frames); the events below are those of the batch's first slot (`leader`).
+        int leader = -1, batch_n = 1;               // first slot of the batch this frame was launched with, frames in that batch
+        bool launched = false;                      // false: submitted but still waiting for its batch to fill (lm_detector_flush / collect launch it)
+        const uint8_t* in_rgb = nullptr;            // the frame the front end reads: the detector's resident frame or the slot's ingest ring entry
+        const uint16_t* in_depth = nullptr;
+        bool have_mask[2] = {false, false};         // lone frames only (Detector.match with masks)
+        int ring = -1;                              // ingest ring entry holding the frame (-1: resident frame)
+        hipEvent_t ev[6] = {};                      // stage timing: front end 0-1, coarse 2-3, refinement 5-4
+        hipEvent_t done = nullptr;                  // recorded after the batch's last kernel: the only event the host waits on
         hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
         hipEvent_t coarse_done = nullptr;           // coarse pass of this slot finished (eager, on `cstream`): `mstream` waits for it
         hipEvent_t local_done = nullptr;            // refinement of this slot finished (eager, on `mstream`): the exchange stream (duplicate removal) waits for it
@@ -144,7 +153,16 @@ struct lm_detector {
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
-    uint64_t n_submitted = 0, n_collected = 0;
+    uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
+    // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
+    int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)
+    int pend_first = 0, pend_n = 0;
+    float pend_threshold = 0.f;
+    // Launched batches the GPU may still be working on, oldest first: (index of the batch's first frame, its leader slot).  A streamed
+    // frame is launched at once while fewer than `keep_queued` batches are queued on the GPU — the GPU never waits for a batch to
+    // fill — and joins the waiting batch otherwise: batches grow to batch_max exactly when the GPU is the bottleneck.
+    std::vector<std::pair<uint64_t, int>> queued;
+    int keep_queued = 2;                            // LM_BATCH_QUEUE
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's
     // pinned buffer (or written there by the caller: lm_detector_ingest_buffer), copied to the entry's device buffers on a
@@ -158,6 +176,7 @@ struct lm_detector {
         DevBuf<uint16_t> d_depth[kSlots];
         hipEvent_t t0[kSlots] = {}, t1[kSlots] = {};   // timing of the H2D (copy stream)
         bool used[kSlots] = {};                        // the slot's frame came in through the ring (lm_timings.h2d_ms from t0/t1)
+        hipEvent_t reader[kSlots] = {};                // front end (of another slot: a resident re-match of the streamed frame) that still reads the entry
     } ingest;
 
     // multi-GPU exchange on the device (exchange.cpp): its own stream, so that the sort of frame k's records, the caller's
@@ -184,9 +203,7 @@ struct lm_detector {
         DevBuf<int32_t> bbox, out;
     } train;
 
-    bool use_graph = true;
-    bool fe_fused = true;            // independent front-end jobs share a launch (k_fe_stage); LM_FE_FUSED=0: one launch per job
-    bool graph_events_ok = true;
+    bool fe_fused = true;            // addTemplate's front end: independent jobs share a launch (k_fe_stage); LM_FE_FUSED=0: one launch per job
 
     lm_timings timings{};
 };
@@ -195,3 +212,4 @@ struct lm_detector {
 // detector.cpp
 int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids);
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out);   // sort_unique < 0: discard the records
+int lm_launch_pending(lm_detector* d);                                                  // launches the frames waiting for their batch to fill

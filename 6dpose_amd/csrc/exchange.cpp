@@ -49,11 +49,12 @@ extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int c
     if (rc) return rc;
     const int slot = (int)((d->n_submitted - 1) % lm_detector::kSlots);            // the frame just submitted
     if (d->xchg.state[slot] != 0) return lm_set_error(LM_ERR_INVALID, "the frame in flight was packed already");
+    if ((rc = lm_launch_pending(d))) return rc;                                     // the exchange follows the frame's kernels in stream order: no waiting for a batch to fill
     lm_detector::Slot& sl = d->slot[slot];
     hipStream_t xs = d->xchg.stream;
-    HIP_TRY(hipStreamWaitEvent(xs, sl.done, 0));                                    // records + counters of this frame are final
+    HIP_TRY(hipStreamWaitEvent(xs, d->slot[sl.leader].done, 0));                    // records + counters of this frame (of its batch) are final
     if ((rc = d->xchg.d_runs.ensure(kXchgMaxCapacity))) return rc;
-    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->cand_cap,
+    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->buf_cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->buf_cand_cap,
                          (uint32_t)capacity, d->xchg.d_runs.p, (uint32_t*)send_block, xs);
     HIP_TRY(hipGetLastError());
     d->xchg.state[slot] = 1;

@@ -29,7 +29,7 @@ struct FeJob {
     float f;                              // colour: weak threshold squared
     LmJob lm[2];                          // build_lm: [0] colour, [1] normals
 };
-constexpr int kFeMaxJobs = 8;             // = kMaxLevels (the last stage builds the linear memories of every level)
+constexpr int kFeMaxJobs = 24;            // 3 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
 struct FeStage { int njobs; FeJob job[kFeMaxJobs]; };
 void fe_job_colour(FeJob& j, const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq);
 void fe_job_normals(FeJob& j, const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr);
@@ -80,26 +80,54 @@ struct TileRec {
 // k_coarse reserves both)
 constexpr int kCandBits = 40;
 constexpr unsigned long long kCandMask = (1ull << kCandBits) - 1ull;
+// ---- frames per launch --------------------------------------------------------------------------------------------------
+// A 2k-template shard does not fill the chip: k_coarse runs at twice, k_local at 1.3x the per-unit cost they reach on a 16k bank
+// (launch / drain latency, one partial wave of workgroups).  In stream mode the matching kernels therefore serve a BATCH of up
+// to kMaxBatch consecutive frames per launch: every frame of the batch owns its arenas, candidate / record buffers, counters and
+// hash table (the per-slot buffers of detector.cpp), the kernels index them by blockIdx.y (k_coarse, k_dedupe) or through the
+// flat work-item index (k_local).  A lone frame is a batch of one.
+constexpr int kMaxBatch = 8;
+constexpr int kCounterWords = 64;             // working counters per result slot: [0] candidates | tiles << kCandBits (k_coarse), [1] distinct,
+                                              // [2] alive, [3] key overflow, [7] block ticket of k_dedupe, [8 + 2 s], [9 + 2 s]: 16x16 evaluations /
+                                              // their algorithmic bytes of the refinement, shard s = block & (kStatShards - 1)
+constexpr int kStatShards = 16;
+struct FrameSlot {                            // device pointers of ONE frame of a batch
+    const uint8_t* lm_arena;                  // linear memories (flat) of the frame
+    const uint8_t* sm_arena;                  // strip-major copy (levels below the top)
+    Candidate* cands;                         // [cand_cap] coarse candidates
+    TileRec* tiles;                           // [tile_cap] or null
+    uint8_t* todo;                            // [cand_cap] or null
+    unsigned long long* counters;             // [kCounterWords] working counters, zero between frames
+    Candidate* matches;                       // [cap] refined records, pinned host memory
+    Candidate* matches_dev;                   // [cap] the same in HBM (on-device NMS, duplicate removal)
+    unsigned long long* dedupe_table;         // open-addressing table of k_dedupe
+    Candidate* distinct;                      // [cap] records without exact duplicates, pinned host memory
+    ulonglong2* distinct_keys;                // the same as 128-bit exchange keys (HBM), may be null
+    unsigned long long* final_dev;            // [8] published counts of the finished frame (HBM): candidates, distinct, alive, key overflow
+    unsigned long long* final_host;           // [8] the same in pinned host memory + [4] tiles, [5] evaluations, [6] algorithmic bytes
+};
+struct FrameBatch {
+    int nb;                                   // frames in this launch (1 .. kMaxBatch)
+    int pad;
+    FrameSlot f[kMaxBatch];
+};
+
 bool tile_plan_possible(const FrameGeom& g);
 size_t coarse_plan_lds_bytes(int Wd, int Hd);
-// counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with `tiles` (and a geometry
-// tile_plan_possible accepts) also counters[0] >> kCandBits = number of tiles, todo[slot] = 1 for the candidates no tile serves.
-void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                   const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, TileRec* tiles /*may be null: no tiles*/, uint32_t tile_cap, uint8_t* todo /*[cap]*/, hipStream_t s);
-// Persistent grid: waves stride over the tiles, then over min(counters[0], cand_cap) candidates (counts read on the device).
-// matches[ci] = refined candidate ci (work = -1: dropped); block_stats (pinned host memory): [0] = candidate count,
-// [8+2*b], [8+2*b+1] = 16x16 evaluations / their algorithmic bytes of block b.
+// Per frame of the batch: counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with tiles
+// (and a geometry tile_plan_possible accepts) also counters[0] >> kCandBits = number of tiles, todo[slot] = 1 for the candidates
+// no tile serves.  Grid (workgroups of templates, frames).
+void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                   const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t tile_cap, hipStream_t s);
+// Persistent grid: waves stride over the tiles of all frames of the batch, then over their candidates (counts read on the device).
+// matches[ci] = refined candidate ci (work = -1: dropped).  Also empties the part of every frame's hash table k_dedupe will use.
 struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
     uint32_t sbase;       // byte offset of the feature's (label, phase) plane inside the strip arena
     uint32_t cell;        // lx | ly << 16   (x / T, y / T)
 };
-void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
-                  const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy, const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
-                  unsigned long long* block_stats, unsigned long long* dedupe_table /*may be null*/, uint32_t dedupe_cap_slots,
-                  const uint8_t* todo /*with tiles: only candidates with todo[ci] != 0 are refined one by one*/,
-                  const TileRec* tiles /*may be null*/, uint32_t tile_cap, int grid_blocks, hipStream_t s);
+void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const FeatStrip* feat_strip,
+                  const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
+                  uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s);
 // slots of k_dedupe's open-addressing table used for n records (power of two, >= 2n, <= cap_slots = dedupe_table_slots(cand_cap)):
 // k_local empties exactly these, k_dedupe hashes into exactly these
 __host__ __device__ inline uint32_t dedupe_slots_for(uint32_t n, uint32_t cap_slots) {
@@ -126,14 +154,12 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
                      const int32_t* view_wh /*[views][2] box override, -1 = template size, may be null*/, int num_views, int top_k,
                      double iou_thresh, void* scratch, TopkSel* sel, int32_t* nsel_status, hipStream_t s);
 size_t topk_nms_scratch_bytes(uint32_t cap);
-// Exact-duplicate removal of the refined records of a frame (nms.hip): counters[0] = candidate slots (from launch_coarse),
-// counters[1] / [2] receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.
-// counters: the frame's working counters ([0] candidates from k_coarse, [1] distinct, [2] alive, [3] key overflow, [7] block ticket).
-// The last block to finish publishes them — final_dev[0..3] (HBM: on-device NMS, exchange) and final_host[1..3] (pinned) — and zeroes
-// the working set for the slot's next frame, so that no memset / copy node surrounds the matching kernels.
-void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys /*HBM: exchange keys of the distinct records, may be null*/,
-                   unsigned long long* final_dev, unsigned long long* final_host, int blocks, hipStream_t s);
+// Exact-duplicate removal of the refined records of every frame of a batch (nms.hip), grid (blocks, frames): counters[1] / [2]
+// receive the distinct / alive counts; `distinct` (pinned host memory) the surviving records, unordered.  The last block of a frame
+// to finish publishes its counts — final_dev[0..3] (HBM: on-device NMS, exchange) and final_host[0..6] (pinned) — and zeroes the
+// frame's working counters for the slot's next frame, so that no memset / copy node surrounds the matching kernels.
+void launch_dedupe(const FrameBatch& fb, uint32_t cap, size_t table_slots, const int32_t* work_cls, const int32_t* work_tid, int blocks,
+                   hipStream_t s);
 size_t dedupe_table_slots(uint32_t cap);
 
 // ---- template extraction on the device (train.hip; LL.cpp:589-643, 888-966, 279-318) ----

@@ -124,11 +124,16 @@ static __device__ __forceinline__ int wave_excl_scan(int mine, int lane, int& to
 // kMaxTilesPerTemplate x 4 words of tile records | the first kPlanHits hit positions; then 4 words per template + 4 for the
 // group's scan.
 __global__ void __launch_bounds__(1024)
-k_coarse(const uint8_t* __restrict__ lm_arena, LevelGeom lv, int level, int levels,
+k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-         const int32_t* __restrict__ work_pyramids, int num_work, int wpt, float threshold, Candidate* __restrict__ cands, uint32_t cap,
-         unsigned long long* __restrict__ counters, TilePlanGeom plan, TileRec* __restrict__ tiles, uint8_t* __restrict__ todo) {
+         const int32_t* __restrict__ work_pyramids, int num_work, int wpt, float threshold, uint32_t cap, TilePlanGeom plan) {
     extern __shared__ uint32_t s_dyn[];
+    const FrameSlot& F = fb.f[blockIdx.y];                        // the frame of the batch this workgroup serves
+    const uint8_t* __restrict__ lm_arena = F.lm_arena;
+    Candidate* __restrict__ cands = F.cands;
+    unsigned long long* __restrict__ counters = F.counters;
+    TileRec* __restrict__ tiles = F.tiles;
+    uint8_t* __restrict__ todo = F.todo;
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler must know it: the
                                                                                          // template's entry and feature offsets then come through SMEM into SGPRs
@@ -422,10 +427,11 @@ size_t coarse_plan_lds_bytes(int Wd, int Hd) {                 // per template o
     return (npos + nw + 4 * (size_t)kMaxTilesPerTemplate + kPlanHits) * sizeof(uint32_t);   // scores | hit bitmap | tile records | hit list
 }
 
-void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                   const int32_t* work_pyramids, int num_work, float threshold, Candidate* cands, uint32_t cap,
-                   unsigned long long* counters, TileRec* tiles, uint32_t tile_cap, uint8_t* todo, hipStream_t s) {
-    if (num_work <= 0) return;
+void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                   const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t tile_cap, hipStream_t s) {
+    if (num_work <= 0 || fb.nb <= 0) return;
+    const TileRec* tiles = fb.f[0].tiles;                      // tiles are planned for all frames of a batch or for none
+    const uint8_t* todo = fb.f[0].todo;
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
     int npos = lv.Wd * lv.Hd;
@@ -450,8 +456,8 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
         group = std::max(1, std::min(std::min(4, std::max(1, max_group)), std::min(16 / waves, (int)((64 * 1024 - 256) / per))));
         lds = per * group + (4 * (size_t)group + 4) * sizeof(uint32_t);
     }
-    hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group), dim3(group * waves * 64), lds, s, lm_arena, lv, level, g.levels, entries,
-                       feat_off, work_pyramids, num_work, waves, threshold, cands, cap, counters, plan, tiles, todo);
+    hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group, fb.nb), dim3(group * waves * 64), lds, s, fb, lv, level, g.levels, entries,
+                       feat_off, work_pyramids, num_work, waves, threshold, cap, plan);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,34 +477,46 @@ void launch_coarse(const uint8_t* lm_arena, const FrameGeom& g, const TemplEntry
 // ---------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256)
-k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_arena, FrameGeom g,
-        const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
+k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
         const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
-        const int32_t* __restrict__ work_pyramids, const Candidate* __restrict__ cands, uint32_t cand_cap,
-        float threshold, Candidate* __restrict__ matches, Candidate* __restrict__ matches_dev, uint32_t cap,
-        const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ block_stats,
-        unsigned long long* __restrict__ dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* __restrict__ todo,
-        const TileRec* __restrict__ tiles, uint32_t tile_cap, int dbg) {
+        const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
+        uint32_t dedupe_cap_slots, uint32_t tile_cap, int dbg) {
     // What bounds it (profiles/r02_pmc_tiles.txt, r02_local_experiments.txt): the vector L1.  Per CU 139k cycles of accesses +
     // 56k cycles stalled on pending misses of the 247k the kernel lasts (round 1: 345k + 37k of 363k) — every 128-byte line is
     // used by exactly one load instruction, so a third of the accesses miss.  Tried and measured WORSE: four waves sharing an
     // item through LDS (119 us: 104 VGPRs), 16 loads in flight per wave (123 us: 99 VGPRs) — occupancy matters more than the
     // length of a wave's chain of load batches —, tiles and singles on different workgroups (117 us: any alternation in the
     // workgroup index aliases with the round-robin over XCDs / shader engines) or on different waves of a workgroup (121 us).
-    // Tiles alone take 72 us, singles alone 58 us, an empty launch of this grid 11 us (LM_LOCAL_DBG = 1 / 2 / 3).
-    __shared__ unsigned long long s_stats[4][2];
+    // Tiles alone take 72 us, singles alone 58 us, an empty launch of this grid 11 us (make DIAG=1, LM_LOCAL_DBG = 1 / 2 / 3).
+    //
+    // Work items of a BATCH of frames: the tiles of frame 0, 1, ... then the candidates of frame 0, 1, ...; s_tend / s_cend hold
+    // the running ends, so a flat item index resolves to (frame, index) with at most nb comparisons (wave-uniform).
+    __shared__ unsigned long long s_acc[kMaxBatch][2];            // per frame: 16x16 evaluations of this block, their algorithmic bytes
+    __shared__ uint32_t s_tend[kMaxBatch + 1], s_cend[kMaxBatch + 1];
     const int lane = threadIdx.x & 63;
-    const uint32_t wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const unsigned long long packed = counters[0];
-    unsigned long long nc = packed & kCandMask;
-    const uint32_t num_cands = nc < cand_cap ? (uint32_t)nc : cand_cap;
-    unsigned long long evals = 0, bytes = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) block_stats[0] = nc;   // candidate count for the host (pinned memory)
-    // the part of k_dedupe's hash table this frame will use, emptied here (k_dedupe runs next on the stream): no memset node
-    if (dedupe_table) {
-        const uint32_t tsize = dedupe_slots_for(num_cands, dedupe_cap_slots);
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) dedupe_table[i] = ~0ull;
+    const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // wave-uniform, and the
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);                                       // compiler must know it: item -> frame -> the frame's pointers stay in SGPRs
+    const int nb = fb.nb;
+    const bool tiled = fb.f[0].tiles != nullptr && !(dbg & 2);
+    if (threadIdx.x == 0) {
+        uint32_t te = 0, ce = 0;
+        s_tend[0] = 0; s_cend[0] = 0;
+        for (int f = 0; f < nb; ++f) {
+            const unsigned long long packed = fb.f[f].counters[0];
+            const unsigned long long nc = packed & kCandMask, nt = packed >> kCandBits;
+            ce += nc < cand_cap ? (uint32_t)nc : cand_cap;
+            te += !tiled ? 0u : (nt < tile_cap ? (uint32_t)nt : tile_cap);
+            s_tend[f + 1] = te; s_cend[f + 1] = ce;
+            s_acc[f][0] = 0; s_acc[f][1] = 0;
+        }
+    }
+    __syncthreads();
+    // the part of k_dedupe's hash table every frame will use, emptied here (k_dedupe runs next on the stream): no memset node
+    for (int f = 0; f < nb; ++f) {
+        unsigned long long* table = fb.f[f].dedupe_table;
+        if (!table) continue;
+        const uint32_t tsize = dedupe_slots_for(s_cend[f + 1] - s_cend[f], dedupe_cap_slots);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) table[i] = ~0ull;
     }
 
     // ---- Tile refinement: the candidates of one template whose coarse cells are neighbours have level-0 windows kTileStep
@@ -508,13 +526,18 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
     // like everywhere else ({own strip, next strip's lane r} shifted by the run's byte phase) into u16 sums of tile columns
     // [16 q, 16 q + 16); every member then takes the first strict maximum of its own 16 x 16 window of those sums — the same
     // integers, the same tie-break (packed key) and the same float expression as the per-candidate path below.
-    if (tiles && !(dbg & 2)) {
-        const unsigned long long nt64 = packed >> kCandBits;
-        const uint32_t ntiles = nt64 < tile_cap ? (uint32_t)nt64 : tile_cap;
+    if (tiled) {
+        const uint32_t ntiles = s_tend[nb];
         const LevelGeom lv = g.lv[0];
         const int T = lv.T, Hd = lv.Hd, offset = T / 2 + (T % 2 - 1);
-        for (uint32_t ti = wave0; ti < ntiles; ti += nwaves) {
-            const TileRec t = tiles[ti];
+        int fr = 0;
+        for (uint32_t gi = wave0; gi < ntiles; gi += nwaves) {
+            while (gi >= (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr + 1])) ++fr;           // wave-uniform: item -> frame
+            const FrameSlot& F = fb.f[fr];
+            const uint8_t* __restrict__ sm_arena = F.sm_arena;
+            Candidate* __restrict__ matches = F.matches;
+            Candidate* __restrict__ matches_dev = F.matches_dev;
+            const TileRec t = F.tiles[gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr])];
             const int work = __builtin_amdgcn_readfirstlane(t.work);
             const uint32_t gxy = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.gxy);
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask);
@@ -597,6 +620,11 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             // members, in slot order
             uint32_t rest = mask;
             int member = 0;
+            if (lane == 0) {
+                const unsigned long long nmem = (unsigned long long)__popc(mask);
+                atomicAdd(&s_acc[fr][0], nmem);
+                atomicAdd(&s_acc[fr][1], nmem * 256ull * (unsigned long long)nf);          // algorithmic response bytes: 256 per feature and member
+            }
             while (rest) {
                 const int bit = __ffs((int)rest) - 1;
                 rest &= rest - 1;
@@ -628,8 +656,6 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
                 }
                 const uint32_t slot = slot_base + (uint32_t)member;
                 ++member;
-                ++evals;
-                bytes += 256ull * nf;
                 if (lane == 0 && slot < cap) {
                     Candidate m;
                     m.x = (gx0 + i * kTileStep + bc) * T + offset;              // LL.cpp:1930-1931: x / T - 8 = the member's window origin
@@ -643,9 +669,19 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
         }
     }
 
-    for (uint32_t ci = wave0; ci < num_cands && !(dbg & 1); ci += nwaves) {
-        if (todo && !todo[ci]) continue;                     // a tile member: refined above (wave-uniform)
-        const Candidate cd = cands[ci];
+    const uint32_t num_cands = s_cend[nb];
+    int fr = 0;
+    for (uint32_t gi = wave0; gi < num_cands && !(dbg & 1); gi += nwaves) {
+        while (gi >= (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[fr + 1])) ++fr;               // wave-uniform: item -> frame
+        const FrameSlot& F = fb.f[fr];
+        const uint32_t ci = gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[fr]);
+        if (tiled && !F.todo[ci]) continue;                  // a tile member: refined above (wave-uniform)
+        const uint8_t* __restrict__ lm_arena = F.lm_arena;
+        const uint8_t* __restrict__ sm_arena = F.sm_arena;
+        Candidate* __restrict__ matches = F.matches;
+        Candidate* __restrict__ matches_dev = F.matches_dev;
+        const Candidate cd = F.cands[ci];
+        unsigned long long evals = 0, bytes = 0;
         const int work = __builtin_amdgcn_readfirstlane(cd.work);
         const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
         int mx = __builtin_amdgcn_readfirstlane(cd.x), my = __builtin_amdgcn_readfirstlane(cd.y);
@@ -791,33 +827,28 @@ k_local(const uint8_t* __restrict__ lm_arena, const uint8_t* __restrict__ sm_are
             matches[ci] = m;
             matches_dev[ci] = m;                 // HBM copy for the on-device NMS / top-K (pipeline.cpp)
         }
+        if (lane == 0) { atomicAdd(&s_acc[fr][0], evals); atomicAdd(&s_acc[fr][1], bytes); }
     }
-    // per-block statistics (16x16 evaluations, their algorithmic bytes): plain stores, summed on the host
-    if (lane == 0) { s_stats[threadIdx.x >> 6][0] = evals; s_stats[threadIdx.x >> 6][1] = bytes; }
+    // statistics (16x16 evaluations, their algorithmic bytes) per frame: summed per block in LDS, then one pair of atomics per
+    // block and frame it worked on into the frame's sharded counters (k_dedupe's last block publishes the totals)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long a = 0, b = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_stats[w][0]; b += s_stats[w][1]; }
-        block_stats[8 + 2 * blockIdx.x] = a;
-        block_stats[8 + 2 * blockIdx.x + 1] = b;
+    if ((int)threadIdx.x < nb && s_acc[threadIdx.x][0] != 0) {
+        unsigned long long* st = fb.f[threadIdx.x].counters + 8 + 2 * (blockIdx.x & (kStatShards - 1));
+        atomicAdd(st, s_acc[threadIdx.x][0]);
+        atomicAdd(st + 1, s_acc[threadIdx.x][1]);
     }
 }
 
-void launch_local(const uint8_t* lm_arena, const uint8_t* sm_arena, const FrameGeom& g, const TemplEntry* entries,
-                  const int32_t* feat_off, const FeatStrip* feat_strip, const uint32_t* feat_xy,
-                  const int32_t* work_pyramids, const Candidate* cands, uint32_t cand_cap,
-                  float threshold, Candidate* matches, Candidate* matches_dev, uint32_t cap, const unsigned long long* counters,
-                  unsigned long long* block_stats, unsigned long long* dedupe_table, uint32_t dedupe_cap_slots, const uint8_t* todo,
-                  const TileRec* tiles, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
-    if (grid_blocks <= 0) return;
-    if (!(tiles && todo && tile_plan_possible(g))) { tiles = nullptr; todo = nullptr; }      // same decision as launch_coarse
+void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const FeatStrip* feat_strip,
+                  const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
+                  uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
+    if (grid_blocks <= 0 || fb.nb <= 0) return;
     int dbg = 0;
 #ifdef LM_DIAG
     dbg = knobs().local_dbg;                                    // timing experiments (wrong results): 1 = tiles only, 2 = singles only
 #endif
-    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, lm_arena, sm_arena, g, entries, feat_off, feat_strip,
-                       feat_xy, work_pyramids, cands, cand_cap, threshold, matches, matches_dev, cap, counters, block_stats,
-                       dedupe_table, dedupe_cap_slots, todo, tiles, tile_cap, dbg);
+    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, fb, g, entries, feat_off, feat_strip, feat_xy, work_pyramids, cand_cap,
+                       threshold, cap, dedupe_cap_slots, tile_cap, dbg);
 }
 
 }  // namespace lm

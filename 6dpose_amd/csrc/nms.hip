@@ -276,10 +276,16 @@ void launch_topk_nms(const Candidate* matches_dev, const unsigned long long* cou
 // survivors to `distinct` (pinned host memory) and, as sort keys, to `distinct_keys` (HBM; exchange.hip).  counters[1] = distinct
 // records, counters[2] = records alive before, counters[3] != 0: a record does not fit the key.
 __global__ void __launch_bounds__(256)
-k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__ counters, uint32_t cap,
-         unsigned long long* __restrict__ table, uint32_t table_mask /*allocated slots - 1*/, Candidate* __restrict__ distinct,
-         const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid, ulonglong2* __restrict__ distinct_keys,
-         unsigned long long* __restrict__ final_dev, unsigned long long* __restrict__ final_host) {
+k_dedupe(FrameBatch fb, uint32_t cap, uint32_t table_mask /*allocated slots - 1*/, const int32_t* __restrict__ work_cls,
+         const int32_t* __restrict__ work_tid) {
+    const FrameSlot& F = fb.f[blockIdx.y];                                           // grid (blocks, frames of the batch)
+    const Candidate* __restrict__ matches = F.matches_dev;
+    unsigned long long* __restrict__ counters = F.counters;
+    unsigned long long* __restrict__ table = F.dedupe_table;
+    Candidate* __restrict__ distinct = F.distinct;
+    ulonglong2* __restrict__ distinct_keys = F.distinct_keys;
+    unsigned long long* __restrict__ final_dev = F.final_dev;
+    unsigned long long* __restrict__ final_host = F.final_host;
     __shared__ bool s_last;
     const unsigned long long nc = counters[0] & kCandMask;                           // low bits: candidates; above: tiles (k_coarse)
     const uint32_t n = (uint32_t)(nc < cap ? nc : cap);
@@ -336,18 +342,20 @@ k_dedupe(const Candidate* __restrict__ matches, unsigned long long* __restrict__
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         const unsigned long long nd = atomicAdd(&counters[1], 0ull), na = atomicAdd(&counters[2], 0ull), bad = atomicAdd(&counters[3], 0ull);
+        unsigned long long evals = 0, lbytes = 0;                                                        // the refinement's sharded statistics
+        for (int q = 0; q < kStatShards; ++q) { evals += atomicAdd(&counters[8 + 2 * q], 0ull); lbytes += atomicAdd(&counters[9 + 2 * q], 0ull); }
         final_dev[0] = nc; final_dev[1] = nd; final_dev[2] = na; final_dev[3] = bad;
-        final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
+        final_host[0] = nc; final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
         final_host[4] = atomicAdd(&counters[0], 0ull) >> kCandBits;                                       // tiles planned by k_coarse
-        for (int q = 0; q < 8; ++q) counters[q] = 0;
+        final_host[5] = evals; final_host[6] = lbytes;
+        for (int q = 0; q < kCounterWords; ++q) counters[q] = 0;
     }
 }
 
-void launch_dedupe(const Candidate* matches_dev, unsigned long long* counters, uint32_t cap, unsigned long long* table, size_t table_slots,
-                   Candidate* distinct, const int32_t* work_cls, const int32_t* work_tid, ulonglong2* distinct_keys,
-                   unsigned long long* final_dev, unsigned long long* final_host, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_dedupe, dim3(blocks), dim3(256), 0, s, matches_dev, counters, cap, table, (uint32_t)(table_slots - 1), distinct, work_cls, work_tid,
-                       distinct_keys, final_dev, final_host);
+void launch_dedupe(const FrameBatch& fb, uint32_t cap, size_t table_slots, const int32_t* work_cls, const int32_t* work_tid, int blocks,
+                   hipStream_t s) {
+    if (fb.nb <= 0 || blocks <= 0) return;
+    hipLaunchKernelGGL(k_dedupe, dim3(blocks, fb.nb), dim3(256), 0, s, fb, cap, (uint32_t)(table_slots - 1), work_cls, work_tid);
 }
 
 size_t dedupe_table_slots(uint32_t cap) {

@@ -260,7 +260,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         }
         HIP_TRY(hipEventRecord(p->e1, s));
         const int slot = (int)((d->n_submitted - 1) % lm_detector::kSlots);          // the frame just submitted
-        launch_topk_nms(d->d_matches_dev.p + (size_t)d->cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->cand_cap, d->d_work.p, d->d_work_cls.p, d->d_work_tid.p, d->d_entries.p,
+        launch_topk_nms(d->d_matches_dev.p + (size_t)d->buf_cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->buf_cand_cap, d->d_work.p, d->d_work_cls.p, d->d_work_tid.p, d->d_entries.p,
                         d->pyramid_levels, p->d_class_base, p->d_view_wh, p->num_views, top_k, nms_iou, p->d_scratch, p->d_sel, p->d_nsel, s);
         launch_icp_bind(p->d_sel, p->d_nsel, p->d_class_base, p->d_view_K, p->d_view_valid, p->num_views, c->d_in, c->d_st, top_k, s);
         HIP_TRY(hipEventRecord(p->e2, s));

@@ -57,7 +57,7 @@ class Timings(ctypes.Structure):
                 ("matches_pre_unique", ctypes.c_int64), ("templates", ctypes.c_int64),
                 ("coarse_bytes", ctypes.c_int64), ("local_bytes", ctypes.c_int64),
                 ("host_submit_ms", ctypes.c_float), ("host_wait_ms", ctypes.c_float),
-                ("host_collect_ms", ctypes.c_float), ("host_merge_ms", ctypes.c_float)]
+                ("host_collect_ms", ctypes.c_float), ("host_merge_ms", ctypes.c_float), ("batch_frames", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -160,6 +160,11 @@ def load_library():
     lib.lm_detector_submit_frame.argtypes = [P, P, P, I, I, F, ctypes.POINTER(S), I]
     lib.lm_detector_ingest_buffer.argtypes = [P, I, I, ctypes.POINTER(P), ctypes.POINTER(P)]
     lib.lm_detector_max_in_flight.restype = I
+    lib.lm_detector_flush.argtypes = [P]
+    lib.lm_detector_set_batch.argtypes = [P, I]
+    lib.lm_detector_get_batch.argtypes = [P]
+    lib.lm_detector_get_batch.restype = I
+    lib.lm_detector_set_batch_queue.argtypes = [P, I]
     lib.lm_detector_set_reference_order.argtypes = [P, I]
     lib.lm_exchange_max_capacity.restype = I
     lib.lm_detector_exchange_stream.argtypes = [P]
@@ -445,7 +450,8 @@ class Detector:
 
     def submitFrame(self, sources, threshold: float, class_ids: Sequence[str] = ()) -> None:
         """Live-stream ingest (lm_detector_submit_frame): hands a NEW host frame to the detector and returns as soon as its
-        upload (pinned ring, copy stream), front end and matching are enqueued; collect() returns the results in submission
+        upload (pinned ring, copy stream) is enqueued; front end and matching are launched for getBatch() consecutive frames at
+        a time (or at flush() / the collect() that needs them); collect() returns the results in submission
         order.  Up to lm_detector_max_in_flight() frames in flight.  `sources` are borrowed only during the call; arrays
         obtained from ingestBuffers() skip the staging copy."""
         rgb, depth = _as_rgb(sources[0]), _as_depth(sources[1])
@@ -453,6 +459,22 @@ class Detector:
             raise RuntimeError("rgb and depth sizes differ")
         carr, n, _names = self._class_args(class_ids)
         _check(self._lib.lm_detector_submit_frame(self._h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], float(threshold), carr, n))
+
+    def flush(self) -> None:
+        """Launches the streamed frames that are still waiting for their batch to fill (lm_detector_flush); collect() does it by itself."""
+        _check(self._lib.lm_detector_flush(self._h))
+
+    def setBatch(self, frames: int) -> None:
+        """Frames per kernel launch in stream mode, 1..8 (lm_detector_set_batch; default 4 or LM_FRAME_BATCH).  Results do not depend on it."""
+        _check(self._lib.lm_detector_set_batch(self._h, int(frames)))
+
+    def setBatchQueue(self, batches: int) -> None:
+        """Streamed frames are launched at once while fewer than `batches` launched batches are unfinished on the GPU (default 2);
+        0 = always wait for a full batch (deterministic batch sizes: tests, kernel measurements)."""
+        _check(self._lib.lm_detector_set_batch_queue(self._h, int(batches)))
+
+    def getBatch(self) -> int:
+        return int(self._lib.lm_detector_get_batch(self._h))
 
     def ingestBuffers(self, width: int, height: int):
         """(rgb uint8 HxWx3, depth uint16 HxW) views of the pinned staging memory the NEXT submitFrame() will upload from

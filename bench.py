@@ -58,10 +58,10 @@ STRONG_OBJECTS = 8            # --scaling strong: configs[3], 8 objects x 2000 t
 THRESHOLD = 75.0
 N_FRAMES = 16                 # distinct host frames in the pool the stream cycles through
 N_PARKED = 4                  # frames parked in HBM for the resident legs (roofline, extras)
-PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "0"))   # frames in flight (<= lm_detector_max_in_flight() = 8): upload, front end, coarse pass, refinement, duplicate removal of
-                                                              # neighbouring frames side by side while the host collects the oldest.  Steady state: 0.216 ms/frame at 3, 0.187 at
-                                                              # 4, 0.178 at 6, 0.177 at 8; the timed region starts and ends with an empty pipeline, and filling / draining a deeper
-                                                              # one costs more, so the default (0) is 4 for runs of fewer than 100 steps and 6 above
+PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "0"))   # frames in flight (<= lm_detector_max_in_flight() = 16): upload, front end, coarse pass, refinement, duplicate removal of
+                                                              # neighbouring BATCHES of frames side by side while the host collects the oldest frame.  Default (0): two batches
+                                                              # (lm_detector_get_batch() = 4 frames share their kernel launches) for short runs, three above 100 steps; the timed
+                                                              # region starts and ends with an empty pipeline, and filling / draining a deeper one costs more
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0         # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 LDS_PEAK_GBS = 150000.0       # ibid. "LDS": ~150 TB/s aggregate for ds_read_b64/b128
@@ -106,15 +106,16 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("LM_BENCH_SCALING", "weak"),
                     help="N>1: weak = one object x --templates per GPU (configs[1] scaled up); strong = a fixed bank of 8 objects x "
                          "--templates (configs[3]) split over the GPUs.  N=1 --scaling strong runs that 16k bank on one GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch in stream mode (lm_detector_set_batch, 1..8; 0 = the library's default, 4)")
+    ap.add_argument("--batch-queue", type=int, default=2, help="launched batches kept queued on the GPU before frames wait for a full batch (lm_detector_set_batch_queue)")
+    ap.add_argument("--roofline-only", action="store_true", help="set-up + the roofline leg only (the command profiled under rocprofv3: every k_local / "
+                                                                 "k_coarse launch of the run then is one of the measured launches, bar the set-up probe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the GPU-vs-oracle comparison of frames 0 and 1 before timing (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extras legs (resident replay, ICP, pipeline, thresholds, 16k bank)")
     ap.add_argument("--exchange", choices=["auto", "host", "device"], default="auto",
                     help="multi-GPU exchange of the match records: on the device (sharded.DeviceExchange; auto = when world > 1) or through the host")
     args = ap.parse_args()
-    global PIPELINE_DEPTH
-    if PIPELINE_DEPTH <= 0:
-        PIPELINE_DEPTH = 4 if args.steps < 100 else 6
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
@@ -148,6 +149,12 @@ def main():
     my_objs = list(range(rank * n_obj // world, (rank + 1) * n_obj // world)) if by_class else list(range(n_obj))
 
     det = lm.Detector(NFEAT[0], T_LEVELS, device=local_rank)
+    if args.batch > 0:
+        det.setBatch(args.batch)
+    BATCH = det.getBatch()
+    global PIPELINE_DEPTH
+    if PIPELINE_DEPTH <= 0:
+        PIPELINE_DEPTH = min(lm.load_library().lm_detector_max_in_flight(), BATCH * (2 if args.steps < 100 else 3))
     frames = noisy_frames(N_FRAMES)
     for k in range(N_PARKED):
         det.storeFrame(k, frames[k])
@@ -200,7 +207,7 @@ def main():
 
     host_t = {"submit": 0.0, "collect": 0.0, "gather": 0.0, "merge": 0.0}
     keys = ("frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "h2d_ms", "total_ms", "coarse_candidates", "local_evals",
-            "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")
+            "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms", "batch_frames")
     acc = {k: 0.0 for k in keys}
     last = {"n": 0}
 
@@ -289,7 +296,7 @@ def main():
         # the timed region (3 slots x ~0.5 ms at the driver's --steps 20 --warmup 5)
         key = "resident" if resident else "live"
         if not primed[key]:
-            run(8, resident)
+            run(lm.load_library().lm_detector_max_in_flight(), resident)
             primed[key] = True
         run(warmup, resident)
         fence()
@@ -307,18 +314,35 @@ def main():
             dt = float(tt.item())
         return dt
 
-    # The roofline leg: frames one at a time, so that every kernel runs alone (in the pipelined region below the coarse pass of
-    # frame k+1 and the duplicate removal of frame k-1 share the GPU with the refinement of frame k, which stretches each
-    # kernel's own duration while shortening the frame).  HIP events on the kernels' stream, recorded by the library.
-    excl = {"coarse_ms": 0.0, "local_ms": 0.0, "coarse_bytes": 0.0, "local_bytes": 0.0}
+    # The roofline leg: ONE batch of frames at a time (submit BATCH host frames -> one front end / k_coarse / k_local / k_dedupe launch
+    # for all of them -> collect them), so that every kernel runs alone on the GPU: in the pipelined region below the coarse pass
+    # of batch k+1 and the duplicate removal of batch k-1 share the GPU with the refinement of batch k, which stretches each
+    # kernel's own duration while shortening the frame.  These are the same launches (same grid, same frames per launch) as
+    # in the timed region.  HIP events on the kernels' streams, recorded by the library around each launch.
+    excl = {"coarse_ms": 0.0, "local_ms": 0.0, "coarse_bytes": 0.0, "local_bytes": 0.0, "frontend_ms": 0.0}
     EXCL = 20
-    for k in range(3 + EXCL):
-        det.selectFrame(k % N_PARKED)
-        det.matchResident(THRESHOLD, classes, sort_unique=False, distinct=True)
-        if k >= 3:
-            tm = det.lastTimings()
-            for q in excl:
-                excl[q] += tm[q] / EXCL
+    det.setBatchQueue(0)                                  # full batches only in this leg (the stream's default launches early while the GPU's queue is short)
+    for rep in range(3 + EXCL):
+        for b in range(BATCH):
+            det.submitFrame(frames[(rep * BATCH + b) % N_FRAMES], THRESHOLD, classes)
+        for b in range(BATCH):
+            det.collect(sort_unique=False, distinct=True)
+            if rep >= 3:
+                tm = det.lastTimings()
+                assert tm["batch_frames"] == BATCH, tm
+                for q in ("coarse_bytes", "local_bytes"):             # algorithmic bytes: per frame -> summed over the launch
+                    excl[q] += tm[q] / EXCL
+                if b == 0:                                              # the stage times are per launch (identical for the frames of a batch)
+                    for q in ("coarse_ms", "local_ms", "frontend_ms"):
+                        excl[q] += tm[q] / EXCL
+    det.setBatchQueue(args.batch_queue)
+    if args.roofline_only:
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps({"roofline_leg": excl, "frames_per_launch": BATCH, "launches": EXCL}))
+            sys.stdout.flush()
+        return
 
     K = max(1, args.steps)
     dt = timed(args.steps, args.warmup)              # THE timed region: a new host frame per step, H2D included
@@ -364,23 +388,25 @@ def main():
                        "parallelism": ("bank-shard x%d (%s) + all-gather" % (world, "by object" if by_class else "by template range")),
                        "ranks_observed": (dist.get_world_size() if use_dist else 1), "backend": (backend if use_dist else None),
                        "exchange": exchange_mode, "exchange_capacity": (ex.capacity if ex is not None else None),
-                       "pipeline_depth": PIPELINE_DEPTH,
+                       "pipeline_depth": PIPELINE_DEPTH, "frames_per_launch_max": BATCH, "batches_kept_queued": args.batch_queue,
+                       "frames_per_launch_mean_timed": mean["batch_frames"],
                        "setup_before_warmup": "8 frames through the ingest ring (each of the library's 8 result slots allocates its pinned staging "
                                               "buffer and instantiates its hipGraph on first use); the timed region starts and ends with an empty pipeline, "
                                               "so at K = 20 it carries one frame latency (~0.45 ms) of fill and drain",
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
-            "stages_ms": {k: mean[k] for k in ("h2d_ms", "frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
+            "stages_ms": dict({k: mean[k] for k in ("h2d_ms", "frontend_ms", "coarse_ms", "local_ms", "d2h_ms", "total_ms")},
+                              note="device time per LAUNCH in the pipelined region; a launch serves frames_per_launch = %d frames (h2d_ms: per frame)" % BATCH),
             "host_wall_ms": dict(host_mean, **{q: mean[q] for q in ("host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms")}),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms, "frames_per_launch": BATCH,
                          "convention": "ALGORITHMIC bytes (SURVEY 8d: one byte per response read the reference performs) per launch / kernel time, "
                                        "against the HBM peak as BASELINE.json's metric asks.  The linear memories are cache-resident, so this is not "
                                        "physical HBM traffic (see `traffic`); the ceilings that physically bound the kernel are below",
                          "vs_cache_ceilings": {"l2_peak_GBps": L2_PEAK_GBS, "frac_of_l2": achieved / L2_PEAK_GBS,
                                                "lds_peak_GBps": LDS_PEAK_GBS, "frac_of_lds": achieved / LDS_PEAK_GBS},
-                         "duration_source": "HIP events around the kernel on its stream, %d frames submitted one at a time inside bench.py (the kernel alone on the GPU)" % EXCL,
+                         "duration_source": "HIP events around the kernel on its stream, %d launches of %d frames each, one launch set at a time inside bench.py (the kernel alone on the GPU)" % (EXCL, BATCH),
                          "in_pipelined_region": {"kernel_ms": kpipe, "GBps": gbps(kbytes, kpipe),
                                                  "note": "same launches in the timed region, sharing the GPU with the next frame's coarse pass and front end; "
                                                          "frame-level: (coarse + local algorithmic bytes) / ms_per_step = %.0f GB/s"

@@ -68,6 +68,8 @@ typedef struct lm_timings {
     float host_wait_ms;    /* host wall time blocked in the stream synchronisation            */
     float host_collect_ms; /* host wall time: read-back bookkeeping + record conversion       */
     float host_merge_ms;   /* host wall time: canonical sort + unique (0 when not requested)  */
+    int32_t batch_frames;  /* frames served by the launches the stage times above belong to (1 for a lone frame;
+                            * lm_detector_submit_frame batches): per-frame device time = stage time / batch_frames */
 } lm_timings;
 
 const char *lm_last_error(void);
@@ -187,7 +189,7 @@ int lm_detector_match_resident(lm_detector *d, float threshold, const char *cons
                                int sort_unique, lm_match **out, size_t *n);
 /* Pipelined stream mode: lm_detector_submit enqueues front end + matching of the current
  * frame and returns; lm_detector_collect waits for the OLDEST submitted frame and returns its matches.
- * Up to lm_detector_max_in_flight() (eight) frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
+ * Up to lm_detector_max_in_flight() (sixteen) frames may be in flight: the front end of frame k+2 and the matching kernels of frame k+1 run on two
  * streams while the host sorts frame k:
  *   select_frame(k+2); submit(); collect() -> frame k; ...
  * lm_detector_match_resident == submit + collect. */
@@ -212,10 +214,23 @@ int lm_detector_set_reference_order(lm_detector *d, int on);
  * Zero-copy variant: lm_detector_ingest_buffer returns the pinned staging pointers the NEXT lm_detector_submit_frame will
  * use (a camera driver / decoder writes the frame there); passing exactly these pointers skips the staging copy.
  * No masks (the reference's callers pass masks=[]).  The frame size may change only with no frame in flight
- * (LM_ERR_INVALID otherwise).  After LM_ERR_OVERFLOW from collect, submit that frame again. */
+ * (LM_ERR_INVALID otherwise).  After LM_ERR_OVERFLOW from collect, submit that frame again.
+ *
+ * Frames per launch: a 2k-template bank does not fill the chip, so consecutive streamed frames share their kernel launches —
+ * the frame's upload starts at once, its front end / coarse pass / refinement / duplicate removal are launched together with
+ * those of the following frames once lm_detector_get_batch() (default 4, LM_FRAME_BATCH, lm_detector_set_batch 1..8) frames
+ * with the same threshold and class list are waiting, or when lm_detector_flush or a lm_detector_collect that needs one of them
+ * is called — or at once while the GPU has fewer than lm_detector_set_batch_queue (default 2, LM_BATCH_QUEUE; 0 = always wait for
+ * a full batch) launched batches still to finish: the GPU never idles waiting for a batch to fill, the first frames of a stream go
+ * out alone, and batches grow to the maximum exactly when the GPU is the bottleneck.  Results are unchanged and still come back per frame, in order; lm_timings.batch_frames says how many frames the
+ * reported launches served.  set_batch(1) restores one launch set per frame (lowest latency). */
 int lm_detector_submit_frame(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, int width, int height,
                              float threshold, const char *const *class_ids, int num_class_ids);
 int lm_detector_ingest_buffer(lm_detector *d, int width, int height, uint8_t **rgb, uint16_t **depth);
+int lm_detector_flush(lm_detector *d);            /* launch the streamed frames that are waiting for their batch to fill */
+int lm_detector_set_batch(lm_detector *d, int frames);
+int lm_detector_get_batch(const lm_detector *d);
+int lm_detector_set_batch_queue(lm_detector *d, int batches);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity

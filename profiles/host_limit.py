@@ -34,5 +34,7 @@ def loop(mode, depth, steps=200, warm=20):
     run(warm)
     t0 = time.perf_counter(); run(steps); return (time.perf_counter() - t0) / steps * 1e3
 
-for depth in (3, 4):
-    print("depth", depth, " ".join("%s %.4f" % (m, loop(m, depth)) for m in ("pageable", "pinned", "pinned_nosort", "resident", "resident_nosort")))
+for batch in [int(b) for b in os.environ.get("BATCHES", "4").split(",")]:
+    det.setBatch(batch)
+    for depth in [int(x) for x in os.environ.get("DEPTHS", "8,12,16").split(",")]:
+        print("batch", batch, "depth", depth, " ".join("%s %.4f" % (m, loop(m, depth)) for m in os.environ.get("MODES", "pageable,pinned,pinned_nosort").split(",")), flush=True)

@@ -615,6 +615,44 @@ def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
     assert det.matchArray(list(frames[6]), 70.0, ["o"]).tobytes() == want[6].tobytes()
     with pytest.raises(RuntimeError):
         det.submitFrame((frames[0][0], frames[0][1][:100]), 70.0, ["o"])
+    # (6) frames per launch: the streamed frames of a batch share ONE front end / coarse / refinement / duplicate-removal launch
+    # (lm_detector_set_batch); per frame the records, the candidate count and the evaluation count are those of the synchronous
+    # call whatever the batch size, also when a batch is cut short by flush(), by collect(), by the end of the slot ring, by a
+    # change of threshold or of the class list
+    stats = []
+    for f in frames:
+        det.matchArray(list(f), 70.0, ["o"])
+        tm = det.lastTimings()
+        assert tm["batch_frames"] == 1
+        stats.append((tm["coarse_candidates"], tm["local_evals"], tm["local_bytes"], tm["matches_pre_unique"]))
+    want65 = [det.matchArray(list(f), 65.0, ["o"]) for f in frames[:3]]
+    det.addClassPacked("p", *synth.make_planted_bank(72, 40, [(p[0], p[1]) for p in pyr], T, nfeat))
+    want_po = [det.matchArray(list(f), 70.0, ["p", "o"]) for f in frames[:3]]
+    assert det.getBatch() == 4
+    for nbatch in (1, 2, 3, 4, 5, 8, 4):
+        det.setBatch(nbatch)
+        det.setBatchQueue(0 if nbatch != 4 else 2)                 # 0: full batches only (deterministic sizes); 2 = default: early launches while the GPU's queue is short
+        seen = set()
+        for k, f in enumerate(frames):
+            det.submitFrame(f, 70.0, ["o"])
+            if k == 8:
+                det.flush()
+        for k in range(n_frames):
+            assert det.collect().tobytes() == want[k].tobytes(), (nbatch, k)
+            tm = det.lastTimings()
+            assert (tm["coarse_candidates"], tm["local_evals"], tm["local_bytes"], tm["matches_pre_unique"]) == stats[k], (nbatch, k)
+            assert 1 <= tm["batch_frames"] <= nbatch
+            seen.add(tm["batch_frames"])
+        assert nbatch in seen or nbatch == 4, (nbatch, seen)
+        # threshold and class list change inside what would be one batch
+        det.submitFrame(frames[0], 70.0, ["o"]); det.submitFrame(frames[1], 65.0, ["o"]); det.submitFrame(frames[2], 65.0, ["o"])
+        det.submitFrame(frames[0], 70.0, ["p", "o"]); det.submitFrame(frames[1], 70.0, ["p", "o"]); det.submitFrame(frames[2], 70.0, ["o"])
+        exp = [want[0], want65[1], want65[2], want_po[0], want_po[1], want[2]]
+        for k, e in enumerate(exp):
+            assert det.collect().tobytes() == e.tobytes(), (nbatch, "mixed", k)
+    with pytest.raises(RuntimeError):
+        det.setBatch(9)
+    det.setBatch(4)
 
 
 def test_config1_size_2k_templates_bit_exact(lm):
