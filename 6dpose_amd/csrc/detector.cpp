@@ -29,6 +29,8 @@ int lm_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* lm_last_error(void) { return g_err.c_str(); }
+static void collector_main(lm_detector* d);
+static void collector_stop(lm_detector* d);
 extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
 extern "C" int lm_device_count(void) {
     int n = 0;
@@ -128,6 +130,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
     if (knobs().frame_batch > 0) d->batch_max = std::min(knobs().frame_batch, kMaxBatch);
     if (knobs().batch_queue > 0) d->keep_queued = knobs().batch_queue;
+    if (const char* ac = getenv("LM_ASYNC_COLLECT")) d->async_collect = ac[0] && ac[0] != '0';
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
@@ -144,6 +147,9 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
 extern "C" void lm_detector_destroy(lm_detector* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    (void)lm_launch_pending(d);
+    collector_stop(d);
+    for (auto& sl : d->slot) { free(sl.prep); sl.prep = nullptr; }
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
     if (d->cstream) (void)hipStreamSynchronize(d->cstream);
@@ -159,7 +165,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
-    d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_strip.release(); d->d_work.release();
+    d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_word.release(); d->d_run_mask.release(); d->d_work.release();
     d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_tiles.release(); d->d_todo.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (int l = 0; l < kMaxLevels; ++l) { d->train.mask[l].release(); d->train.lab[l].release(); d->train.hrun[l].release(); }
     d->train.keys.release(); d->train.counts.release(); d->train.bbox.release(); d->train.out.release();
@@ -771,7 +777,7 @@ static int upload_bank(lm_detector* d) {
     d->work_valid = false;
     std::vector<int32_t> off;
     std::vector<uint32_t> xy;
-    std::vector<FeatStrip> strip;
+    std::vector<uint32_t> word, rmask;          // levels below the top: feat_word per feature, run_mask per 8 features (lm_kernels.h)
     const uint32_t pad_xy = 0x80008000u;   // x = y = -32768: never inside an image
     int flat = 0;
     for (auto& kv : d->class_templates) {
@@ -794,7 +800,7 @@ static int upload_bank(lm_detector* d) {
                 if (tp[2 * l + 1].width != e.width || tp[2 * l + 1].height != e.height)
                     return lm_set_error(LM_ERR_INVALID, "modalities of one pyramid level disagree on width/height");
                 int mnx = 32767, mny = 32767, mxx = -32768, mxy = -32768;
-                struct Rec { int32_t off; uint32_t xy; FeatStrip fs; int cls; };
+                struct Rec { int32_t off; uint32_t xy; uint32_t base0; int cls; };
                 std::vector<Rec> recs;
                 const bool top = (l == L - 1);
                 const long zero16 = (zero_off + 15) & ~15L;      // 16-aligned start of the zero tail
@@ -810,10 +816,10 @@ static int upload_bank(lm_detector* d) {
                         Rec r{};
                         r.off = (int32_t)o;
                         r.xy = (uint32_t)(uint16_t)(int16_t)f.x | ((uint32_t)(uint16_t)(int16_t)f.y << 16);
-                        r.fs = FeatStrip{0, 0};
-                        if (!top && f.x >= 0 && f.y >= 0) {   // only read on the fast path, where x, y >= 0
-                            r.fs.sbase = (uint32_t)((long)lv.sm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * splane);
-                            r.fs.cell = (uint32_t)(f.x / T) | ((uint32_t)(f.y / T) << 16);
+                        r.base0 = szero;
+                        if (!top && f.x >= 0 && f.y >= 0) {   // only read on the fast path, where x, y >= 0: the 16-byte row of the feature's own cell
+                            const long lx = f.x / T, ly = f.y / T;
+                            r.base0 = (uint32_t)((long)lv.sm_off[m] + ((long)f.label * T * T + (gy * T + gx)) * splane + ((lx >> 4) * lv.Hd + ly) * 16);
                         }
                         // alignment class: byte phase of the run start (top level: flat offset; below: plane column)
                         r.cls = top ? (int)(o & 15) : (f.x >= 0 ? (f.x / T) & 15 : 0);
@@ -823,22 +829,30 @@ static int upload_bank(lm_detector* d) {
                 if (e.nf == 0) mnx = mny = mxx = mxy = 0;
                 e.min_x = (int16_t)mnx; e.min_y = (int16_t)mny; e.max_x = (int16_t)mxx; e.max_y = (int16_t)mxy;
                 std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.cls < b.cls; });
+                std::vector<uint8_t> starts;             // per feature of this entry: 1 = first of a class run
+                auto push_feat = [&](int32_t o, uint32_t pxy, uint32_t base0, int cls, bool start) {
+                    off.push_back(o); xy.push_back(pxy); word.push_back((base0 & ~15u) | (uint32_t)cls); starts.push_back(start ? 1 : 0);
+                };
                 auto push_pad = [&](int cls) {           // a feature that reads zeros, in alignment class `cls`
-                    off.push_back((int32_t)(zero16 + (top ? cls : 0)));
-                    xy.push_back(pad_xy);
-                    strip.push_back(FeatStrip{szero, (uint32_t)cls});
+                    push_feat((int32_t)(zero16 + (top ? cls : 0)), pad_xy, szero, cls, false);
                 };
                 int last_cls = 0;
                 for (size_t i = 0; i < recs.size();) {
                     size_t j = i;
                     while (j < recs.size() && recs[j].cls == recs[i].cls) ++j;
-                    for (size_t k = i; k < j; ++k) { off.push_back(recs[k].off); xy.push_back(recs[k].xy); strip.push_back(recs[k].fs); }
+                    // a run: <= kRunMax (even) features of one class, so that the packed-byte sums of the refinement cannot overflow
+                    for (size_t k = i; k < j; ++k) push_feat(recs[k].off, recs[k].xy, recs[k].base0, recs[k].cls, (k - i) % kRunMax == 0);
                     last_cls = recs[i].cls;
                     if (!top && ((j - i) & 1)) push_pad(last_cls);   // the refinement consumes features in same-class pairs
                     i = j;
                 }
                 while ((off.size() - e.feat_start) % kFeatBatch) push_pad(last_cls);
                 e.nf_padded = (uint16_t)(off.size() - e.feat_start);
+                for (size_t k = 0; k < starts.size(); k += kFeatBatch) {           // kFeatBatch == 8: one mask word per batch
+                    uint32_t mk = 0;
+                    for (int u = 0; u < kFeatBatch; ++u) mk |= (uint32_t)starts[k + u] << u;
+                    rmask.push_back(mk);
+                }
                 d->h_entries.push_back(e);
             }
             ++flat;
@@ -848,13 +862,15 @@ static int upload_bank(lm_detector* d) {
     if ((rc = d->d_entries.ensure(std::max<size_t>(1, d->h_entries.size())))) return rc;
     if ((rc = d->d_feat_off.ensure(std::max<size_t>(1, off.size())))) return rc;
     if ((rc = d->d_feat_xy.ensure(std::max<size_t>(1, xy.size())))) return rc;
-    if ((rc = d->d_feat_strip.ensure(std::max<size_t>(1, strip.size())))) return rc;
+    if ((rc = d->d_feat_word.ensure(std::max<size_t>(1, word.size())))) return rc;
+    if ((rc = d->d_run_mask.ensure(std::max<size_t>(1, rmask.size())))) return rc;
     if (!d->h_entries.empty())
         HIP_TRY(hipMemcpy(d->d_entries.p, d->h_entries.data(), d->h_entries.size() * sizeof(TemplEntry), hipMemcpyHostToDevice));
     if (!off.empty()) {
         HIP_TRY(hipMemcpy(d->d_feat_off.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->d_feat_xy.p, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d->d_feat_strip.p, strip.data(), strip.size() * sizeof(FeatStrip), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_feat_word.p, word.data(), word.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->d_run_mask.p, rmask.data(), rmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     d->bank_dirty = false;
     d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
@@ -1203,8 +1219,7 @@ static int local_grid(lm_detector* d, int nb) {
 // nearest-neighbour pyramid, pyrDown to the next level} per level, then the linear memories of every level), every stage ONE launch
 // that carries the jobs of all frames of the batch.  Frame b keeps its intermediates in level_bufs(b, l) and writes the arenas of its
 // own result slot.  7 launches per frame (round 2's per-slot graph) -> 3 per batch.
-static int run_frontend_batch(lm_detector* d, int first, int nb) {
-    hipStream_t s = d->stream;
+static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) {
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
     int rc;
@@ -1362,14 +1377,14 @@ int lm_launch_pending(lm_detector* d) {
     int rc;
     for (int b = 0; b < nb; ++b)
         if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
-    hipStream_t s = d->stream, ms = d->mstream;
+    hipStream_t ms = d->mstream, s = knobs().serial >= 2 ? ms : d->stream;
     // the frames' uploads (copy stream) before the front end
     for (int b = 0; b < nb; ++b) {
         const int ring = d->slot[(first + b) % lm_detector::kSlots].ring;
         if (ring >= 0) HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0));
     }
     HIP_TRY(hipEventRecord(lead.ev[0], s));
-    if ((rc = run_frontend_batch(d, first, nb))) return rc;
+    if ((rc = run_frontend_batch(d, first, nb, s))) return rc;
     HIP_TRY(hipEventRecord(lead.ev[1], s));
     HIP_TRY(hipEventRecord(lead.fe_done, s));
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1392,7 +1407,7 @@ int lm_launch_pending(lm_detector* d) {
         // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
         // the hash tables k_dedupe uses
         if (num_work > 0)
-            launch_local(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_strip.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
+            launch_local(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                          (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, local_grid(d, nb), ms);
         HIP_TRY(hipEventRecord(lead.ev[4], ms));
         return LM_OK;
@@ -1410,7 +1425,7 @@ int lm_launch_pending(lm_detector* d) {
     // with work already in flight each stage has its own stream — coarse(k+1) and dedupe(k) run beside local(k) / local(k+1) —
     // while a lone launch (synchronous call, on-device pipeline, the first batch of a stream) keeps all three on the matching
     // stream: no extra cross-stream hops on the latency path.  Cross-stream ordering and the host wait use eagerly recorded events.
-    if (d->n_launched != d->n_collected) {
+    if (d->n_launched != d->n_collected && knobs().serial == 0) {
         HIP_TRY(hipStreamWaitEvent(d->cstream, lead.fe_done, 0));
         if ((rc = enqueue_coarse(d->cstream))) return rc;
         HIP_TRY(hipEventRecord(lead.coarse_done, d->cstream));
@@ -1434,6 +1449,21 @@ int lm_launch_pending(lm_detector* d) {
     }
     d->queued.emplace_back(d->n_launched, first);
     d->n_launched += (uint64_t)nb;
+    // streamed frames: the collector thread prepares their result lists as soon as the batch has finished
+    if (d->async_collect && !d->reference_order && lead.ring >= 0 && num_work > 0) {
+        lm_detector::Collector& C = d->collector;
+        for (int b = 0; b < nb; ++b) {
+            lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
+            sl.ready.store(0, std::memory_order_relaxed);
+            sl.prep_queued = true;
+        }
+        {
+            std::lock_guard<std::mutex> lk(C.mu);
+            if (!C.started) { C.stop = false; C.th = std::thread(collector_main, d); C.started = true; }
+            C.jobs.emplace_back(first, nb);
+        }
+        C.cv_work.notify_one();
+    }
     return LM_OK;
 }
 
@@ -1454,6 +1484,79 @@ int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_id
     return lm_launch_pending(d);
 }
 
+// The distinct records of a finished frame (k_dedupe's output in the slot's pinned memory) as lm_match, canonically sorted + uniqued
+// (Detector::match's list under the canonical order of SURVEY A12).  Returns the count; *res is malloc'ed.
+static size_t canonical_list_of(const lm_detector::Slot& sl, uint64_t nd, lm_match** res_out, float* convert_ms, float* merge_ms) {
+    const auto t0 = std::chrono::steady_clock::now();
+    lm_match* res = (lm_match*)malloc(std::max<size_t>(1, (size_t)nd) * sizeof(lm_match));
+    *res_out = res;
+    if (!res) return 0;
+    const std::vector<int32_t>& wcls = *sl.work_cls;
+    const std::vector<int32_t>& wtid = *sl.work_tid;
+    size_t w = 0;
+    const Candidate* src = sl.h_distinct;
+    for (uint64_t i = 0; i < nd; ++i) {
+        const Candidate& c = src[i];
+        if (c.work < 0) continue;
+        res[w].x = c.x; res[w].y = c.y; res[w].similarity = c.score;
+        res[w].class_index = wcls[c.work];
+        res[w].template_id = wtid[c.work];
+        ++w;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const size_t n = lm_merge_matches(res, w);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (convert_ms) *convert_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    if (merge_ms) *merge_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    return n;
+}
+
+static void collector_main(lm_detector* d) {
+    (void)hipSetDevice(d->device);
+    lm_detector::Collector& C = d->collector;
+    for (;;) {
+        std::pair<int, int> job;
+        {
+            std::unique_lock<std::mutex> lk(C.mu);
+            C.cv_work.wait(lk, [&] { return C.stop || !C.jobs.empty(); });
+            if (C.jobs.empty()) return;                  // stop requested and nothing left
+            job = C.jobs.front();
+            C.jobs.pop_front();
+        }
+        const int first = job.first, nb = job.second;
+        // the batch's last kernel (its leader's event); errors surface in lm_collect_frame.  Polled, not hipEventSynchronize: a thread
+        // blocked inside the runtime's wait made every HIP call of the submitting thread take ~0.1 ms (0.30 ms per submit_frame)
+        for (;;) {
+            const hipError_t q = hipEventQuery(d->slot[first].done);
+            if (q != hipErrorNotReady) break;
+            for (int i = 0; i < 200; ++i) __builtin_ia32_pause();       // ~3-5 us between queries
+        }
+        (void)hipGetLastError();
+        for (int b = 0; b < nb; ++b) {
+            lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
+            int state = 2;
+            sl.prep = nullptr; sl.prep_n = 0;
+            const unsigned long long* hc = sl.h_counters;
+            if (sl.num_work > 0 && hc[0] <= sl.cand_cap && hc[0] <= sl.match_cap && hc[1] <= hc[0]) {
+                sl.prep_n = canonical_list_of(sl, hc[1], &sl.prep, &sl.prep_collect_ms, &sl.prep_merge_ms);
+                if (sl.prep) state = 1;
+            }
+            sl.ready.store(state, std::memory_order_release);
+        }
+        { std::lock_guard<std::mutex> lk(C.mu); }
+        C.cv_done.notify_all();
+    }
+}
+
+static void collector_stop(lm_detector* d) {
+    lm_detector::Collector& C = d->collector;
+    if (!C.started) return;
+    { std::lock_guard<std::mutex> lk(C.mu); C.stop = true; }
+    C.cv_work.notify_all();
+    if (C.th.joinable()) C.th.join();
+    C.started = false;
+}
+
 // Wait for the oldest frame in flight and turn its records into lm_match.  Returns 1 when a buffer
 // overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
@@ -1466,6 +1569,21 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         if (rc) return rc;
     }
     lm_detector::Slot& lead = d->slot[sl.leader];       // the events are those of the batch's first slot
+    lm_match* prepared = nullptr;
+    size_t prepared_n = 0;
+    bool have_prepared = false;
+    if (sl.prep_queued) {                               // the collector thread owns the slot until it has marked it ready
+        if (sl.ready.load(std::memory_order_acquire) == 0) {
+            for (int spin = 0; spin < 2000 && sl.ready.load(std::memory_order_acquire) == 0; ++spin) __builtin_ia32_pause();
+            if (sl.ready.load(std::memory_order_acquire) == 0) {
+                std::unique_lock<std::mutex> lk(d->collector.mu);
+                d->collector.cv_done.wait(lk, [&] { return sl.ready.load(std::memory_order_acquire) != 0; });
+            }
+        }
+        have_prepared = sl.ready.load(std::memory_order_acquire) == 1;
+        prepared = sl.prep; prepared_n = sl.prep_n;
+        sl.prep = nullptr; sl.prep_n = 0; sl.prep_queued = false;
+    }
     HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
     sl.pending = false;
@@ -1483,6 +1601,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     if (ncand > sl.cand_cap || ncand > sl.match_cap) {   // never drop silently: grow, caller reruns the frame
         d->cand_cap = std::max<uint32_t>(d->cand_cap, (uint32_t)(ncand + ncand / 4 + 1024));
         d->ingest.used[slot_index] = false;
+        free(prepared);
         return 1;
     }
     lm_timings tm{};
@@ -1513,11 +1632,21 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     }
     // the stage times are those of the LAUNCHES, which serve batch_frames frames: per frame = time / batch_frames
     if (sort_unique < 0) {                            // pipeline mode: the records stay on the device
+        free(prepared);
         d->timings = tm;
         if (out) *out = nullptr;
         if (n_out) *n_out = 0;
         return LM_OK;
     }
+    if (have_prepared && sort_unique == 1 && !d->reference_order) {   // the collector thread has the list ready: hand it over
+        tm.host_submit_ms = std::chrono::duration<float, std::milli>(sl.t1 - sl.t0).count();
+        tm.host_wait_ms = std::chrono::duration<float, std::milli>(t2 - sl.t1).count();
+        tm.host_collect_ms = sl.prep_collect_ms; tm.host_merge_ms = sl.prep_merge_ms;   // spent on the collector thread
+        d->timings = tm;
+        *out = prepared; *n_out = prepared_n;
+        return LM_OK;
+    }
+    free(prepared);
     // sort_unique = 0: every record alive (the raw pre-unique multiset); 1 / 2: the records without exact duplicates
     // (k_dedupe) — what std::unique would leave of them anyway — canonically sorted + uniqued (1) or as they are (2);
     // 3: the reference's own output, permutation and surviving duplicates included (below)
@@ -1723,6 +1852,12 @@ extern "C" int lm_detector_set_batch(lm_detector* d, int frames) {
 }
 
 extern "C" int lm_detector_get_batch(const lm_detector* d) { return d ? d->batch_max : 0; }
+
+extern "C" int lm_detector_set_async_collect(lm_detector* d, int on) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    d->async_collect = on != 0;       // frames already launched keep what they were launched with
+    return LM_OK;
+}
 
 extern "C" int lm_detector_set_batch_queue(lm_detector* d, int batches) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");

@@ -1,8 +1,13 @@
 // Private view of the detector shared by detector.cpp and pipeline.cpp (not part of the C ABI).
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/amd_linemod.h"
@@ -102,7 +107,7 @@ struct lm_detector {
     DevBuf<TemplEntry> d_entries;
     DevBuf<int32_t> d_feat_off;
     DevBuf<uint32_t> d_feat_xy;
-    DevBuf<FeatStrip> d_feat_strip;
+    DevBuf<uint32_t> d_feat_word, d_run_mask;       // refinement levels: feature words + class-run masks (lm_kernels.h)
     // work list
     std::vector<int32_t> work_pyr;
     std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;   // shared with in-flight result slots
@@ -139,6 +144,12 @@ struct lm_detector {
         const uint16_t* in_depth = nullptr;
         bool have_mask[2] = {false, false};         // lone frames only (Detector.match with masks)
         int ring = -1;                              // ingest ring entry holding the frame (-1: resident frame)
+        // prepared by the collector thread (streamed frames): the frame's Detector::match list, ready when `ready` != 0
+        bool prep_queued = false;                   // a collector job covers this frame
+        std::atomic<int> ready{0};                  // 0 not yet, 1 list prepared, 2 nothing prepared (overflow: the caller's path decides)
+        lm_match* prep = nullptr;
+        size_t prep_n = 0;
+        float prep_collect_ms = 0.f, prep_merge_ms = 0.f;
         hipEvent_t ev[6] = {};                      // stage timing: front end 0-1, coarse 2-3, refinement 5-4
         hipEvent_t done = nullptr;                  // recorded after the batch's last kernel: the only event the host waits on
         hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
@@ -163,6 +174,17 @@ struct lm_detector {
     // fill — and joins the waiting batch otherwise: batches grow to batch_max exactly when the GPU is the bottleneck.
     std::vector<std::pair<uint64_t, int>> queued;
     int keep_queued = 2;                            // LM_BATCH_QUEUE
+    // Collector thread (streamed frames): waits for a launched batch on the host and turns each frame's records into the canonical
+    // Detector::match list (conversion, sort, unique: ~45 us per frame at 2k templates) while the caller's thread submits the next
+    // frames; lm_detector_collect then only hands the list over.  One per detector, started with the first streamed batch.
+    struct Collector {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv_work, cv_done;
+        std::deque<std::pair<int, int>> jobs;       // (first slot, frames) of launched batches, in launch order
+        bool stop = false, started = false;
+    } collector;
+    bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's
     // pinned buffer (or written there by the caller: lm_detector_ingest_buffer), copied to the entry's device buffers on a

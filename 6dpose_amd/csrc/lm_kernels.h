@@ -121,12 +121,17 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
                    const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t tile_cap, hipStream_t s);
 // Persistent grid: waves stride over the tiles of all frames of the batch, then over their candidates (counts read on the device).
 // matches[ci] = refined candidate ci (work = -1: dropped).  Also empties the part of every frame's hash table k_dedupe will use.
-struct FeatStrip {        // per feature of a level below the top: strip-plane base + decimated cell
-    uint32_t sbase;       // byte offset of the feature's (label, phase) plane inside the strip arena
-    uint32_t cell;        // lx | ly << 16   (x / T, y / T)
-};
-void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const FeatStrip* feat_strip,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
+// Per feature of a level below the top ONE word, feat_word = base0 | cls: base0 = byte offset (a multiple of 16) inside the strip
+// arena of the 16-byte row of the feature's own cell — plane base + ((lx >> 4) * Hd + ly) * 16 — and cls = lx & 15, the alignment
+// class (features of an entry are sorted by it).  The window origin of a work item (gx, gy) adds the same K = ((gx >> 4) * Hd + gy)
+// * 16 to every feature, plus one strip (Hd * 16) for the classes whose column carries into the next strip (cls + (gx & 15) >= 16):
+// both are folded into the lanes' VGPR offset once per class run, and the word (class bits masked) is the load's scalar offset — one
+// scalar instruction per feature for the address (round 2: 9, and 8 for the run bookkeeping).
+// run_mask[f / 8] bit (f % 8): feature f starts a new class run (class change, or 62 features of one class: the packed-byte sums hold
+// 63 x 4).  Runs have even length and start at even indices (the per-candidate path loads same-class pairs).
+constexpr int kRunMax = 62;
+void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
+                  const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
                   uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s);
 // slots of k_dedupe's open-addressing table used for n records (power of two, >= 2n, <= cap_slots = dedupe_table_slots(cand_cap)):
 // k_local empties exactly these, k_dedupe hashes into exactly these

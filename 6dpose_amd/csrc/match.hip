@@ -478,7 +478,7 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
 
 __global__ void __launch_bounds__(256)
 k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-        const FeatStrip* __restrict__ feat_strip, const uint32_t* __restrict__ feat_xy,
+        const uint32_t* __restrict__ feat_word, const uint32_t* __restrict__ run_mask, const uint32_t* __restrict__ feat_xy,
         const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
         uint32_t dedupe_cap_slots, uint32_t tile_cap, int dbg) {
     // What bounds it (profiles/r02_pmc_tiles.txt, r02_local_experiments.txt): the vector L1.  Per CU 139k cycles of accesses +
@@ -497,6 +497,19 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // wave-uniform, and the
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);                                       // compiler must know it: item -> frame -> the frame's pointers stay in SGPRs
     const int nb = fb.nb;
+    // Frame -> XCD affinity.  Workgroup b runs on XCD b % 8 (observed on gfx950, not a contract: only speed depends on it), each XCD has
+    // its own 4 MB L2, and the strip planes of ONE frame are 4.9 MB at VGA.  With the items of a batch dealt to the waves in flat order
+    // every L2 holds lines of all the batch's frames: L2 hit rate 94 % -> 76 %, fabric traffic per frame x4 (profiles/r03_pmc_batch_flat.txt).
+    // So when the batch size divides 8, frame f is served by the workgroups of XCDs [f * 8 / nb, (f + 1) * 8 / nb) only.
+    int f_lo = 0, f_hi = nb;
+    uint32_t w_first = wave0, w_step = nwaves;
+    if (nb > 1 && (8 % nb) == 0 && (gridDim.x & 7) == 0) {
+        const int per = 8 / nb, xcd = (int)(blockIdx.x & 7);
+        f_lo = xcd / per; f_hi = f_lo + 1;
+        const uint32_t wpb = blockDim.x >> 6;
+        w_first = ((blockIdx.x >> 3) * (uint32_t)per + (uint32_t)(xcd % per)) * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        w_step = (gridDim.x >> 3) * (uint32_t)per * wpb;
+    }
     const bool tiled = fb.f[0].tiles != nullptr && !(dbg & 2);
     if (threadIdx.x == 0) {
         uint32_t te = 0, ce = 0;
@@ -527,11 +540,11 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     // [16 q, 16 q + 16); every member then takes the first strict maximum of its own 16 x 16 window of those sums — the same
     // integers, the same tie-break (packed key) and the same float expression as the per-candidate path below.
     if (tiled) {
-        const uint32_t ntiles = s_tend[nb];
+        const uint32_t ntiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[f_hi]);
         const LevelGeom lv = g.lv[0];
         const int T = lv.T, Hd = lv.Hd, offset = T / 2 + (T % 2 - 1);
-        int fr = 0;
-        for (uint32_t gi = wave0; gi < ntiles; gi += nwaves) {
+        int fr = f_lo;
+        for (uint32_t gi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[f_lo]) + w_first; gi < ntiles; gi += w_step) {
             while (gi >= (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr + 1])) ++fr;           // wave-uniform: item -> frame
             const FrameSlot& F = fb.f[fr];
             const uint8_t* __restrict__ sm_arena = F.sm_arena;
@@ -552,13 +565,20 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             int q = (lane >= R) + (lane >= 2 * R), r = lane - q * R;
             const bool active = lane < R * S;
             if (!active) { q = 0; r = 0; }                                     // idle lanes repeat lane 0's (valid) loads
+            // Addressing (lm_kernels.h, feat_word): a feature's load = arena resource + lane VGPR + the feature's word (less its class
+            // bits) as scalar offset.  The VGPR carries the lane's (strip, row) offset, the item's window origin K and the strip
+            // carry of the run's class, rebuilt once per class run: ONE scalar instruction per feature.  (Every offset stays a
+            // multiple of 16: folding the class bits into the VGPR as well made the loads return wrong data.)
             const BufRsrc strips = make_rsrc(sm_arena);
             const uint32_t lane_off = (uint32_t)(q * Hd + r) * 16u;
+            const uint32_t K0 = (uint32_t)((gx0 >> 4) * Hd + gy0) * 16u, HS = (uint32_t)Hd * 16u;
+            const int gxl = gx0 & 15;
             const int nb_lane = (lane + R < 64 ? lane + R : lane) << 2;       // the lane holding the next strip of this row
             uint32_t aE[4] = {0, 0, 0, 0}, aO[4] = {0, 0, 0, 0};              // u16x2 sums: aE[k] = cols 4k, 4k+2; aO[k] = cols 4k+1, 4k+3
-            const FeatStrip* fs = feat_strip + e.feat_start;
+            const uint32_t* fw = feat_word + e.feat_start;
+            const uint32_t* rm = run_mask + (e.feat_start >> 3);
             uint32_t r8[4] = {0, 0, 0, 0};
-            int cur = -1, cnt = 0;
+            int cur = -1;
             auto flush = [&](int cls) {
                 uint32_t x[8];
 #pragma unroll
@@ -588,32 +608,36 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                 for (int k = 0; k < 4; ++k) add_bytes(o4[k], aE[k], aO[k]);
             };
             if (nfp > 0) {
-                FeatStrip c[kFeatBatch];
+                uint32_t c[kFeatBatch], m = rm[0];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
+                for (int u = 0; u < kFeatBatch; ++u) c[u] = fw[u];                    // wave-uniform -> SMEM
+                uint32_t vK = lane_off;                                                 // rebuilt at the first feature (always a run start)
                 for (int f = 0; f < nfp; f += kFeatBatch) {
                     const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
-                    FeatStrip cn[kFeatBatch];
+                    uint32_t cn[kFeatBatch];
+                    const uint32_t mn = rm[fn >> 3];
 #pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
+                    for (int u = 0; u < kFeatBatch; ++u) cn[u] = fw[fn + u];
                     uint4 v[kFeatBatch];
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) {
-                        const uint32_t xa = (c[u].cell & 0xFFFF) + (uint32_t)gx0, ya = (c[u].cell >> 16) + (uint32_t)gy0;
-                        v[u] = ld_buf16(strips, lane_off, c[u].sbase + ((xa >> 4) * (uint32_t)Hd + ya) * 16u);
+                        if (m & (1u << u)) {                                            // a class run starts: its lane offset
+                            const int cls = (int)(c[u] & 15);
+                            vK = lane_off + K0 + (cls + gxl >= 16 ? HS : 0u);
+                        }
+                        v[u] = ld_buf16(strips, vK, c[u] & ~15u);
                     }
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) {
-                        const int cls = (int)(c[u].cell & 15);
-                        if (cls != cur || cnt == 63) {
+                        if (m & (1u << u)) {
                             if (cur >= 0) flush(cur);
-                            cur = cls; cnt = 0;
+                            cur = (int)(c[u] & 15);
                         }
-                        r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // <= 63 x 4 per byte
-                        ++cnt;
+                        r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // <= 62 x 4 per byte (host: runs of <= kRunMax)
                     }
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
+                    m = mn;
                 }
                 if (cur >= 0) flush(cur);
             }
@@ -669,9 +693,9 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
         }
     }
 
-    const uint32_t num_cands = s_cend[nb];
-    int fr = 0;
-    for (uint32_t gi = wave0; gi < num_cands && !(dbg & 1); gi += nwaves) {
+    const uint32_t num_cands = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[f_hi]);
+    int fr = f_lo;
+    for (uint32_t gi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[f_lo]) + w_first; gi < num_cands && !(dbg & 1); gi += w_step) {
         while (gi >= (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[fr + 1])) ++fr;               // wave-uniform: item -> frame
         const FrameSlot& F = fb.f[fr];
         const uint32_t ci = gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cend[fr]);
@@ -709,13 +733,16 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             if (all_in) {
                 const int half = lane >> 5, l5 = lane & 31, r = l5 >> 1, h = l5 & 1;
                 const uint32_t HS = (uint32_t)Hd * 16u;
-                const BufRsrc strips = make_rsrc(sm_arena);
+                const BufRsrc strips = make_rsrc(sm_arena);        // addressing as in the tile path: lane VGPR (rebuilt per class run) + feature word
                 const uint32_t lane_off = h * HS + (uint32_t)r * 16u;
+                const uint32_t K0 = (uint32_t)((gx >> 4) * Hd + gy) * 16u;
+                const int gxl = gx & 15;
                 uint32_t w[4] = {0, 0, 0, 0};                   // u16x2: cols (0,2) (1,3) (4,6) (5,7) of this lane's 8 columns
                 if (nfp > 0) {
-                    const FeatStrip* fs = feat_strip + e.feat_start;
+                    const uint32_t* fw = feat_word + e.feat_start;
+                    const uint32_t* rm = run_mask + (e.feat_start >> 3);
                     uint32_t r8[4] = {0, 0, 0, 0};
-                    int cur = -1, cnt = 0;
+                    int cur = -1;
                     auto flush = [&](int cls) {
                         uint32_t own[4], par[4];
 #pragma unroll
@@ -740,36 +767,37 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                         add_bytes(o0, w[0], w[1]);
                         add_bytes(o1, w[2], w[3]);
                     };
-                    FeatStrip c[kFeatBatch];
+                    uint32_t c[kFeatBatch], m = rm[0];
 #pragma unroll
-                    for (int u = 0; u < kFeatBatch; ++u) c[u] = fs[u];                    // wave-uniform -> SMEM
+                    for (int u = 0; u < kFeatBatch; ++u) c[u] = fw[u];                    // wave-uniform -> SMEM
+                    uint32_t vK = lane_off;
                     for (int f = 0; f < nfp; f += kFeatBatch) {
                         const int fn = f + kFeatBatch < nfp ? f + kFeatBatch : f;           // prefetch the next batch
-                        FeatStrip cn[kFeatBatch];
+                        uint32_t cn[kFeatBatch];
+                        const uint32_t mn = rm[fn >> 3];
 #pragma unroll
-                        for (int u = 0; u < kFeatBatch; ++u) cn[u] = fs[fn + u];
+                        for (int u = 0; u < kFeatBatch; ++u) cn[u] = fw[fn + u];
                         uint4 v[kFeatBatch / 2];
 #pragma unroll
                         for (int k = 0; k < kFeatBatch / 2; ++k) {
-                            // features 2k (lanes 0-31) and 2k+1 (lanes 32-63): same alignment class by construction
-                            const uint32_t xa = (c[2 * k].cell & 0xFFFF) + gx, ya = (c[2 * k].cell >> 16) + gy;
-                            const uint32_t xb = (c[2 * k + 1].cell & 0xFFFF) + gx, yb = (c[2 * k + 1].cell >> 16) + gy;
-                            const uint32_t ba = c[2 * k].sbase + ((xa >> 4) * Hd + ya) * 16u;
-                            const uint32_t bb = c[2 * k + 1].sbase + ((xb >> 4) * Hd + yb) * 16u;
-                            v[k] = ld_buf16(strips, lane_off + (half ? bb : ba), 0u);
+                            // features 2k (lanes 0-31) and 2k+1 (lanes 32-63): one class run by construction (runs start at even indices)
+                            if (m & (1u << (2 * k))) {
+                                const int cls = (int)(c[2 * k] & 15);
+                                vK = lane_off + K0 + (cls + gxl >= 16 ? HS : 0u);
+                            }
+                            v[k] = ld_buf16(strips, vK + ((half ? c[2 * k + 1] : c[2 * k]) & ~15u), 0u);   // (a lane offset that wraps below zero against the scalar offset reads zeros)
                         }
 #pragma unroll
                         for (int k = 0; k < kFeatBatch / 2; ++k) {
-                            const int cls = (int)(c[2 * k].cell & 15);
-                            if (cls != cur || cnt == 31) {
+                            if (m & (1u << (2 * k))) {
                                 if (cur >= 0) flush(cur);
-                                cur = cls; cnt = 0;
+                                cur = (int)(c[2 * k] & 15);
                             }
-                            r8[0] += v[k].x; r8[1] += v[k].y; r8[2] += v[k].z; r8[3] += v[k].w;   // <= 31 x 4 per byte and half
-                            ++cnt;
+                            r8[0] += v[k].x; r8[1] += v[k].y; r8[2] += v[k].z; r8[3] += v[k].w;   // <= 31 x 4 per byte and half (host: runs of <= kRunMax)
                         }
 #pragma unroll
                         for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
+                        m = mn;
                     }
                     if (cur >= 0) flush(cur);
                 }
@@ -839,15 +867,15 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     }
 }
 
-void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const FeatStrip* feat_strip,
-                  const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
+void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
+                  const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
                   uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
     if (grid_blocks <= 0 || fb.nb <= 0) return;
     int dbg = 0;
 #ifdef LM_DIAG
     dbg = knobs().local_dbg;                                    // timing experiments (wrong results): 1 = tiles only, 2 = singles only
 #endif
-    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, fb, g, entries, feat_off, feat_strip, feat_xy, work_pyramids, cand_cap,
+    hipLaunchKernelGGL(k_local, dim3(grid_blocks), dim3(256), 0, s, fb, g, entries, feat_off, feat_word, run_mask, feat_xy, work_pyramids, cand_cap,
                        threshold, cap, dedupe_cap_slots, tile_cap, dbg);
 }
 

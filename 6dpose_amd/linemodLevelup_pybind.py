@@ -165,6 +165,7 @@ def load_library():
     lib.lm_detector_get_batch.argtypes = [P]
     lib.lm_detector_get_batch.restype = I
     lib.lm_detector_set_batch_queue.argtypes = [P, I]
+    lib.lm_detector_set_async_collect.argtypes = [P, I]
     lib.lm_detector_set_reference_order.argtypes = [P, I]
     lib.lm_exchange_max_capacity.restype = I
     lib.lm_detector_exchange_stream.argtypes = [P]
@@ -472,6 +473,10 @@ class Detector:
         """Streamed frames are launched at once while fewer than `batches` launched batches are unfinished on the GPU (default 2);
         0 = always wait for a full batch (deterministic batch sizes: tests, kernel measurements)."""
         _check(self._lib.lm_detector_set_batch_queue(self._h, int(batches)))
+
+    def setAsyncCollect(self, on: bool) -> None:
+        """Streamed frames: prepare the result lists on the library's collector thread (default) or inside collect() (lm_detector_set_async_collect)."""
+        _check(self._lib.lm_detector_set_async_collect(self._h, 1 if on else 0))
 
     def getBatch(self) -> int:
         return int(self._lib.lm_detector_get_batch(self._h))

@@ -79,6 +79,7 @@ class DeviceExchange:
         self.device_collective = self.collective and dist.get_backend(group) == "nccl"
         if shard:                      # shard=False: the caller partitioned the bank itself (e.g. whole classes per rank)
             detector.setShard(self.rank, self.world)
+        detector.setAsyncCollect(False)   # the merged list of all ranks comes from the device exchange: no per-rank host list to prepare
         self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
         self.slots = lm.load_library().lm_detector_max_in_flight()
         self.next = 0

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Counter passes for the hot kernels (run on the GPU box through gpurun).  One rocprofv3 run per
 # --pmc group (SQ 8 slots, TCC 4 slots; FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2), kernel-trace only,
-# as MI355X_MICROARCH.md §rocprofv3 PMC slots prescribes.  Usage: pmc_run.sh <out_dir> <tag>
+# as MI355X_MICROARCH.md §rocprofv3 PMC slots prescribes.  Usage: pmc_run.sh <out_dir> <tag> [kernels]
+# The profiled command is bench.py's roofline leg alone (--roofline-only): every k_local / k_coarse / k_fe_stage / k_dedupe dispatch
+# of the run but the set-up probe is one of the launches bench.py's `roofline` object describes (frames_per_launch frames each).
 set -u
-OUT=${1:-gpurun_out/pmc}; TAG=${2:-r01}
+OUT=${1:-gpurun_out/pmc}; TAG=${2:-r03}; KERNELS=${3:-k_local,k_coarse,k_fe_stage,k_dedupe}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+CMD=${PMC_CMD:-"python $ROOT/bench.py --roofline-only --no-parity-gate"}
 i=0
 for grp in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
@@ -20,4 +22,10 @@ for grp in \
   timeout 240 rocprofv3 --kernel-trace --pmc $grp -d $ROOT/$OUT/p$i -o $TAG -- $CMD > $ROOT/$OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $grp" >> $ROOT/$OUT/passes.txt
 done
-rocprofv3 -L > $ROOT/$OUT/counters_list.txt 2>&1
+python - <<PY
+import sys
+sys.path.insert(0, "$ROOT/profiles")
+import rocpd_pmc
+rocpd_pmc.main("$ROOT/$OUT/p*/*_results.db", "$ROOT/$OUT/pmc_$TAG.txt", tuple("$KERNELS".split(",")))
+PY
+find $ROOT/$OUT -name "*_results.db" -delete
