@@ -31,6 +31,7 @@ int lm_set_error(int code, const char* fmt, ...) {
 extern "C" const char* lm_last_error(void) { return g_err.c_str(); }
 static void collector_main(lm_detector* d);
 static void collector_stop(lm_detector* d);
+static void copier_stop(lm_detector* d);
 extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
 extern "C" int lm_device_count(void) {
     int n = 0;
@@ -149,6 +150,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     (void)hipSetDevice(d->device);
     (void)lm_launch_pending(d);
     collector_stop(d);
+    copier_stop(d);
     for (auto& sl : d->slot) { free(sl.prep); sl.prep = nullptr; }
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
@@ -890,14 +892,19 @@ static bool match_eq(const lm_match& a, const lm_match& b) {   // Match::operato
 }
 // LSD radix sort on the 112-bit key (~similarity bits, template_id | class, y, x), 11-bit digits,
 // digits that are constant over the input are skipped.  Equivalent to std::sort(match_less).
-extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
+// distinct_input: the records hold no exact duplicates (k_dedupe removed them on the device): the hash pass is skipped.
+// Scratch buffers are per thread and reused (a frame's list is merged in ~20 us; six allocations were a third of it).
+static size_t merge_matches_impl(lm_match* m, size_t n, bool distinct_input) {
     if (!m || n == 0) return 0;
     if (n < 64) {
         std::sort(m, m + n, match_less);
         return (size_t)(std::unique(m, m + n, match_eq) - m);
     }
     struct Key { uint64_t hi, lo; };
-    std::vector<Key> keys(n);
+    static thread_local std::vector<Key> keys;
+    static thread_local std::vector<uint32_t> idx, tmp, table;
+    static thread_local std::vector<lm_match> out;
+    keys.resize(n);
     bool radix_ok = true;
     for (size_t i = 0; i < n; ++i) {
         uint32_t sb;
@@ -912,15 +919,17 @@ extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
         std::sort(m, m + n, match_less);
         return (size_t)(std::unique(m, m + n, match_eq) - m);
     }
-    // Exact duplicates (same x, y, similarity, class AND template: several coarse candidates of one
-    // template refined to the same position) are adjacent in the canonical order and removed by the
-    // unique step anyway: drop them first with an open-addressing hash so that the sort sees ~n/5.
-    std::vector<uint32_t> idx;
+    idx.clear();
     idx.reserve(n);
-    {
+    if (distinct_input) {
+        for (size_t i = 0; i < n; ++i) idx.push_back((uint32_t)i);
+    } else {
+        // Exact duplicates (same x, y, similarity, class AND template: several coarse candidates of one
+        // template refined to the same position) are adjacent in the canonical order and removed by the
+        // unique step anyway: drop them first with an open-addressing hash so that the sort sees ~n/5.
         size_t cap = 64;
         while (cap < 2 * n) cap <<= 1;
-        std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
+        table.assign(cap, 0xFFFFFFFFu);
         for (size_t i = 0; i < n; ++i) {
             uint64_t h = (keys[i].hi * 0x9E3779B97F4A7C15ull) ^ (keys[i].lo * 0xC2B2AE3D27D4EB4Full);
             size_t slot = (size_t)(h ^ (h >> 29)) & (cap - 1);
@@ -933,18 +942,21 @@ extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
         }
     }
     const size_t nu = idx.size();
-    std::vector<uint32_t> tmp(nu);
+    tmp.resize(nu);
     constexpr int BITS = 11, NB = 1 << BITS;
-    std::vector<uint32_t> hist(NB);
+    uint32_t hist[NB];
+    // which bits vary at all: digits whose bits are constant over the input need no pass (and no histogram)
+    uint64_t or_lo = 0, and_lo = ~0ull, or_hi = 0, and_hi = ~0ull;
+    for (size_t i = 0; i < nu; ++i) { const Key& k = keys[idx[i]]; or_lo |= k.lo; and_lo &= k.lo; or_hi |= k.hi; and_hi &= k.hi; }
+    const uint64_t var_lo = or_lo ^ and_lo, var_hi = or_hi ^ and_hi;
     for (int word = 0; word < 2; ++word)          // lo word first (least significant)
         for (int shift = 0; shift < (word == 0 ? 48 : 64); shift += BITS) {
-            std::fill(hist.begin(), hist.end(), 0u);
+            if ((((word == 0 ? var_lo : var_hi) >> shift) & (NB - 1)) == 0) continue;   // constant digit
+            memset(hist, 0, sizeof(hist));
             for (size_t i = 0; i < nu; ++i) {
                 uint64_t k = word == 0 ? keys[idx[i]].lo : keys[idx[i]].hi;
                 ++hist[(k >> shift) & (NB - 1)];
             }
-            uint64_t k0 = word == 0 ? keys[idx[0]].lo : keys[idx[0]].hi;
-            if (hist[(k0 >> shift) & (NB - 1)] == nu) continue;   // constant digit
             uint32_t sum = 0;
             for (int b = 0; b < NB; ++b) { uint32_t c = hist[b]; hist[b] = sum; sum += c; }
             for (size_t i = 0; i < nu; ++i) {
@@ -954,7 +966,7 @@ extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
             }
             idx.swap(tmp);
         }
-    std::vector<lm_match> out;
+    out.clear();
     out.reserve(nu);
     for (size_t i = 0; i < nu; ++i) {
         const lm_match& c = m[idx[i]];
@@ -963,6 +975,7 @@ extern "C" size_t lm_merge_matches(lm_match* m, size_t n) {
     memcpy(m, out.data(), out.size() * sizeof(lm_match));
     return out.size();
 }
+extern "C" size_t lm_merge_matches(lm_match* m, size_t n) { return merge_matches_impl(m, n, false); }
 
 // numpy nms of the driver (linemod_and_levelup_test.py:34-61)
 extern "C" int lm_nms_boxes(const double* boxes, const double* scores, int n, double thresh, int32_t* keep) {
@@ -1504,7 +1517,7 @@ static size_t canonical_list_of(const lm_detector::Slot& sl, uint64_t nd, lm_mat
         ++w;
     }
     const auto t1 = std::chrono::steady_clock::now();
-    const size_t n = lm_merge_matches(res, w);
+    const size_t n = merge_matches_impl(res, w, true);
     const auto t2 = std::chrono::steady_clock::now();
     if (convert_ms) *convert_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     if (merge_ms) *merge_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
@@ -1548,6 +1561,53 @@ static void collector_main(lm_detector* d) {
     }
 }
 
+static void copier_main(lm_detector* d) {
+    lm_detector::CopyHelper& H = d->copier;
+    uint64_t last = 0;
+    for (;;) {
+        int spins = 0;
+        while (H.seq.load(std::memory_order_acquire) == last) {
+            if (H.stop.load(std::memory_order_acquire)) return;
+            if (++spins < 40000) { __builtin_ia32_pause(); continue; }          // ~0.5 ms of spinning, then sleep
+            std::unique_lock<std::mutex> lk(H.mu);
+            H.asleep.store(1, std::memory_order_seq_cst);
+            H.cv.wait(lk, [&] { return H.stop.load() || H.seq.load(std::memory_order_seq_cst) != last; });
+            H.asleep.store(0, std::memory_order_seq_cst);
+            spins = 0;
+        }
+        last = H.seq.load(std::memory_order_acquire);
+        memcpy(H.dst, H.src, H.bytes);
+        H.done.store(last, std::memory_order_release);
+    }
+}
+
+static void copier_stop(lm_detector* d) {
+    lm_detector::CopyHelper& H = d->copier;
+    if (!H.started) return;
+    { std::lock_guard<std::mutex> lk(H.mu); H.stop.store(true, std::memory_order_release); }
+    H.cv.notify_all();
+    if (H.th.joinable()) H.th.join();
+    H.started = false;
+}
+
+// dst <- src split over the caller's thread (first part) and the helper (rest)
+static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
+    lm_detector::CopyHelper& H = d->copier;
+    const bool same_a = a == dst, same_b = b == dst + na;           // zero-copy: the caller filled lm_detector_ingest_buffer's pointers
+    if (same_a || same_b || na + nb < (1u << 19)) {                  // small frames: one thread
+        if (!same_a) memcpy(dst, a, na);
+        if (!same_b) memcpy(dst + na, b, nb);
+        return;
+    }
+    if (!H.started) { H.stop.store(false); H.th = std::thread(copier_main, d); H.started = true; }
+    H.src = b; H.dst = dst + na; H.bytes = nb;
+    const uint64_t job = H.seq.load(std::memory_order_relaxed) + 1;
+    H.seq.store(job, std::memory_order_seq_cst);      // seq_cst on both sides: the store may not pass the load of `asleep` (the helper would sleep on a posted job)
+    if (H.asleep.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(H.mu); H.cv.notify_one(); }
+    memcpy(dst, a, na);
+    while (H.done.load(std::memory_order_acquire) != job) __builtin_ia32_pause();
+}
+
 static void collector_stop(lm_detector* d) {
     lm_detector::Collector& C = d->collector;
     if (!C.started) return;
@@ -1561,6 +1621,7 @@ static void collector_stop(lm_detector* d) {
 // overflowed (capacity has been raised; the frame has to be submitted again), 0 on success.
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out) {
     if (d->n_collected == d->n_submitted) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
+    const auto t_enter = std::chrono::steady_clock::now();
     const int slot_index = (int)(d->n_collected % lm_detector::kSlots);
     lm_detector::Slot& sl = d->slot[slot_index];
     HIP_TRY(hipSetDevice(d->device));
@@ -1722,7 +1783,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     }
     size_t n = w;
     const auto t3 = std::chrono::steady_clock::now();
-    if (sort_unique == 1) n = lm_merge_matches(res, w);
+    if (sort_unique == 1) n = merge_matches_impl(res, w, use_distinct);
     const auto t4 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<float, std::milli>(b - a).count();
@@ -1731,6 +1792,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.host_wait_ms = ms(sl.t1, t2);       // includes whatever the caller did between submit and collect
     tm.host_collect_ms = ms(t2, t3);
     tm.host_merge_ms = ms(t3, t4);
+    d->host_prof[5] += std::chrono::duration<double>(t2 - t_enter).count();
+    d->host_prof[6] += tm.host_collect_ms * 1e-3; d->host_prof[7] += tm.host_merge_ms * 1e-3;
     d->timings = tm;
     *out = res; *n_out = n;
     return LM_OK;
@@ -1812,8 +1875,9 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     if ((rc = ingest_entry(d, r, n))) return rc;
     lm_detector::Ingest& g = d->ingest;
     uint8_t* st = (uint8_t*)g.pinned[r];
-    if (rgb != st) memcpy(st, rgb, n * 3);                        // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
-    if ((const uint8_t*)depth != st + n * 3) memcpy(st + n * 3, depth, n * 2);
+    const auto tp0 = std::chrono::steady_clock::now();
+    staged_copy(d, st, rgb, n * 3, (const uint8_t*)depth, n * 2);  // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
+    const auto tp1 = std::chrono::steady_clock::now();
     if (g.reader[r]) {                                            // a resident re-match of the entry's previous frame may still read it (another slot's front end)
         HIP_TRY(hipStreamWaitEvent(g.stream, g.reader[r], 0));
         g.reader[r] = nullptr;
@@ -1827,13 +1891,21 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     d->last_h2d_ms = 0.f;
     d->frame_valid = true;
     const uint64_t before = d->n_submitted;
+    const auto tp2 = std::chrono::steady_clock::now();
     rc = slot_begin(d, threshold, class_ids, num_class_ids, g.d_rgb[r].p, g.d_depth[r].p, d->have_mask, r);
     if (rc) return rc;
     if (d->n_submitted == before + 1) g.used[r] = true;
+    const auto tp3 = std::chrono::steady_clock::now();
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    d->host_prof[0] += 1; d->host_prof[1] += secs(tp0, tp1); d->host_prof[2] += secs(tp1, tp2); d->host_prof[3] += secs(tp2, tp3);
     // Launched at once while the GPU has fewer than keep_queued batches queued (it must never wait for a batch to fill: the first
     // frames of a stream go out alone), otherwise when batch_max frames are waiting; lm_detector_flush / lm_detector_collect launch a
     // partial batch.  So the batches are as large as the GPU's backlog allows and no larger.
-    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || batches_queued(d) < d->keep_queued) return lm_launch_pending(d);
+    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || batches_queued(d) < d->keep_queued) {
+        rc = lm_launch_pending(d);
+        d->host_prof[4] += secs(tp3, std::chrono::steady_clock::now());
+        return rc;
+    }
     return LM_OK;
 }
 
@@ -1852,6 +1924,12 @@ extern "C" int lm_detector_set_batch(lm_detector* d, int frames) {
 }
 
 extern "C" int lm_detector_get_batch(const lm_detector* d) { return d ? d->batch_max : 0; }
+
+extern "C" int lm_detector_host_profile(lm_detector* d, double* out8, int reset) {
+    if (!d || !out8) return lm_set_error(LM_ERR_INVALID, "null argument");
+    for (int i = 0; i < 8; ++i) { out8[i] = d->host_prof[i]; if (reset) d->host_prof[i] = 0; }
+    return LM_OK;
+}
 
 extern "C" int lm_detector_set_async_collect(lm_detector* d, int on) {
     if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");

@@ -184,7 +184,25 @@ struct lm_detector {
         std::deque<std::pair<int, int>> jobs;       // (first slot, frames) of launched batches, in launch order
         bool stop = false, started = false;
     } collector;
-    bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0
+    // Staging copy of a streamed frame: the caller's thread copies the colour image, a helper thread the depth image (1.5 MB at VGA:
+    // 40 us on one core, the largest item of the host's per-frame work).  The helper spins for a while after a job (a stream hands it
+    // one every ~150 us) and sleeps on the condition variable otherwise.
+    struct CopyHelper {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<uint64_t> seq{0}, done{0};
+        std::atomic<int> asleep{0};
+        const void* src = nullptr;
+        void* dst = nullptr;
+        size_t bytes = 0;
+        std::atomic<bool> stop{false};
+        bool started = false;
+    } copier;
+    // host-side wall time of the streamed path, accumulated (lm_detector_host_profile): [0] frames, [1] staging copy, [2] H2D enqueue,
+    // [3] slot bookkeeping, [4] batch launches, [5] collect: waiting for the GPU, [6] record conversion, [7] canonical sort + unique
+    double host_prof[8] = {};
+    bool async_collect = false;                     // lm_detector_set_async_collect / LM_ASYNC_COLLECT=1 (measured: pays only when the host thread is the bottleneck)
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's
     // pinned buffer (or written there by the caller: lm_detector_ingest_buffer), copied to the entry's device buffers on a

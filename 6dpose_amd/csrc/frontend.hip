@@ -341,8 +341,59 @@ static __device__ __forceinline__ void build_lm_body(const int bx, const int by,
     }
 }
 
+// The same with dword stores (Wd % 4 == 0: the four positions of a lane quad share a row and a strip): every lane still ORs its own
+// T x T pixels, then the quad exchanges the four OR bytes and lane k of the quad stores labels 2k and 2k + 1 for all four positions —
+// one dword each to the flat plane and to the strip plane, 4 stores per lane instead of 16 byte stores (the launch is bound by the
+// number of store instructions: 44 MB per 4-frame batch took 48 us = 0.9 TB/s).
+static __device__ __forceinline__ void build_lm_body4(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS) {
+    const int idx = bx * 256 + (int)threadIdx.x;         // decimated raster index
+    const int phase = by;
+    const int npos = Wd * Hd;
+    if (idx >= npos) return;                             // whole quads: npos is a multiple of 4
+    const int ry = idx / Wd, rx = idx - ry * Wd;
+    const int rs = phase / T, cs = phase - rs * T;
+    const int y = ry * T + rs, x = rx * T + cs;
+    uint32_t v = 0;
+    const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
+    for (int r = y; r < ye; ++r) {
+        const uint8_t* row = J.quant + (size_t)r * W;
+        if (J.mask) {
+            const uint8_t* mrow = J.mask + (size_t)r * W;
+            for (int c = x; c < xe; ++c) v |= mrow[c] ? (uint32_t)row[c] : 0u;
+        } else {
+            for (int c = x; c < xe; ++c) v |= row[c];
+        }
+    }
+    const int lane = (int)threadIdx.x & 63, k4 = lane & 3, q0 = lane & ~3;
+    uint32_t vq[4], adj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vq[k] = (uint32_t)__shfl((int)v, q0 + k, 64);
+        adj[k] = ((vq[k] << 1) | (vq[k] >> 7) | (vq[k] >> 1) | (vq[k] << 7)) & 0xFFu;
+    }
+    const int idx0 = idx - k4, rx0 = rx - k4;            // first position of the quad
+    const size_t plane = (size_t)T * T * npos;
+    const size_t splane1 = (size_t)NS * Hd * 16;
+    uint8_t* o = J.lm + (size_t)phase * npos + idx0;
+    uint8_t* so = J.strips ? J.strips + (size_t)phase * splane1 + ((size_t)(rx0 >> 4) * Hd + ry) * 16 + (rx0 & 15) : nullptr;
+#pragma unroll
+    for (int li = 0; li < 2; ++li) {
+        const int ori = 2 * k4 + li;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = ((vq[k] >> ori) & 1u) ? 4u : (((adj[k] >> ori) & 1u) ? 1u : 0u);
+            packed |= r << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(o + plane * ori) = packed;
+        if (so) *reinterpret_cast<uint32_t*>(so + splane1 * T * T * ori) = packed;
+    }
+}
+static __host__ __device__ __forceinline__ bool build_lm_vec4(int W, int H, int T) { return ((W / T) & 3) == 0; }   // then npos and every plane base are multiples of 4 too
+
 __global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS) {
-    build_lm_body(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
+    if (build_lm_vec4(W, H, T)) build_lm_body4(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
+    else build_lm_body(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
 }
 
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
@@ -369,7 +420,10 @@ k_fe_stage(FeStage st) {
         case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
         case kFePyrDown: pyrdown_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.H, J.a, J.b); break;
         case kFeNnDown: nn_down2_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.a); break;
-        case kFeBuildLm: build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16); break;
+        case kFeBuildLm:
+            if (build_lm_vec4(J.W, J.H, J.a)) build_lm_body4(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16);
+            else build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16);
+            break;
         default: break;
     }
 }

@@ -405,9 +405,15 @@ class Detector:
 
     def _class_args(self, class_ids):
         ids = [c for c in (class_ids or [])]
-        arr = (ctypes.c_char_p * len(ids))(*[c.encode() for c in ids]) if ids else None
-        names = ids if ids else self.classIds()
-        return arr, len(ids), names
+        if not ids:
+            return None, 0, self.classIds()
+        key = tuple(ids)
+        hit = self.__dict__.setdefault("_cls_cache", {}).get(key)      # a stream passes the same list every frame
+        if hit is None:
+            if len(self._cls_cache) > 64:
+                self._cls_cache.clear()
+            hit = self._cls_cache[key] = ((ctypes.c_char_p * len(ids))(*[c.encode() for c in ids]), len(ids), ids)
+        return hit
 
     def _mask_args(self, masks, shape):
         if masks is None or len(masks) == 0:
@@ -477,6 +483,15 @@ class Detector:
     def setAsyncCollect(self, on: bool) -> None:
         """Streamed frames: prepare the result lists on the library's collector thread (default) or inside collect() (lm_detector_set_async_collect)."""
         _check(self._lib.lm_detector_set_async_collect(self._h, 1 if on else 0))
+
+    def hostProfile(self, reset: bool = True) -> dict:
+        """Accumulated host wall time of the streamed path (lm_detector_host_profile), seconds."""
+        out = (ctypes.c_double * 8)()
+        f = self._lib.lm_detector_host_profile
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        _check(f(self._h, out, 1 if reset else 0))
+        k = ("frames", "staging_copy", "h2d_enqueue", "slot_bookkeeping", "batch_launches", "collect_wait", "record_conversion", "sort_unique")
+        return dict(zip(k, [float(x) for x in out]))
 
     def getBatch(self) -> int:
         return int(self._lib.lm_detector_get_batch(self._h))
@@ -578,8 +593,9 @@ class Detector:
         try:
             if n == 0:
                 return np.zeros(0, MATCH_DTYPE)
-            buf = ctypes.string_at(out, n * ctypes.sizeof(_CMatch))
-            return np.frombuffer(buf, MATCH_DTYPE).copy()
+            arr = np.empty(n, MATCH_DTYPE)
+            ctypes.memmove(arr.ctypes.data, out, n * ctypes.sizeof(_CMatch))
+            return arr
         finally:
             self._lib.lm_free(out)
 
@@ -610,6 +626,11 @@ class Detector:
         t = Timings()
         _check(self._lib.lm_detector_last_timings(self._h, ctypes.byref(t)))
         return t.as_dict()
+
+    def lastTimingsInto(self, t: "Timings") -> None:
+        """lm_timings of the last collected frame into a caller-owned Timings struct (a per-frame loop that must stay cheap
+        keeps an array of them and reads the fields afterwards)."""
+        self._lib.lm_detector_last_timings(self._h, ctypes.byref(t))
 
     def readStage(self, level: int, kind: int) -> np.ndarray:
         """Device intermediates of the last front end run (tests): kind 0/1 quantised colour/normal,

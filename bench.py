@@ -59,9 +59,9 @@ THRESHOLD = 75.0
 N_FRAMES = 16                 # distinct host frames in the pool the stream cycles through
 N_PARKED = 4                  # frames parked in HBM for the resident legs (roofline, extras)
 PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "0"))   # frames in flight (<= lm_detector_max_in_flight() = 16): upload, front end, coarse pass, refinement, duplicate removal of
-                                                              # neighbouring BATCHES of frames side by side while the host collects the oldest frame.  Default (0): two batches
-                                                              # (lm_detector_get_batch() = 4 frames share their kernel launches) for short runs, three above 100 steps; the timed
-                                                              # region starts and ends with an empty pipeline, and filling / draining a deeper one costs more
+                                                              # neighbouring BATCHES of frames side by side while the host collects the oldest frame.  Default (0): three batches
+                                                              # (lm_detector_get_batch() = 4 frames share their kernel launches: 12 frames); the timed region starts and ends
+                                                              # with an empty pipeline (profiles/host_profile.py: 20 steps 0.201 ms/frame at 8 in flight, 0.187 at 12)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0         # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 LDS_PEAK_GBS = 150000.0       # ibid. "LDS": ~150 TB/s aggregate for ds_read_b64/b128
@@ -97,6 +97,35 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def dry_ranks(args):
+    """`--gpus N` rehearsed on one GPU: N rank processes under torch.distributed.run, gloo instead of RCCL (N
+    processes cannot share one device through RCCL), every rank on device 0.  Both scalings; each run checks the device exchange
+    against the host path AND the merged list against the unsharded match.  The times only prove the path (N processes time-slice
+    one GPU)."""
+    n = args.dry_ranks
+    out = {"dry_ranks": n, "backend": "gloo", "device": 0}
+    rc_all = 0
+    for scaling in ("weak", "strong"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__), "--gpus", str(n), "--scaling", scaling, "--steps", str(min(args.steps, 8)),
+               "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--check-unsharded", "--templates", str(args.templates)]
+        env = dict(os.environ, LM_BENCH_BACKEND="gloo", LM_BENCH_DEVICE="0", OMP_NUM_THREADS="2")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        rc_all |= r.returncode
+        if r.returncode != 0 or not line:
+            out[scaling] = {"rc": r.returncode, "stderr_tail": r.stderr[-1500:]}
+            continue
+        d = json.loads(line[-1])
+        out[scaling] = {"rc": 0, "ranks_observed": d["config"]["ranks_observed"], "templates_per_rank": d["config"].get("templates_per_rank"),
+                        "templates_total": d["config"]["templates_total"], "exchange": d["config"]["exchange"],
+                        "exchange_capacity": d["config"]["exchange_capacity"], "equals_unsharded": d["config"].get("unsharded_check"),
+                        "parallelism": d["config"]["parallelism"], "ms_per_step_time_sliced": d["ms_per_step"], "value": d["value"]}
+    print(json.dumps(out))
+    return 1 if rc_all else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,12 +139,19 @@ def main():
     ap.add_argument("--batch-queue", type=int, default=2, help="launched batches kept queued on the GPU before frames wait for a full batch (lm_detector_set_batch_queue)")
     ap.add_argument("--roofline-only", action="store_true", help="set-up + the roofline leg only (the command profiled under rocprofv3: every k_local / "
                                                                  "k_coarse launch of the run then is one of the measured launches, bar the set-up probe)")
+    ap.add_argument("--check-unsharded", action="store_true", help="N > 1: rank 0 also matches frame 0 with the WHOLE bank on one detector and the sharded, "
+                                                                   "gathered list has to equal it (abort otherwise)")
+    ap.add_argument("--dry-ranks", type=int, default=0, help="rehearsal of `--gpus N` on ONE GPU: N processes over gloo (all on device 0), both scalings, "
+                                                             "each checked against the unsharded match; prints one JSON line with both bench lines")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes of the roofline leg (quote the committed numbers instead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the GPU-vs-oracle comparison of frames 0 and 1 before timing (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extras legs (resident replay, ICP, pipeline, thresholds, 16k bank)")
     ap.add_argument("--exchange", choices=["auto", "host", "device"], default="auto",
                     help="multi-GPU exchange of the match records: on the device (sharded.DeviceExchange; auto = when world > 1) or through the host")
     args = ap.parse_args()
+    if args.dry_ranks > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(dry_ranks(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
@@ -154,7 +190,7 @@ def main():
     BATCH = det.getBatch()
     global PIPELINE_DEPTH
     if PIPELINE_DEPTH <= 0:
-        PIPELINE_DEPTH = min(lm.load_library().lm_detector_max_in_flight(), BATCH * (2 if args.steps < 100 else 3))
+        PIPELINE_DEPTH = min(lm.load_library().lm_detector_max_in_flight(), BATCH * 3)
     frames = noisy_frames(N_FRAMES)
     for k in range(N_PARKED):
         det.storeFrame(k, frames[k])
@@ -198,6 +234,34 @@ def main():
         if not ok:
             ex = None
 
+    # N > 1: what every rank searches, and (--check-unsharded) the sharded result of frame 0 against ONE detector holding the whole
+    # bank (rank 0 builds it): the gathered, merged list must be the unsharded Detector.match list, entry by entry.
+    templates_per_rank, unsharded = None, None
+    if use_dist and world > 1:
+        mine = args.templates * len(my_objs) if by_class else (args.templates * n_obj * (rank + 1) // world - args.templates * n_obj * rank // world)
+        templates_per_rank = [None] * world
+        dist.all_gather_object(templates_per_rank, int(mine))
+        if args.check_unsharded:
+            det.selectFrame(0)
+            got = sharded.match_sharded(det, None, THRESHOLD, classes, device=dev, resident=True, exchange=ex, shard=not by_class)
+            if got is None or (ex is not None and len(got) == 0):
+                got = sharded.match_sharded(det, None, THRESHOLD, classes, device=dev, resident=True, shard=not by_class)
+            okf = 1
+            if rank == 0:
+                full = lm.Detector(NFEAT[0], T_LEVELS, device=local_rank)
+                for o in range(n_obj):
+                    full.addClassPacked(classes[o], *(banks[classes[o]] if classes[o] in banks else synth.make_planted_bank(1234 + o, args.templates, quant, T_LEVELS, NFEAT)))
+                want = full.matchArray(list(frames[0]), THRESHOLD, classes)
+                okf = int(got.tobytes() == want.tobytes())
+                unsharded = {"equal": bool(okf), "matches": int(len(want)), "sharded_matches": int(len(got)), "templates": args.templates * n_obj}
+                del full
+            flag = torch.tensor([okf], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    sys.stderr.write("bench.py: the sharded match differs from the unsharded one: %s\n" % json.dumps(unsharded))
+                sys.exit(4)
+
     # Parity gate ("parity gate before any timing counts"): the GPU's Detector.match of pool frames 0 and 1
     # against the CPU oracle (quantisation in numpy, match loops = the SSE C port pinned to the reference's lines) - bit-exact
     # (x, y, similarity, template_id) in the canonical order, or the bench aborts without a number.
@@ -210,6 +274,7 @@ def main():
             "matches_pre_unique", "coarse_bytes", "local_bytes", "host_submit_ms", "host_wait_ms", "host_collect_ms", "host_merge_ms", "batch_frames")
     acc = {k: 0.0 for k in keys}
     last = {"n": 0}
+    tlog = {"buf": (lm.Timings * (max(1, args.steps) + 64))(), "n": 0}
 
     # Pipelined stream (depth 3): the GPU uploads / prepares frame k+2 and matches frame k+1 while the host collects / sorts / gathers frame k.
     inflight_frames, redo = [], []
@@ -259,9 +324,9 @@ def main():
             out = lm.merge_matches(allrec)
             t3 = time.perf_counter()
         host_t["collect"] += t1 - t0; host_t["gather"] += t2 - t1; host_t["merge"] += t3 - t2
-        tm = det.lastTimings()
-        for q in keys:
-            acc[q] += tm[q]
+        if tlog["n"] < len(tlog["buf"]):                        # the frame's lm_timings, read out after the timed region (one ctypes call here)
+            det.lastTimingsInto(tlog["buf"][tlog["n"]])
+            tlog["n"] += 1
         last["n"] = len(out)
 
     def run(nsteps, resident=False, first=0):
@@ -302,12 +367,16 @@ def main():
         fence()
         for q in host_t:
             host_t[q] = 0.0
-        for q in acc:
-            acc[q] = 0.0
+        tlog["n"] = 0
         t0 = time.perf_counter()
         run(nsteps, resident, first=warmup)      # exactly K submits and K collects inside the timed region
         fence()
         dt = time.perf_counter() - t0
+        for q in acc:
+            acc[q] = 0.0
+        for i in range(tlog["n"]):
+            for q in keys:
+                acc[q] += getattr(tlog["buf"][i], q)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -388,6 +457,7 @@ def main():
                        "parallelism": ("bank-shard x%d (%s) + all-gather" % (world, "by object" if by_class else "by template range")),
                        "ranks_observed": (dist.get_world_size() if use_dist else 1), "backend": (backend if use_dist else None),
                        "exchange": exchange_mode, "exchange_capacity": (ex.capacity if ex is not None else None),
+                       "templates_per_rank": templates_per_rank, "unsharded_check": unsharded,
                        "pipeline_depth": PIPELINE_DEPTH, "frames_per_launch_max": BATCH, "batches_kept_queued": args.batch_queue,
                        "frames_per_launch_mean_timed": mean["batch_frames"],
                        "setup_before_warmup": "8 frames through the ingest ring (each of the library's 8 result slots allocates its pinned staging "
@@ -438,15 +508,44 @@ def main():
                                   "the slowest slice 15-25 us), kNN 0.28, voxel + grid sorts 0.33, normals 0.06, points + bbox 0.07",
                 "f64_flops_note": "a point-to-plane evaluation is ~200 f64 operations per source point: 16 x 7k points = 22 MFLOP per launch, "
                                   "0.4 TFLOP/s of the 78 TFLOP/s f64 vector peak - the chain is nowhere near an arithmetic bound"}
-        traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # PMC pass of the same command (FETCH_SIZE x2 + WRITE_SIZE)
-        if os.path.exists(traffic):
-            try:
-                tj = json.load(open(traffic))
-                if tj.get("kernel") == kname:
-                    out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = tj.get("source")
-            except (OSError, ValueError):
-                pass
+        # PMC counters of the dominant kernel, measured NOW: separate rocprofv3 --pmc passes over `bench.py --roofline-only` (the
+        # same launches as the roofline leg above), corrected as MI355X_MICROARCH.md (HBM) prescribes.  Without rocprofv3 (or with
+        # --no-pmc) the numbers of the last committed pass (profiles/roofline_traffic.json) are quoted and labelled as such.
+        pm = None if (args.no_pmc or args.no_extras or world != 1 or strong) else pmc_live(kname, args)
+        rf = out["roofline"]
+        if pm is not None:
+            hbm = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0      # FETCH_SIZE / WRITE_SIZE are in KB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+            kcycles = pm["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
+            rf.update({
+                "traffic": hbm,
+                "traffic_source": "live: rocprofv3 --kernel-trace --pmc passes of `bench.py --roofline-only` run by this bench.py (FETCH_SIZE x2 + WRITE_SIZE, "
+                                  "mean per %s dispatch of %d frames); memory-side (fabric) bytes, Infinity-Cache hits included" % (kname, BATCH),
+                "hbm_frac_physical": hbm / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None,
+                "l1_accesses_per_launch": pm["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                "l1_pending_stall_cycles_per_launch": pm["TCP_PENDING_STALL_CYCLES_sum"],
+                "frac_of_tcp_cycles": ((pm["TCP_TOTAL_CACHE_ACCESSES_sum"] + pm["TCP_PENDING_STALL_CYCLES_sum"]) / (256.0 * kcycles)) if kcycles > 0 else None,
+                "l1_accesses_per_vmem_instruction": pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / pm["SQ_INSTS_VMEM_RD"] if pm["SQ_INSTS_VMEM_RD"] else None,
+                "bytes_loaded": pm["SQ_INSTS_VMEM_RD"] * 64 * 16,
+                "bytes_loaded_note": "wave-level 16-byte load instructions x 64 lanes x 16 B: an upper bound (tiles keep 60 of 64 lanes busy)",
+                "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None,
+                "insts_per_launch": {"salu": pm["SQ_INSTS_SALU"], "valu": pm["SQ_INSTS_VALU"], "vmem_rd": pm["SQ_INSTS_VMEM_RD"], "waves": pm["SQ_WAVES"]},
+                "kernel_us_profiled": kcycles / 2400.0,
+                "what_bounds_it": "the vector L1 (TCP): one 64-byte access per cycle and CU; accesses + cycles stalled on pending misses over the CU cycles of "
+                                  "the launch = frac_of_tcp_cycles.  `frac` (algorithmic bytes / HBM peak) exceeds 1 because the linear memories are "
+                                  "cache-resident and a tile's window region is loaded once for all its members; hbm_frac_physical is the real HBM share"})
+        else:
+            traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # last committed PMC pass (profiles/pmc_run.sh)
+            if os.path.exists(traffic):
+                try:
+                    tj = json.load(open(traffic))
+                    if tj.get("kernel") == kname:
+                        rf["traffic"] = tj.get("hbm_bytes_per_launch")
+                        rf["traffic_source"] = "NOT measured by this run - committed pass: " + str(tj.get("source"))
+                        for q in ("l1_accesses_per_launch", "frac_of_tcp_cycles", "hbm_frac_physical", "bytes_loaded", "frames_per_launch"):
+                            if q in tj:
+                                rf.setdefault(q if q != "frames_per_launch" else "traffic_frames_per_launch", tj[q])
+                except (OSError, ValueError):
+                    pass
         if world == 1 and not strong and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(noisy_frames(N_FRAMES), banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
@@ -502,7 +601,56 @@ def parity_gate(det, frames, bank, classes, n_templates, n_frames=2):
     return out
 
 
-def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=4, depth=3):
+PMC_PASSES = (("FETCH_SIZE", "GRBM_GUI_ACTIVE"),
+              ("WRITE_SIZE", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum"),
+              ("SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_WAVES", "TCC_HIT_sum", "TCC_MISS_sum"))
+
+
+def pmc_live(kernel, args, timeout=120):
+    """Mean per dispatch of `kernel` of the counters in PMC_PASSES, one rocprofv3 run per pass (SQ, TCC and TCP counters do not all
+    fit one pass; --kernel-trace + --pmc only, nothing else traced) over `python bench.py --roofline-only`.  None if rocprofv3 is not
+    there or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="lm_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for i, grp in enumerate(PMC_PASSES):
+            outdir = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--kernel-trace", "--pmc"] + list(grp) + ["-d", outdir, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--roofline-only",
+                                                                  "--no-parity-gate", "--templates", str(args.templates)] + (["--batch", str(args.batch)] if args.batch > 0 else [])
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            dbs = glob.glob(os.path.join(outdir, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            cols = [c[1] for c in con.execute("pragma table_info('counters_collection')")]
+            name_col = "kernel_name" if "kernel_name" in cols else "name"
+            rows = con.execute("select counter_name, dispatch_id, sum(value) from counters_collection where %s like ? group by counter_name, dispatch_id"
+                               % name_col, ("%" + kernel + "%",)).fetchall()
+            con.close()
+            per = {}
+            for cname, _disp, val in rows:
+                per.setdefault(cname, []).append(val)
+            for cname, v in per.items():
+                vals[cname] = sum(v) / len(v)                # every dispatch of the leg serves frames_per_launch frames
+        need = [c for grp in PMC_PASSES for c in grp]
+        if any(c not in vals for c in need):
+            return None
+        return vals
+    except (OSError, subprocess.SubprocessError, sqlite3.Error):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=8, depth=8):
     """Seconds per frame of the live-stream path (a host frame per step, `depth` in flight) + mean timings."""
     acc, n = {}, 0
     def go(k0, cnt, record):
@@ -862,7 +1010,7 @@ def real_fixture_leg(device, steps=40, target=2000):
     got = det.matchArray([rgb, dep], THRESHOLD, classes)
     equal = same_records(got, want)
     frames = [(rgb.copy(), dep.copy()) for _ in range(4)]
-    dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps, depth=PIPELINE_DEPTH or 4)
+    dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps)
     n = pb.num_pyramids
     return {"workload": "test.cpp:111-130 detect_test: fixture frame 0000 (BGR) x bank 127 tiled x%d = %d template pyramids, Detector(127,{5,8}), "
                         "threshold 75, 640x480" % (reps, n),

@@ -233,9 +233,12 @@ int lm_detector_get_batch(const lm_detector *d);
 int lm_detector_set_batch_queue(lm_detector *d, int batches);
 /* Streamed frames: a host thread of the library (one per detector) waits for each launched batch and prepares every frame's
  * Detector::match list (record conversion, canonical sort, unique) while the caller submits the next frames; lm_detector_collect
- * (sort_unique = 1) then only hands the list over.  On by default (LM_ASYNC_COLLECT=0 / set_async_collect(d, 0): the caller's
- * thread does that work inside lm_detector_collect, as for lone frames).  Results are identical either way. */
+ * (sort_unique = 1) then only hands the list over.  Off by default (LM_ASYNC_COLLECT=1 / set_async_collect(d, 1) turn it on): it
+ * pays when the calling thread is the bottleneck of the stream, and costs a little otherwise.  Results are identical either way. */
 int lm_detector_set_async_collect(lm_detector *d, int on);
+/* Host-side wall time (seconds, accumulated) the library spent on streamed frames: out8 = {frames, staging copy, H2D enqueue, slot
+ * bookkeeping, batch launches, collect: waiting for the GPU, record conversion, canonical sort + unique}; reset != 0 clears it. */
+int lm_detector_host_profile(lm_detector *d, double *out8, int reset);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity
