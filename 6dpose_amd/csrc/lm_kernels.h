@@ -67,14 +67,15 @@ struct Candidate {        // coarse hit, and (same layout) final match record
 
 // Tile refinement (match.hip): candidates of one template whose coarse cells are neighbours share most of their level-0
 // windows; k_coarse groups them into tiles, k_local accumulates a tile's window region once for all its members.
-constexpr int kTileStep = 4;      // level-0 cells between the windows of neighbouring coarse cells: 2 * T_top / T_0 must equal this
+constexpr int kTileStep = 4;      // most level-0 cells between the windows of neighbouring coarse cells: 2 * T_top / T_0 <= this
+constexpr int kTileMaskBits = 10; // member bits of TileRec::mask (kTileNx x kTileNy); above them the window steps, 3 bits each: columns 1..4, second row
 constexpr int kTileNx = 5;        // coarse cells per tile: 16 + 4 * 4 = 32 columns = the part of 3 strips that survives any byte phase
 constexpr int kTileNy = 2;        //                        16 + 4 rows; 20 rows x 3 strips = 60 of the 64 lanes of a load
 struct TileRec {
     int32_t work;                 // work-list index (-> template pyramid)
     uint32_t gxy;                 // int16 gx0 | int16 gy0 << 16: level-0 cell of the first member's window origin (x / T - 8, LL.cpp:1380)
     uint32_t slot_base;           // its members own the candidate slots [slot_base, slot_base + popcount(mask)), row-major by (j, i)
-    uint32_t mask;                // bit i + kTileNx * j: the candidate of coarse cell (c0 + i, r0 + j) is a member
+    uint32_t mask;                // bit i + kTileNx * j: the candidate of coarse cell (c0 + i, r0 + j) is a member; bits kTileMaskBits..: window steps
 };
 // counters[0] of a frame's working counters: candidates in the low kCandBits bits, tiles planned above them (one atomic of
 // k_coarse reserves both)

@@ -343,7 +343,7 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
             for (int sft = 0; sft < kTileNx - 1; ++sft)                     // tight on the left: a lone column of members needs two strips, not three
                 if (!__ballot(in && cx == c0)) ++c0;
             const int bit = in ? (cx - c0) + kTileNx * (cy - r) : 0;
-            uint32_t mask = in ? 1u << bit : 0u;
+            uint32_t mask = in ? 1u << bit : 0u;                              // (members only: kTileMaskBits bits)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mask |= (uint32_t)__shfl_xor((int)mask, o, 64);
             if (in) { my_rel = next + (uint32_t)__popc(mask & ((1u << bit) - 1u)); member = true; elig = false; }
@@ -351,7 +351,13 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
                 s_tile[4 * ntile + 0] = (uint32_t)work;
                 s_tile[4 * ntile + 1] = (uint32_t)(uint16_t)(int16_t)(fine_x0(c0) / T0 - 8) | ((uint32_t)(uint16_t)(int16_t)(fine_x0(r) / T0 - 8) << 16);
                 s_tile[4 * ntile + 2] = next;
-                s_tile[4 * ntile + 3] = mask;
+                // window origins of the block's columns / second row relative to the first, in level-0 cells: 2 T_top / T_0 apart on
+                // average, e.g. always 4 for T = {4, 8} and 3, 3, 3, 3, 4, ... for the reference's default T = {5, 8} (LL.cpp:1868-1881)
+                uint32_t steps = 0;
+#pragma unroll
+                for (int i = 1; i < kTileNx; ++i) steps |= (uint32_t)(fine_x0(c0 + i) / T0 - fine_x0(c0 + i - 1) / T0) << (3 * (i - 1));
+                steps |= (uint32_t)(fine_x0(r + 1) / T0 - fine_x0(r) / T0) << (3 * (kTileNx - 1));
+                s_tile[4 * ntile + 3] = mask | (steps << kTileMaskBits);
             }
             next += (uint32_t)best_n;
             ++ntile;
@@ -411,13 +417,14 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
     }
 }
 
-// Tiles are planned for two-level pyramids whose coarse cells lie exactly kTileStep fine cells apart (T = {4, 8}, {2, 4}, ...)
+// Tiles are planned for two-level pyramids whose neighbouring coarse cells have level-0 windows at most kTileStep cells apart
+// (T_0 <= T_top <= 2 T_0: T = {4, 8}, {2, 4}, and the reference's default {5, 8}, where the step alternates between 3 and 4 cells)
 // and whose coarse grid fits the planner's LDS; anything else keeps the plain per-wave candidate emission.
 bool tile_plan_possible(const FrameGeom& g) {
     if (g.levels != 2) return false;
     const LevelGeom& top = g.lv[1];
     const LevelGeom& l0 = g.lv[0];
-    if (2 * top.T != kTileStep * l0.T) return false;
+    if (2 * top.T > kTileStep * l0.T || top.T < l0.T) return false;      // 2 <= step <= kTileStep: 5 columns span <= 16 cells, a second row <= 4
     const size_t npos = (size_t)top.Wd * top.Hd;
     return npos >= 1 && coarse_plan_lds_bytes(top.Wd, top.Hd) <= 60 * 1024;   // at least one template per workgroup
 }
@@ -553,7 +560,9 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             const TileRec t = F.tiles[gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr])];
             const int work = __builtin_amdgcn_readfirstlane(t.work);
             const uint32_t gxy = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.gxy);
-            const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask);
+            const uint32_t mask_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask);
+            const uint32_t mask = mask_word & ((1u << kTileMaskBits) - 1u), steps = mask_word >> kTileMaskBits;   // members | window steps (3 bits each)
+            const int dy1 = (int)((steps >> (3 * (kTileNx - 1))) & 7u);        // window origin of the second row of members
             const uint32_t slot_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.slot_base);
             const int gx0 = (int16_t)(gxy & 0xFFFF), gy0 = (int16_t)(gxy >> 16);
             const int pyr = __builtin_amdgcn_readfirstlane(work_pyramids[work]);
@@ -561,7 +570,7 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             const int nf = e.nf, nfp = e.nf_padded;
             const uint32_t cols = (mask | (mask >> kTileNx)) & ((1u << kTileNx) - 1u);
             const int S = cols > 1u ? 3 : 2;                                   // a second column of candidates needs a third strip
-            const int R = (mask >> kTileNx) ? 16 + kTileStep : 16;
+            const int R = (mask >> kTileNx) ? 16 + dy1 : 16;
             int q = (lane >= R) + (lane >= 2 * R), r = lane - q * R;
             const bool active = lane < R * S;
             if (!active) { q = 0; r = 0; }                                     // idle lanes repeat lane 0's (valid) loads
@@ -653,12 +662,28 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                 const int bit = __ffs((int)rest) - 1;
                 rest &= rest - 1;
                 const int j = bit / kTileNx, i = bit - j * kTileNx;
-                const int rr = r - j * kTileStep;                              // row of this lane inside the member's window
+                int dx = 0;                                                     // window origin of the member's column (wave-uniform)
+                for (int u = 0; u < i; ++u) dx += (int)((steps >> (3 * u)) & 7u);
+                const int dy = j ? dy1 : 0;
+                const int rr = r - dy;                                          // row of this lane inside the member's window
                 uint32_t key = 0;
-                if (active && q < 2 && rr >= 0 && rr < 16) {
+                if (active && q < 2 && rr >= 0 && rr < 16 && (dx & 3)) {        // a window that starts inside a 4-column group: column by column
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int col = 16 * q + 4 * k - i * kTileStep;         // window column of the lane's 4-column group k
+                        const uint32_t raws4[4] = {aE[k] & 0xFFFF, aO[k] & 0xFFFF, aE[k] >> 16, aO[k] >> 16};
+#pragma unroll
+                        for (int tcol = 0; tcol < 4; ++tcol) {
+                            const int col = 16 * q + 4 * k + tcol - dx;
+                            if (col >= 0 && col < 16) {
+                                const uint32_t kk = (raws4[tcol] << 8) | (255u - (uint32_t)(rr * 16 + col));
+                                key = kk > key ? kk : key;
+                            }
+                        }
+                    }
+                } else if (active && q < 2 && rr >= 0 && rr < 16) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int col = 16 * q + 4 * k - dx;                    // window column of the lane's 4-column group k
                         if (col >= 0 && col < 16) {
                             const uint32_t idx = (uint32_t)(rr * 16 + col);
                             const uint32_t k0 = ((aE[k] & 0xFFFF) << 8) | (255u - idx), k1 = ((aO[k] & 0xFFFF) << 8) | (255u - (idx + 1));
@@ -682,8 +707,8 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                 ++member;
                 if (lane == 0 && slot < cap) {
                     Candidate m;
-                    m.x = (gx0 + i * kTileStep + bc) * T + offset;              // LL.cpp:1930-1931: x / T - 8 = the member's window origin
-                    m.y = (gy0 + j * kTileStep + br) * T + offset;
+                    m.x = (gx0 + dx + bc) * T + offset;                         // LL.cpp:1930-1931: x / T - 8 = the member's window origin
+                    m.y = (gy0 + dy + br) * T + offset;
                     m.score = best;
                     m.work = best < threshold ? -1 : work;                      // LL.cpp:1935
                     matches[slot] = m;

@@ -350,14 +350,32 @@ def test_tile_refinement_is_exact(lm):
         assert st2["coarse_candidates"] > 150
         same_records(d2.matchArray([rgb2, dep2], thr2, ["o"]), lo.canonical_sort_unique(raw2))
         assert d2.lastTimings()["coarse_candidates"] == st2["coarse_candidates"]
-    # a geometry the planner does not tile (coarse cells 16/5 fine cells apart) takes the per-candidate path unchanged
-    od58 = lo.OracleDetector(63, [5, 8])
-    p58 = od58.quantize_pyramid(rgb, dep)
-    b58 = synth.make_planted_bank(19, 120, [(p[0], p[1]) for p in p58], [5, 8], (63, 31))
-    d58 = lm.Detector(63, [5, 8], device=0)
-    d58.addClassPacked("o", *b58)
-    raw, _ = oracle_matches(od58, rgb, dep, b58, [5, 8], 70.0)
-    same_records(d58.matchArray([rgb, dep], 70.0, ["o"]), lo.canonical_sort_unique(raw))
+    # the reference's default geometry T = {5, 8} (Detector(), LL.cpp:1663-1692: every fixture bank): the windows of neighbouring coarse
+    # cells lie 16 / 5 level-0 cells apart - 3, 3, 3, 3, 4, ... - and the tiles carry those steps; also T = {6, 8} (steps 2 and 3) and
+    # {3, 4}.  Tiled == per-candidate path == oracle, statistics included; T = {4, 16} (8 cells apart) is not tiled and still exact.
+    for (T5, nf5, thr5, seed5) in (([5, 8], (63, 31), 70.0, 19), ([5, 8], (127, 63), 60.0, 20), ([6, 8], (64, 32), 65.0, 21), ([3, 4], (64, 32), 65.0, 22),
+                                   ([4, 16], (64, 32), 60.0, 23)):
+        W5, H5 = (640, 480) if T5[0] not in (3, 6) else (768, 480)
+        rgb5, dep5 = synth.make_frame(5, W5, H5)
+        od5 = lo.OracleDetector(nf5[0], T5)
+        p5 = od5.quantize_pyramid(rgb5, dep5)
+        b5 = synth.make_planted_bank(seed5, 160, [(p[0], p[1]) for p in p5], T5, nf5)
+        raw, st5 = oracle_matches(od5, rgb5, dep5, b5, T5, thr5)
+        want5 = lo.canonical_sort_unique(raw)
+        assert len(want5) > 0
+        stats = []
+        for tiles_on in ("1", "0"):
+            os.environ["LM_TILES"] = tiles_on
+            try:
+                d5 = lm.Detector(nf5[0], T5, device=0)
+            finally:
+                del os.environ["LM_TILES"]
+            d5.addClassPacked("o", *b5)
+            same_records(d5.matchArray([rgb5, dep5], thr5, ["o"]), want5)
+            tm5 = d5.lastTimings()
+            assert tm5["coarse_candidates"] == st5["coarse_candidates"]
+            stats.append((tm5["local_evals"], tm5["local_bytes"], tm5["matches_pre_unique"]))
+        assert stats[0] == stats[1], (T5, stats)
 
 
 def test_sharded_equals_unsharded_on_one_device(lm):
