@@ -40,52 +40,116 @@ extern "C" int lm_exchange_max_capacity(void) { return (int)kXchgMaxCapacity; }
 
 extern "C" size_t lm_exchange_block_bytes(int capacity) { return valid_capacity(capacity) ? 16 + (size_t)capacity * 16 : 0; }
 
-extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int capacity) {
-    if (!d || !send_block) return lm_set_error(LM_ERR_INVALID, "null argument");
+extern "C" uint64_t lm_detector_frames_submitted(const lm_detector* d) { return d ? d->n_submitted : 0; }
+extern "C" uint64_t lm_detector_frames_launched(const lm_detector* d) { return d ? d->n_launched : 0; }
+extern "C" uint64_t lm_detector_frames_collected(const lm_detector* d) { return d ? d->n_collected : 0; }
+
+// The exchange of a GROUP of n consecutive frames, first = the number of its first frame in submission order (sharded.DeviceExchange:
+// one all-gather carries the blocks of the whole group).  The frames must have been LAUNCHED (streamed frames wait for their batch:
+// lm_detector_frames_launched, lm_detector_flush) and not collected yet.  Frame first + i packs into send_blocks + i * block bytes; ONE
+// launch of each kernel serves the group.
+extern "C" int lm_detector_exchange_pack_group(lm_detector* d, uint64_t first, int n, void* send_blocks, int capacity) {
+    if (!d || !send_blocks || n < 1 || n > kMaxBatch) return lm_set_error(LM_ERR_INVALID, "bad argument");
     if (!valid_capacity(capacity)) return lm_set_error(LM_ERR_INVALID, "capacity must be a power of two in [256, %u]", kXchgMaxCapacity);
-    if (d->n_submitted == d->n_collected) return lm_set_error(LM_ERR_INVALID, "no frame in flight: call lm_detector_submit first");
+    if (first < d->n_collected || first + (uint64_t)n > d->n_launched)
+        return lm_set_error(LM_ERR_INVALID, "frames %llu..%llu are not all in flight on the device (collected %llu, launched %llu, submitted %llu)", (unsigned long long)first,
+                            (unsigned long long)(first + n - 1), (unsigned long long)d->n_collected, (unsigned long long)d->n_launched, (unsigned long long)d->n_submitted);
     HIP_TRY(hipSetDevice(d->device));
     int rc = ensure_exchange(d);
     if (rc) return rc;
-    const int slot = (int)((d->n_submitted - 1) % lm_detector::kSlots);            // the frame just submitted
-    if (d->xchg.state[slot] != 0) return lm_set_error(LM_ERR_INVALID, "the frame in flight was packed already");
-    if ((rc = lm_launch_pending(d))) return rc;                                     // the exchange follows the frame's kernels in stream order: no waiting for a batch to fill
-    lm_detector::Slot& sl = d->slot[slot];
+    if ((rc = d->xchg.d_runs.ensure((size_t)kXchgMaxCapacity * kMaxBatch))) return rc;
+    const size_t blk = lm_exchange_block_bytes(capacity);
     hipStream_t xs = d->xchg.stream;
-    HIP_TRY(hipStreamWaitEvent(xs, d->slot[sl.leader].done, 0));                    // records + counters of this frame (of its batch) are final
-    if ((rc = d->xchg.d_runs.ensure(kXchgMaxCapacity))) return rc;
-    launch_exchange_pack(d->d_distinct_keys.p + (size_t)d->buf_cand_cap * slot, d->d_final.p + 8 * (size_t)slot, d->buf_cand_cap,
-                         (uint32_t)capacity, d->xchg.d_runs.p, (uint32_t*)send_block, xs);
+    XchgGroup G{};
+    G.n = n;
+    int last_leader = -1;
+    for (int i = 0; i < n; ++i) {
+        const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
+        if (d->xchg.state[slot] != 0) return lm_set_error(LM_ERR_INVALID, "frame %llu was packed already", (unsigned long long)(first + i));
+        const int leader = d->slot[slot].leader;
+        if (leader != last_leader) { HIP_TRY(hipStreamWaitEvent(xs, d->slot[leader].done, 0)); last_leader = leader; }   // records + counters of the frame's batch are final
+        G.f[i].keys = d->d_distinct_keys.p + (size_t)d->buf_cand_cap * slot;
+        G.f[i].counters = d->d_final.p + 8 * (size_t)slot;
+        G.f[i].runs = d->xchg.d_runs.p + (size_t)kXchgMaxCapacity * i;
+        G.f[i].block = (uint32_t*)((uint8_t*)send_blocks + (size_t)i * blk);
+    }
+    launch_exchange_pack_group(G, d->buf_cand_cap, (uint32_t)capacity, xs);
     HIP_TRY(hipGetLastError());
-    d->xchg.state[slot] = 1;
-    d->xchg.cap[slot] = capacity;
+    for (int i = 0; i < n; ++i) {
+        const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
+        d->xchg.state[slot] = 1;
+        d->xchg.cap[slot] = capacity;
+    }
     return LM_OK;
 }
 
-extern "C" int lm_detector_exchange_merge(lm_detector* d, const void* recv_blocks, int world, int capacity) {
-    if (!d || !recv_blocks || world < 1) return lm_set_error(LM_ERR_INVALID, "bad argument");
-    if (d->n_submitted == d->n_collected) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
-    const int slot = (int)((d->n_submitted - 1) % lm_detector::kSlots);
-    if (d->xchg.state[slot] != 1 || d->xchg.cap[slot] != capacity)
-        return lm_set_error(LM_ERR_INVALID, "lm_detector_exchange_pack(capacity %d) has to precede the merge of a frame", capacity);
+// recv_blocks: the group's blocks of rank 0, frame first + i at recv_blocks + i * block bytes; rank j's lie j * rank_stride_bytes further
+// (0 = n * block bytes: every rank sent its n blocks back to back).
+extern "C" int lm_detector_exchange_merge_group_strided(lm_detector* d, uint64_t first, int n, const void* recv_blocks, int world, int capacity, size_t rank_stride_bytes) {
+    if (!d || !recv_blocks || world < 1 || n < 1 || n > kMaxBatch || (rank_stride_bytes & 3)) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (first < d->n_collected || first + (uint64_t)n > d->n_launched) return lm_set_error(LM_ERR_INVALID, "frames %llu.. are not in flight on the device", (unsigned long long)first);
+    const size_t blk = lm_exchange_block_bytes(capacity);
+    if (!blk) return lm_set_error(LM_ERR_INVALID, "bad capacity");
+    if (!rank_stride_bytes) rank_stride_bytes = (size_t)n * blk;
     HIP_TRY(hipSetDevice(d->device));
     const size_t words = (size_t)kXchgHeaderWords + (size_t)world * capacity * 5;
-    int rc = d->xchg.d_merged[slot].ensure(words);                                   // the slot's previous frame was collected: buffers are idle
-    if (rc) return rc;
-    if (d->xchg.h_words[slot] < words) {
-        if (d->xchg.h_merged[slot]) (void)hipHostFree(d->xchg.h_merged[slot]);
-        d->xchg.h_merged[slot] = nullptr; d->xchg.h_words[slot] = 0;
-        HIP_TRY(hipHostMalloc((void**)&d->xchg.h_merged[slot], words * sizeof(int32_t), hipHostMallocDefault));
-        d->xchg.h_words[slot] = words;
+    XchgGroup G{};
+    G.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
+        if (d->xchg.state[slot] != 1 || d->xchg.cap[slot] != capacity)
+            return lm_set_error(LM_ERR_INVALID, "lm_detector_exchange_pack(capacity %d) has to precede the merge of a frame", capacity);
+        int rc = d->xchg.d_merged[slot].ensure(words);                                   // the slot's previous frame was collected: buffers are idle
+        if (rc) return rc;
+        if (d->xchg.h_words[slot] < words) {
+            if (d->xchg.h_merged[slot]) (void)hipHostFree(d->xchg.h_merged[slot]);
+            d->xchg.h_merged[slot] = nullptr; d->xchg.h_words[slot] = 0;
+            HIP_TRY(hipHostMalloc((void**)&d->xchg.h_merged[slot], words * sizeof(int32_t), hipHostMallocDefault));
+            d->xchg.h_words[slot] = words;
+        }
+        G.f[i].recv = (const uint32_t*)((const uint8_t*)recv_blocks + (size_t)i * blk);
+        G.f[i].merged = d->xchg.d_merged[slot].p;
     }
     hipStream_t xs = d->xchg.stream;
-    launch_exchange_merge((const uint32_t*)recv_blocks, world, (uint32_t)capacity, d->xchg.d_merged[slot].p, xs);
+    launch_exchange_merge_group(G, world, (uint32_t)capacity, xs, (uint32_t)(rank_stride_bytes / 4));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d->xchg.h_merged[slot], d->xchg.d_merged[slot].p, words * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
-    HIP_TRY(hipEventRecord(d->xchg.done[slot], xs));
-    d->xchg.state[slot] = 2;
-    d->xchg.world[slot] = world;
+    for (int i = 0; i < n; ++i) {
+        const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
+        HIP_TRY(hipMemcpyAsync(d->xchg.h_merged[slot], d->xchg.d_merged[slot].p, words * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
+        HIP_TRY(hipEventRecord(d->xchg.done[slot], xs));
+        d->xchg.state[slot] = 2;
+        d->xchg.world[slot] = world;
+    }
     return LM_OK;
+}
+extern "C" int lm_detector_exchange_merge_group(lm_detector* d, uint64_t first, int n, const void* recv_blocks, int world, int capacity) {
+    return lm_detector_exchange_merge_group_strided(d, first, n, recv_blocks, world, capacity, 0);
+}
+
+// One frame: a group of one.
+extern "C" int lm_detector_exchange_pack_frame(lm_detector* d, uint64_t frame_no, void* send_block, int capacity) {
+    return lm_detector_exchange_pack_group(d, frame_no, 1, send_block, capacity);
+}
+extern "C" int lm_detector_exchange_merge_frame_strided(lm_detector* d, uint64_t frame_no, const void* recv_blocks, int world, int capacity, size_t rank_stride_bytes) {
+    return lm_detector_exchange_merge_group_strided(d, frame_no, 1, recv_blocks, world, capacity, rank_stride_bytes ? rank_stride_bytes : lm_exchange_block_bytes(capacity));
+}
+extern "C" int lm_detector_exchange_merge_frame(lm_detector* d, uint64_t frame_no, const void* recv_blocks, int world, int capacity) {
+    return lm_detector_exchange_merge_frame_strided(d, frame_no, recv_blocks, world, capacity, 0);
+}
+
+// The frame just submitted (launching whatever waits for its batch): the one-frame-at-a-time form of the two calls above.
+extern "C" int lm_detector_exchange_pack(lm_detector* d, void* send_block, int capacity) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (d->n_submitted == d->n_collected) return lm_set_error(LM_ERR_INVALID, "no frame in flight: call lm_detector_submit first");
+    int rc = lm_launch_pending(d);                                                   // the exchange follows the frame's kernels in stream order
+    if (rc) return rc;
+    return lm_detector_exchange_pack_frame(d, d->n_submitted - 1, send_block, capacity);
+}
+
+extern "C" int lm_detector_exchange_merge(lm_detector* d, const void* recv_blocks, int world, int capacity) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (d->n_submitted == d->n_collected) return lm_set_error(LM_ERR_INVALID, "no frame in flight");
+    return lm_detector_exchange_merge_frame(d, d->n_submitted - 1, recv_blocks, world, capacity);
 }
 
 static int exchange_collect(lm_detector* d, lm_match* dst, size_t dst_capacity, lm_match** out, size_t* n_out, int* failed) {

@@ -106,9 +106,13 @@ __device__ __forceinline__ uint32_t pack_flags(const unsigned long long* counter
 // grid cap / 256.  runs[b * 256 ..] = sorted chunk b of the rank's keys, padded with ~0 keys (which sort last).
 // Workgroup 0 writes the block header {count, flags, capacity, 0}.
 __global__ void __launch_bounds__(kWG)
-k_exchange_sort256(const ulonglong2* __restrict__ keys, const unsigned long long* __restrict__ counters, uint32_t cand_cap, uint32_t cap,
-                   ulonglong2* __restrict__ runs, uint32_t* __restrict__ block) {
+k_exchange_sort256(XchgGroup G, uint32_t cand_cap, uint32_t cap) {
     __shared__ ulonglong2 s[kWG];
+    const XchgFrame& F = G.f[blockIdx.y];                                 // grid (chunks, frames of the group)
+    const ulonglong2* __restrict__ keys = F.keys;
+    const unsigned long long* __restrict__ counters = F.counters;
+    ulonglong2* __restrict__ runs = F.runs;
+    uint32_t* __restrict__ block = F.block;
     const uint32_t flags = pack_flags(counters, cand_cap, cap);
     const unsigned long long nd = counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -134,9 +138,12 @@ k_exchange_sort256(const ulonglong2* __restrict__ keys, const unsigned long long
 
 // grid cap / 256.  The rank's sorted chunks -> one sorted run in block + 4 words.
 __global__ void __launch_bounds__(kWG)
-k_exchange_merge256(const ulonglong2* __restrict__ runs, const unsigned long long* __restrict__ counters, uint32_t cand_cap, uint32_t cap,
-                    uint32_t* __restrict__ block) {
+k_exchange_merge256(XchgGroup G, uint32_t cand_cap, uint32_t cap) {
     __shared__ RankLds L;
+    const XchgFrame& F = G.f[blockIdx.y];
+    const ulonglong2* __restrict__ runs = F.runs;
+    const unsigned long long* __restrict__ counters = F.counters;
+    uint32_t* __restrict__ block = F.block;
     if (pack_flags(counters, cand_cap, cap)) return;
     const uint32_t n = (uint32_t)counters[1];
     const int self = blockIdx.x;
@@ -155,9 +162,11 @@ k_exchange_merge256(const ulonglong2* __restrict__ runs, const unsigned long lon
 // grid (cap / 256, W).  blocks: W blocks of block_words uint32 each.  merged: kXchgHeaderWords words, then 5-word records
 // (x, y, similarity, class position — or -1 - class position when std::unique drops the record —, template id).
 __global__ void __launch_bounds__(kWG)
-k_exchange_merge(const uint32_t* __restrict__ blocks, int W, uint32_t cap, uint32_t block_words, int32_t* __restrict__ merged) {
+k_exchange_merge(XchgGroup G, int W, uint32_t cap, uint32_t block_words) {
     __shared__ RankLds L;
     __shared__ uint32_t s_or, s_total;
+    const uint32_t* __restrict__ blocks = G.f[blockIdx.z].recv;           // grid (chunks, ranks, frames of the group)
+    int32_t* __restrict__ merged = G.f[blockIdx.z].merged;
     const int self = blockIdx.y;
     const uint32_t b = blockIdx.x;
     if (threadIdx.x == 0) { s_or = 0; s_total = 0; }
@@ -199,16 +208,17 @@ k_exchange_merge(const uint32_t* __restrict__ blocks, int W, uint32_t cap, uint3
     o[4] = (int32_t)(uint32_t)(key.x & 0xFFFFFFFFu);
 }
 
-void launch_exchange_pack(const ulonglong2* distinct_keys, const unsigned long long* counters, uint32_t cand_cap, uint32_t cap,
-                          ulonglong2* runs_scratch, uint32_t* block, hipStream_t s) {
-    const dim3 grid((cap + kWG - 1) / kWG);
-    hipLaunchKernelGGL(k_exchange_sort256, grid, dim3(kWG), 0, s, distinct_keys, counters, cand_cap, cap, runs_scratch, block);
-    hipLaunchKernelGGL(k_exchange_merge256, grid, dim3(kWG), 0, s, runs_scratch, counters, cand_cap, cap, block);
+void launch_exchange_pack_group(const XchgGroup& G, uint32_t cand_cap, uint32_t cap, hipStream_t s) {
+    if (G.n <= 0) return;
+    const dim3 grid((cap + kWG - 1) / kWG, G.n);
+    hipLaunchKernelGGL(k_exchange_sort256, grid, dim3(kWG), 0, s, G, cand_cap, cap);
+    hipLaunchKernelGGL(k_exchange_merge256, grid, dim3(kWG), 0, s, G, cand_cap, cap);
 }
 
-void launch_exchange_merge(const uint32_t* blocks, int world, uint32_t cap, int32_t* merged, hipStream_t s) {
-    const uint32_t block_words = 4 + cap * 4;
-    hipLaunchKernelGGL(k_exchange_merge, dim3((cap + kWG - 1) / kWG, world), dim3(kWG), 0, s, blocks, world, cap, block_words, merged);
+void launch_exchange_merge_group(const XchgGroup& G, int world, uint32_t cap, hipStream_t s, uint32_t rank_stride_words) {
+    if (G.n <= 0) return;
+    const uint32_t block_words = rank_stride_words ? rank_stride_words : 4 + cap * 4;   // distance between the blocks of consecutive ranks
+    hipLaunchKernelGGL(k_exchange_merge, dim3((cap + kWG - 1) / kWG, world, G.n), dim3(kWG), 0, s, G, world, cap, block_words);
 }
 
 }  // namespace lm

@@ -206,8 +206,18 @@ __device__ __forceinline__ ulonglong2 xchg_make_key(int x, int y, float sim, int
 }
 __device__ __forceinline__ bool xchg_key_fits(int x, int y, int cls, int tid) { return x >= -32768 && x <= 32767 && y >= -32768 && y <= 32767 && cls >= 0 && tid >= 0; }
 // counters: [0] coarse candidates, [1] distinct records, [3] != 0: a record did not fit the key (all written by the matching stream)
-void launch_exchange_pack(const ulonglong2* distinct_keys, const unsigned long long* counters, uint32_t cand_cap, uint32_t cap,
-                          ulonglong2* runs_scratch /*cap keys*/, uint32_t* block, hipStream_t s);
-void launch_exchange_merge(const uint32_t* blocks, int world, uint32_t cap, int32_t* merged, hipStream_t s);
+// The exchange kernels serve a GROUP of frames per launch (grid.y / grid.z = frame): per frame the distinct keys and published counters of
+// its result slot, a scratch for the sorted 256-key runs, the block it contributes, and — after the all-gather — this frame's block of rank 0
+// (rank j's lies j * rank stride further) and the merged list.
+struct XchgFrame {
+    const ulonglong2* keys; const unsigned long long* counters; ulonglong2* runs; uint32_t* block;     // pack
+    const uint32_t* recv; int32_t* merged;                                                               // merge
+};
+struct XchgGroup { int n; int pad; XchgFrame f[kMaxBatch]; };
+// counters: [0] coarse candidates, [1] distinct records, [3] != 0: a record did not fit the key (all written by the matching stream)
+void launch_exchange_pack_group(const XchgGroup& G, uint32_t cand_cap, uint32_t cap, hipStream_t s);
+// rank_stride_words: distance between consecutive ranks' blocks (0 = packed: one block per rank; a gathered group of frames has the blocks of
+// all its frames between two ranks)
+void launch_exchange_merge_group(const XchgGroup& G, int world, uint32_t cap, hipStream_t s, uint32_t rank_stride_words = 0);
 
 }  // namespace lm

@@ -174,6 +174,15 @@ def load_library():
     lib.lm_exchange_block_bytes.restype = ctypes.c_size_t
     lib.lm_detector_exchange_pack.argtypes = [P, P, I]
     lib.lm_detector_exchange_merge.argtypes = [P, P, I, I]
+    U64 = ctypes.c_uint64
+    lib.lm_detector_exchange_pack_frame.argtypes = [P, U64, P, I]
+    lib.lm_detector_exchange_merge_frame.argtypes = [P, U64, P, I, I]
+    lib.lm_detector_exchange_merge_frame_strided.argtypes = [P, U64, P, I, I, ctypes.c_size_t]
+    lib.lm_detector_exchange_pack_group.argtypes = [P, U64, I, P, I]
+    lib.lm_detector_exchange_merge_group.argtypes = [P, U64, I, P, I, I]
+    for f in (lib.lm_detector_frames_submitted, lib.lm_detector_frames_launched, lib.lm_detector_frames_collected):
+        f.argtypes = [P]
+        f.restype = U64
     lib.lm_detector_exchange_collect_into.argtypes = [P, P, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I)]
     lib.lm_detector_exchange_collect.argtypes = [P, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I)]
     lib.lm_detector_collect.argtypes = [P, I, ctypes.POINTER(ctypes.POINTER(_CMatch)), ctypes.POINTER(ctypes.c_size_t)]
@@ -560,6 +569,29 @@ class Detector:
         if not h:
             raise RuntimeError(self._lib.lm_last_error().decode("utf-8", "replace"))
         return int(h)
+
+    def framesSubmitted(self) -> int:
+        """Frames submitted so far = the number the next submitted frame gets (lm_detector_frames_submitted)."""
+        return int(self._lib.lm_detector_frames_submitted(self._h))
+
+    def framesLaunched(self) -> int:
+        """Frames whose kernels have been launched (streamed frames wait for their batch; lm_detector_frames_launched)."""
+        return int(self._lib.lm_detector_frames_launched(self._h))
+
+    def framesCollected(self) -> int:
+        return int(self._lib.lm_detector_frames_collected(self._h))
+
+    def exchangePackFrame(self, frame_no: int, send_ptr: int, capacity: int) -> None:
+        _check(self._lib.lm_detector_exchange_pack_frame(self._h, frame_no, ctypes.c_void_p(send_ptr), capacity))
+
+    def exchangeMergeFrame(self, frame_no: int, recv_ptr: int, world: int, capacity: int, rank_stride_bytes: int = 0) -> None:
+        _check(self._lib.lm_detector_exchange_merge_frame_strided(self._h, frame_no, ctypes.c_void_p(recv_ptr), world, capacity, rank_stride_bytes))
+
+    def exchangePackGroup(self, first: int, n: int, send_ptr: int, capacity: int) -> None:
+        _check(self._lib.lm_detector_exchange_pack_group(self._h, first, n, ctypes.c_void_p(send_ptr), capacity))
+
+    def exchangeMergeGroup(self, first: int, n: int, recv_ptr: int, world: int, capacity: int) -> None:
+        _check(self._lib.lm_detector_exchange_merge_group(self._h, first, n, ctypes.c_void_p(recv_ptr), world, capacity))
 
     def exchangePack(self, send_ptr: int, capacity: int) -> None:
         _check(self._lib.lm_detector_exchange_pack(self._h, ctypes.c_void_p(send_ptr), capacity))

@@ -69,7 +69,7 @@ class DeviceExchange:
     def __init__(self, detector: "lm.Detector", device, group=None, capacity: int = 4096, force: bool = False, shard: bool = True):
         import torch
         import torch.distributed as dist
-        self.det, self.group = detector, group
+        self.det, self.group_handle = detector, group
         self.dev = torch.device(device)
         self.world, self.rank = 1, 0
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -82,7 +82,7 @@ class DeviceExchange:
         detector.setAsyncCollect(False)   # the merged list of all ranks comes from the device exchange: no per-rank host list to prepare
         self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
         self.slots = lm.load_library().lm_detector_max_in_flight()
-        self.next = 0
+        self.queue = []                 # numbers of the frames submitted whose exchange is not enqueued yet
         self._alloc(capacity)
 
     def _alloc(self, capacity: int):
@@ -91,38 +91,72 @@ class DeviceExchange:
         nbytes = lm.load_library().lm_exchange_block_bytes(capacity)
         if nbytes == 0:
             raise ValueError("capacity must be a power of two in [256, %d]" % lm.load_library().lm_exchange_max_capacity())
-        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
-        self.recv = [torch.zeros(nbytes * self.world, dtype=torch.uint8, device=self.dev) for _ in range(self.slots)]
-        self.cap_of = [capacity] * self.slots
+        self.block_bytes = nbytes
+        # one send / receive buffer per GROUP of frames in flight: the blocks of up to `group` consecutive frames travel in ONE all-gather
+        self.group = max(1, min(self.det.getBatch(), self.slots))
+        self.sets = self.slots // self.group + 2
+        self.send = [torch.zeros(nbytes * self.group, dtype=torch.uint8, device=self.dev) for _ in range(self.sets)]
+        self.recv = [torch.zeros(nbytes * self.group * self.world, dtype=torch.uint8, device=self.dev) for _ in range(self.sets)]
+        # views for every group size, made once (slicing a tensor and asking for its data_ptr cost ~10 us per frame in the loop)
+        self.views = [[(s[:n * nbytes], r[:n * nbytes * self.world]) for n in range(self.group + 1)] for s, r in zip(self.send, self.recv)]
+        self.ptrs = [(s.data_ptr(), r.data_ptr()) for s, r in zip(self.send, self.recv)]
+        self.next_set = 0
 
     def submit(self, threshold: float, class_ids: Sequence[str] = (), frame=None) -> None:
         """frame=None: the detector's current frame (setFrame / selectFrame); frame=(rgb, depth): a new host frame through
-        the live-stream ingest (Detector.submitFrame)."""
-        import torch
-        k = self.next
-        self.next = (k + 1) % self.slots
+        the live-stream ingest (Detector.submitFrame).  Streamed frames share their kernel launches (a batch is launched when it
+        is full or the GPU's queue runs short), and their exchange — sort, all-gather, merge on the exchange stream — is enqueued
+        for a whole GROUP of consecutive frames at a time, once they have been launched, with one collective per group: `_pump`.
+        Which frames form a group depends only on the sequence of submit / collect calls, never on GPU timing, so every rank
+        issues the same collectives in the same order."""
+        frame_no = self.det.framesSubmitted()
         if frame is None:
             self.det.submit(threshold, class_ids)
         else:
             self.det.submitFrame(frame, threshold, class_ids)
-        send, recv, cap = self.send[k], self.recv[k], self.cap_of[k]
-        self.det.exchangePack(send.data_ptr(), cap)
+        self.queue.append(frame_no)
+        self._pump(False)
+
+    def _pump(self, force: bool) -> None:
+        """Exchange of the frames waiting in self.queue, head first.  Not forced: every FULL group whose frames have all been
+        launched.  Forced (collect() needs the oldest frame and it is still queued): ONE group from the head — full if that many
+        frames have been submitted, else all there are.  Group boundaries so depend only on the numbers of frames submitted at the
+        calls, which are the same on every rank; GPU timing only decides WHEN a rank enqueues a group."""
+        while len(self.queue) >= self.group and self.queue[self.group - 1] < self.det.framesLaunched():
+            self._exchange_group(self.group)
+        if force and self.queue and self.queue[0] <= self.det.framesCollected():   # (still queued after the full groups above)
+            n = min(self.group, len(self.queue))
+            if self.queue[n - 1] >= self.det.framesLaunched():
+                self.det.flush()
+            self._exchange_group(n)
+
+    def _exchange_group(self, n: int) -> None:
+        import torch
+        frames = self.queue[:n]
+        del self.queue[:n]
+        k = self.next_set
+        self.next_set = (k + 1) % self.sets
+        cap = self.capacity
+        send, recv = self.views[k][n]
+        send_ptr, recv_ptr = self.ptrs[k]
+        self.det.exchangePackGroup(frames[0], n, send_ptr, cap)
         if not self.collective:
-            recv = send
+            recv_ptr = send_ptr
         elif self.device_collective:
-            with torch.cuda.stream(self.stream):                 # RCCL orders itself after the pack kernel / before the merge
-                self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            with torch.cuda.stream(self.stream):                 # RCCL orders itself after the pack kernels / before the merges
+                self.dist.all_gather_into_tensor(recv, send, group=self.group_handle)
         else:                                                    # backend without device collectives: stage through the host
             with torch.cuda.stream(self.stream):
                 mine = send.cpu()
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
-                self.dist.all_gather(parts, mine, group=self.group)
+                self.dist.all_gather(parts, mine, group=self.group_handle)
                 recv.copy_(torch.cat(parts), non_blocking=False)
-        self.det.exchangeMerge(recv.data_ptr(), self.world, cap)
+        self.det.exchangeMergeGroup(frames[0], n, recv_ptr, self.world, cap)
 
     def collect(self, into: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """Oldest frame in flight.  `into` (MATCH_DTYPE, world * capacity records) avoids the allocation and a copy; the
         result is then a view of it."""
+        self._pump(True)                                           # forced only if the oldest frame still waits for its group
         out, failed = self.det.exchangeCollect() if into is None else self.det.exchangeCollectInto(into)
         if out is None and failed > self.capacity:               # a run did not fit: larger blocks from the next submit on, if they exist
             cap = self.capacity
@@ -142,7 +176,6 @@ class DeviceExchange:
         if cap:
             self._pending_capacity = None
             self._alloc(cap)
-            self.next = 0
 
 
 def match_sharded(detector: "lm.Detector", sources, threshold: float, class_ids: Sequence[str] = (), masks=(),

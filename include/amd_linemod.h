@@ -160,6 +160,21 @@ void *lm_detector_exchange_stream(lm_detector *d);
 size_t lm_exchange_block_bytes(int capacity);
 int lm_detector_exchange_pack(lm_detector *d, void *send_block, int capacity);
 int lm_detector_exchange_merge(lm_detector *d, const void *recv_blocks, int world, int capacity);
+/* The same for a frame named by its number in submission order (0, 1, ...): a streamed frame is launched with its batch, so its
+ * exchange is enqueued once lm_detector_frames_launched() has passed it (sharded.DeviceExchange does this for every frame, in
+ * order, after each submit and before each collect).  frames_submitted() is the number the next submitted frame gets. */
+uint64_t lm_detector_frames_submitted(const lm_detector *d);
+uint64_t lm_detector_frames_launched(const lm_detector *d);
+uint64_t lm_detector_frames_collected(const lm_detector *d);
+int lm_detector_exchange_pack_frame(lm_detector *d, uint64_t frame_no, void *send_block, int capacity);
+int lm_detector_exchange_merge_frame(lm_detector *d, uint64_t frame_no, const void *recv_blocks, int world, int capacity);
+/* One all-gather for a GROUP of frames: every rank sends [frame][block] and receives [rank][frame][block]; recv_blocks = this frame's
+ * block of rank 0, rank j's lies j * rank_stride_bytes further. */
+int lm_detector_exchange_merge_frame_strided(lm_detector *d, uint64_t frame_no, const void *recv_blocks, int world, int capacity,
+                                             size_t rank_stride_bytes);
+/* ... and the n frames of a group in one call: frame first + i uses block i of send_blocks / of every rank's part of recv_blocks. */
+int lm_detector_exchange_pack_group(lm_detector *d, uint64_t first, int n, void *send_blocks, int capacity);
+int lm_detector_exchange_merge_group(lm_detector *d, uint64_t first, int n, const void *recv_blocks, int world, int capacity);
 int lm_detector_exchange_collect(lm_detector *d, lm_match **out, size_t *n, int *failed);
 /* the same into caller memory (capacity records; world * capacity always suffices): no allocation, one pass */
 int lm_detector_exchange_collect_into(lm_detector *d, lm_match *dst, size_t capacity, size_t *n, int *failed);
