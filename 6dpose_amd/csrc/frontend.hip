@@ -55,41 +55,48 @@ static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 constexpr int kCTX = 32, kCTY = 16;           // output tile
 static __device__ __forceinline__ void color_quant_body(const int bx, const int by, const uint8_t* __restrict__ rgb, float* __restrict__ mag,
                                                         uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
-    // virtual coordinates: tile origin (x0, y0); halos: rgb 5, blurred 2, quantised 1
-    __shared__ uint8_t s_rgb[kCTY + 10][kCTX + 10][3];
-    __shared__ uint16_t s_tmp[kCTY + 10][kCTX + 4][3];     // horizontal pass at columns clamp(x0-2 .. x0+TX+1), all halo rows
-    __shared__ uint8_t s_sm[kCTY + 4][kCTX + 4][3];         // smoothed at clamp(y0-2 ..), clamp(x0-2 ..)
+    // virtual coordinates: tile origin (x0, y0); halos: rgb 5, blurred 2, quantised 1.
+    // The three channels of a pixel travel as ONE LDS word (R | G << 8 | B << 16) and R, B share the multiply-adds of the horizontal
+    // pass (7 taps x 255 x 72 <= 65280 fits 16 bits): the stage was bound by its byte-wide LDS reads (21 + 21 + 24 per output pixel;
+    // now 7 + 7 + 8).  The integer results are the same.
+    __shared__ uint32_t s_rgb[kCTY + 10][kCTX + 10];
+    __shared__ uint2 s_tmp[kCTY + 10][kCTX + 4];           // horizontal pass at columns clamp(x0-2 .. x0+TX+1), all halo rows: {R | B << 16, G}
+    __shared__ uint32_t s_sm[kCTY + 4][kCTX + 4];           // smoothed at clamp(y0-2 ..), clamp(x0-2 ..), packed like s_rgb
     __shared__ uint8_t s_q[kCTY + 2][kCTX + 2];             // 16-bin code & 7 at y0-1 .., x0-1 .. (0 outside the interior)
     __shared__ float s_mag[kCTY][kCTX];
     const int x0 = bx * kCTX, y0 = by * kCTY, tid = threadIdx.x;
-    const int w7[7] = {8, 28, 56, 72, 56, 28, 8};
+    const uint32_t w7[7] = {8, 28, 56, 72, 56, 28, 8};
     for (int i = tid; i < (kCTY + 10) * (kCTX + 10); i += 256) {
         const int ty = i / (kCTX + 10), tx = i - ty * (kCTX + 10);
         const uint8_t* p = rgb + ((size_t)clampi(y0 - 5 + ty, 0, H - 1) * W + clampi(x0 - 5 + tx, 0, W - 1)) * 3;
-        s_rgb[ty][tx][0] = p[0]; s_rgb[ty][tx][1] = p[1]; s_rgb[ty][tx][2] = p[2];
+        s_rgb[ty][tx] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
     }
     __syncthreads();
     // horizontal pass: rows = all halo rows (virtual y0-5+ty, already clamped by the load), columns cx = clamp(x0-2+tx)
     for (int i = tid; i < (kCTY + 10) * (kCTX + 4); i += 256) {
         const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
         const int cx = clampi(x0 - 2 + tx, 0, W - 1) - (x0 - 5);           // tile column of the clamped centre
-        int a0 = 0, a1 = 0, a2 = 0;
+        uint32_t arb = 0, ag = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { a0 += w7[k] * s_rgb[ty][cx + k - 3][0]; a1 += w7[k] * s_rgb[ty][cx + k - 3][1]; a2 += w7[k] * s_rgb[ty][cx + k - 3][2]; }
-        s_tmp[ty][tx][0] = (uint16_t)a0; s_tmp[ty][tx][1] = (uint16_t)a1; s_tmp[ty][tx][2] = (uint16_t)a2;
+        for (int k = 0; k < 7; ++k) {
+            const uint32_t px = s_rgb[ty][cx + k - 3];
+            arb += w7[k] * (px & 0x00FF00FFu);
+            ag += w7[k] * ((px >> 8) & 0xFFu);
+        }
+        s_tmp[ty][tx] = make_uint2(arb, ag);
     }
     __syncthreads();
     // vertical pass at rows cy = clamp(y0-2+ty)
     for (int i = tid; i < (kCTY + 4) * (kCTX + 4); i += 256) {
         const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
         const int cy = clampi(y0 - 2 + ty, 0, H - 1) - (y0 - 5);           // tile row of the clamped centre
+        uint32_t ar = 0, ag = 0, ab = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            int a = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) a += w7[k] * s_tmp[cy + k - 3][tx][c];
-            s_sm[ty][tx][c] = (uint8_t)((a + 32768) >> 16);
+        for (int k = 0; k < 7; ++k) {
+            const uint2 t = s_tmp[cy + k - 3][tx];
+            ar += w7[k] * (t.x & 0xFFFFu); ab += w7[k] * (t.x >> 16); ag += w7[k] * t.y;
         }
+        s_sm[ty][tx] = ((ar + 32768u) >> 16) | (((ag + 32768u) >> 16) << 8) | (((ab + 32768u) >> 16) << 16);
     }
     __syncthreads();
     // Sobel + strongest channel + quantisation at (y0-1+ty, x0-1+tx); s_sm index of virtual (vy, vx) = (vy - y0 + 2, vx - x0 + 2)
@@ -100,14 +107,22 @@ static __device__ __forceinline__ void color_quant_body(const int bx, const int 
         if (x >= 0 && y >= 0 && x < W && y < H) {
             const int sy = ty + 1, sx = tx + 1;                             // this pixel in s_sm; its neighbours are the clamped ones by construction
             int dxs[3], dys[3], mags[3];
+            {
+                // the 3x3 neighbourhood as packed words; R and B ride one 32-bit lane each way (a + 2 b + c <= 1020 fits 16 bits)
+                const uint32_t p00 = s_sm[sy - 1][sx - 1], p01 = s_sm[sy - 1][sx], p02 = s_sm[sy - 1][sx + 1];
+                const uint32_t p10 = s_sm[sy][sx - 1], p12 = s_sm[sy][sx + 1];
+                const uint32_t p20 = s_sm[sy + 1][sx - 1], p21 = s_sm[sy + 1][sx], p22 = s_sm[sy + 1][sx + 1];
+                auto rb = [](uint32_t p) { return p & 0x00FF00FFu; };
+                auto gg = [](uint32_t p) { return (p >> 8) & 0xFFu; };
+                const uint32_t xp_rb = rb(p02) + 2u * rb(p12) + rb(p22), xn_rb = rb(p00) + 2u * rb(p10) + rb(p20);
+                const uint32_t yp_rb = rb(p20) + 2u * rb(p21) + rb(p22), yn_rb = rb(p00) + 2u * rb(p01) + rb(p02);
+                const int xp_g = (int)(gg(p02) + 2u * gg(p12) + gg(p22)), xn_g = (int)(gg(p00) + 2u * gg(p10) + gg(p20));
+                const int yp_g = (int)(gg(p20) + 2u * gg(p21) + gg(p22)), yn_g = (int)(gg(p00) + 2u * gg(p01) + gg(p02));
+                dxs[0] = (int)(xp_rb & 0xFFFFu) - (int)(xn_rb & 0xFFFFu); dys[0] = (int)(yp_rb & 0xFFFFu) - (int)(yn_rb & 0xFFFFu);
+                dxs[1] = xp_g - xn_g;                                     dys[1] = yp_g - yn_g;
+                dxs[2] = (int)(xp_rb >> 16) - (int)(xn_rb >> 16);         dys[2] = (int)(yp_rb >> 16) - (int)(yn_rb >> 16);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int a00 = s_sm[sy - 1][sx - 1][c], a01 = s_sm[sy - 1][sx][c], a02 = s_sm[sy - 1][sx + 1][c];
-                const int a10 = s_sm[sy][sx - 1][c], a12 = s_sm[sy][sx + 1][c];
-                const int a20 = s_sm[sy + 1][sx - 1][c], a21 = s_sm[sy + 1][sx][c], a22 = s_sm[sy + 1][sx + 1][c];
-                dxs[c] = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
-                dys[c] = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-                mags[c] = dxs[c] * dxs[c] + dys[c] * dys[c];
+                for (int c = 0; c < 3; ++c) mags[c] = dxs[c] * dxs[c] + dys[c] * dys[c];
             }
             int bdx, bdy, bmag;
             if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
@@ -204,22 +219,44 @@ static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__
         const uint16_t* p = depth + (size_t)y * W + x;
         long long d = p[0];
         if (d < dist_thr) {
-            long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
             const int oi[8] = {-r, 0, r, -r, r, -r, 0, r};
             const int oj[8] = {-r, -r, -r, 0, 0, r, r, r};
+            float nx, ny, nz;
+            if (diff_thr <= 150) {
+                // the reference's `long` arithmetic (LL.cpp:701-819) in 32 bits: |delta| < diff_thr on every tap that counts, so
+                // |b| <= 40 diff_thr, |ddx|, |ddy| <= 12000 diff_thr, 1150 |ddx| <= 1.38e7 diff_thr < 2^31 and det * d <= 22500 * 65535
+                // < 2^31 — the same integers, a third of the instructions (64-bit multiplies are emulated)
+                int A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+                const int di = (int)d;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                long long delta = (long long)p[oj[k] * W + oi[k]] - d;
-                long long ad = delta < 0 ? -delta : delta;
-                long long f = ad < diff_thr ? 1 : 0;
-                long long fi = f * oi[k], fj = f * oj[k];
-                A0 += fi * oi[k]; A1 += fi * oj[k]; A3 += fj * oj[k];
-                b0 += fi * delta; b1 += fj * delta;
+                for (int k = 0; k < 8; ++k) {
+                    const int delta = (int)p[oj[k] * W + oi[k]] - di;
+                    const int ad = delta < 0 ? -delta : delta;
+                    if (ad < diff_thr) {
+                        A0 += oi[k] * oi[k]; A1 += oi[k] * oj[k]; A3 += oj[k] * oj[k];
+                        b0 += oi[k] * delta; b1 += oj[k] * delta;
+                    }
+                }
+                const int det = A0 * A3 - A1 * A1;
+                const int ddx = A3 * b0 - A1 * b1;
+                const int ddy = -A1 * b0 + A0 * b1;
+                nx = (float)(1150 * ddx); ny = (float)(1150 * ddy); nz = (float)(-det * di);
+            } else {
+                long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    long long delta = (long long)p[oj[k] * W + oi[k]] - d;
+                    long long ad = delta < 0 ? -delta : delta;
+                    long long f = ad < diff_thr ? 1 : 0;
+                    long long fi = f * oi[k], fj = f * oj[k];
+                    A0 += fi * oi[k]; A1 += fi * oj[k]; A3 += fj * oj[k];
+                    b0 += fi * delta; b1 += fj * delta;
+                }
+                long long det = A0 * A3 - A1 * A1;
+                long long ddx = A3 * b0 - A1 * b1;
+                long long ddy = -A1 * b0 + A0 * b1;
+                nx = (float)(1150 * ddx); ny = (float)(1150 * ddy); nz = (float)(-det * d);
             }
-            long long det = A0 * A3 - A1 * A1;
-            long long ddx = A3 * b0 - A1 * b1;
-            long long ddy = -A1 * b0 + A0 * b1;
-            float nx = (float)(1150 * ddx), ny = (float)(1150 * ddy), nz = (float)(-det * d);
             float ss = __fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz));
             float sq = __fsqrt_rn(ss);
             if (sq > 0.f) {
@@ -309,6 +346,35 @@ void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t
 // every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so that a 16x16 window
 // touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.  (The frame is a few hundred
 // KB: the T*T byte reads per thread hit L1/L2; what counts here is one launch instead of four.)
+// OR of the T x T quantised pixels at and right / below (x, y) (zero beyond the edges; the mask applied as quantize() does): spread, LL.cpp:1094-1109
+static __device__ __forceinline__ uint32_t spread_or(const LmJob& J, const int x, const int y, const int W, const int H, const int T) {
+    uint32_t v = 0;
+    const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
+    if (!J.mask && x + T <= W) {
+        // the T pixels of a row as (unaligned) dwords: the launch is bound by the NUMBER of loads (T x T byte loads per position: 20 M per
+        // VGA frame, on a load path that retires a wave load in ~32 cycles whatever its width)
+        uint32_t acc = 0;
+        for (int r = y; r < ye; ++r) {
+            const uint8_t* row = J.quant + (size_t)r * W + x;
+            int c = 0;
+            for (; c + 4 <= T; c += 4) { uint32_t w; __builtin_memcpy(&w, row + c, 4); acc |= w; }
+            for (; c < T; ++c) acc |= row[c];
+        }
+        v = (acc | (acc >> 8) | (acc >> 16) | (acc >> 24)) & 0xFFu;
+    } else {
+        for (int r = y; r < ye; ++r) {
+            const uint8_t* row = J.quant + (size_t)r * W;
+            if (J.mask) {
+                const uint8_t* mrow = J.mask + (size_t)r * W;
+                for (int c = x; c < xe; ++c) v |= mrow[c] ? (uint32_t)row[c] : 0u;
+            } else {
+                for (int c = x; c < xe; ++c) v |= row[c];
+            }
+        }
+    }
+    return v;
+}
+
 static __device__ __forceinline__ void build_lm_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS) {
     int idx = bx * 256 + threadIdx.x;                    // decimated raster index
     int phase = by;                                      // r_start*T + c_start
@@ -317,17 +383,7 @@ static __device__ __forceinline__ void build_lm_body(const int bx, const int by,
     int ry = idx / Wd, rx = idx - ry * Wd;
     int rs = phase / T, cs = phase - rs * T;
     int y = ry * T + rs, x = rx * T + cs;
-    uint32_t v = 0;
-    const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
-    for (int r = y; r < ye; ++r) {
-        const uint8_t* row = J.quant + (size_t)r * W;
-        if (J.mask) {
-            const uint8_t* mrow = J.mask + (size_t)r * W;
-            for (int c = x; c < xe; ++c) v |= mrow[c] ? (uint32_t)row[c] : 0u;
-        } else {
-            for (int c = x; c < xe; ++c) v |= row[c];
-        }
-    }
+    const uint32_t v = spread_or(J, x, y, W, H, T);
     uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
     size_t plane = (size_t)T * T * npos;
     uint8_t* o = J.lm + (size_t)phase * npos + idx;
@@ -353,17 +409,7 @@ static __device__ __forceinline__ void build_lm_body4(const int bx, const int by
     const int ry = idx / Wd, rx = idx - ry * Wd;
     const int rs = phase / T, cs = phase - rs * T;
     const int y = ry * T + rs, x = rx * T + cs;
-    uint32_t v = 0;
-    const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
-    for (int r = y; r < ye; ++r) {
-        const uint8_t* row = J.quant + (size_t)r * W;
-        if (J.mask) {
-            const uint8_t* mrow = J.mask + (size_t)r * W;
-            for (int c = x; c < xe; ++c) v |= mrow[c] ? (uint32_t)row[c] : 0u;
-        } else {
-            for (int c = x; c < xe; ++c) v |= row[c];
-        }
-    }
+    const uint32_t v = spread_or(J, x, y, W, H, T);
     const int lane = (int)threadIdx.x & 63, k4 = lane & 3, q0 = lane & ~3;
     uint32_t vq[4], adj[4];
 #pragma unroll

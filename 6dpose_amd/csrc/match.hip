@@ -474,10 +474,10 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
 //
 // Fast path (every feature's 16x16 window inside its plane — always, except for oversized templates):
 // gathers from the strip-major copy of the linear memories ([strip of 16 columns][row][16 B]).  A
-// window spans two strips, so 32 lanes x one aligned 16-byte load cover it: lane (row r, strip h).
+// window spans two strips, so 32 lanes x one aligned 16-byte load cover it: lane (strip h, row r), rows fastest.
 // The two half-waves work on two features of the same alignment class at a time; class runs are
 // accumulated in packed u8 and realigned once per run: half-waves combined (lane ^ 32), strip pairs
-// exchanged (lane ^ 1), v_alignbyte by the run's byte phase, widened into the u16 window
+// exchanged (lane ^ 16), v_alignbyte by the run's byte phase, widened into the u16 window
 // accumulators (lane (r,h) keeps window columns 8h..8h+7 of row r).
 // Slow path: flat layout, per-feature bounds test, exactly the reference's reads (wrap-around included).
 // First strict maximum (LL.cpp:1920) = wave max-reduction of the packed key (raw << 8 | 255 - index).
@@ -756,7 +756,9 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             const bool all_in = e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 &&
                                 ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= Hd);
             if (all_in) {
-                const int half = lane >> 5, l5 = lane & 31, r = l5 >> 1, h = l5 & 1;
+                // lane = (feature of the pair, strip h, row r) with the ROWS fastest: a quad of lanes reads 4 consecutive 16-byte rows of one strip
+                // (one or two 64-byte lines) instead of 2 rows x 2 strips (profiles/r03_tcp_rotation_microbench.txt: 41 -> 36.6 cycles per wave load)
+                const int half = lane >> 5, l5 = lane & 31, r = l5 & 15, h = l5 >> 4;
                 const uint32_t HS = (uint32_t)Hd * 16u;
                 const BufRsrc strips = make_rsrc(sm_arena);        // addressing as in the tile path: lane VGPR (rebuilt per class run) + feature word
                 const uint32_t lane_off = h * HS + (uint32_t)r * 16u;
@@ -773,7 +775,7 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             own[k] = r8[k] + (uint32_t)__shfl_xor((int)r8[k], 32, 64);   // both features of the pair
-                            par[k] = (uint32_t)__shfl_xor((int)own[k], 1, 64);            // the other strip of this row
+                            par[k] = (uint32_t)__shfl_xor((int)own[k], 16, 64);           // the other strip of this row
                             r8[k] = 0;
                         }
                         // bytes [c0 + 8h, +8) of the 32-byte row {strip S0, strip S0+1}; c0 = window start inside strip S0
