@@ -62,6 +62,7 @@ PIPELINE_DEPTH = int(os.environ.get("LM_BENCH_DEPTH", "0"))   # frames in flight
                                                               # neighbouring BATCHES of frames side by side while the host collects the oldest frame.  Default (0): three batches
                                                               # (lm_detector_get_batch() = 4 frames share their kernel launches: 12 frames); the timed region starts and ends
                                                               # with an empty pipeline (profiles/host_profile.py: 20 steps 0.201 ms/frame at 8 in flight, 0.187 at 12)
+LOAD_CYCLES_L2, LOAD_CYCLES_L1 = 31.5, 23.5   # CU cycles per 16-byte wave load, lines from L2 / all from L1 (profiles/r03_tcp_rotation_microbench.txt, patterns 0 and 7)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0         # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 LDS_PEAK_GBS = 150000.0       # ibid. "LDS": ~150 TB/s aggregate for ds_read_b64/b128
@@ -530,6 +531,14 @@ def main():
                 "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None,
                 "insts_per_launch": {"salu": pm["SQ_INSTS_SALU"], "valu": pm["SQ_INSTS_VALU"], "vmem_rd": pm["SQ_INSTS_VMEM_RD"], "waves": pm["SQ_WAVES"]},
                 "kernel_us_profiled": kcycles / 2400.0,
+                # the load path itself: a 16-byte-per-lane wave load retires in ~31.5 CU cycles when its lines come from L2 and 23.5 when they
+                # all hit L1, whatever the alignment of the lanes' quads and whether a lane asks for 8 or 16 bytes
+                # (profiles/tcp_rotation_microbench.hip -> profiles/r03_tcp_rotation_microbench.txt)
+                "cu_cycles_per_wave_load": (256.0 * kcycles / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
+                "load_path": {"microbench_cycles_per_wave_load_l2_resident": LOAD_CYCLES_L2, "microbench_cycles_per_wave_load_l1_hits": LOAD_CYCLES_L1,
+                              "frac": (LOAD_CYCLES_L2 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kcycles)) if kcycles > 0 else None,
+                              "note": "frac = what the same number of wave loads costs in the micro-benchmark of the access pattern alone / the kernel's CU cycles: "
+                                      "the kernel runs at this fraction of the rate its load instructions can be retired at; fewer wave loads, not faster ones, is what is left"},
                 "what_bounds_it": "the vector L1 (TCP): one 64-byte access per cycle and CU; accesses + cycles stalled on pending misses over the CU cycles of "
                                   "the launch = frac_of_tcp_cycles.  `frac` (algorithmic bytes / HBM peak) exceeds 1 because the linear memories are "
                                   "cache-resident and a tile's window region is loaded once for all its members; hbm_frac_physical is the real HBM share"})

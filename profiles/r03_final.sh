@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round 3: every number DESIGN.md section 7 quotes, in one call on one GPU box.  Usage (GPU box): profiles/r03_final.sh [out_dir]
+OUT=${1:-gpurun_out/r03final}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $ROOT/$OUT
+cd $ROOT
+(timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/pytest_gpu.log
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err
+timeout 300 python bench.py --steps 200 --no-extras --no-cpu-baseline > $OUT/bench_steps200.json 2> $OUT/bench_steps200.err
+timeout 300 python bench.py --steps 200 --no-extras --no-cpu-baseline --batch 1 > $OUT/bench_steps200_batch1.json 2> $OUT/bench_steps200_batch1.err
+timeout 300 python bench.py --scaling strong --steps 50 --no-extras --no-cpu-baseline > $OUT/bench_strong_n1_16k.json 2> $OUT/bench_strong_n1_16k.err
+timeout 300 python bench.py --dry-ranks 8 --steps 8 > $OUT/dry_ranks8.json 2> $OUT/dry_ranks8.err
+timeout 200 python profiles/host_profile.py 2>&1 | grep steps > $OUT/host_profile.txt
+timeout 300 python profiles/short_run_sweep.py 2>&1 | grep batch > $OUT/short_run_sweep.txt
+[ -x bin_tmp/tcp_rot ] && ./bin_tmp/tcp_rot > $OUT/tcp_rotation_microbench.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o roof -- python $ROOT/bench.py --roofline-only --no-parity-gate > $ROOT/$OUT/roofline_only.json 2> $ROOT/$OUT/roofline_only.err
+DB=$(find $ROOT/$OUT/prof -name "*_results.db" | head -1)
+[ -n "$DB" ] && python $ROOT/profiles/rocpd_summary.py $DB $ROOT/$OUT/kernel_stats_roofline_leg.txt > /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_bench -o bench -- python $ROOT/bench.py --no-extras --no-cpu-baseline --no-pmc --steps 200 > $ROOT/$OUT/bench_under_rocprof.json 2> /dev/null
+DB=$(find $ROOT/$OUT/prof_bench -name "*_results.db" | head -1)
+[ -n "$DB" ] && python $ROOT/profiles/rocpd_summary.py $DB $ROOT/$OUT/kernel_stats_bench_steps200.txt > /dev/null
+find $ROOT/$OUT -name "*_results.db" -delete
+cd $ROOT
+profiles/pmc_run.sh $OUT/pmc r03 > /dev/null 2>&1
+tail -3 $OUT/pytest_gpu.log
+python - <<PY
+import json
+for f in ("bench_default", "bench_driver_flags", "bench_steps200", "bench_steps200_batch1", "bench_strong_n1_16k"):
+    try:
+        d = json.load(open("$OUT/%s.json" % f))
+        print(f, "ms/step %.4f value %.3g" % (d["ms_per_step"], d["value"]), d["config"].get("frames_per_launch_mean_timed"))
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
