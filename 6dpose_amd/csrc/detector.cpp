@@ -118,6 +118,11 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
         delete d;
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
     }
+    // the copy stream of the live-stream ingest too, now: every stream of the detector takes its hardware queue before anything created
+    // later (torch, RCCL) does
+    if (hipStreamCreateWithFlags(&d->ingest.stream, hipStreamNonBlocking) == hipSuccess)
+        for (int i = 0; i < lm_detector::kSlots; ++i) { (void)hipEventCreate(&d->ingest.t0[i]); (void)hipEventCreate(&d->ingest.t1[i]); }
+    else d->ingest.stream = nullptr;
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
     for (auto& sl : d->slot) {
         for (auto& e : sl.ev) (void)hipEventCreate(&e);
