@@ -230,6 +230,7 @@ struct lm_detector {
         hipEvent_t done[kSlots] = {};
         int state[kSlots] = {};                     // 0 idle, 1 packed, 2 merged (result on its way to h_merged)
         int cap[kSlots] = {}, world[kSlots] = {};
+        int done_slot[kSlots] = {};                 // the slot whose `done` event covers this frame's group
     } xchg;
     int local_blocks = 0;
     int num_cus = 256;

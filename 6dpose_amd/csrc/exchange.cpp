@@ -109,16 +109,17 @@ extern "C" int lm_detector_exchange_merge_group_strided(lm_detector* d, uint64_t
         }
         G.f[i].recv = (const uint32_t*)((const uint8_t*)recv_blocks + (size_t)i * blk);
         G.f[i].merged = d->xchg.d_merged[slot].p;
+        HIP_TRY(hipHostGetDevicePointer((void**)&G.f[i].host, d->xchg.h_merged[slot], 0));
     }
     hipStream_t xs = d->xchg.stream;
-    launch_exchange_merge_group(G, world, (uint32_t)capacity, xs, (uint32_t)(rank_stride_bytes / 4));
+    launch_exchange_merge_group(G, world, (uint32_t)capacity, xs, (uint32_t)(rank_stride_bytes / 4));   // merge + copy-out to the pinned buffers
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(d->xchg.done[(int)(first % lm_detector::kSlots)], xs));  // one event for the group: its first slot's
     for (int i = 0; i < n; ++i) {
         const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
-        HIP_TRY(hipMemcpyAsync(d->xchg.h_merged[slot], d->xchg.d_merged[slot].p, words * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
-        HIP_TRY(hipEventRecord(d->xchg.done[slot], xs));
         d->xchg.state[slot] = 2;
         d->xchg.world[slot] = world;
+        d->xchg.done_slot[slot] = (int)(first % lm_detector::kSlots);
     }
     return LM_OK;
 }
@@ -158,7 +159,7 @@ static int exchange_collect(lm_detector* d, lm_match* dst, size_t dst_capacity, 
     const int slot = (int)(d->n_collected % lm_detector::kSlots);
     if (d->xchg.state[slot] != 2) return lm_set_error(LM_ERR_INVALID, "the oldest frame in flight was not exchanged (pack + merge)");
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(d->xchg.done[slot]));                                // the merged list is in pinned memory
+    HIP_TRY(hipEventSynchronize(d->xchg.done[d->xchg.done_slot[slot]]));             // the merged list (of the frame's whole group) is in pinned memory
     d->xchg.state[slot] = 0;
     const int rc = lm_collect_frame(d, -1, nullptr, nullptr);                        // retires the frame (timings, overflow bookkeeping)
     if (rc < 0) return rc;

@@ -215,10 +215,26 @@ void launch_exchange_pack_group(const XchgGroup& G, uint32_t cand_cap, uint32_t 
     hipLaunchKernelGGL(k_exchange_merge256, grid, dim3(kWG), 0, s, G, cand_cap, cap);
 }
 
+// The merged list of every frame of the group into its pinned host buffer: header + the records actually there (16-byte stores).  A
+// kernel instead of one hipMemcpyAsync per frame: the copies were the only D2H transfers of the stream path, they sat on the calling
+// thread (a call could take 0.3 ms) and moved the whole capacity (82 KB per frame at 4096 records) instead of what the frame produced.
+__global__ void __launch_bounds__(kWG)
+k_exchange_copyout(XchgGroup G) {
+    const int32_t* __restrict__ src = G.f[blockIdx.y].merged;
+    int32_t* __restrict__ dst = G.f[blockIdx.y].host;
+    const uint32_t records = src[1] ? 0u : (uint32_t)src[0];              // flags set: header only
+    const uint32_t words = kXchgHeaderWords + records * 5u;
+    const uint32_t quads = (words + 3u) >> 2;                              // both buffers hold whole 16-byte units (allocated for the capacity)
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (uint32_t i = blockIdx.x * kWG + threadIdx.x; i < quads; i += gridDim.x * kWG) d4[i] = s4[i];
+}
+
 void launch_exchange_merge_group(const XchgGroup& G, int world, uint32_t cap, hipStream_t s, uint32_t rank_stride_words) {
     if (G.n <= 0) return;
     const uint32_t block_words = rank_stride_words ? rank_stride_words : 4 + cap * 4;   // distance between the blocks of consecutive ranks
     hipLaunchKernelGGL(k_exchange_merge, dim3((cap + kWG - 1) / kWG, world, G.n), dim3(kWG), 0, s, G, world, cap, block_words);
+    if (G.f[0].host) hipLaunchKernelGGL(k_exchange_copyout, dim3(16, G.n), dim3(kWG), 0, s, G);
 }
 
 }  // namespace lm

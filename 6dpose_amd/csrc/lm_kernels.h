@@ -212,6 +212,7 @@ __device__ __forceinline__ bool xchg_key_fits(int x, int y, int cls, int tid) { 
 struct XchgFrame {
     const ulonglong2* keys; const unsigned long long* counters; ulonglong2* runs; uint32_t* block;     // pack
     const uint32_t* recv; int32_t* merged;                                                               // merge
+    int32_t* host;                                                                                       // the merged list's pinned host copy (device pointer), may be null
 };
 struct XchgGroup { int n; int pad; XchgFrame f[kMaxBatch]; };
 // counters: [0] coarse candidates, [1] distinct records, [3] != 0: a record did not fit the key (all written by the matching stream)

@@ -12,6 +12,7 @@
 //   5  tile with only 2 of the 3 strips loaded (40 active lanes, the others masked off): is the cost per active lane?
 //   6  tile, 3 strips, but 8-byte loads (half the bytes per lane)
 //   7  tile, all 64 lanes re-reading ONE small region (L1 hits only): the issue rate of the load path itself
+//   8-11  tile with only the first 40 / 32 / 20 / 16 lanes alive (the others leave the kernel at once): cost per active lane or per instruction?
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -26,6 +27,7 @@ __global__ void __launch_bounds__(256) k_bench(const uint8_t* __restrict__ arena
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t* f = feats + (size_t)wave * feats_per_wave;      // per feature: byte offset of (strip S0, row y0)
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (P >= 8) { const int alive = P == 8 ? 40 : P == 9 ? 32 : P == 10 ? 20 : 16; if (lane >= alive) return; }
     if (P <= 1 || P >= 5) {
         const int q = lane / 20 > 2 ? 0 : lane / 20, j = lane >= 60 ? 0 : lane % 20;
         for (int i = 0; i < feats_per_wave; i += 8) {
@@ -34,7 +36,7 @@ __global__ void __launch_bounds__(256) k_bench(const uint8_t* __restrict__ arena
             for (int u = 0; u < 8; ++u) {
                 const uint32_t b = f[i + u];
                 uint32_t off;
-                if (P == 0 || P >= 5) off = (P == 7 ? (b & 0xFFF0u) : b) + q * strip_stride + j * 16;
+                if (P == 0 || P >= 5) off = (P == 7 ? (b & 0xFFF0u) : b) + q * strip_stride + j * 16;   // (P >= 8: the same addresses, fewer lanes)
                 else { const uint32_t rho = (b >> 4) & 3; off = (b & ~63u) + q * strip_stride + ((((uint32_t)j + 4 - rho) % 20) + rho) * 16; }
                 if (P == 5) { v[u] = make_uint4(0, 0, 0, 0); if (lane < 40) v[u] = *reinterpret_cast<const uint4*>(arena + off); }
                 else if (P == 6) { const uint2 t = *reinterpret_cast<const uint2*>(arena + off); v[u] = make_uint4(t.x, t.y, 0, 0); }
@@ -74,7 +76,7 @@ int main() {
     CK(hipMalloc(&d_f, 4 * (size_t)waves * feats_per_wave)); CK(hipMalloc(&d_out, 8 * waves));
     std::vector<uint32_t> hf((size_t)waves * feats_per_wave);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int P = 0; P < 8; ++P) {
+    for (int P = 0; P < 12; ++P) {
         srand(1);
         const int rows = (P <= 1 || P >= 5) ? 24 : 20, strips = (P <= 1 || P >= 5) ? 3 : 2;
         for (auto& b : hf) {
@@ -93,6 +95,10 @@ int main() {
             if (P == 5) hipLaunchKernelGGL(k_bench<5>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
             if (P == 6) hipLaunchKernelGGL(k_bench<6>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
             if (P == 7) hipLaunchKernelGGL(k_bench<7>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
+            if (P == 8) hipLaunchKernelGGL(k_bench<8>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
+            if (P == 9) hipLaunchKernelGGL(k_bench<9>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
+            if (P == 10) hipLaunchKernelGGL(k_bench<10>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
+            if (P == 11) hipLaunchKernelGGL(k_bench<11>, dim3(768), dim3(256), 0, 0, d_arena, d_f, feats_per_wave, (uint32_t)Hd * 16, d_out);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) best = ms;
