@@ -17,6 +17,10 @@ void upload_normal_lut(const uint8_t lut400[400]) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(c_normal_lut), lut400, 400);
 }
 
+// n / d by a multiplier the host prepares (lm_kernels.h, FeJob): exact while n * d < 2^32; m = 0 stands for d = 1
+static __host__ __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+static __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m) { return m ? __umulhi(n, m) : n; }   // n / d for n * d < 2^32
+
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- cv::phase(dx, dy, angle, true): OpenCV fastAtan2 polynomial (LL.cpp:423; Appendix A.3) -----
@@ -346,19 +350,42 @@ void launch_nn_down2(const uint8_t* src, uint8_t* dst, int W, int H, hipStream_t
 // every plane cut into 16-column strips stored strip-major ([strip][row][16 B]), so that a 16x16 window
 // touches 2 strips x 256 contiguous bytes instead of 16 rows x 1 cache line.  (The frame is a few hundred
 // KB: the T*T byte reads per thread hit L1/L2; what counts here is one launch instead of four.)
-// OR of the T x T quantised pixels at and right / below (x, y) (zero beyond the edges; the mask applied as quantize() does): spread, LL.cpp:1094-1109
-static __device__ __forceinline__ uint32_t spread_or(const LmJob& J, const int x, const int y, const int W, const int H, const int T) {
+// OR of the T x T quantised pixels at and right / below (x, y) (zero beyond the edges; the mask applied as quantize() does): spread, LL.cpp:1094-1109.
+// kT > 0: T known at compile time — the rows' loads are all issued before the first is waited for (with a run-time T the compiler
+// emitted load, wait, OR per row: T dependent L2 round trips per thread were most of the linear-memory launch).
+template <int kT>
+static __device__ __forceinline__ uint32_t spread_or_t(const LmJob& J, const int x, const int y, const int W, const int H, const int Trt) {
+    const int T = kT > 0 ? kT : Trt;
     uint32_t v = 0;
     const int ye = y + T < H ? y + T : H, xe = x + T < W ? x + T : W;
-    if (!J.mask && x + T <= W) {
-        // the T pixels of a row as (unaligned) dwords: the launch is bound by the NUMBER of loads (T x T byte loads per position: 20 M per
-        // VGA frame, on a load path that retires a wave load in ~32 cycles whatever its width)
+    if (!J.mask && x + T <= W && (kT == 0 || y + T <= H)) {
+        // the T pixels of a row as (unaligned) dwords
         uint32_t acc = 0;
-        for (int r = y; r < ye; ++r) {
-            const uint8_t* row = J.quant + (size_t)r * W + x;
-            int c = 0;
-            for (; c + 4 <= T; c += 4) { uint32_t w; __builtin_memcpy(&w, row + c, 4); acc |= w; }
-            for (; c < T; ++c) acc |= row[c];
+        if (kT > 0) {
+            uint32_t w[kT > 0 ? kT * ((kT + 3) / 4) : 1];
+#pragma unroll
+            for (int r = 0; r < kT; ++r) {
+                const uint8_t* row = J.quant + (size_t)(y + r) * W + x;
+#pragma unroll
+                for (int c = 0; c < (kT + 3) / 4; ++c) {
+                    if (4 * c + 4 <= kT) __builtin_memcpy(&w[r * ((kT + 3) / 4) + c], row + 4 * c, 4);
+                    else {                                               // the last 1-3 pixels of the row
+                        uint32_t t = 0;
+#pragma unroll
+                        for (int b = 4 * c; b < kT; ++b) t |= row[b];
+                        w[r * ((kT + 3) / 4) + c] = t;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kT * ((kT + 3) / 4); ++i) acc |= w[i];
+        } else {
+            for (int r = y; r < ye; ++r) {
+                const uint8_t* row = J.quant + (size_t)r * W + x;
+                int c = 0;
+                for (; c + 4 <= T; c += 4) { uint32_t w; __builtin_memcpy(&w, row + c, 4); acc |= w; }
+                for (; c < T; ++c) acc |= row[c];
+            }
         }
         v = (acc | (acc >> 8) | (acc >> 16) | (acc >> 24)) & 0xFFu;
     } else {
@@ -374,14 +401,24 @@ static __device__ __forceinline__ uint32_t spread_or(const LmJob& J, const int x
     }
     return v;
 }
+static __device__ __forceinline__ uint32_t spread_or(const LmJob& J, const int x, const int y, const int W, const int H, const int T) {
+    switch (T) {                                                         // wave-uniform
+        case 2: return spread_or_t<2>(J, x, y, W, H, T);
+        case 4: return spread_or_t<4>(J, x, y, W, H, T);
+        case 5: return spread_or_t<5>(J, x, y, W, H, T);
+        case 8: return spread_or_t<8>(J, x, y, W, H, T);
+        default: return spread_or_t<0>(J, x, y, W, H, T);
+    }
+}
 
-static __device__ __forceinline__ void build_lm_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS) {
+static __device__ __forceinline__ void build_lm_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS, uint32_t m_wd,
+                                                     uint32_t m_t) {
     int idx = bx * 256 + threadIdx.x;                    // decimated raster index
     int phase = by;                                      // r_start*T + c_start
     int npos = Wd * Hd;
     if (idx >= npos) return;
-    int ry = idx / Wd, rx = idx - ry * Wd;
-    int rs = phase / T, cs = phase - rs * T;
+    int ry = (int)fast_div((uint32_t)idx, m_wd), rx = idx - ry * Wd;
+    int rs = (int)fast_div((uint32_t)phase, m_t), cs = phase - rs * T;
     int y = ry * T + rs, x = rx * T + cs;
     const uint32_t v = spread_or(J, x, y, W, H, T);
     uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
@@ -401,13 +438,14 @@ static __device__ __forceinline__ void build_lm_body(const int bx, const int by,
 // T x T pixels, then the quad exchanges the four OR bytes and lane k of the quad stores labels 2k and 2k + 1 for all four positions —
 // one dword each to the flat plane and to the strip plane, 4 stores per lane instead of 16 byte stores (the launch is bound by the
 // number of store instructions: 44 MB per 4-frame batch took 48 us = 0.9 TB/s).
-static __device__ __forceinline__ void build_lm_body4(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS) {
+static __device__ __forceinline__ void build_lm_body4(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS, uint32_t m_wd,
+                                                      uint32_t m_t) {
     const int idx = bx * 256 + (int)threadIdx.x;         // decimated raster index
     const int phase = by;
     const int npos = Wd * Hd;
     if (idx >= npos) return;                             // whole quads: npos is a multiple of 4
-    const int ry = idx / Wd, rx = idx - ry * Wd;
-    const int rs = phase / T, cs = phase - rs * T;
+    const int ry = (int)fast_div((uint32_t)idx, m_wd), rx = idx - ry * Wd;
+    const int rs = (int)fast_div((uint32_t)phase, m_t), cs = phase - rs * T;
     const int y = ry * T + rs, x = rx * T + cs;
     const uint32_t v = spread_or(J, x, y, W, H, T);
     const int lane = (int)threadIdx.x & 63, k4 = lane & 3, q0 = lane & ~3;
@@ -435,18 +473,17 @@ static __device__ __forceinline__ void build_lm_body4(const int bx, const int by
         if (so) *reinterpret_cast<uint32_t*>(so + splane1 * T * T * ori) = packed;
     }
 }
-static __host__ __device__ __forceinline__ bool build_lm_vec4(int W, int H, int T) { return ((W / T) & 3) == 0; }   // then npos and every plane base are multiples of 4 too
 
-__global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS) {
-    if (build_lm_vec4(W, H, T)) build_lm_body4(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
-    else build_lm_body(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS);
+__global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int H, int T, int Wd, int Hd, int NS, uint32_t m_wd, uint32_t m_t) {
+    if ((Wd & 3) == 0) build_lm_body4(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS, m_wd, m_t);
+    else build_lm_body(blockIdx.x, blockIdx.y, blockIdx.z ? j1 : j0, W, H, T, Wd, Hd, NS, m_wd, m_t);
 }
 
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T, hipStream_t s) {
     int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
     LmJob j0{quant[0], mask[0], lm[0], strips[0]}, j1{quant[1], mask[1], lm[1], strips[1]};
-    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS);
+    hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS, div_magic((uint32_t)Wd), div_magic((uint32_t)T));
 }
 
 // ---- several independent front-end jobs in ONE launch ---------------------------------------------------------------------
@@ -460,15 +497,16 @@ k_fe_stage(FeStage st) {
     while (j + 1 < st.njobs && (int)blockIdx.x >= st.job[j + 1].first) ++j;
     const FeJob& J = st.job[j];
     const int local = (int)blockIdx.x - J.first;
-    const int bx = local % J.gx, by = (local / J.gx) % J.gy, bz = local / (J.gx * J.gy);
+    const int bz = (int)fast_div((uint32_t)local, J.m_gxgy), rem = local - bz * J.gx * J.gy;
+    const int by = (int)fast_div((uint32_t)rem, J.m_gx), bx = rem - by * J.gx;
     switch (J.kind) {
         case kFeColour: color_quant_body(bx, by, (const uint8_t*)J.in, (float*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.f); break;
         case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
         case kFePyrDown: pyrdown_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.H, J.a, J.b); break;
         case kFeNnDown: nn_down2_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.a); break;
         case kFeBuildLm:
-            if (build_lm_vec4(J.W, J.H, J.a)) build_lm_body4(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16);
-            else build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.W / J.a, J.H / J.a, (J.W / J.a + 15) / 16);
+            if ((J.Wd & 3) == 0) build_lm_body4(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
+            else build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
             break;
         default: break;
     }
@@ -493,6 +531,7 @@ void fe_job_nn_down2(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H) {
 void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T) {
     j = FeJob{}; j.kind = kFeBuildLm; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
+    j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
     j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0]}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1]};
 }
 void launch_fe_stage(FeStage& st, hipStream_t s) {
@@ -500,7 +539,9 @@ void launch_fe_stage(FeStage& st, hipStream_t s) {
     for (int i = 0; i < st.njobs; ++i) {
         const int blocks = st.job[i].gx * st.job[i].gy * st.job[i].gz;
         if (blocks <= 0) continue;                         // an empty job (degenerate level) is dropped
-        st.job[n] = st.job[i]; st.job[n].first = total; total += blocks; ++n;
+        st.job[n] = st.job[i]; st.job[n].first = total; total += blocks;
+        st.job[n].m_gx = div_magic((uint32_t)st.job[n].gx); st.job[n].m_gxgy = div_magic((uint32_t)(st.job[n].gx * st.job[n].gy));
+        ++n;
     }
     st.njobs = n;
     if (total > 0) hipLaunchKernelGGL(k_fe_stage, dim3(total), dim3(256), 0, s, st);

@@ -27,6 +27,11 @@ struct FeJob {
     const void* in; void* out0; void* out1;
     int W, H, a, b;                       // a, b: normals thresholds / pyrDown output size / T
     float f;                              // colour: weak threshold squared
+    // Divisions by run-time values cost ~25 instructions each on the GPU and the bodies are short: the quotients a block / thread needs
+    // (flat block index -> job-local (bx, by, bz); linear-memory index -> (row, column); phase -> (row, column) inside the T x T cell)
+    // come from multipliers the host prepares: n / d = umulhi(n, m), m = ceil(2^32 / d), exact while n * d < 2^32 (m = 0 stands for d = 1).
+    uint32_t m_gx, m_gxgy, m_wd, m_t;
+    int Wd, Hd;                           // build_lm: decimated size
     LmJob lm[2];                          // build_lm: [0] colour, [1] normals
 };
 constexpr int kFeMaxJobs = 24;            // 3 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
