@@ -136,6 +136,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (const char* ff = getenv("LM_FE_FUSED")) d->fe_fused = ff[0] && ff[0] != '0';
     if (knobs().frame_batch > 0) d->batch_max = std::min(knobs().frame_batch, kMaxBatch);
     if (knobs().batch_queue > 0) d->keep_queued = knobs().batch_queue;
+    if (knobs().launch_slack_us > 0) d->launch_slack_ms = knobs().launch_slack_us * 1e-3f;
     if (const char* ac = getenv("LM_ASYNC_COLLECT")) d->async_collect = ac[0] && ac[0] != '0';
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
@@ -1378,6 +1379,33 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
     return LM_OK;
 }
 
+static inline double host_seconds(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(t.time_since_epoch()).count(); }
+
+// Batches launched and not yet finished on the GPU (an event query per finished batch, none in the steady state of a full queue).
+static int batches_queued(lm_detector* d) {
+    while (!d->queued.empty() && hipEventQuery(d->slot[d->queued.front().slot].done) == hipSuccess) d->queued.erase(d->queued.begin());
+    (void)hipGetLastError();                                  // hipErrorNotReady is not an error
+    return (int)d->queued.size();
+}
+
+// GPU time of a batch of n frames: measured, or scaled from the nearest measured size (a batch costs about four frames' worth of
+// fixed latency + its frames), or 0 when nothing has been measured yet.
+static float batch_ms_estimate(const lm_detector* d, int n) {
+    if (d->batch_ms[n] > 0.f) return d->batch_ms[n];
+    for (int k = 1; k <= kMaxBatch; ++k)
+        for (int m : {n - k, n + k})
+            if (m >= 1 && m <= kMaxBatch && d->batch_ms[m] > 0.f) return d->batch_ms[m] * (4.f + (float)n) / (4.f + (float)m);
+    return 0.f;
+}
+
+// Should the frames waiting for their batch go out now?  `after` = host time the question is asked for (now at a submit; at a collect
+// about to block, the moment the awaited batch is expected to finish).
+static bool partial_batch_due(lm_detector* d, double at) {
+    if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
+    if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
+    return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
+}
+
 // Enqueue the whole device pipeline of the frames waiting in slots [pend_first, pend_first + pend_n): ONE front end, coarse pass,
 // refinement and duplicate removal for all of them (asynchronous).
 int lm_launch_pending(lm_detector* d) {
@@ -1465,7 +1493,13 @@ int lm_launch_pending(lm_detector* d) {
         lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
         sl.launched = true; sl.leader = first; sl.batch_n = nb; sl.t1 = now;
     }
-    d->queued.emplace_back(d->n_launched, first);
+    {
+        const double t = host_seconds(now);
+        const bool idle = batches_queued(d) == 0;
+        if (idle) d->gpu_free_at = std::min(d->gpu_free_at, t);
+        d->gpu_free_at = std::max(d->gpu_free_at, t) + 1e-3 * batch_ms_estimate(d, nb);
+        d->queued.push_back({d->n_launched, first, nb, t, idle});
+    }
     d->n_launched += (uint64_t)nb;
     // streamed frames: the collector thread prepares their result lists as soon as the batch has finished
     if (d->async_collect && !d->reference_order && lead.ring >= 0 && num_work > 0) {
@@ -1483,13 +1517,6 @@ int lm_launch_pending(lm_detector* d) {
         C.cv_work.notify_one();
     }
     return LM_OK;
-}
-
-// Batches launched and not yet finished on the GPU (an event query per finished batch, none in the steady state of a full queue).
-static int batches_queued(lm_detector* d) {
-    while (!d->queued.empty() && hipEventQuery(d->slot[d->queued.front().second].done) == hipSuccess) d->queued.erase(d->queued.begin());
-    (void)hipGetLastError();                                  // hipErrorNotReady is not an error
-    return (int)d->queued.size();
 }
 
 // The detector's current frame (lm_detector_set_frame / select_frame, or the frame a previous submit_frame left current) as a
@@ -1650,10 +1677,54 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
         prepared = sl.prep; prepared_n = sl.prep_n;
         sl.prep = nullptr; sl.prep_n = 0; sl.prep_queued = false;
     }
+    // Keep the GPU-time model current.  If the wait below blocks on the first frame of a batch, the batch finished when the wait
+    // returned: that pins the estimate of when the GPU runs dry and — with the start of the batch known too (the previous batch's
+    // end seen the same way, or an idle GPU at launch) — gives the batch's duration.  Frames waiting for their batch go out BEFORE
+    // the wait if the GPU would have (almost) nothing left when it ends, or after it if it has by then.
+    const bool batch_head = !d->queued.empty() && d->queued.front().first_frame == d->n_collected && d->queued.front().slot == sl.leader;
+    bool blocked = false;
+    lm_detector::QueuedBatch head{};
+    auto later_ms = [&]() {                              // estimated GPU time of the batches launched after this frame's
+        double ms = 0.0;
+        for (const lm_detector::QueuedBatch& q : d->queued)
+            if (q.first_frame > d->n_collected) ms += batch_ms_estimate(d, q.frames);
+        return ms;
+    };
+    if (batch_head) {
+        head = d->queued.front();
+        blocked = hipEventQuery(lead.done) == hipErrorNotReady;
+        (void)hipGetLastError();
+        if (blocked && d->pend_n > 0 && d->keep_queued > 0 && batch_ms_estimate(d, d->pend_n) > 0.f && later_ms() <= d->launch_slack_ms) {
+            int rc = lm_launch_pending(d);
+            if (rc) return rc;
+        }
+    }
     HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
+    {
+        const double now = host_seconds(t2), dry_at = now + 1e-3 * later_ms();
+        if (batch_head && blocked) {
+            const bool start_known = head.gpu_idle_at_launch || (d->last_done_at >= 0.0 && d->last_done_end == head.first_frame);
+            if (start_known) {
+                const double start = head.gpu_idle_at_launch ? head.launched_at : std::max(d->last_done_at, head.launched_at);
+                const float ms = (float)((now - start) * 1e3);
+                float& e = d->batch_ms[head.frames];
+                if (ms > 0.f && ms < 1e3f) e = e > 0.f ? 0.75f * e + 0.25f * ms : ms;
+            }
+            d->gpu_free_at = dry_at;
+            d->last_done_at = now;
+            d->last_done_end = head.first_frame + (uint64_t)head.frames;
+        } else {
+            d->gpu_free_at = std::min(d->gpu_free_at, dry_at);
+            if (batch_head) { d->last_done_at = -1.0; d->last_done_end = head.first_frame + (uint64_t)head.frames; }
+        }
+        if (batch_ms_estimate(d, std::max(1, d->pend_n)) > 0.f && partial_batch_due(d, now)) {
+            int rc = lm_launch_pending(d);
+            if (rc) return rc;
+        }
+    }
     sl.pending = false;
-    while (!d->queued.empty() && d->queued.front().first <= d->n_collected) d->queued.erase(d->queued.begin());   // this frame's batch and everything before it are done
+    while (!d->queued.empty() && d->queued.front().first_frame <= d->n_collected) d->queued.erase(d->queued.begin());   // this frame's batch and everything before it are done
     if (d->xchg.state[slot_index] != 0) {               // exchange work of this frame may still read the slot's buffers
         HIP_TRY(hipStreamSynchronize(d->xchg.stream));
         d->xchg.state[slot_index] = 0;
@@ -1903,10 +1974,9 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     const auto tp3 = std::chrono::steady_clock::now();
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     d->host_prof[0] += 1; d->host_prof[1] += secs(tp0, tp1); d->host_prof[2] += secs(tp1, tp2); d->host_prof[3] += secs(tp2, tp3);
-    // Launched at once while the GPU has fewer than keep_queued batches queued (it must never wait for a batch to fill: the first
-    // frames of a stream go out alone), otherwise when batch_max frames are waiting; lm_detector_flush / lm_detector_collect launch a
-    // partial batch.  So the batches are as large as the GPU's backlog allows and no larger.
-    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || batches_queued(d) < d->keep_queued) {
+    // A full batch goes out at once; a partial one when the GPU is about to run out of work (partial_batch_due); lm_detector_flush /
+    // lm_detector_collect launch what is left.  So the batches are as large as the GPU's backlog allows and no larger.
+    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || partial_batch_due(d, host_seconds(std::chrono::steady_clock::now()))) {
         rc = lm_launch_pending(d);
         d->host_prof[4] += secs(tp3, std::chrono::steady_clock::now());
         return rc;

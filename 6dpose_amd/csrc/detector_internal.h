@@ -169,11 +169,27 @@ struct lm_detector {
     int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)
     int pend_first = 0, pend_n = 0;
     float pend_threshold = 0.f;
-    // Launched batches the GPU may still be working on, oldest first: (index of the batch's first frame, its leader slot).  A streamed
-    // frame is launched at once while fewer than `keep_queued` batches are queued on the GPU — the GPU never waits for a batch to
-    // fill — and joins the waiting batch otherwise: batches grow to batch_max exactly when the GPU is the bottleneck.
-    std::vector<std::pair<uint64_t, int>> queued;
+    // Launched batches the GPU may still be working on, oldest first.  When does a streamed frame that does not fill its batch go
+    // out?  The GPU must never wait for a batch to fill, and a batch launched early is a small one (a lone frame costs ~2.5x its
+    // share of a batch of four).  The detector therefore keeps an estimate of when the GPU will have finished what it was given
+    // (`gpu_free_at`: launch times + the measured duration of batches of each size, corrected whenever a collect sees a batch
+    // finish) and launches a partial batch when that moment is closer than `launch_slack_ms` — the enqueue latency of a batch —
+    // either at a submit or just before a collect blocks.  Without a measured duration yet the rule is the backlog in batches:
+    // launch while fewer than `keep_queued` are unfinished.  keep_queued = 0 switches both off (batches of exactly batch_max frames;
+    // flush / collect launch what is left).
+    struct QueuedBatch {
+        uint64_t first_frame;                       // index of the batch's first frame
+        int slot, frames;                           // its leader slot, its size
+        double launched_at;                         // host clock (seconds, steady_clock)
+        bool gpu_idle_at_launch;                    // nothing unfinished before it: it started when it was launched
+    };
+    std::vector<QueuedBatch> queued;
     int keep_queued = 2;                            // LM_BATCH_QUEUE
+    float batch_ms[kMaxBatch + 1] = {};             // measured GPU time of a batch of n frames (moving average); 0 = not seen yet
+    double gpu_free_at = 0.0;                       // estimate, host clock
+    double last_done_at = -1.0;                     // when the most recently collected batch finished, if a collect saw it happen (-1: unknown)
+    uint64_t last_done_end = 0;                     // index of the frame after that batch
+    float launch_slack_ms = 0.15f;                  // LM_LAUNCH_SLACK_US
     // Collector thread (streamed frames): waits for a launched batch on the host and turns each frame's records into the canonical
     // Detector::match list (conversion, sort, unique: ~45 us per frame at 2k templates) while the caller's thread submits the next
     // frames; lm_detector_collect then only hands the list over.  One per detector, started with the first streamed batch.
