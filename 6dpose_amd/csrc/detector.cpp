@@ -176,6 +176,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_word.release(); d->d_run_mask.release(); d->d_work.release();
     d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_tiles.release(); d->d_todo.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (int l = 0; l < kMaxLevels; ++l) { d->train.mask[l].release(); d->train.lab[l].release(); d->train.hrun[l].release(); }
+    d->train.user_mask.release();
     d->train.keys.release(); d->train.counts.release(); d->train.bbox.release(); d->train.out.release();
     for (auto& sl : d->slot) {
         if (sl.h_matches) (void)hipHostFree(sl.h_matches);
@@ -443,12 +444,99 @@ static int add_template_resident(lm_detector* d, const uint8_t* mask, int width,
     return (int)tps.size() - 1;
 }
 
+// The scratch of the device selection for `views` views of the current geometry, and the maps it reads (the detector's level buffers).
+static int train_buffers(lm_detector* d, int views, TrainGeom& g) {
+    lm_detector::Train& T = d->train;
+    const int L = d->pyramid_levels;
+    const size_t out_words = 4 + 3 * (size_t)std::max(1, d->num_features);
+    int rc;
+    g.levels = L;
+    for (int l = 0; l < L; ++l) {
+        const LevelBufs& b = d->lvl[l];
+        const size_t nl = (size_t)b.W * b.H;
+        if ((rc = T.mask[l].ensure(nl)) || (rc = T.lab[l].ensure(nl)) || (rc = T.hrun[l].ensure(nl))) return rc;
+        g.W[l] = b.W; g.H[l] = b.H; g.mag[l] = b.mag.p; g.ang[l] = b.ang.p; g.nrm[l] = b.nrm.p;
+        g.mask[l] = T.mask[l].p; g.lab[l] = T.lab[l].p; g.hrun[l] = T.hrun[l].p;
+    }
+    const size_t keys_view = (size_t)L * 2 * kTrainCap, counts_view = (size_t)L * 16;
+    if ((rc = T.keys.ensure(keys_view * views)) || (rc = T.counts.ensure(counts_view * views)) || (rc = T.bbox.ensure(4 * (size_t)views)) ||
+        (rc = T.out.ensure((size_t)views * L * 2 * out_words)))
+        return rc;
+    return LM_OK;
+}
+
+// One view's output of k_train_select ([levels][2][out_words], every status 1) as a template pyramid of the class: cropTemplates,
+// the bank's limits, push_back.  Returns the template id.
+static int push_selected_pyramid(lm_detector* d, std::vector<TemplatePyramid>& tps, const int32_t* out_view, size_t out_words) {
+    const int L = d->pyramid_levels;
+    TemplatePyramid tp((size_t)2 * L);
+    for (int e = 0; e < 2 * L; ++e) {
+        const int32_t* o = out_view + (size_t)e * out_words;
+        Template& t = tp[e];
+        t.pyramid_level = e / 2;
+        t.features.resize((size_t)o[1]);
+        for (int k = 0; k < o[1]; ++k) t.features[k] = Feature{o[4 + 3 * k], o[4 + 3 * k + 1], o[4 + 3 * k + 2]};
+    }
+    crop_templates(tp);
+    int rc = validate_pyramid(d, tp);
+    if (rc) return rc;
+    tps.push_back(std::move(tp));
+    return (int)tps.size() - 1;
+}
+
+// Detector::addTemplate with an object mask, selection on the device (train.hip): the quantised maps never leave HBM, only the
+// chosen features come back.  Candidate lists beyond what the selection kernel sorts in LDS go to add_template_resident.
+static int add_template_device(lm_detector* d, const uint8_t* mask, int width, int height, const char* class_id) {
+    int rc;
+    if ((rc = run_frontend(d, false))) return rc;
+    d->frame_valid = false;   // LM arena not built for this frame
+    lm_detector::Train& T = d->train;
+    const int L = d->pyramid_levels;
+    const int nf_cap = std::max(1, d->num_features);
+    const size_t out_words = 4 + 3 * (size_t)nf_cap, npx = (size_t)width * height;
+    TrainGeom g{};
+    if ((rc = train_buffers(d, 1, g)) || (rc = T.user_mask.ensure(npx))) return rc;
+    hipStream_t s = d->stream;
+    HIP_TRY(hipMemcpyAsync(T.user_mask.p, mask, npx, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(T.counts.p, 0, (size_t)L * 16 * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(T.bbox.p, 0x80, 4 * sizeof(int32_t), s));
+    launch_train_prep(d->frame_depth.p, T.user_mask.p, g, d->strong_threshold * d->strong_threshold, d->extract_threshold, T.keys.p, kTrainCap, T.counts.p,
+                      T.bbox.p, s);
+    if (launch_train_select(T.keys.p, T.counts.p, g, kTrainCap, d->num_features, nf_cap, 1, T.out.p, s))
+        return lm_set_error(LM_ERR_HIP, "cannot reserve LDS for the selection kernel");
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h_out((size_t)L * 2 * out_words);
+    HIP_TRY(hipMemcpyAsync(h_out.data(), T.out.p, h_out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool ok = true, host_path = false;
+    for (int e = 0; e < 2 * L; ++e) {
+        const int32_t st = h_out[(size_t)e * out_words];
+        host_path |= st == 2;
+        ok &= st == 1;
+    }
+    if (host_path) return add_template_resident(d, mask, width, height, class_id);
+    std::vector<TemplatePyramid>& tps = d->class_templates[class_id];   // created even on failure, LL.cpp:1947
+    d->bank_dirty = true;
+    if (!ok) return -1;
+    return push_selected_pyramid(d, tps, h_out.data(), out_words);
+}
+
 extern "C" int lm_detector_add_template(lm_detector* d, const uint8_t* rgb, const uint16_t* depth, const uint8_t* mask,
                                         int width, int height, const char* class_id) {
     if (!d || !class_id) return lm_set_error(LM_ERR_INVALID, "null argument");
     int rc = upload_frame(d, rgb, depth, width, height, nullptr, false);
     if (rc) return rc;
-    return add_template_resident(d, mask, width, height, class_id);
+    // with an object mask (what every training loop of the reference passes) the selection runs on the device; LM_TRAIN_HOST=1 and
+    // detectors beyond kTrainMaxFeatures features keep it on the host, as does a call without mask (no erosion, candidates anywhere)
+    const char* force_host = getenv("LM_TRAIN_HOST");
+    bool on_device = mask && !(force_host && force_host[0] && force_host[0] != '0') && d->num_features >= 1 && d->num_features <= kTrainMaxFeatures;
+    if (on_device) {          // the device works on object / background; a grey mask (cv::erode takes minima, cv::subtract differences) stays on the host
+        uint8_t v = 0;
+        const size_t npx = (size_t)width * height;
+        for (size_t i = 0; i < npx && on_device; ++i)
+            if (mask[i]) { if (!v) v = mask[i]; else on_device = mask[i] == v; }
+    }
+    return on_device ? add_template_device(d, mask, width, height, class_id) : add_template_resident(d, mask, width, height, class_id);
 }
 
 // render_train (linemod_and_levelup_test.py:170-252) on the device: the rendered colour / depth images go from the
@@ -521,18 +609,8 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
         // ---- device selection: prepare every view of the chunk, select them all in one launch ----
         lm_detector::Train& T = d->train;
         TrainGeom g{};
-        g.levels = L;
-        for (int l = 0; l < L; ++l) {
-            const LevelBufs& b = d->lvl[l];
-            const size_t nl = (size_t)b.W * b.H;
-            if ((rc = T.mask[l].ensure(nl)) || (rc = T.lab[l].ensure(nl)) || (rc = T.hrun[l].ensure(nl))) return rc;
-            g.W[l] = b.W; g.H[l] = b.H; g.mag[l] = b.mag.p; g.ang[l] = b.ang.p; g.nrm[l] = b.nrm.p;
-            g.mask[l] = T.mask[l].p; g.lab[l] = T.lab[l].p; g.hrun[l] = T.hrun[l].p;
-        }
+        if ((rc = train_buffers(d, n, g))) return rc;
         const size_t keys_view = (size_t)L * 2 * kTrainCap, counts_view = (size_t)L * 16;
-        if ((rc = T.keys.ensure(keys_view * n)) || (rc = T.counts.ensure(counts_view * n)) || (rc = T.bbox.ensure(4 * (size_t)n)) ||
-            (rc = T.out.ensure((size_t)n * L * 2 * out_words)))
-            return rc;
         hipStream_t s = d->stream;
         HIP_TRY(hipMemsetAsync(T.counts.p, 0, counts_view * n * sizeof(uint32_t), s));
         HIP_TRY(hipMemsetAsync(T.bbox.p, 0x80, 4 * (size_t)n * sizeof(int32_t), s));        // large negative: k_train_mask takes maxima
@@ -544,7 +622,7 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
             HIP_TRY(hipMemcpyAsync(d->frame_rgb.p, m->d_rgb + (size_t)i * npx * 3, npx * 3, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(d->frame_depth.p, m->d_depth + (size_t)i * npx, npx * 2, hipMemcpyDeviceToDevice, s));
             if ((rc = run_frontend(d, false))) return rc;
-            launch_train_prep(d->frame_depth.p, g, strong_sq, d->extract_threshold, T.keys.p + keys_view * i, kTrainCap, T.counts.p + counts_view * i,
+            launch_train_prep(d->frame_depth.p, nullptr, g, strong_sq, d->extract_threshold, T.keys.p + keys_view * i, kTrainCap, T.counts.p + counts_view * i,
                               T.bbox.p + 4 * (size_t)i, s);
         }
         if (launch_train_select(T.keys.p, T.counts.p, g, kTrainCap, d->num_features, nf_cap, n, T.out.p, s))
@@ -573,18 +651,7 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
                     id = add_rendered_view_host(d, m, i, width, height, class_id, hdepth, hmask, nullptr);
                     if (id < -1) return id;
                 } else if (ok) {
-                    TemplatePyramid tp((size_t)2 * L);
-                    for (int e = 0; e < 2 * L; ++e) {
-                        const int32_t* o = &h_out[((size_t)i * L * 2 + e) * out_words];
-                        Template& t = tp[e];
-                        t.pyramid_level = e / 2;
-                        t.features.resize((size_t)o[1]);
-                        for (int k = 0; k < o[1]; ++k) t.features[k] = Feature{o[4 + 3 * k], o[4 + 3 * k + 1], o[4 + 3 * k + 2]};
-                    }
-                    crop_templates(tp);
-                    if ((rc = validate_pyramid(d, tp))) return rc;
-                    tps.push_back(std::move(tp));
-                    id = (int)tps.size() - 1;
+                    if ((id = push_selected_pyramid(d, tps, &h_out[(size_t)i * L * 2 * out_words], out_words)) < -1) return id;
                 }
             }
             if (box_wh) {                                                      // xmax - xmin, ymax - ymin (:235-236)

@@ -253,7 +253,7 @@ struct lm_detector {
 
     // template extraction on the device (train.hip): scratch of the view being prepared + per-view candidate lists of a chunk
     struct Train {
-        DevBuf<uint8_t> mask[kMaxLevels], lab[kMaxLevels];
+        DevBuf<uint8_t> mask[kMaxLevels], lab[kMaxLevels], user_mask;
         DevBuf<int32_t> hrun[kMaxLevels];
         DevBuf<unsigned long long> keys;
         DevBuf<uint32_t> counts;

@@ -187,7 +187,8 @@ struct TrainGeom {                            // the maps of the view being prep
     int32_t* hrun[kMaxLevels];                // distance to the end of the pixel's same-label run along its row
 };
 // keys_view: [levels][2][cap] sort keys / (distance, position, label) records; counts_view: [levels][16]; bbox_view: [4] = {max(-x), max(-y), max(x), max(y)}
-void launch_train_prep(const uint16_t* depth, const TrainGeom& g, float strong_sq, int extract_threshold, unsigned long long* keys_view,
+// user_mask (W0 x H0, nonzero = object) replaces depth > 0 when given
+void launch_train_prep(const uint16_t* depth, const uint8_t* user_mask, const TrainGeom& g, float strong_sq, int extract_threshold, unsigned long long* keys_view,
                        uint32_t cap, uint32_t* counts_view, int32_t* bbox_view, hipStream_t s);
 // out: [views][levels][2][4 + 3 * nf_cap]: status (1 ok, 0 too few candidates, 2 leave it to the host path), count, -, -, then x, y, label
 int launch_train_select(const unsigned long long* keys, const uint32_t* counts, const TrainGeom& g, uint32_t cap, int num_features, int nf_cap,

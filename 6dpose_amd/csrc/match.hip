@@ -126,7 +126,7 @@ static __device__ __forceinline__ int wave_excl_scan(int mine, int lane, int& to
 __global__ void __launch_bounds__(1024)
 k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
          const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-         const int32_t* __restrict__ work_pyramids, int num_work, int wpt, float threshold, uint32_t cap, TilePlanGeom plan) {
+         const int32_t* __restrict__ work_pyramids, int num_work, int wpt, int cpw, float threshold, uint32_t cap, TilePlanGeom plan) {
     extern __shared__ uint32_t s_dyn[];
     const FrameSlot& F = fb.f[blockIdx.y];                        // the frame of the batch this workgroup serves
     const uint8_t* __restrict__ lm_arena = F.lm_arena;
@@ -165,10 +165,14 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
         __syncthreads();
     }
 
-    for (int chunk0 = wave * kChunksPerWave; chunk0 * 16 < npos; chunk0 += nwaves * kChunksPerWave) {
+    // A wave owns cpw <= kChunksPerWave consecutive 16-position chunks, one per lane; lane cpw reads the chunk after them (the
+    // realignment of a run needs the next lane's bytes) and the lanes above it sit the loads out: the chunks of the map are split
+    // EVENLY over the template's waves — 1200 positions are 38 + 37 lanes, not 63 + 12 — because a 16-byte wave load costs the
+    // texture path ~24 cycles at 40 lanes, 31.5 at 64 and still 22.7 at 12 (profiles/r03_tcp_rotation_microbench.txt).
+    for (int chunk0 = wave * cpw; chunk0 * 16 < npos; chunk0 += nwaves * cpw) {
         const int j0 = (chunk0 + lane) * 16;                   // first position owned by this lane
         uint32_t even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0};
-        if (chunk0 * 16 < tp && nfp > 0) {                     // wave-uniform
+        if (chunk0 * 16 < tp && nfp > 0 && lane <= cpw) {      // wave-uniform but for the idle lanes
             const BufRsrc arena = make_rsrc(lm_arena);
             uint32_t r8[4] = {0, 0, 0, 0};                      // packed-u8 sums of the current class run
             int cur = -1, cnt = 0;
@@ -235,7 +239,7 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
         uint32_t hit_mask = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (live && lane < kChunksPerWave && j0 + k < npos && score_of(raw_at(k), nf) > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
+            if (live && lane < cpw && j0 + k < npos && score_of(raw_at(k), nf) > threshold) hit_mask |= 1u << k;   // LL.cpp:1844
         if (plan.enabled) {
             // the hits of the whole template are collected in LDS; slots, tiles and records follow once all of them are known
             if (hit_mask) {
@@ -442,9 +446,11 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
     const int level = g.levels - 1;
     const LevelGeom lv = g.lv[level];
     int npos = lv.Wd * lv.Hd;
-    int waves = (npos + kChunksPerWave * 16 - 1) / (kChunksPerWave * 16);
+    const int nchunks = (npos + 15) / 16;
+    int waves = (nchunks + kChunksPerWave - 1) / kChunksPerWave;
     if (waves > 16) waves = 16;
     if (waves < 1) waves = 1;
+    const int cpw = std::min(kChunksPerWave, std::max(1, (nchunks + waves - 1) / waves));   // the map's chunks evenly over the waves
     TilePlanGeom plan{};
     size_t lds = 0;
     int group = 1;
@@ -464,7 +470,7 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
         lds = per * group + (4 * (size_t)group + 4) * sizeof(uint32_t);
     }
     hipLaunchKernelGGL(k_coarse, dim3((num_work + group - 1) / group, fb.nb), dim3(group * waves * 64), lds, s, fb, lv, level, g.levels, entries,
-                       feat_off, work_pyramids, num_work, waves, threshold, cap, plan);
+                       feat_off, work_pyramids, num_work, waves, cpw, threshold, cap, plan);
 }
 
 // ---------------------------------------------------------------------------------------------

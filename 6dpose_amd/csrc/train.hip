@@ -3,7 +3,7 @@
 // QuantizedPyramid::selectScatteredFeatures (LL.cpp:279-318) — after the quantisers of frontend.hip.  gfx950 only.
 //
 // Per view (pixel-parallel, on the detector's stream right after the view's front end):
-//   k_train_mask   object mask = rendered depth > 0, its nearest-neighbour pyramid (LL.cpp:576, 877), bounding box
+//   k_train_mask   object mask = rendered depth > 0 (or the caller's object_mask != 0: single-image addTemplate), its nearest-neighbour pyramid (LL.cpp:576, 877), bounding box
 //   k_train_prep   colour candidates: pixels of (mask - erode(mask)) with an orientation and magnitude > strong^2, as sort keys
 //                  (score desc, row-major position asc = the order std::stable_sort leaves); normal labels inside erode^2(mask)
 //   k_train_runs   per labelled pixel: distance to the end of its same-label run along the row
@@ -29,13 +29,13 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 }  // namespace
 
 __global__ void __launch_bounds__(256)
-k_train_mask(const uint16_t* __restrict__ depth, TrainGeom g, int32_t* __restrict__ bbox) {
+k_train_mask(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ user_mask, TrainGeom g, int32_t* __restrict__ bbox) {
     const int W = g.W[0], H = g.H[0];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
     if (i < W * H) {
         const int x = i % W, y = i / W;
-        const bool on = depth[i] > 0;
+        const bool on = user_mask ? user_mask[i] != 0 : depth[i] > 0;   // addTemplate's object_mask, or the rendered view's depth > 0
         const uint8_t v = on ? 255 : 0;
         g.mask[0][i] = v;
         for (int l = 1; l < g.levels; ++l) {
@@ -259,10 +259,10 @@ k_train_select(const unsigned long long* __restrict__ keys_all, const uint32_t* 
     if (lane == 0) { out[0] = 1; out[1] = ns; }
 }
 
-void launch_train_prep(const uint16_t* depth, const TrainGeom& g, float strong_sq, int extract_threshold, unsigned long long* keys_view,
+void launch_train_prep(const uint16_t* depth, const uint8_t* user_mask, const TrainGeom& g, float strong_sq, int extract_threshold, unsigned long long* keys_view,
                        uint32_t cap, uint32_t* counts_view, int32_t* bbox_view, hipStream_t s) {
     const int n0 = g.W[0] * g.H[0];
-    hipLaunchKernelGGL(k_train_mask, dim3((n0 + 255) / 256), dim3(256), 0, s, depth, g, bbox_view);
+    hipLaunchKernelGGL(k_train_mask, dim3((n0 + 255) / 256), dim3(256), 0, s, depth, user_mask, g, bbox_view);
     const dim3 grid((n0 + 255) / 256, g.levels);              // level l uses the first W_l * H_l / 256 blocks of its row
     hipLaunchKernelGGL(k_train_prep, grid, dim3(256), 0, s, g, strong_sq, keys_view, cap, counts_view);
     hipLaunchKernelGGL(k_train_runs, grid, dim3(256), 0, s, g);

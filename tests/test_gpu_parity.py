@@ -790,6 +790,26 @@ def test_add_template_reproduces_reference_golden(lm, tmp_path):
     assert t_o == t_g == 0
     for a, b in zip(det.getTemplates("s", 0), od.class_templates["s"][0]):
         assert (a.width, a.height) == (b.width, b.height) and np.array_equal(a.features, b.features)
+    # with an object mask the selection runs on the device (train.hip) — the golden above went through it; it, the host selection
+    # (LM_TRAIN_HOST=1) and a grey mask (minima / differences of cv::erode / cv::subtract: always the host) all equal the oracle
+    yy, xx = np.mgrid[0:240, 0:320]
+    ell = (((xx - 160) / 120.0) ** 2 + ((yy - 120) / 90.0) ** 2 <= 1.0).astype(np.uint8) * 255
+    ell[100:140, 150:170] = 0
+    grey = ell.copy()
+    grey[ell > 0] = 200
+    grey[60:180:7, 80:240:5] = 90
+    for name, m, envs in (("ell", ell, ("0", "1")), ("grey", grey, ("0",))):
+        assert od.addTemplate([srgb, sdep], name, m) == 0
+        want = od.class_templates[name][0]
+        for env in envs:
+            os.environ["LM_TRAIN_HOST"] = env
+            try:
+                dd = lm.Detector(device=0)
+                assert dd.addTemplate([srgb, sdep], name, m) == 0
+            finally:
+                os.environ.pop("LM_TRAIN_HOST", None)
+            for a, b in zip(dd.getTemplates(name, 0), want):
+                assert (a.width, a.height) == (b.width, b.height) and np.array_equal(a.features, b.features), (name, env)
     # writeClasses -> readClasses round trip (oracle reader parses the product's YAML too)
     det.writeClasses(str(tmp_path / "%s.yaml"))
     _, mods, levels, pyr2 = lo.read_class_yaml(str(tmp_path / "06_template.yaml"))
