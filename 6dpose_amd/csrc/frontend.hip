@@ -8,6 +8,7 @@
 // that no FMA contraction or reassociation can occur (the reference is x86-64 SSE2 scalar float,
 // OpenCV semantics per SURVEY Appendix A).
 #include "lm_kernels.h"
+#include "knobs.h"
 
 namespace lm {
 
@@ -491,24 +492,31 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
 // mostly launch latency.  The jobs that do not depend on each other share a launch: stage k = {colour chain of level k,
 // normals + median (k = 0) or nearest-neighbour normals of level k, pyrDown to level k + 1}; the last launch builds the linear
 // memories of every level.  A job is a range of the flat block index; the bodies are the kernels above, unchanged.
+// The workgroups are persistent: a tile takes a workgroup ~1.5 us, and the dispatcher hands an XCD a new workgroup only every
+// ~30 ns — with one workgroup per tile (10.8k for the first stage of four VGA frames) a CU held 1.3 workgroups on average and the
+// stage took as long as the dispatcher needed (42 us; profiles/r03_pmc.txt: 5 waves per CU).  A few workgroups per CU walk the
+// tiles instead (flat index + k * grid).
 __global__ void __launch_bounds__(256)
-k_fe_stage(FeStage st) {
-    int j = 0;
-    while (j + 1 < st.njobs && (int)blockIdx.x >= st.job[j + 1].first) ++j;
-    const FeJob& J = st.job[j];
-    const int local = (int)blockIdx.x - J.first;
-    const int bz = (int)fast_div((uint32_t)local, J.m_gxgy), rem = local - bz * J.gx * J.gy;
-    const int by = (int)fast_div((uint32_t)rem, J.m_gx), bx = rem - by * J.gx;
-    switch (J.kind) {
-        case kFeColour: color_quant_body(bx, by, (const uint8_t*)J.in, (float*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.f); break;
-        case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
-        case kFePyrDown: pyrdown_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.H, J.a, J.b); break;
-        case kFeNnDown: nn_down2_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.a); break;
-        case kFeBuildLm:
-            if ((J.Wd & 3) == 0) build_lm_body4(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
-            else build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
-            break;
-        default: break;
+k_fe_stage(FeStage st, int total) {
+    for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
+        int j = 0;
+        while (j + 1 < st.njobs && blk >= st.job[j + 1].first) ++j;
+        const FeJob& J = st.job[j];
+        const int local = blk - J.first;
+        const int bz = (int)fast_div((uint32_t)local, J.m_gxgy), rem = local - bz * J.gx * J.gy;
+        const int by = (int)fast_div((uint32_t)rem, J.m_gx), bx = rem - by * J.gx;
+        switch (J.kind) {
+            case kFeColour: color_quant_body(bx, by, (const uint8_t*)J.in, (float*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.f); break;
+            case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
+            case kFePyrDown: pyrdown_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.H, J.a, J.b); break;
+            case kFeNnDown: nn_down2_body(bx, by, (const uint8_t*)J.in, (uint8_t*)J.out0, J.W, J.a); break;
+            case kFeBuildLm:
+                if ((J.Wd & 3) == 0) build_lm_body4(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
+                else build_lm_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
+                break;
+            default: break;
+        }
+        if (blk + (int)gridDim.x < total) __syncthreads();      // the next tile reuses the bodies' LDS
     }
 }
 
@@ -544,7 +552,15 @@ void launch_fe_stage(FeStage& st, hipStream_t s) {
         ++n;
     }
     st.njobs = n;
-    if (total > 0) hipLaunchKernelGGL(k_fe_stage, dim3(total), dim3(256), 0, s, st);
+    if (total <= 0) return;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const int per_cu = knobs().fe_wgs_per_cu;
+    const int grid = per_cu > 0 ? std::min(total, cus * per_cu) : total;
+    hipLaunchKernelGGL(k_fe_stage, dim3(grid), dim3(256), 0, s, st, total);
 }
 
 }  // namespace lm
