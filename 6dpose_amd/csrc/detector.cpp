@@ -1324,6 +1324,24 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
     FeStage st{};
     auto flush = [&]() { if (st.njobs) launch_fe_stage(st, s); st.njobs = 0; };
     auto room = [&](int jobs) { if (st.njobs + jobs > kFeMaxJobs) flush(); };
+    auto build_lm_jobs = [&](int l) {                        // linear memories of level l of every frame (its quantised maps are complete)
+        for (int b = 0; b < nb; ++b) {
+            const int arena = (first + b) % lm_detector::kSlots;
+            const lm_detector::Slot& sl = d->slot[arena];
+            LevelBufs& B = d->level_bufs(b, l);
+            const LevelGeom& lv = d->geom.lv[l];
+            const bool strips = l < L - 1;
+            const uint8_t* quant[2] = {B.ang.p, B.nrm.p};
+            const uint8_t* mask[2] = {sl.have_mask[0] ? d->lvl[l].mask[0].p : nullptr, sl.have_mask[1] ? d->lvl[l].mask[1].p : nullptr};
+            uint8_t* lmp[2] = {d->lm_arena[arena].p + lv.lm_off[0], d->lm_arena[arena].p + lv.lm_off[1]};
+            uint8_t* smp[2] = {strips ? d->sm_arena[arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[arena].p + lv.sm_off[1] : nullptr};
+            room(1);
+            fe_job_build_lm(st.job[st.njobs++], quant, mask, lmp, smp, B.W, B.H, lv.T);
+        }
+    };
+    // Launch l quantises level l of every frame and — beside it, they only need level l - 1 — builds the linear memories of level
+    // l - 1; a last launch builds those of the top level.  (The memories of level 0 are 3/4 of that work: they no longer wait for
+    // the quantisation of the small levels, and the last launch is a quarter of what it was.)
     for (int l = 0; l < L; ++l) {
         st.njobs = 0;
         for (int b = 0; b < nb; ++b) {
@@ -1337,23 +1355,10 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
             else fe_job_nn_down2(st.job[st.njobs++], d->level_bufs(b, l - 1).nrm.p, B.nrm.p, d->level_bufs(b, l - 1).W, d->level_bufs(b, l - 1).H);   // LL.cpp:857-880
             if (l + 1 < L) fe_job_pyrdown(st.job[st.njobs++], src, d->level_bufs(b, l + 1).rgb.p, B.W, B.H);                     // LL.cpp:557-581
         }
+        if (l > 0) build_lm_jobs(l - 1);
         flush();
     }
-    for (int b = 0; b < nb; ++b) {
-        const int arena = (first + b) % lm_detector::kSlots;
-        const lm_detector::Slot& sl = d->slot[arena];
-        for (int l = 0; l < L; ++l) {
-            LevelBufs& B = d->level_bufs(b, l);
-            const LevelGeom& lv = d->geom.lv[l];
-            const bool strips = l < L - 1;
-            const uint8_t* quant[2] = {B.ang.p, B.nrm.p};
-            const uint8_t* mask[2] = {sl.have_mask[0] ? d->lvl[l].mask[0].p : nullptr, sl.have_mask[1] ? d->lvl[l].mask[1].p : nullptr};
-            uint8_t* lmp[2] = {d->lm_arena[arena].p + lv.lm_off[0], d->lm_arena[arena].p + lv.lm_off[1]};
-            uint8_t* smp[2] = {strips ? d->sm_arena[arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[arena].p + lv.sm_off[1] : nullptr};
-            room(1);
-            fe_job_build_lm(st.job[st.njobs++], quant, mask, lmp, smp, B.W, B.H, lv.T);
-        }
-    }
+    build_lm_jobs(L - 1);
     flush();
     d->last_arena = first;                               // read_stage: the maps of level_bufs(0, .) belong to the batch's first frame
     HIP_TRY(hipGetLastError());
@@ -1374,7 +1379,7 @@ static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, Fra
     F.dedupe_table = d->d_hash.p + dedupe_table_slots(cc) * (size_t)si;
     F.distinct_keys = d->d_distinct_keys.p + (size_t)cc * si;
     F.final_dev = d->d_final.p + 8 * (size_t)si;
-    HIP_TRY(hipHostGetDevicePointer((void**)&F.matches, sl.h_matches, 0));
+    F.matches = nullptr;                                  // (k_local no longer stores the raw records into host memory: 16-byte PCIe writes per candidate)
     HIP_TRY(hipHostGetDevicePointer((void**)&F.distinct, sl.h_distinct, 0));
     HIP_TRY(hipHostGetDevicePointer((void**)&F.final_host, sl.h_counters, 0));
     *out = F;
@@ -1438,6 +1443,7 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
     sl.threshold = threshold; sl.num_work = num_work; sl.coarse_bytes = d->work_coarse_bytes; sl.h2d_ms = d->last_h2d_ms;
     sl.work_cls = d->work_cls; sl.work_tid = d->work_tid;
     sl.cand_cap = d->buf_cand_cap; sl.cands = d->d_cands.p + (size_t)d->buf_cand_cap * si;
+    sl.matches_dev = d->d_matches_dev.p + (size_t)d->buf_cand_cap * si;
     sl.in_rgb = rgb; sl.in_depth = depth; sl.have_mask[0] = have_mask[0]; sl.have_mask[1] = have_mask[1]; sl.ring = ring;
     sl.launched = false; sl.pending = true; sl.leader = -1; sl.batch_n = 0;
     if (d->pend_n == 0) { d->pend_first = si; d->pend_threshold = threshold; }
@@ -1818,6 +1824,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     const uint64_t evals = sl.num_work > 0 ? hc[5] : 0, lbytes = sl.num_work > 0 ? hc[6] : 0;
     uint64_t nm = 0;
     const Candidate* hm = sl.h_matches;
+    if (sl.num_work > 0 && ncand > 0 && (sort_unique == 0 || sort_unique == 3 || d->reference_order))   // the raw per-candidate records, for the callers that want them
+        HIP_TRY(hipMemcpy(sl.h_matches, sl.matches_dev, (size_t)ncand * sizeof(Candidate), hipMemcpyDeviceToHost));
     if (sl.num_work == 0) nm = 0;
     else if (sort_unique == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
     else nm = hc[2];                                   // counted on the device by k_dedupe: no pass over the raw records

@@ -132,7 +132,7 @@ struct lm_detector {
     // Result slots: the refinement kernel of a later frame writes into one pinned buffer while the host
     // collects an earlier frame from another (lm_detector_submit / lm_detector_collect).
     struct Slot {
-        Candidate* h_matches = nullptr;             // pinned, device-visible: k_local writes matches here
+        Candidate* h_matches = nullptr;             // pinned: the raw records, copied from matches_dev when a collect asks for them
         Candidate* h_distinct = nullptr;            // pinned: the same without exact duplicates (k_dedupe), unordered
         uint32_t match_cap = 0;
         unsigned long long* h_counters = nullptr;   // pinned: [0] candidate count, [1] distinct records, [2] records alive, [8..] 2 words of statistics per refinement block
@@ -160,6 +160,7 @@ struct lm_detector {
         int num_work = 0;
         uint32_t cand_cap = 0;                      // the candidate capacity / buffer this frame was submitted with (d->cand_cap may grow before it is collected)
         const Candidate* cands = nullptr;
+        const Candidate* matches_dev = nullptr;     // the frame's refined records in HBM (one per candidate, work = -1: dropped)
         int64_t coarse_bytes = 0;
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;

@@ -104,8 +104,8 @@ struct FrameSlot {                            // device pointers of ONE frame of
     TileRec* tiles;                           // [tile_cap] or null
     uint8_t* todo;                            // [cand_cap] or null
     unsigned long long* counters;             // [kCounterWords] working counters, zero between frames
-    Candidate* matches;                       // [cap] refined records, pinned host memory
-    Candidate* matches_dev;                   // [cap] the same in HBM (on-device NMS, duplicate removal)
+    Candidate* matches;                       // unused (round 2: a pinned host copy of matches_dev written by k_local; the host now fetches matches_dev when asked)
+    Candidate* matches_dev;                   // [cap] refined records in HBM, one per candidate (duplicate removal, on-device NMS, exchange)
     unsigned long long* dedupe_table;         // open-addressing table of k_dedupe
     Candidate* distinct;                      // [cap] records without exact duplicates, pinned host memory
     ulonglong2* distinct_keys;                // the same as 128-bit exchange keys (HBM), may be null
@@ -126,7 +126,7 @@ size_t coarse_plan_lds_bytes(int Wd, int Hd);
 void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
                    const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t tile_cap, hipStream_t s);
 // Persistent grid: waves stride over the tiles of all frames of the batch, then over their candidates (counts read on the device).
-// matches[ci] = refined candidate ci (work = -1: dropped).  Also empties the part of every frame's hash table k_dedupe will use.
+// matches_dev[ci] = refined candidate ci (work = -1: dropped).  Also empties the part of every frame's hash table k_dedupe will use.
 // Per feature of a level below the top ONE word, feat_word = base0 | cls: base0 = byte offset (a multiple of 16) inside the strip
 // arena of the 16-byte row of the feature's own cell — plane base + ((lx >> 4) * Hd + ly) * 16 — and cls = lx & 15, the alignment
 // class (features of an entry are sorted by it).  The window origin of a work item (gx, gy) adds the same K = ((gx >> 4) * Hd + gy)

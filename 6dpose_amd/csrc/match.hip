@@ -561,7 +561,6 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             while (gi >= (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr + 1])) ++fr;           // wave-uniform: item -> frame
             const FrameSlot& F = fb.f[fr];
             const uint8_t* __restrict__ sm_arena = F.sm_arena;
-            Candidate* __restrict__ matches = F.matches;
             Candidate* __restrict__ matches_dev = F.matches_dev;
             const TileRec t = F.tiles[gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tend[fr])];
             const int work = __builtin_amdgcn_readfirstlane(t.work);
@@ -717,7 +716,6 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                     m.y = (gy0 + dy + br) * T + offset;
                     m.score = best;
                     m.work = best < threshold ? -1 : work;                      // LL.cpp:1935
-                    matches[slot] = m;
                     matches_dev[slot] = m;
                 }
             }
@@ -733,7 +731,6 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
         if (tiled && !F.todo[ci]) continue;                  // a tile member: refined above (wave-uniform)
         const uint8_t* __restrict__ lm_arena = F.lm_arena;
         const uint8_t* __restrict__ sm_arena = F.sm_arena;
-        Candidate* __restrict__ matches = F.matches;
         Candidate* __restrict__ matches_dev = F.matches_dev;
         const Candidate cd = F.cands[ci];
         unsigned long long evals = 0, bytes = 0;
@@ -881,12 +878,12 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
             if (sim < threshold) alive = false;                 // remove_if(MatchPredicate), LL.cpp:1935
         }
         // No atomics: the result of candidate ci goes to slot ci (work = -1 when it dropped below the
-        // threshold on the way up, LL.cpp:1935); the host compacts.  matches[] is pinned host memory.
+        // threshold on the way up, LL.cpp:1935).
         if (lane == 0 && ci < cap) {
             Candidate m;
             m.x = mx; m.y = my; m.score = sim; m.work = alive ? work : -1;
-            matches[ci] = m;
-            matches_dev[ci] = m;                 // HBM copy for the on-device NMS / top-K (pipeline.cpp)
+            matches_dev[ci] = m;                 // in HBM: k_dedupe, the on-device NMS / top-K (pipeline.cpp) and the exchange read it there; the host
+                                                 // fetches the raw records only when asked for them (lm_collect_frame, sort_unique = 0)
         }
         if (lane == 0) { atomicAdd(&s_acc[fr][0], evals); atomicAdd(&s_acc[fr][1], bytes); }
     }

@@ -12,7 +12,7 @@ timeout 300 python bench.py --steps 200 --no-extras --no-cpu-baseline --batch 1 
 timeout 300 python bench.py --scaling strong --steps 50 --no-extras --no-cpu-baseline > $OUT/bench_strong_n1_16k.json 2> $OUT/bench_strong_n1_16k.err
 timeout 300 python bench.py --dry-ranks 8 --steps 8 > $OUT/dry_ranks8.json 2> $OUT/dry_ranks8.err
 timeout 200 python profiles/host_profile.py 2>&1 | grep steps > $OUT/host_profile.txt
-timeout 300 python profiles/short_run_sweep.py 2>&1 | grep batch > $OUT/short_run_sweep.txt
+timeout 200 python profiles/short_run_timeline.py 2>&1 | grep -A1 "^rep" > $OUT/short_run_timeline.txt
 [ -x bin_tmp/tcp_rot ] && ./bin_tmp/tcp_rot > $OUT/tcp_rotation_microbench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o roof -- python $ROOT/bench.py --roofline-only --no-parity-gate > $ROOT/$OUT/roofline_only.json 2> $ROOT/$OUT/roofline_only.err
