@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "detector_internal.h"
+#include <sched.h>
+#include <ctype.h>
 #include "render_internal.h"
 
 // ---- errors -----------------------------------------------------------------------------------
@@ -33,6 +35,51 @@ static void collector_main(lm_detector* d);
 static void collector_stop(lm_detector* d);
 static void copier_stop(lm_detector* d);
 extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
+// Binds the calling thread to the CPUs next to `device` (its PCI function's local_cpulist in sysfs): pinned staging buffers are then
+// allocated, filled and read by the copy engine on the GPU's own NUMA node.  On a two-socket host a process that happens to start on
+// the far socket otherwise uploads every frame across the socket link (0.12 instead of 0.065 ms per VGA frame).
+extern "C" int lm_bind_thread_near_device(int device, char* cpulist_out, size_t cap) {
+    if (cpulist_out && cap) cpulist_out[0] = 0;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return lm_set_error(LM_ERR_NO_DEVICE, "no PCI bus id for device %d", device);
+    }
+    for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return lm_set_error(LM_ERR_IO, "cannot read %s", path.c_str());
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return lm_set_error(LM_ERR_IO, "empty %s", path.c_str());
+    cpu_set_t want, have;
+    CPU_ZERO(&want);
+    int ncpu = 0;
+    for (const char* p = line; *p;) {                          // "0-47,96-143"
+        if (*p < '0' || *p > '9') { ++p; continue; }
+        char* e = nullptr;
+        long a = strtol(p, &e, 10), b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &want); ++ncpu; }
+        p = e;
+    }
+    if (ncpu == 0) return lm_set_error(LM_ERR_IO, "no CPUs listed in %s", path.c_str());
+    if (sched_getaffinity(0, sizeof(have), &have) == 0) {       // never widen what the caller (cgroup, numactl, taskset) allowed
+        cpu_set_t both;
+        CPU_AND(&both, &want, &have);
+        if (CPU_COUNT(&both) == 0) return lm_set_error(LM_ERR_INVALID, "none of the device's local CPUs (%s) is allowed for this thread", line);
+        want = both;
+    }
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return lm_set_error(LM_ERR_INVALID, "sched_setaffinity failed");
+    if (cpulist_out && cap) {
+        size_t n = strlen(line);
+        while (n && (line[n - 1] == '\n' || line[n - 1] == ' ')) line[--n] = 0;
+        snprintf(cpulist_out, cap, "%s", line);
+    }
+    return LM_OK;
+}
+
 extern "C" int lm_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -49,6 +49,17 @@ class _CMatch(ctypes.Structure):
                 ("class_index", ctypes.c_int32), ("template_id", ctypes.c_int32)]
 
 
+def bind_near_device(device: int = 0):
+    """lm_bind_thread_near_device: the calling thread onto the CPUs next to the GPU; returns the CPU list, or None where sysfs does not tell."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(4096)
+    lib.lm_bind_thread_near_device.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    lib.lm_bind_thread_near_device.restype = ctypes.c_int
+    if lib.lm_bind_thread_near_device(int(device), buf, 4096) != 0:
+        return None
+    return buf.value.decode()
+
+
 class Timings(ctypes.Structure):
     """lm_timings (include/amd_linemod.h)."""
     _fields_ = [("h2d_ms", ctypes.c_float), ("frontend_ms", ctypes.c_float), ("coarse_ms", ctypes.c_float),

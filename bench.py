@@ -185,6 +185,10 @@ def main():
     # The detector first, the process group after it: the HIP runtime hands a new stream the least used hardware queue of its
     # priority pool, and the detector's streams should not have to share queues with the ones torch / RCCL create (measured, world 1
     # over RCCL on one box: 0.26-0.28 ms per step with the process group first, 0.19 with the detector first)
+    # and before the detector, the CPUs: this process (its helper threads, its pinned staging buffers) onto the NUMA node of its GPU —
+    # what `numactl --cpunodebind` does for a deployment; LM_NO_BIND=1 leaves the placement to the scheduler
+    all_cpus = os.sched_getaffinity(0)
+    host_cpus = None if os.environ.get("LM_NO_BIND") else lm.bind_near_device(local_rank)
     det = lm.Detector(NFEAT[0], T_LEVELS, device=local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -457,7 +461,7 @@ def main():
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "parity_checked": bool(parity and parity["ok"]), "parity": parity,
-            "config": {"workload": workload,
+            "config": {"workload": workload, "host_cpus": host_cpus,
                        "frame_source": "host memory, a new frame per step through lm_detector_submit_frame (pinned ring + copy stream); "
                                        "H2D inside the timed region; pool of %d distinct noisy frames, step number stamped in" % N_FRAMES,
                        "templates_total": total_templates, "objects": n_obj, "templates_this_rank": my_templates,
@@ -563,6 +567,7 @@ def main():
                 except (OSError, ValueError):
                     pass
         if world == 1 and not strong and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)          # the CPU baseline (its all-cores variant) gets every core the process started with
             out["cpu_baseline"] = cpu_baseline(noisy_frames(N_FRAMES), banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         if world == 1 and not strong and not args.no_extras:

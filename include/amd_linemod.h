@@ -76,6 +76,11 @@ const char *lm_last_error(void);
 const char *lm_version(void);
 /* Number of visible HIP devices (0 when none / runtime unavailable). */
 int lm_device_count(void);
+/* Binds the CALLING THREAD (and the threads it starts afterwards) to the CPUs local to `device` (sysfs local_cpulist of its PCI
+ * function), within what the thread was allowed before; cpulist_out (optional) receives the list.  Call it before creating the
+ * detector: the pinned staging buffers of lm_detector_submit_frame then live on the GPU's NUMA node.  A deployment that already
+ * runs under numactl / a cpuset needs nothing.  No reference counterpart (the reference has no device). */
+int lm_bind_thread_near_device(int device, char *cpulist_out, size_t cap);
 
 /* ---- Detector -------------------------------------------------------------------------------
  * Detector(), Detector(T), Detector(num_features, T): pybind11.cpp:26-28, LL.cpp:1663-1692.
