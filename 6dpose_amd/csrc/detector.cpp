@@ -1518,10 +1518,19 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
     return 0.f;
 }
 
-// Should the frames waiting for their batch go out now?  `after` = host time the question is asked for (now at a submit; at a collect
-// about to block, the moment the awaited batch is expected to finish).
+// Should the frames waiting for their batch go out now?  `at` = host time the question is asked for.
+//   * nothing launched is still uncollected: the GPU is idle, the frame goes out (the first frame of a stream, a caller that
+//     collects every frame before the next);
+//   * the caller submits in a tight loop (frames arrive less than 2.5 launches' worth of host time apart): only full batches.  A
+//     launch costs the calling thread ~0.1 ms (seven kernel launches + events) whatever the batch size, so a stream of partial
+//     batches makes the HOST the bottleneck at the pace of one launch per frame, the GPU keeps up with it, looks about to run dry
+//     at every submit — and the stream stays there (measured: 0.213 instead of 0.155 ms per frame).  lm_detector_collect launches
+//     what is left when it is about to block on the last launched batch, so nothing waits for frames that never come;
+//   * frames arrive sparsely (a camera): the GPU-time model — launch when the GPU's estimated backlog is shorter than the slack.
 static bool partial_batch_due(lm_detector* d, double at) {
     if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
+    if (d->n_launched == d->n_collected) return true;
+    if (d->submit_gap_ms < 2.5f * d->launch_cost_ms) return false;
     if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
 }
@@ -1838,7 +1847,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
             d->gpu_free_at = std::min(d->gpu_free_at, dry_at);
             if (batch_head) { d->last_done_at = -1.0; d->last_done_end = head.first_frame + (uint64_t)head.frames; }
         }
-        if (batch_ms_estimate(d, std::max(1, d->pend_n)) > 0.f && partial_batch_due(d, now)) {
+        const bool idle_after = d->n_launched == d->n_collected + 1;         // this was the last launched frame: the GPU has nothing left
+        if (d->pend_n > 0 && d->keep_queued > 0 && (idle_after || (batch_ms_estimate(d, d->pend_n) > 0.f && partial_batch_due(d, now)))) {
             int rc = lm_launch_pending(d);
             if (rc) return rc;
         }
@@ -2098,9 +2108,19 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     d->host_prof[0] += 1; d->host_prof[1] += secs(tp0, tp1); d->host_prof[2] += secs(tp1, tp2); d->host_prof[3] += secs(tp2, tp3);
     // A full batch goes out at once; a partial one when the GPU is about to run out of work (partial_batch_due); lm_detector_flush /
     // lm_detector_collect launch what is left.  So the batches are as large as the GPU's backlog allows and no larger.
-    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || partial_batch_due(d, host_seconds(std::chrono::steady_clock::now()))) {
+    {   // how fast the frames arrive (moving average of the gap between submits; a pause counts as 10 ms)
+        const double t = host_seconds(tp3);
+        if (d->last_submit_at > 0.0) {
+            const float gap = (float)std::min(10.0, (t - d->last_submit_at) * 1e3);
+            d->submit_gap_ms = d->submit_gap_ms > 0.f ? 0.75f * d->submit_gap_ms + 0.25f * gap : gap;
+        }
+        d->last_submit_at = t;
+    }
+    if (d->pend_n >= std::max(1, std::min(d->batch_max, kMaxBatch)) || partial_batch_due(d, host_seconds(tp3))) {
         rc = lm_launch_pending(d);
-        d->host_prof[4] += secs(tp3, std::chrono::steady_clock::now());
+        const double cost = secs(tp3, std::chrono::steady_clock::now());
+        d->host_prof[4] += cost;
+        d->launch_cost_ms = 0.75f * d->launch_cost_ms + 0.25f * (float)std::min(1.0, cost * 1e3);
         return rc;
     }
     return LM_OK;

@@ -191,6 +191,9 @@ struct lm_detector {
     double last_done_at = -1.0;                     // when the most recently collected batch finished, if a collect saw it happen (-1: unknown)
     uint64_t last_done_end = 0;                     // index of the frame after that batch
     float launch_slack_ms = 0.15f;                  // LM_LAUNCH_SLACK_US
+    double last_submit_at = 0.0;                    // lm_detector_submit_frame: host clock of the previous call,
+    float submit_gap_ms = 0.f;                      // moving average of the gap between calls (0 = no second call yet: treated as sparse),
+    float launch_cost_ms = 0.1f;                    // and of the host time one lm_launch_pending takes
     // Collector thread (streamed frames): waits for a launched batch on the host and turns each frame's records into the canonical
     // Detector::match list (conversion, sort, unique: ~45 us per frame at 2k templates) while the caller's thread submits the next
     // frames; lm_detector_collect then only hands the list over.  One per detector, started with the first streamed batch.
