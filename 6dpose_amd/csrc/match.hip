@@ -166,9 +166,17 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
     }
 
     // A wave owns cpw <= kChunksPerWave consecutive 16-position chunks, one per lane; lane cpw reads the chunk after them (the
-    // realignment of a run needs the next lane's bytes) and the lanes above it sit the loads out: the chunks of the map are split
-    // EVENLY over the template's waves — 1200 positions are 38 + 37 lanes, not 63 + 12 — because a 16-byte wave load costs the
-    // texture path ~24 cycles at 40 lanes, 31.5 at 64 and still 22.7 at 12 (profiles/r03_tcp_rotation_microbench.txt).
+    // realignment of a run needs the next lane's bytes) and the lanes above it sit the loads out.  Only the chunks below the
+    // template's position count tp carry sums: those are split EVENLY over as few waves as hold them — a template with tp <= 1008
+    // keeps one wave (of ceil(tp / 16) + 1 lanes) and its second wave only scans zeros, 1200 positions are 38 + 37 lanes, not
+    // 63 + 12 — because a 16-byte wave load costs the texture path ~24 cycles at 40 lanes, 31.5 at 64 and still 22.7 at 12
+    // (profiles/r03_tcp_rotation_microbench.txt).
+    {
+        const int nch = ((tp < npos ? tp : npos) + 15) >> 4;
+        const int wn = (nch + kChunksPerWave - 1) / kChunksPerWave;
+        cpw = wn >= 1 && wn <= nwaves ? (nch + wn - 1) / wn : kChunksPerWave;
+        if (cpw < 1) cpw = 1;
+    }
     for (int chunk0 = wave * cpw; chunk0 * 16 < npos; chunk0 += nwaves * cpw) {
         const int j0 = (chunk0 + lane) * 16;                   // first position owned by this lane
         uint32_t even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0};

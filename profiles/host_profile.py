@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "6dpose_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import bench, linemodLevelup_pybind as lm, synth
 W, H = bench.W, bench.H
+print('host cpus:', None if os.environ.get('LM_NO_BIND') else lm.bind_near_device(0), flush=True)   # as bench.py does (LM_NO_BIND=1: leave the placement to the scheduler)
 det = lm.Detector(bench.NFEAT[0], bench.T_LEVELS, device=0)
 frames = bench.noisy_frames(16)
 det.addClassPacked("_probe", np.zeros((0, 3), np.int32), np.zeros(1, np.int32), np.zeros((0, 2), np.int32))
