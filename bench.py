@@ -364,9 +364,9 @@ def main():
     primed = {"live": False, "resident": False}
 
     def timed(nsteps, warmup, resident=False):
-        # one-time set-up, before the W warm-up steps: every slot of the result ring (lm_detector kSlots = 8) creates its pinned
-        # staging buffer and instantiates its hipGraph the first time a frame lands in it - with W < 8 that would happen inside
-        # the timed region (3 slots x ~0.5 ms at the driver's --steps 20 --warmup 5)
+        # one-time set-up, before the W warm-up steps: every slot of the result ring (lm_detector_max_in_flight() = 16) allocates its
+        # pinned staging buffer and device buffers the first time a frame lands in it - with W < 16 that would happen inside the
+        # timed region (~0.5 ms per slot at the driver's --steps 20 --warmup 5)
         key = "resident" if resident else "live"
         if not primed[key]:
             run(lm.load_library().lm_detector_max_in_flight(), resident)
@@ -472,8 +472,8 @@ def main():
                        "templates_per_rank": templates_per_rank, "unsharded_check": unsharded,
                        "pipeline_depth": PIPELINE_DEPTH, "frames_per_launch_max": BATCH, "batches_kept_queued": args.batch_queue,
                        "frames_per_launch_mean_timed": mean["batch_frames"],
-                       "setup_before_warmup": "8 frames through the ingest ring (each of the library's 8 result slots allocates its pinned staging "
-                                              "buffer and instantiates its hipGraph on first use); the timed region starts and ends with an empty pipeline, "
+                       "setup_before_warmup": "16 frames through the ingest ring (each of the library's 16 result slots allocates its pinned staging "
+                                              "buffer and device buffers on first use); the timed region starts and ends with an empty pipeline, "
                                               "so at K = 20 it carries one frame latency (~0.45 ms) of fill and drain",
                        "coarse_candidates_per_step": mean["coarse_candidates"], "matches_pre_unique_per_step": mean["matches_pre_unique"],
                        "matches_final_last_step": n_final, "templates_per_sec": total_templates * K / dt},
