@@ -824,6 +824,24 @@ def test_add_template_reproduces_reference_golden(lm, tmp_path):
         lm.Detector([5, 8, 8], device=0).readClasses(["s"], str(tmp_path / "%s.yaml"))   # pyramid_levels, LL.cpp:2052
 
 
+def test_bind_near_device_stays_within_the_allowed_cpus(lm):
+    """lm_bind_thread_near_device: the GPU's local CPUs (sysfs), never more than the thread was allowed before."""
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = lm.bind_near_device(0)
+        if cpus is None:
+            pytest.skip("sysfs does not list the GPU's local CPUs on this box")
+        now = os.sched_getaffinity(0)
+        assert now and now <= before
+        listed = set()
+        for part in cpus.split(","):
+            a, _, b = part.partition("-")
+            listed.update(range(int(a), int(b or a) + 1))
+        assert now <= listed
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_detector_params_write_read_round_trip(lm, tmp_path):
     """Detector::write / read (LL.cpp:2013-2041): parameters survive the YAML, read() clears the classes, and a detector
     configured from the file matches like the one that wrote it."""

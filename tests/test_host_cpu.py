@@ -186,6 +186,9 @@ def test_new_entry_points_fail_loudly_without_a_gpu():
         mod.Mesh(V, np.array([[0, 1, 3]], np.int32))            # face index checked before any device use
     with pytest.raises(RuntimeError):
         mod.Mesh("/nonexistent/model.ply")
+    # host placement helper: without a device it reports nothing and leaves the caller's affinity alone
+    before = os.sched_getaffinity(0)
+    assert mod.bind_near_device(0) is None and os.sched_getaffinity(0) == before
 
 
 def _bank_file_bytes(levels, classes):
