@@ -1530,7 +1530,7 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 static bool partial_batch_due(lm_detector* d, double at) {
     if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
     if (d->n_launched == d->n_collected) return true;
-    if (d->submit_gap_ms < 2.5f * d->launch_cost_ms) return false;
+    if (d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms) return false;   // (0: no second submit yet — sparse until shown otherwise)
     if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
 }
@@ -1816,14 +1816,14 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     auto later_ms = [&]() {                              // estimated GPU time of the batches launched after this frame's
         double ms = 0.0;
         for (const lm_detector::QueuedBatch& q : d->queued)
-            if (q.first_frame > d->n_collected) ms += batch_ms_estimate(d, q.frames);
+            if (q.first_frame > d->n_collected) { const float e = batch_ms_estimate(d, q.frames); ms += e > 0.f ? e : 1e3; }   // not timed yet: plenty
         return ms;
     };
     if (batch_head) {
         head = d->queued.front();
         blocked = hipEventQuery(lead.done) == hipErrorNotReady;
         (void)hipGetLastError();
-        if (blocked && d->pend_n > 0 && d->keep_queued > 0 && batch_ms_estimate(d, d->pend_n) > 0.f && later_ms() <= d->launch_slack_ms) {
+        if (blocked && d->pend_n > 0 && d->keep_queued > 0 && later_ms() <= d->launch_slack_ms) {   // (no batch launched after this one: 0, with or without a GPU-time model)
             int rc = lm_launch_pending(d);
             if (rc) return rc;
         }
