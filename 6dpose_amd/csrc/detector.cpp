@@ -217,6 +217,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     }
     if (d->ingest.stream) (void)hipStreamDestroy(d->ingest.stream);
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
+    for (int a = 0; a < lm_detector::kSlots; ++a) d->bits_arena[a].release();
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
@@ -313,6 +314,12 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
         const bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena[a].cap;
         if ((rc = d->sm_arena[a].ensure(std::max<size_t>(sarena, 256)))) return rc;
         if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena[a].p, 0, d->sm_arena[a].cap, d->stream));
+        if (knobs().bitplanes) {                             // the strip arena's layout at half the offsets; its zero planes stay zero
+            const size_t bbytes = std::max<size_t>(sarena, 256) / 2 + 64;
+            const bool realloc_bits = bbytes > d->bits_arena[a].cap;
+            if ((rc = d->bits_arena[a].ensure(bbytes))) return rc;
+            if (realloc_bits || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->bits_arena[a].p, 0, d->bits_arena[a].cap, d->stream));
+        }
     }
     for (int l = 0; l < L; ++l) {
         LevelBufs& b = d->lvl[l];
@@ -994,6 +1001,8 @@ static int upload_bank(lm_detector* d) {
         HIP_TRY(hipMemcpy(d->d_feat_word.p, word.data(), word.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->d_run_mask.p, rmask.data(), rmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    d->bits_bank_ok = true;
+    for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) d->bits_bank_ok = d->bits_bank_ok && d->h_entries[i].nf <= 511;
     d->bank_dirty = false;
     d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
     return LM_OK;
@@ -1412,6 +1421,11 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
     return LM_OK;
 }
 
+// The bit-plane refinement (match.hip): two-level pyramids, banks of at most 511 features per level-0 entry; LM_BITPLANES=0: off.
+static bool bits_active(const lm_detector* d, int num_work) {
+    return knobs().bitplanes && num_work > 0 && d->geom.levels == 2 && d->bits_bank_ok;
+}
+
 // Device pointers of result slot `si` (everything a frame in flight owns).
 static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, FrameSlot* out) {
     lm_detector::Slot& sl = d->slot[si];
@@ -1475,7 +1489,7 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
         HIP_TRY(hipMemset(d->d_final.p, 0, 8 * (size_t)K * sizeof(unsigned long long)));
     }
     // tile refinement (match.hip): two-level pyramids with a tileable geometry; the buffers exist per result slot
-    const bool tiled = d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
+    const bool tiled = (d->use_tiles && num_work > 0 && tile_plan_possible(d->geom)) || bits_active(d, num_work);   // (the bit-plane path uses the todo bytes)
     const uint32_t tile_cap = d->buf_cand_cap / 2;      // a tile has at least two members
     if (tiled && (d->d_tiles.cap < (size_t)tile_cap * K || d->d_todo.cap < (size_t)d->buf_cand_cap * K)) {
         if ((rc = lm_launch_pending(d))) return rc;
@@ -1545,7 +1559,8 @@ int lm_launch_pending(lm_detector* d) {
     lm_detector::Slot& lead = d->slot[first];
     const int num_work = lead.num_work;
     const float threshold = lead.threshold;
-    const bool tiled = d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
+    const bool bits = bits_active(d, num_work);
+    const bool tiled = !bits && d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
     const uint32_t tile_cap = d->buf_cand_cap / 2;
     FrameBatch fb{};
     fb.nb = nb;
@@ -1560,6 +1575,17 @@ int lm_launch_pending(lm_detector* d) {
     }
     HIP_TRY(hipEventRecord(lead.ev[0], s));
     if ((rc = run_frontend_batch(d, first, nb, s))) return rc;
+    BitsBatch bb{};
+    FrameBatch fb_rest = fb;                                  // for k_local's per-candidate path on what k_local_bits leaves (todo = 1)
+    if (bits) {
+        for (int b = 0; b < nb; ++b) {
+            const int si = (first + b) % lm_detector::kSlots;
+            bb.strips[b] = d->sm_arena[si].p; bb.bits[b] = d->bits_arena[si].p;
+            fb.f[b].todo = fb_rest.f[b].todo = d->d_todo.p + (size_t)d->buf_cand_cap * si;
+            fb_rest.f[b].tiles = d->d_tiles.p + (size_t)tile_cap * si;   // non-null: "only the candidates marked todo"; no tile was planned
+        }
+        launch_pack_bits(bb, nb, d->geom.lv[0], s);
+    }
     HIP_TRY(hipEventRecord(lead.ev[1], s));
     HIP_TRY(hipEventRecord(lead.fe_done, s));
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1581,6 +1607,12 @@ int lm_launch_pending(lm_detector* d) {
         // persistent refinement grid over the tiles and then the remaining candidates of every frame of the batch; the counts are
         // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
         // the hash tables k_dedupe uses
+        if (bits) {
+            launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
+                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), d->num_cus * 4 * std::max(1, std::min(nb, 4)), ms);   // a wave serves 8 candidates: ~2k groups per frame at configs[1]
+            launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
+                         (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
+        } else
         if (num_work > 0)
             launch_local(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                          (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, local_grid(d, nb), ms);
@@ -2124,6 +2156,12 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
         return rc;
     }
     return LM_OK;
+}
+
+// 1 when the refinement of the current bank and frame geometry runs on bit planes (k_local_bits), 0 when on the byte strip planes
+// (k_local: three or more pyramid levels, a template with more than 511 features at level 0, LM_BITPLANES=0).  Valid after a match.
+extern "C" int lm_detector_refines_on_bit_planes(const lm_detector* d) {
+    return d && !d->bank_dirty && bits_active(d, 1) ? 1 : 0;
 }
 
 extern "C" int lm_detector_flush(lm_detector* d) {

@@ -165,6 +165,8 @@ struct lm_detector {
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
+    DevBuf<uint8_t> bits_arena[kSlots];             // bit-plane copy of the strip arena (half its size)
+    bool bits_bank_ok = false;                      // every level-0 template entry has at most 511 features (the counters of k_local_bits)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
     int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)

@@ -118,6 +118,14 @@ struct FrameBatch {
     FrameSlot f[kMaxBatch];
 };
 
+// Bit-plane refinement (match.hip): per frame of a batch the strip arena it is packed from and its bit
+// arena (the strip arena's layout at half the offsets: 8-byte records instead of 16-byte rows).
+struct BitsBatch { const uint8_t* strips[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
+void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s);
+// two-level pyramids, at most 511 features per template entry: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path
+void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
+                       const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
+                       hipStream_t s);
 bool tile_plan_possible(const FrameGeom& g);
 size_t coarse_plan_lds_bytes(int Wd, int Hd);
 // Per frame of the batch: counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with tiles

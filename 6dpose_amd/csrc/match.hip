@@ -905,6 +905,204 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     }
 }
 
+// ---- Bit-plane refinement (the default for two-level pyramids whose templates have at most 511 features per level-0
+// entry, LM_BITPLANES=0 switches back to the tiles above).  A response is 0, 1 or 4, so a position's sum is n1 + 4 n4 with n1 / n4 = the number of features whose
+// response there is 1 / 4: two 1-bit planes per (label, phase) carry what the byte planes do.  k_pack_bits turns every 16-byte row of
+// the strip planes into an 8-byte record {is-1 bits of cells [16 s, 16 s + 32) | is-4 bits of the same cells << 32} — strips 32 cells
+// wide at a stride of 16, so every 16-cell window lies inside ONE record, and the bit arena is the strip arena at half the offsets.
+// k_local_bits: 8 lanes per candidate (lane j = window rows 2j, 2j + 1 = one 16-byte load of two records), 8 candidates per wave,
+// one feature per candidate and load instruction: a wave load serves 8 (candidate, feature) pairs instead of 2, and needs neither
+// tiles nor alignment classes (the window's cell offset is a per-lane shift).  Sums are bit-sliced (a dword = 32 positions of one
+// counter bit), features enter eight at a time through carry-save adders; integers only once per candidate.  The algorithm is
+// profiles/bitplane_model.py, which is checked against the byte evaluation and the oracle on the CPU.
+static __device__ __forceinline__ void csa(uint32_t& sum, uint32_t& carry, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t t = a ^ b;
+    carry = (a & b) | (t & c);
+    sum = t ^ c;
+}
+// eight 1-bit inputs into {ones, twos, fours} + a bit-sliced counter of the eights (6 levels: counts up to 511)
+static __device__ __forceinline__ void add8(const uint32_t (&x)[8], uint32_t& ones, uint32_t& twos, uint32_t& fours, uint32_t (&hi)[6]) {
+    uint32_t ta, tb, fa, fb, e;
+    csa(ones, ta, ones, x[0], x[1]);
+    csa(ones, tb, ones, x[2], x[3]);
+    csa(twos, fa, twos, ta, tb);
+    csa(ones, ta, ones, x[4], x[5]);
+    csa(ones, tb, ones, x[6], x[7]);
+    csa(twos, fb, twos, ta, tb);
+    csa(fours, e, fours, fa, fb);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const uint32_t t = hi[k] & e; hi[k] ^= e; e = t; }
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;             // record = ((plane * NS + s) * Hd + row)
+    if (i >= records) return;
+    const uint32_t q = i / (uint32_t)Hd, s = q % (uint32_t)NS;
+    const uint8_t* src = B.strips[blockIdx.y] + sm_off0 + (size_t)i * 16;
+    const uint4 a = *reinterpret_cast<const uint4*>(src);
+    uint4 b = make_uint4(0, 0, 0, 0);
+    if (s + 1 < (uint32_t)NS) b = *reinterpret_cast<const uint4*>(src + (size_t)Hd * 16);      // the next strip of this row
+    auto four = [](uint32_t d, int sh) -> uint32_t { return ((((d >> sh) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };   // bit sh of 4 bytes -> 4 bits
+    auto bits = [&](const uint4& v, int sh) -> uint32_t { return four(v.x, sh) | (four(v.y, sh) << 4) | (four(v.z, sh) << 8) | (four(v.w, sh) << 12); };
+    uint2 r;
+    r.x = bits(a, 0) | (bits(b, 0) << 16);                           // response 1 = bit 0, response 4 = bit 2 of the byte
+    r.y = bits(a, 2) | (bits(b, 2) << 16);
+    *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (sm_off0 >> 1) + (size_t)i * 8) = r;
+}
+
+__global__ void __launch_bounds__(256)
+k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restrict__ entries, const uint32_t* __restrict__ feat_word,
+             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, uint32_t zero_off) {
+    __shared__ unsigned long long s_acc[kMaxBatch][2];
+    __shared__ uint32_t s_cnt[kMaxBatch];
+    const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
+    const int nb = fb.nb;
+    // frame -> XCD affinity as in k_local
+    int f_lo = 0, f_hi = nb;
+    uint32_t w_first = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), w_step = gridDim.x * (blockDim.x >> 6);
+    if (nb > 1 && (8 % nb) == 0 && (gridDim.x & 7) == 0) {
+        const int per = 8 / nb, xcd = (int)(blockIdx.x & 7);
+        f_lo = xcd / per; f_hi = f_lo + 1;
+        const uint32_t wpb = blockDim.x >> 6;
+        w_first = ((blockIdx.x >> 3) * (uint32_t)per + (uint32_t)(xcd % per)) * wpb + (threadIdx.x >> 6);
+        w_step = (gridDim.x >> 3) * (uint32_t)per * wpb;
+    }
+    if ((int)threadIdx.x < nb) {
+        const unsigned long long nc = fb.f[threadIdx.x].counters[0] & kCandMask;
+        s_cnt[threadIdx.x] = nc < cand_cap ? (uint32_t)nc : cand_cap;
+        s_acc[threadIdx.x][0] = 0; s_acc[threadIdx.x][1] = 0;
+    }
+    __syncthreads();
+    for (int f = 0; f < nb; ++f) {                                  // k_dedupe's hash table, emptied here like k_local does
+        unsigned long long* table = fb.f[f].dedupe_table;
+        if (!table) continue;
+        const uint32_t tsize = dedupe_slots_for(s_cnt[f], dedupe_cap_slots);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) table[i] = ~0ull;
+    }
+    const LevelGeom lv = g.lv[0];
+    const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
+    const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+    const uint32_t HS8 = (uint32_t)Hd * 8u;
+    for (int fr = f_lo; fr < f_hi; ++fr) {
+        const FrameSlot& F = fb.f[fr];
+        const BufRsrc bits = make_rsrc(B.bits[fr]);
+        const uint32_t nc = s_cnt[fr], ngroups = (nc + 7u) >> 3;
+        for (uint32_t gi = w_first; gi < ngroups; gi += w_step) {
+            const uint32_t ci = gi * 8u + (uint32_t)grp;
+            const bool valid = ci < nc;
+            Candidate cd{0, 0, 0.f, 0};
+            if (valid) cd = F.cands[ci];
+            const int work = cd.work;
+            const int pyr = work_pyramids[work];
+            const TemplEntry e = entries[(size_t)pyr * g.levels];
+            // LL.cpp:1871-1880 (the clamp) and 1380-1381 (window origin), exactly as k_local
+            const int max_x = W - e.width - border, max_y = H - e.height - border;
+            int x = cd.x * 2 + 1, y = cd.y * 2 + 1;
+            x = x > border ? x : border;  y = y > border ? y : border;
+            x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
+            const int gx = x / T - 8, gy = y / T - 8;
+            const int off_x = gx * T, off_y = gy * T;
+            const bool all_in = e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 &&
+                                ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= Hd);
+            const bool fast = valid && all_in;
+            if (valid && j == 0) F.todo[ci] = fast ? 0 : 1;         // the others (oversized templates, features outside the frame) go to k_local's per-candidate path
+            const int nf = e.nf, nfp = fast ? (int)e.nf_padded : 0;
+            int nmax = nfp;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            const uint32_t K = (uint32_t)(((gx >> 4) * Hd + gy + 2 * j) * 8);
+            const int gxl = gx & 15;
+            uint32_t ones1 = 0, twos1 = 0, fours1 = 0, hi1[6] = {0, 0, 0, 0, 0, 0};
+            uint32_t ones4 = 0, twos4 = 0, fours4 = 0, hi4[6] = {0, 0, 0, 0, 0, 0};
+            const uint32_t* fw = feat_word + e.feat_start;
+            for (int f0 = 0; f0 < nmax; f0 += kFeatBatch) {
+                const bool on = f0 < nfp;                           // this candidate still has features (uniform over its 8 lanes)
+                const uint32_t wv = on ? fw[f0 + j] : 0u;           // lane j of the group fetches word f0 + j; the group shares them below
+                uint4 v[kFeatBatch];
+                uint32_t sh[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) {
+                    const uint32_t w = (uint32_t)__shfl((int)wv, (lane & ~7) + u, 64);
+                    const uint32_t sum = (w & 15u) + (uint32_t)gxl;
+                    sh[u] = sum & 15u;
+                    const uint32_t off = on ? ((w & ~15u) >> 1) + K + (sum >= 16u ? HS8 : 0u) : zero_off;
+                    v[u] = ld_buf16(bits, off, 0u);                // rows 2j, 2j + 1: {is-1, is-4} of 32 cells each
+                }
+                uint32_t x1[kFeatBatch], x4[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) {
+                    x1[u] = ((v[u].x >> sh[u]) & 0xFFFFu) | ((v[u].z >> sh[u]) << 16);
+                    x4[u] = ((v[u].y >> sh[u]) & 0xFFFFu) | ((v[u].w >> sh[u]) << 16);
+                }
+                add8(x1, ones1, twos1, fours1, hi1);
+                add8(x4, ones4, twos4, fours4, hi4);
+            }
+            // S = n1 + 4 n4, bit-sliced (12 bits: <= 511 + 4 x 511), then the lane's maximum and its first position
+            const uint32_t n1[9] = {ones1, twos1, fours1, hi1[0], hi1[1], hi1[2], hi1[3], hi1[4], hi1[5]};
+            const uint32_t n4[9] = {ones4, twos4, fours4, hi4[0], hi4[1], hi4[2], hi4[3], hi4[4], hi4[5]};
+            uint32_t S[12], carry = 0;
+            S[0] = n1[0]; S[1] = n1[1];
+#pragma unroll
+            for (int k = 2; k < 12; ++k) {
+                const uint32_t a = k < 9 ? n1[k] : 0u, b = k - 2 < 9 ? n4[k - 2] : 0u;
+                csa(S[k], carry, a, b, carry);
+            }
+            uint32_t mask = 0xFFFFFFFFu, val = 0;
+#pragma unroll
+            for (int k = 11; k >= 0; --k) {
+                const uint32_t t = mask & S[k];
+                if (t) { mask = t; val |= 1u << k; }
+            }
+            const uint32_t first = (uint32_t)__ffs((int)mask) - 1u;           // lowest position index of the lane's maximum; index = 32 j + bit
+            uint32_t key = (val << 8) | (255u - (32u * (uint32_t)j + first));
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
+            const int raw = (int)(key >> 8);
+            int br = -1, bc = -1;                               // LL.cpp:1910-1911
+            float best = 0.f;
+            if (raw > 0) {
+                const int idx = 255 - (int)(key & 0xFF);
+                br = idx >> 4; bc = idx & 15;
+                best = score_of(raw, nf);
+            }
+            if (fast && j == 0) {
+                if (ci < cap) {
+                    Candidate m;
+                    m.x = (x / T - 8 + bc) * T + offset;        // LL.cpp:1930-1931
+                    m.y = (y / T - 8 + br) * T + offset;
+                    m.score = best;
+                    m.work = best < threshold ? -1 : work;      // LL.cpp:1935
+                    F.matches_dev[ci] = m;
+                }
+                atomicAdd(&s_acc[fr][0], 1ull);
+                atomicAdd(&s_acc[fr][1], 256ull * (unsigned long long)nf);
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb && s_acc[threadIdx.x][0] != 0) {
+        unsigned long long* st = fb.f[threadIdx.x].counters + 8 + 2 * (blockIdx.x & (kStatShards - 1));
+        atomicAdd(st, s_acc[threadIdx.x][0]);
+        atomicAdd(st + 1, s_acc[threadIdx.x][1]);
+    }
+}
+
+void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s) {
+    const uint32_t records = (uint32_t)(2 * 8 * lv.T * lv.T) * (uint32_t)lv.NS * (uint32_t)lv.Hd;
+    hipLaunchKernelGGL(k_pack_bits, dim3((records + 255) / 256, nb), dim3(256), 0, s, B, lv.sm_off[0], records, lv.NS, lv.Hd);
+}
+void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
+                       const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
+                       hipStream_t s) {
+    const LevelGeom& lv = g.lv[0];
+    const uint32_t splane = (uint32_t)lv.NS * (uint32_t)lv.Hd * 16u;
+    const uint32_t zero_off = (lv.sm_off[1] + 8u * (uint32_t)(lv.T * lv.T) * splane) >> 1;      // the all-zero plane, in bit-arena offsets
+    hipLaunchKernelGGL(k_local_bits, dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap,
+                       dedupe_cap_slots, zero_off);
+}
+
 void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
                   const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
                   uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s) {

@@ -513,6 +513,13 @@ class Detector:
         k = ("frames", "staging_copy", "h2d_enqueue", "slot_bookkeeping", "batch_launches", "collect_wait", "record_conversion", "sort_unique")
         return dict(zip(k, [float(x) for x in out]))
 
+    def refinesOnBitPlanes(self) -> bool:
+        """lm_detector_refines_on_bit_planes: which refinement kernel the current bank / geometry uses (valid after a match)."""
+        f = self._lib.lm_detector_refines_on_bit_planes
+        f.argtypes = [ctypes.c_void_p]
+        f.restype = ctypes.c_int
+        return bool(f(self._h))
+
     def getBatch(self) -> int:
         return int(self._lib.lm_detector_get_batch(self._h))
 

@@ -441,7 +441,9 @@ def main():
     if rank == 0:
         # dominant kernel of this rank, timed alone (see the roofline leg above)
         if excl["local_ms"] >= excl["coarse_ms"]:
-            kname, kms, kbytes, kpipe = "k_local", excl["local_ms"], excl["local_bytes"], mean["local_ms"]
+            # (local_ms brackets the refinement launches: k_local_bits + a k_local launch for the candidates it leaves — oversized templates —,
+            # or k_local alone when the bank / geometry keeps the byte planes)
+            kname, kms, kbytes, kpipe = ("k_local_bits" if det.refinesOnBitPlanes() else "k_local"), excl["local_ms"], excl["local_bytes"], mean["local_ms"]
         else:
             kname, kms, kbytes, kpipe = "k_coarse", excl["coarse_ms"], excl["coarse_bytes"], mean["coarse_ms"]
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -538,7 +540,10 @@ def main():
                 "frac_of_tcp_cycles": ((pm["TCP_TOTAL_CACHE_ACCESSES_sum"] + pm["TCP_PENDING_STALL_CYCLES_sum"]) / (256.0 * kcycles)) if kcycles > 0 else None,
                 "l1_accesses_per_vmem_instruction": pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / pm["SQ_INSTS_VMEM_RD"] if pm["SQ_INSTS_VMEM_RD"] else None,
                 "bytes_loaded": pm["SQ_INSTS_VMEM_RD"] * 64 * 16,
-                "bytes_loaded_note": "wave-level 16-byte load instructions x 64 lanes x 16 B: an upper bound (tiles keep 60 of 64 lanes busy)",
+                "bytes_loaded_note": ("wave-level load instructions x 64 lanes x 16 B: an upper bound (k_local_bits: one 16-byte record load per 8 (candidate, feature) pairs, "
+                                      "plus a 4-byte feature-word load per 8 of those and the candidates' records)" if kname == "k_local_bits" else
+                                      "wave-level 16-byte load instructions x 64 lanes x 16 B: an upper bound (tiles keep 60 of 64 lanes busy)"),
+                "valu_issue_frac": (4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kcycles)) if kcycles > 0 else None,     # wave64 on 16-lane SIMDs: 4 cycles per instruction, 1024 SIMDs
                 "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None,
                 "insts_per_launch": {"salu": pm["SQ_INSTS_SALU"], "valu": pm["SQ_INSTS_VALU"], "vmem_rd": pm["SQ_INSTS_VMEM_RD"], "waves": pm["SQ_WAVES"]},
                 "kernel_us_profiled": kcycles / 2400.0,
@@ -550,9 +555,13 @@ def main():
                               "frac": (LOAD_CYCLES_L2 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kcycles)) if kcycles > 0 else None,
                               "note": "frac = what the same number of wave loads costs in the micro-benchmark of the access pattern alone / the kernel's CU cycles: "
                                       "the kernel runs at this fraction of the rate its load instructions can be retired at; fewer wave loads, not faster ones, is what is left"},
-                "what_bounds_it": "the vector L1 (TCP): one 64-byte access per cycle and CU; accesses + cycles stalled on pending misses over the CU cycles of "
-                                  "the launch = frac_of_tcp_cycles.  `frac` (algorithmic bytes / HBM peak) exceeds 1 because the linear memories are "
-                                  "cache-resident and a tile's window region is loaded once for all its members; hbm_frac_physical is the real HBM share"})
+                "what_bounds_it": ("k_local_bits reads the responses as two 1-bit planes (n1 + 4 n4 = the byte sum): a 16-byte wave load serves 8 (candidate, feature) "
+                                   "pairs, so `frac` (ALGORITHMIC response bytes / HBM peak) is far above 1 - 256 algorithmic bytes per pair are 16 loaded ones, from L2.  "
+                                   "The candidates are the vector L1 (frac_of_tcp_cycles, load_path.frac) and the VALU (valu_issue_frac: carry-save adders on bit-sliced "
+                                   "counters); hbm_frac_physical is the real HBM share" if kname == "k_local_bits" else
+                                   "the vector L1 (TCP): one 64-byte access per cycle and CU; accesses + cycles stalled on pending misses over the CU cycles of "
+                                   "the launch = frac_of_tcp_cycles.  `frac` (algorithmic bytes / HBM peak) exceeds 1 because the linear memories are "
+                                   "cache-resident and a tile's window region is loaded once for all its members; hbm_frac_physical is the real HBM share")})
         else:
             traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # last committed PMC pass (profiles/pmc_run.sh)
             if os.path.exists(traffic):
@@ -654,7 +663,7 @@ def pmc_live(kernel, args, timeout=120):
             cols = [c[1] for c in con.execute("pragma table_info('counters_collection')")]
             name_col = "kernel_name" if "kernel_name" in cols else "name"
             rows = con.execute("select counter_name, dispatch_id, sum(value) from counters_collection where %s like ? group by counter_name, dispatch_id"
-                               % name_col, ("%" + kernel + "%",)).fetchall()
+                               % name_col, ("%" + kernel + "(%",)).fetchall()
             con.close()
             per = {}
             for cname, _disp, val in rows:

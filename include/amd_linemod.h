@@ -259,6 +259,9 @@ int lm_detector_set_async_collect(lm_detector *d, int on);
 /* Host-side wall time (seconds, accumulated) the library spent on streamed frames: out8 = {frames, staging copy, H2D enqueue, slot
  * bookkeeping, batch launches, collect: waiting for the GPU, record conversion, canonical sort + unique}; reset != 0 clears it. */
 int lm_detector_host_profile(lm_detector *d, double *out8, int reset);
+/* 1 when the local refinement (similarityLocal, LL.cpp:1366-1428) of the current bank and frame geometry runs on bit planes
+ * (kernel k_local_bits), 0 when on byte planes (k_local): which kernel a profile of the match shows.  Valid after a match. */
+int lm_detector_refines_on_bit_planes(const lm_detector *d);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity

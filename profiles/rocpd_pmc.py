@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 
 
-def main(pattern, out=None, kernels=("k_local", "k_coarse")):
+def main(pattern, out=None, kernels=("k_local_bits", "k_local", "k_coarse")):
     acc = defaultdict(lambda: defaultdict(list))
     for db in sorted(glob.glob(pattern)):
         con = sqlite3.connect(db)
@@ -15,7 +15,7 @@ def main(pattern, out=None, kernels=("k_local", "k_coarse")):
                            % (name_col, name_col)).fetchall()
         for kname, cname, _disp, val in rows:
             for k in kernels:
-                if k in kname:
+                if (k + "(") in kname:           # "k_local(" does not match "k_local_bits("
                     acc[k][cname].append(val)
     lines = []
     for k in kernels:
