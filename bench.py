@@ -485,6 +485,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms, "frames_per_launch": BATCH,
+                         "kernel_ms_covers": ("the events bracket the refinement of a batch: k_local_bits and the (nearly empty) k_local launch that takes the candidates "
+                                              "it leaves; kernel_us_profiled below is k_local_bits alone" if kname == "k_local_bits" else "one k_local launch"),
                          "convention": "ALGORITHMIC bytes (SURVEY 8d: one byte per response read the reference performs) per launch / kernel time, "
                                        "against the HBM peak as BASELINE.json's metric asks.  The linear memories are cache-resident, so this is not "
                                        "physical HBM traffic (see `traffic`); the ceilings that physically bound the kernel are below",
