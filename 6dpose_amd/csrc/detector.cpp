@@ -218,6 +218,9 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (d->ingest.stream) (void)hipStreamDestroy(d->ingest.stream);
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
     for (int a = 0; a < lm_detector::kSlots; ++a) d->bits_arena[a].release();
+#ifdef LM_COARSE_BITS
+    for (int a = 0; a < lm_detector::kSlots; ++a) d->cbits_arena[a].release();
+#endif
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
@@ -314,6 +317,14 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
         const bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena[a].cap;
         if ((rc = d->sm_arena[a].ensure(std::max<size_t>(sarena, 256)))) return rc;
         if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena[a].p, 0, d->sm_arena[a].cap, d->stream));
+#ifdef LM_COARSE_BITS
+        if (knobs().coarse_bits) {                           // pairs over the top level's two blocks (zero tails included)
+            const LevelGeom& top = g.lv[L - 1];
+            d->cbits_byte0 = top.lm_off[0] & ~31u;
+            d->cbits_npairs = (uint32_t)((top.lm_off[1] + d->lm_block_bytes[L - 1] - d->cbits_byte0 + 31) / 32);
+            if ((rc = d->cbits_arena[a].ensure((size_t)d->cbits_npairs * 8 + 64))) return rc;
+        }
+#endif
         if (knobs().bitplanes) {                             // the strip arena's layout at half the offsets; its zero planes stay zero
             const size_t bbytes = std::max<size_t>(sarena, 256) / 2 + 64;
             const bool realloc_bits = bbytes > d->bits_arena[a].cap;
@@ -1001,6 +1012,10 @@ static int upload_bank(lm_detector* d) {
         HIP_TRY(hipMemcpy(d->d_feat_word.p, word.data(), word.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->d_run_mask.p, rmask.data(), rmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+#ifdef LM_COARSE_BITS
+    d->cbits_bank_ok = true;
+    for (size_t i = (size_t)L - 1; i < d->h_entries.size(); i += (size_t)L) d->cbits_bank_ok = d->cbits_bank_ok && d->h_entries[i].nf <= 511;
+#endif
     d->bits_bank_ok = true;
     for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) d->bits_bank_ok = d->bits_bank_ok && d->h_entries[i].nf <= 511;
     d->bank_dirty = false;
@@ -1586,6 +1601,17 @@ int lm_launch_pending(lm_detector* d) {
         }
         launch_pack_bits(bb, nb, d->geom.lv[0], s);
     }
+#ifdef LM_COARSE_BITS
+    TopBits tb{};
+    const bool cbits = bits && knobs().coarse_bits && d->cbits_bank_ok;
+    if (cbits) {
+        for (int b = 0; b < nb; ++b) {
+            const int si = (first + b) % lm_detector::kSlots;
+            tb.lm[b] = d->lm_arena[si].p; tb.bits[b] = d->cbits_arena[si].p;
+        }
+        launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
+    }
+#endif
     HIP_TRY(hipEventRecord(lead.ev[1], s));
     HIP_TRY(hipEventRecord(lead.fe_done, s));
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1598,6 +1624,10 @@ int lm_launch_pending(lm_detector* d) {
     auto enqueue_coarse = [&](hipStream_t st) -> int {
         HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
+#ifdef LM_COARSE_BITS
+        if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, st);
+        else
+#endif
         launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
         HIP_TRY(hipEventRecord(lead.ev[3], st));
         return LM_OK;

@@ -165,6 +165,11 @@ struct lm_detector {
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
+#ifdef LM_COARSE_BITS
+    DevBuf<uint8_t> cbits_arena[kSlots];            // pair stream of the top level's flat memories (make CBITS=1, LM_COARSE_BITS=1; match.hip)
+    bool cbits_bank_ok = false;                     // every top-level template entry has at most 511 features
+    uint32_t cbits_byte0 = 0, cbits_npairs = 0;
+#endif
     DevBuf<uint8_t> bits_arena[kSlots];             // bit-plane copy of the strip arena (half its size)
     bool bits_bank_ok = false;                      // every level-0 template entry has at most 511 features (the counters of k_local_bits)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;

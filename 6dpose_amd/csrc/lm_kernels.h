@@ -126,6 +126,15 @@ void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
                        hipStream_t s);
+#ifdef LM_COARSE_BITS
+// Bit-plane coarse pass (match.hip, make CBITS=1; never run on a GPU yet): per frame of a batch the flat arena and the pair stream packed
+// from bytes [byte0, byte0 + 32 npairs) of it (the top level's blocks of both modalities with their zero tails).
+struct TopBits { const uint8_t* lm[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
+void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, hipStream_t s);
+// candidates only (no tile planning): for the bit-plane refinement; top-level template entries of at most 511 features
+void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, hipStream_t s);
+#endif
 bool tile_plan_possible(const FrameGeom& g);
 size_t coarse_plan_lds_bytes(int Wd, int Hd);
 // Per frame of the batch: counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with tiles

@@ -1103,6 +1103,137 @@ void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom
                        dedupe_cap_slots, zero_off);
 }
 
+#ifdef LM_COARSE_BITS
+// ---- Bit-plane coarse pass (make CBITS=1 + LM_COARSE_BITS=1; NOT in the default library: written after the round's GPU time was spent,
+// compiled and modelled — profiles/bitplane_coarse_model.py equals the byte evaluation — but never run on a GPU).  The top level's flat
+// linear memories as ONE pair stream {is-1 dword, is-4 dword} per 32 arena bytes (k_pack_top); a template's map is walked 32 positions
+// per lane: a feature's load = two consecutive pairs per lane (16 bytes) at pair index (offset >> 5) + lane, funnel-shifted by
+// offset & 31 — the offset is wave-uniform, so both are scalar —, i.e. ONE wave load per feature and 2048 positions instead of one
+// per 1008 (and 38 live lanes at VGA).  Sums bit-sliced as in k_local_bits; the threshold test is a bit-sliced comparison with the
+// smallest raw sum that passes, so integers are formed only for the hits.  No tile planning (the bit-plane refinement needs none).
+__global__ void __launch_bounds__(256)
+k_pack_top(TopBits B, uint32_t byte0, uint32_t npairs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= npairs) return;
+    const uint8_t* src = B.lm[blockIdx.y] + byte0 + (size_t)i * 32;
+    const uint4 a = *reinterpret_cast<const uint4*>(src), b = *reinterpret_cast<const uint4*>(src + 16);
+    auto four = [](uint32_t d, int sh) -> uint32_t { return ((((d >> sh) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+    auto bits = [&](const uint4& v, int sh) -> uint32_t { return four(v.x, sh) | (four(v.y, sh) << 4) | (four(v.z, sh) << 8) | (four(v.w, sh) << 12); };
+    uint2 r;
+    r.x = bits(a, 0) | (bits(b, 0) << 16);
+    r.y = bits(a, 2) | (bits(b, 2) << 16);
+    *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (size_t)i * 8) = r;
+}
+
+__global__ void __launch_bounds__(256)
+k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
+              const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0) {
+    const FrameSlot& F = fb.f[blockIdx.y];
+    Candidate* __restrict__ cands = F.cands;
+    unsigned long long* __restrict__ counters = F.counters;
+    const int lane = threadIdx.x & 63;
+    const int work = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // a wave per template
+    if (work >= num_work) return;
+    const int pyr = work_pyramids[work];
+    const TemplEntry e = entries[(size_t)pyr * levels + level];
+    const int nf = e.nf, nfp = e.nf_padded;
+    const int32_t* fo = feat_off + e.feat_start;
+    const int Wd = lv.Wd, Hd = lv.Hd, T = lv.T, npos = Wd * Hd;
+    const int wf = (e.width - 1) / T + 1, hf = (e.height - 1) / T + 1;      // LL.cpp:1299-1309
+    const int tp = (Hd - hf) * Wd + (Wd - wf) + 1;
+    const int offset = T / 2 + (T % 2 - 1);                                 // LL.cpp:1846
+    const int limit = tp < npos ? tp : npos;                                // positions that carry sums
+    // the smallest raw sum whose score passes (score_of is monotone in raw): LL.cpp:1844 `> threshold`
+    int rmin = (int)(threshold * (float)(4 * nf) / 100.f);
+    if (rmin < 0) rmin = 0;
+    while (rmin > 0 && score_of(rmin, nf) > threshold) --rmin;
+    while (rmin <= 4 * nf && !(score_of(rmin, nf) > threshold)) ++rmin;
+    const BufRsrc bits = make_rsrc(B.bits[blockIdx.y]);
+    for (int P0 = 0; P0 < npos; P0 += 2048) {
+        const int pos0 = P0 + 32 * lane;                                    // first position of this lane
+        uint32_t ones1 = 0, twos1 = 0, fours1 = 0, hi1[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t ones4 = 0, twos4 = 0, fours4 = 0, hi4[6] = {0, 0, 0, 0, 0, 0};
+        if (P0 < limit && nfp > 0 && pos0 < limit) {                        // (lanes beyond the map sit the loads out)
+            for (int f = 0; f < nfp; f += kFeatBatch) {
+                uint4 v[kFeatBatch];
+                uint32_t sh[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) {
+                    const uint32_t ob = (uint32_t)fo[f + u] - byte0 + (uint32_t)P0;      // wave-uniform -> SMEM / SALU
+                    sh[u] = ob & 31u;
+                    v[u] = ld_buf16(bits, (uint32_t)lane * 8u, (ob >> 5) * 8u);          // pairs q + lane and q + lane + 1
+                }
+                uint32_t x1[kFeatBatch], x4[kFeatBatch];
+#pragma unroll
+                for (int u = 0; u < kFeatBatch; ++u) {
+                    x1[u] = __builtin_amdgcn_alignbit(v[u].z, v[u].x, sh[u]);            // bits [s, s + 32) of {is-1 of pair q + lane + 1 : pair q + lane}
+                    x4[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].y, sh[u]);
+                }
+                add8(x1, ones1, twos1, fours1, hi1);
+                add8(x4, ones4, twos4, fours4, hi4);
+            }
+        }
+        const uint32_t n1[9] = {ones1, twos1, fours1, hi1[0], hi1[1], hi1[2], hi1[3], hi1[4], hi1[5]};
+        const uint32_t n4[9] = {ones4, twos4, fours4, hi4[0], hi4[1], hi4[2], hi4[3], hi4[4], hi4[5]};
+        uint32_t S[12], carry = 0;
+        S[0] = n1[0]; S[1] = n1[1];
+#pragma unroll
+        for (int k = 2; k < 12; ++k) csa(S[k], carry, k < 9 ? n1[k] : 0u, k - 2 < 9 ? n4[k - 2] : 0u, carry);
+        uint32_t gt = 0, eq = 0xFFFFFFFFu;                                  // S >= rmin, bit-sliced
+#pragma unroll
+        for (int k = 11; k >= 0; --k) {
+            if ((rmin >> k) & 1) eq &= S[k];                                // wave-uniform
+            else { gt |= eq & S[k]; eq &= ~S[k]; }
+        }
+        uint32_t hit_mask = rmin < 4096 ? (gt | eq) : 0u;
+        // positions at or beyond the template's position count hold zero sums (LL.cpp:1299-1309): they are hits only if zero passes
+        const int live = limit - pos0;                                      // positions of this lane that carry sums
+        const uint32_t summed = live >= 32 ? 0xFFFFFFFFu : (live > 0 ? (1u << live) - 1u : 0u);
+        const int inmap = npos - pos0;
+        const uint32_t mapped = inmap >= 32 ? 0xFFFFFFFFu : (inmap > 0 ? (1u << inmap) - 1u : 0u);
+        const bool zero_passes = score_of(0, nf) > threshold;
+        hit_mask = (hit_mask & summed) | (zero_passes ? (mapped & ~summed) : 0u);
+        int total;
+        const int before = wave_excl_scan(__popc(hit_mask), lane, total);
+        if (total > 0) {                                                    // wave-uniform
+            unsigned long long wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&counters[0], (unsigned long long)total);
+            wbase = bcast_u64(wbase, 0);
+            unsigned long long slot = wbase + (unsigned long long)before;
+            uint32_t m = hit_mask;
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                if (slot < cap) {
+                    int raw = 0;
+                    if ((summed >> b) & 1u) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) raw |= (int)((S[k] >> b) & 1u) << k;
+                    }
+                    const int jpos = pos0 + b;
+                    const int cy = jpos / Wd, cx = jpos - cy * Wd;
+                    Candidate c;
+                    c.x = cx * T + offset; c.y = cy * T + offset; c.score = score_of(raw, nf); c.work = work;
+                    cands[slot] = c;
+                }
+                ++slot;
+            }
+        }
+    }
+}
+
+void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_top, dim3((npairs + 255) / 256, nb), dim3(256), 0, s, B, byte0, npairs);
+}
+void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, hipStream_t s) {
+    if (num_work <= 0 || fb.nb <= 0) return;
+    const int level = g.levels - 1;
+    hipLaunchKernelGGL(k_coarse_bits, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+                       work_pyramids, num_work, threshold, cap, byte0);
+}
+#endif  // LM_COARSE_BITS
+
 void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
                   const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
                   uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s) {
