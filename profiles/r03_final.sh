@@ -11,6 +11,7 @@ timeout 300 python bench.py --steps 200 --no-extras --no-cpu-baseline > $OUT/ben
 timeout 300 python bench.py --steps 200 --no-extras --no-cpu-baseline --batch 1 > $OUT/bench_steps200_batch1.json 2> $OUT/bench_steps200_batch1.err
 timeout 300 python bench.py --scaling strong --steps 50 --no-extras --no-cpu-baseline > $OUT/bench_strong_n1_16k.json 2> $OUT/bench_strong_n1_16k.err
 timeout 300 python bench.py --dry-ranks 8 --steps 8 > $OUT/dry_ranks8.json 2> $OUT/dry_ranks8.err
+timeout 100 python profiles/bitplane_check.py 2>&1 | grep -E "frame|PARITY" > $OUT/bitplane_check.txt
 timeout 200 python profiles/host_profile.py 2>&1 | grep steps > $OUT/host_profile.txt
 timeout 200 python profiles/short_run_timeline.py 2>&1 | grep -A1 "^rep" > $OUT/short_run_timeline.txt
 [ -x bin_tmp/tcp_rot ] && ./bin_tmp/tcp_rot > $OUT/tcp_rotation_microbench.txt 2>&1
