@@ -1,0 +1,25 @@
+"""The numpy models of the bit-plane kernels (profiles/bitplane_model.py: k_pack_bits + k_local_bits; profiles/bitplane_coarse_model.py: the
+coarse pass of make CBITS=1) against the byte evaluation and the oracle, on a sample of the bench workload.  CPU only: they state the
+layouts and the lane-level algorithms the HIP kernels implement."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, step):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script), str(step)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_refinement_model_equals_byte_evaluation_and_oracle():
+    text = _run("bitplane_model.py", 100)
+    assert "bit-plane == byte evaluation: True" in text, text
+    assert "equal (as multisets): True" in text, text
+
+
+def test_coarse_model_equals_byte_evaluation():
+    text = _run("bitplane_coarse_model.py", 50)
+    assert "bit-plane coarse pass == byte evaluation: True" in text, text
