@@ -1018,6 +1018,19 @@ static int upload_bank(lm_detector* d) {
 #endif
     d->bits_bank_ok = true;
     for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) d->bits_bank_ok = d->bits_bank_ok && d->h_entries[i].nf <= 511;
+    // Does EVERY candidate of this bank have its level-0 windows inside their planes (k_local's `all_in`)?  The refinement clamps the window
+    // origin to x in [8T, W - width - 8T] (LL.cpp:1871-1880), so with that interval non-empty, gx = x / T - 8 >= 0 and
+    // (max_x + gx T) / T + 16 <= (max_x + W - width - 16 T) / T + 16 <= W / T whenever max_x <= width (W is a multiple of T); the same in y.
+    // Then k_local_bits leaves nothing for k_local's per-candidate path and the second launch is skipped.
+    d->bits_all_in = true;
+    {
+        const LevelGeom& l0 = d->geom.lv[0];
+        for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) {
+            const TemplEntry& e = d->h_entries[i];
+            d->bits_all_in = d->bits_all_in && e.min_x >= 0 && e.min_y >= 0 && e.max_x <= e.width && e.max_y <= e.height &&
+                             l0.W - e.width - 16 * l0.T >= 0 && l0.H - e.height - 16 * l0.T >= 0 && l0.W % l0.T == 0 && l0.H % l0.T == 0;
+        }
+    }
     d->bank_dirty = false;
     d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
     return LM_OK;
@@ -1640,8 +1653,9 @@ int lm_launch_pending(lm_detector* d) {
         if (bits) {
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                               (uint32_t)dedupe_table_slots(d->buf_cand_cap), d->num_cus * 4 * std::max(1, std::min(nb, 4)), ms);   // a wave serves 8 candidates: ~2k groups per frame at configs[1]
-            launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
-                         (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
+            if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
+                launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
+                             (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
         } else
         if (num_work > 0)
             launch_local(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,

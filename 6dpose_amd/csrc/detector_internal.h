@@ -171,6 +171,7 @@ struct lm_detector {
     uint32_t cbits_byte0 = 0, cbits_npairs = 0;
 #endif
     DevBuf<uint8_t> bits_arena[kSlots];             // bit-plane copy of the strip arena (half its size)
+    bool bits_all_in = false;                       // ... and every candidate's level-0 windows lie inside their planes: no second (k_local) launch
     bool bits_bank_ok = false;                      // every level-0 template entry has at most 511 features (the counters of k_local_bits)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
