@@ -15,7 +15,7 @@ def main(pattern, out=None, kernels=("k_local_bits", "k_local", "k_coarse")):
                            % (name_col, name_col)).fetchall()
         for kname, cname, _disp, val in rows:
             for k in kernels:
-                if (k + "(") in kname:           # "k_local(" does not match "k_local_bits("
+                if (k + "(") in kname or ("%d%sE" % (len(k), k)) in kname:           # exactly this kernel, demangled or mangled name ("k_local(" is not "k_local_bits(")
                     acc[k][cname].append(val)
     lines = []
     for k in kernels:
