@@ -217,10 +217,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     }
     if (d->ingest.stream) (void)hipStreamDestroy(d->ingest.stream);
     for (int a = 0; a < lm_detector::kSlots; ++a) { d->lm_arena[a].release(); d->sm_arena[a].release(); }
-    for (int a = 0; a < lm_detector::kSlots; ++a) d->bits_arena[a].release();
-#ifdef LM_COARSE_BITS
-    for (int a = 0; a < lm_detector::kSlots; ++a) d->cbits_arena[a].release();
-#endif
+    for (int a = 0; a < lm_detector::kSlots; ++a) { d->bits_arena[a].release(); d->cbits_arena[a].release(); }
     for (auto& b : d->slot_rgb) b.release();
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
@@ -317,15 +314,16 @@ static int setup_geometry(lm_detector* d, int W, int H, bool check_match_precond
         const bool realloc_sarena = std::max<size_t>(sarena, 256) > d->sm_arena[a].cap;
         if ((rc = d->sm_arena[a].ensure(std::max<size_t>(sarena, 256)))) return rc;
         if (realloc_sarena || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->sm_arena[a].p, 0, d->sm_arena[a].cap, d->stream));
-#ifdef LM_COARSE_BITS
-        if (knobs().coarse_bits) {                           // pairs over the top level's two blocks (zero tails included)
+        {   // pair stream of the top level's two blocks (zero tails included); written whole by every front end, so never cleared
             const LevelGeom& top = g.lv[L - 1];
             d->cbits_byte0 = top.lm_off[0] & ~31u;
             d->cbits_npairs = (uint32_t)((top.lm_off[1] + d->lm_block_bytes[L - 1] - d->cbits_byte0 + 31) / 32);
-            if ((rc = d->cbits_arena[a].ensure((size_t)d->cbits_npairs * 8 + 64))) return rc;
+            const size_t cbytes = (size_t)d->cbits_npairs * 8 + 64;
+            const bool realloc_cbits = cbytes > d->cbits_arena[a].cap;
+            if ((rc = d->cbits_arena[a].ensure(cbytes))) return rc;
+            if (realloc_cbits || d->fW != W || d->fH != H) HIP_TRY(hipMemsetAsync(d->cbits_arena[a].p, 0, d->cbits_arena[a].cap, d->stream));
         }
-#endif
-        if (knobs().bitplanes) {                             // the strip arena's layout at half the offsets; its zero planes stay zero
+        {   // strip records: the strip arena's layout at half the offsets; its zero planes stay zero
             const size_t bbytes = std::max<size_t>(sarena, 256) / 2 + 64;
             const bool realloc_bits = bbytes > d->bits_arena[a].cap;
             if ((rc = d->bits_arena[a].ensure(bbytes))) return rc;
@@ -1012,24 +1010,24 @@ static int upload_bank(lm_detector* d) {
         HIP_TRY(hipMemcpy(d->d_feat_word.p, word.data(), word.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->d_run_mask.p, rmask.data(), rmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-#ifdef LM_COARSE_BITS
-    d->cbits_bank_ok = true;
-    for (size_t i = (size_t)L - 1; i < d->h_entries.size(); i += (size_t)L) d->cbits_bank_ok = d->cbits_bank_ok && d->h_entries[i].nf <= 511;
-#endif
-    d->bits_bank_ok = true;
-    for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) d->bits_bank_ok = d->bits_bank_ok && d->h_entries[i].nf <= 511;
-    // Does EVERY candidate of this bank have its level-0 windows inside their planes (k_local's `all_in`)?  The refinement clamps the window
-    // origin to x in [8T, W - width - 8T] (LL.cpp:1871-1880), so with that interval non-empty, gx = x / T - 8 >= 0 and
-    // (max_x + gx T) / T + 16 <= (max_x + W - width - 16 T) / T + 16 <= W / T whenever max_x <= width (W is a multiple of T); the same in y.
-    // Then k_local_bits leaves nothing for k_local's per-candidate path and the second launch is skipped.
+    // counter widths of the bit-plane kernels: the largest entry at the top level (k_coarse_bits) and below it (k_local_bits)
+    d->bits_max_nf = 0; d->cbits_max_nf = 0;
+    for (size_t i = 0; i < d->h_entries.size(); ++i) {
+        int& mx = (int)(i % (size_t)L) == L - 1 ? d->cbits_max_nf : d->bits_max_nf;
+        mx = std::max(mx, (int)d->h_entries[i].nf);
+    }
+    // Does EVERY candidate of this bank have its windows inside their planes at every level below the top (k_local's `all_in`)?  The
+    // refinement clamps the window origin to x in [8T, W - width - 8T] (LL.cpp:1871-1880), so with that interval non-empty, gx = x / T - 8 >= 0
+    // and (max_x + gx T) / T + 16 <= (max_x + W - width - 16 T) / T + 16 <= W / T whenever max_x <= width (W is a multiple of T); the same in
+    // y.  Then k_local_bits leaves nothing for k_local's per-candidate path and the second launch is skipped.
     d->bits_all_in = true;
-    {
-        const LevelGeom& l0 = d->geom.lv[0];
-        for (size_t i = 0; i < d->h_entries.size(); i += (size_t)L) {
-            const TemplEntry& e = d->h_entries[i];
-            d->bits_all_in = d->bits_all_in && e.min_x >= 0 && e.min_y >= 0 && e.max_x <= e.width && e.max_y <= e.height &&
-                             l0.W - e.width - 16 * l0.T >= 0 && l0.H - e.height - 16 * l0.T >= 0 && l0.W % l0.T == 0 && l0.H % l0.T == 0;
-        }
+    for (size_t i = 0; i < d->h_entries.size(); ++i) {
+        const int l = (int)(i % (size_t)L);
+        if (l == L - 1) continue;
+        const LevelGeom& lv = d->geom.lv[l];
+        const TemplEntry& e = d->h_entries[i];
+        d->bits_all_in = d->bits_all_in && e.min_x >= 0 && e.min_y >= 0 && e.max_x <= e.width && e.max_y <= e.height &&
+                         lv.W - e.width - 16 * lv.T >= 0 && lv.H - e.height - 16 * lv.T >= 0 && lv.W % lv.T == 0 && lv.H % lv.T == 0;
     }
     d->bank_dirty = false;
     d->bank_geom_W = d->fW; d->bank_geom_H = d->fH;
@@ -1374,6 +1372,8 @@ static int sync_all_streams(lm_detector* d) {
     return LM_OK;
 }
 
+static bool tiles_wanted(const lm_detector* d) { return d->use_tiles && d->refine_mode != 2; }   // LM_TILES=0 / lm_detector_set_paths(2, .): every candidate on its own
+
 // Grid of the refinement kernel for a batch of nb frames.  Per-candidate path (LM_TILES=0): 3 workgroups (12 waves) per CU — alone it
 // is as fast as with every wave slot taken (it is bound by the vector L1, not by latency), and the free slots let the coarse pass of
 // the next frame and the front end run beside it.  With tiles the work items are fewer and larger (a tile = two singles' worth of
@@ -1382,7 +1382,13 @@ static int sync_all_streams(lm_detector* d) {
 // 103 (16 and more), profiles/r02_sweep_local_blocks.txt.  A batch has nb times the items: the grid grows with it.
 static int local_grid(lm_detector* d, int nb) {
     if (knobs().local_blocks > 0) return knobs().local_blocks;
-    return d->num_cus * (d->use_tiles ? 16 : 3) * std::max(1, std::min(nb, 4));
+    return d->num_cus * (tiles_wanted(d) ? 16 : 3) * std::max(1, std::min(nb, 4));
+}
+
+// Grid of k_local_bits: a wave serves 8 candidates (~2k groups per frame at configs[1]); 4 workgroups per CU and frame of the batch.
+static int bits_grid(lm_detector* d, int nb) {
+    if (knobs().local_blocks > 0) return knobs().local_blocks;
+    return d->num_cus * 4 * std::max(1, std::min(nb, 4));
 }
 
 // Front end of a batch: the same three stages a lone frame takes (k_fe_stage: {colour chain, normals + median or their
@@ -1449,11 +1455,15 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
     return LM_OK;
 }
 
-// The bit-plane refinement (match.hip): two-level pyramids, banks of at most 511 features per level-0 entry; LM_BITPLANES=0: off.
+// The bit-plane refinement (match.hip): any pyramid with a level below the top; entries of up to 16383 features (two
+// modalities of the reference's 8191, LL.cpp:1291).  LM_BITPLANES=0 / lm_detector_set_paths: the byte paths.
 static bool bits_active(const lm_detector* d, int num_work) {
-    return knobs().bitplanes && num_work > 0 && d->geom.levels == 2 && d->bits_bank_ok;
+    return knobs().bitplanes && d->refine_mode == 0 && num_work > 0 && d->geom.levels >= 2 && d->bits_max_nf <= 16383;
 }
-
+// ... and the coarse pass on the pair stream of the top level (it plans no tiles, so only together with the bit-plane refinement)
+static bool cbits_active(const lm_detector* d, int num_work) {
+    return bits_active(d, num_work) && knobs().coarse_bits && d->coarse_mode == 0 && d->cbits_max_nf <= 16383;
+}
 // Device pointers of result slot `si` (everything a frame in flight owns).
 static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, FrameSlot* out) {
     lm_detector::Slot& sl = d->slot[si];
@@ -1517,7 +1527,7 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
         HIP_TRY(hipMemset(d->d_final.p, 0, 8 * (size_t)K * sizeof(unsigned long long)));
     }
     // tile refinement (match.hip): two-level pyramids with a tileable geometry; the buffers exist per result slot
-    const bool tiled = (d->use_tiles && num_work > 0 && tile_plan_possible(d->geom)) || bits_active(d, num_work);   // (the bit-plane path uses the todo bytes)
+    const bool tiled = (tiles_wanted(d) && num_work > 0 && tile_plan_possible(d->geom)) || bits_active(d, num_work);   // (the bit-plane path uses the todo bytes)
     const uint32_t tile_cap = d->buf_cand_cap / 2;      // a tile has at least two members
     if (tiled && (d->d_tiles.cap < (size_t)tile_cap * K || d->d_todo.cap < (size_t)d->buf_cand_cap * K)) {
         if ((rc = lm_launch_pending(d))) return rc;
@@ -1588,7 +1598,7 @@ int lm_launch_pending(lm_detector* d) {
     const int num_work = lead.num_work;
     const float threshold = lead.threshold;
     const bool bits = bits_active(d, num_work);
-    const bool tiled = !bits && d->use_tiles && num_work > 0 && tile_plan_possible(d->geom);
+    const bool tiled = !bits && tiles_wanted(d) && num_work > 0 && tile_plan_possible(d->geom);
     const uint32_t tile_cap = d->buf_cand_cap / 2;
     FrameBatch fb{};
     fb.nb = nb;
@@ -1612,11 +1622,10 @@ int lm_launch_pending(lm_detector* d) {
             fb.f[b].todo = fb_rest.f[b].todo = d->d_todo.p + (size_t)d->buf_cand_cap * si;
             fb_rest.f[b].tiles = d->d_tiles.p + (size_t)tile_cap * si;   // non-null: "only the candidates marked todo"; no tile was planned
         }
-        launch_pack_bits(bb, nb, d->geom.lv[0], s);
+        for (int l = 0; l + 1 < d->geom.levels; ++l) launch_pack_bits(bb, nb, d->geom.lv[l], s);
     }
-#ifdef LM_COARSE_BITS
     TopBits tb{};
-    const bool cbits = bits && knobs().coarse_bits && d->cbits_bank_ok;
+    const bool cbits = cbits_active(d, num_work);
     if (cbits) {
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
@@ -1624,7 +1633,6 @@ int lm_launch_pending(lm_detector* d) {
         }
         launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
     }
-#endif
     HIP_TRY(hipEventRecord(lead.ev[1], s));
     HIP_TRY(hipEventRecord(lead.fe_done, s));
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1637,11 +1645,8 @@ int lm_launch_pending(lm_detector* d) {
     auto enqueue_coarse = [&](hipStream_t st) -> int {
         HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
-#ifdef LM_COARSE_BITS
-        if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, st);
-        else
-#endif
-        launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
+        if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, st);
+        else launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
         HIP_TRY(hipEventRecord(lead.ev[3], st));
         return LM_OK;
     };
@@ -1652,7 +1657,7 @@ int lm_launch_pending(lm_detector* d) {
         // the hash tables k_dedupe uses
         if (bits) {
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
-                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), d->num_cus * 4 * std::max(1, std::min(nb, 4)), ms);   // a wave serves 8 candidates: ~2k groups per frame at configs[1]
+                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms);
             if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
                 launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
@@ -2203,9 +2208,28 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
 }
 
 // 1 when the refinement of the current bank and frame geometry runs on bit planes (k_local_bits), 0 when on the byte strip planes
-// (k_local: three or more pyramid levels, a template with more than 511 features at level 0, LM_BITPLANES=0).  Valid after a match.
+// (k_local: single-level pyramids have no refinement; LM_BITPLANES=0; lm_detector_set_paths).  Valid after a match.
 extern "C" int lm_detector_refines_on_bit_planes(const lm_detector* d) {
     return d && !d->bank_dirty && bits_active(d, 1) ? 1 : 0;
+}
+
+extern "C" int lm_detector_set_paths(lm_detector* d, int refine, int coarse) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    if (refine < 0 || refine > 2 || coarse < 0 || coarse > 1) return lm_set_error(LM_ERR_INVALID, "refine must be 0 (bit planes), 1 (tiles) or 2 (per candidate), coarse 0 (bit planes) or 1 (bytes)");
+    if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them first");
+    int rc = lm_launch_pending(d);
+    if (rc) return rc;
+    d->refine_mode = refine; d->coarse_mode = coarse;
+    return LM_OK;
+}
+
+extern "C" int lm_detector_get_paths(const lm_detector* d, int* refine, int* coarse) {
+    if (!d || !refine || !coarse) return lm_set_error(LM_ERR_INVALID, "null argument");
+    if (d->bank_dirty) return lm_set_error(LM_ERR_INVALID, "no match yet: the paths follow from the bank and the frame geometry");
+    const bool bits = bits_active(d, 1);
+    *refine = bits ? 0 : (d->geom.levels >= 2 && tiles_wanted(d) && tile_plan_possible(d->geom) ? 1 : 2);
+    *coarse = cbits_active(d, 1) ? 0 : 1;
+    return LM_OK;
 }
 
 extern "C" int lm_detector_flush(lm_detector* d) {

@@ -165,14 +165,16 @@ struct lm_detector {
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
-#ifdef LM_COARSE_BITS
-    DevBuf<uint8_t> cbits_arena[kSlots];            // pair stream of the top level's flat memories (make CBITS=1, LM_COARSE_BITS=1; match.hip)
-    bool cbits_bank_ok = false;                     // every top-level template entry has at most 511 features
-    uint32_t cbits_byte0 = 0, cbits_npairs = 0;
-#endif
-    DevBuf<uint8_t> bits_arena[kSlots];             // bit-plane copy of the strip arena (half its size)
-    bool bits_all_in = false;                       // ... and every candidate's level-0 windows lie inside their planes: no second (k_local) launch
-    bool bits_bank_ok = false;                      // every level-0 template entry has at most 511 features (the counters of k_local_bits)
+    // Bit planes (match.hip): both matching kernels read 1-bit response planes by default.
+    DevBuf<uint8_t> cbits_arena[kSlots];            // pair stream of the top level's flat memories (k_coarse_bits)
+    uint32_t cbits_byte0 = 0, cbits_npairs = 0;     // ... = arena bytes [byte0, byte0 + 32 npairs): the top level's two blocks with their zero tails
+    DevBuf<uint8_t> bits_arena[kSlots];             // strip records of the levels below the top (the strip arena's layout at half the offsets; k_local_bits)
+    int bits_max_nf = 0, cbits_max_nf = 0;          // largest feature count of a template entry below the top level / at the top level (which counter width the kernels need)
+    bool bits_all_in = false;                       // every candidate's windows lie inside their planes at every level: k_local_bits leaves nothing to k_local
+    // Which kernels match() uses (lm_detector_set_paths; tests and measurements of the byte paths).  refine: 0 = bit planes when the pyramid has a
+    // level below the top (default), 1 = byte strip planes with tiles (round 2-3's k_local), 2 = byte planes, every candidate on its own
+    // (round 1).  coarse: 0 = pair stream when the refinement runs on bit planes (default), 1 = byte linear memories (k_coarse).
+    int refine_mode = 0, coarse_mode = 0;
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
     int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)

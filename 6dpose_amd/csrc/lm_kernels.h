@@ -118,23 +118,25 @@ struct FrameBatch {
     FrameSlot f[kMaxBatch];
 };
 
-// Bit-plane refinement (match.hip): per frame of a batch the strip arena it is packed from and its bit
-// arena (the strip arena's layout at half the offsets: 8-byte records instead of 16-byte rows).
+// Bit planes (match.hip).  Levels below the top: per frame of a batch the strip arena the records are packed from
+// (launch_pack_bits; the front end writes them itself when nothing reads the strip bytes) and its bit arena — the strip arena's layout at
+// half the offsets: per plane row and strip an 8-byte record of 32 cells x {is 1, is 4} instead of a 16-byte row.
 struct BitsBatch { const uint8_t* strips[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
+constexpr int kBitsSmallMax = 511;            // features per template entry the 9-bit counters hold; larger entries (<= 16383) take the 14-bit instantiation
 void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s);
-// two-level pyramids, at most 511 features per template entry: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path
+// Every level below the top: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path (windows leaving their planes);
+// max_features = the largest nf of the bank's entries below the top level.
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       hipStream_t s);
-#ifdef LM_COARSE_BITS
-// Bit-plane coarse pass (match.hip, make CBITS=1; never run on a GPU yet): per frame of a batch the flat arena and the pair stream packed
-// from bytes [byte0, byte0 + 32 npairs) of it (the top level's blocks of both modalities with their zero tails).
+                       int max_features, hipStream_t s);
+// Coarse pass on bit planes: per frame of a batch the flat arena and the pair stream of bytes [byte0, byte0 + 32 npairs) of it (the top
+// level's blocks of both modalities with their zero tails): launch_pack_top packs it from the bytes, the front end writes it directly when
+// nothing reads the top level's bytes (frontend.hip, top_bits_body: the stream must be zero before).
 struct TopBits { const uint8_t* lm[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
 void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, hipStream_t s);
-// candidates only (no tile planning): for the bit-plane refinement; top-level template entries of at most 511 features
+// candidates only (no tiles); max_features = the largest nf of the bank's top-level entries
 void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, hipStream_t s);
-#endif
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s);
 bool tile_plan_possible(const FrameGeom& g);
 size_t coarse_plan_lds_bytes(int Wd, int Hd);
 // Per frame of the batch: counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with tiles

@@ -89,7 +89,8 @@ constexpr int kPlanHits = 64;                  // hits per template (raster orde
 // Everything the planner of k_coarse needs to know about the level below the top (two-level pyramids whose coarse cells are
 // kTileStep fine cells apart; plan.enabled == 0 otherwise).
 struct TilePlanGeom {
-    int enabled;
+    int enabled;                               // the hits of a workgroup's templates are collected in LDS and their slots reserved with ONE atomic
+    int tiles;                                 // ... and grouped into tiles (k_local's tile path); 0: every hit stays a single (bit-plane refinement: it needs no tiles)
     int W0, H0, T0, Wd0, Hd0;                  // level 0: image size, step, decimated grid
     uint32_t tile_cap;
     int dbg;                                   // LM_COARSE_DBG (timing experiments only): 1 = no grouping, 2 = no global atomic (wrong results)
@@ -319,8 +320,8 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
         auto fine_x0 = [&](int c) { return (c * T + offset) * 2 + 1; };   // LL.cpp:1868-1869 for the coarse cell's candidate
         int cx = -100, cy = -100;
         bool elig = false;
-        if (lane < nplan) {
-            p = (int)s_list[lane];
+        if (lane < nplan) p = (int)s_list[lane];
+        if (lane < nplan && plan.tiles) {
             cy = p / Wd; cx = p - cy * Wd;
             // a tile may serve the hit iff LL.cpp:1871-1880 does not clamp it and it is on the fast path of the refinement (all
             // windows inside their planes) — from the entry's feature bounding box, exactly like k_local's `all_in`
@@ -332,7 +333,7 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
         }
         uint32_t next = 0;                                                  // slots handed out so far
         bool member = false;
-        while (ntile < kMaxTilesPerTemplate && !(plan.dbg & 1)) {
+        while (plan.tiles && ntile < kMaxTilesPerTemplate && !(plan.dbg & 1)) {
             const unsigned long long eb = __ballot(elig);
             if (!eb) break;
             const int seed = __ffsll((long long)eb) - 1;                   // first eligible hit in raster order: top row of its block
@@ -421,7 +422,7 @@ k_coarse(FrameBatch fb, LevelGeom lv, int level, int levels,
             before += (uint32_t)total;
         }
     }
-    if (lane < ntile && tbase + lane < plan.tile_cap) {
+    if (lane < ntile && tiles && tbase + lane < plan.tile_cap) {
         TileRec t;
         t.work = (int32_t)s_tile[4 * lane]; t.gxy = s_tile[4 * lane + 1];
         t.slot_base = (uint32_t)(base + s_tile[4 * lane + 2]); t.mask = s_tile[4 * lane + 3];
@@ -462,8 +463,13 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
     TilePlanGeom plan{};
     size_t lds = 0;
     int group = 1;
-    if (tiles && todo && tile_cap > 0 && tile_plan_possible(g)) {
+    // Tiles are planned for k_local's tile path (tiles != null); with only `todo` given (the bit-plane refinement overwrites it) the hits are
+    // still collected per workgroup — one reservation atomic instead of one per wave — but nothing is grouped: no tile half of counters[0].
+    const bool plan_tiles = tiles && todo && tile_cap > 0 && tile_plan_possible(g);
+    const bool group_only = !tiles && todo && npos >= 1 && coarse_plan_lds_bytes(lv.Wd, lv.Hd) <= 60 * 1024;
+    if (plan_tiles || group_only) {
         plan.enabled = 1;
+        plan.tiles = plan_tiles ? 1 : 0;
         plan.W0 = g.lv[0].W; plan.H0 = g.lv[0].H; plan.T0 = g.lv[0].T; plan.Wd0 = g.lv[0].Wd; plan.Hd0 = g.lv[0].Hd;
         plan.tile_cap = tile_cap;
         const int max_group = knobs().coarse_group;
@@ -905,23 +911,27 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     }
 }
 
-// ---- Bit-plane refinement (the default for two-level pyramids whose templates have at most 511 features per level-0
-// entry, LM_BITPLANES=0 switches back to the tiles above).  A response is 0, 1 or 4, so a position's sum is n1 + 4 n4 with n1 / n4 = the number of features whose
-// response there is 1 / 4: two 1-bit planes per (label, phase) carry what the byte planes do.  k_pack_bits turns every 16-byte row of
-// the strip planes into an 8-byte record {is-1 bits of cells [16 s, 16 s + 32) | is-4 bits of the same cells << 32} — strips 32 cells
-// wide at a stride of 16, so every 16-cell window lies inside ONE record, and the bit arena is the strip arena at half the offsets.
-// k_local_bits: 8 lanes per candidate (lane j = window rows 2j, 2j + 1 = one 16-byte load of two records), 8 candidates per wave,
-// one feature per candidate and load instruction: a wave load serves 8 (candidate, feature) pairs instead of 2, and needs neither
-// tiles nor alignment classes (the window's cell offset is a per-lane shift).  Sums are bit-sliced (a dword = 32 positions of one
-// counter bit), features enter eight at a time through carry-save adders; integers only once per candidate.  The algorithm is
-// profiles/bitplane_model.py, which is checked against the byte evaluation and the oracle on the CPU.
+// ---- Bit planes: the default encoding of the response memories for both matching kernels --------------------------
+// A response is 0, 1 or 4, so a position's sum is n1 + 4 n4 with n1 / n4 = the number of features whose response there is 1 / 4: two bits
+// per cell carry what the byte planes do, and the sums can be kept BIT-SLICED (one dword = 32 positions of one counter bit), features
+// entering through carry-save adders; integers are formed once per candidate / only for the hits.
+//
+// Levels below the top ("strip records", read by k_local_bits): the strip arena at half the offsets — per plane row and 16-column strip s an
+// 8-byte record holding cells [16 s, 16 s + 32) of that row with TWO BITS PER CELL, bit 2c = "the response of cell 16 s + c is 1", bit
+// 2c + 1 = "it is 4".  Strips are 32 cells wide at a stride of 16, so any 16-cell window of a row lies inside ONE record and comes out of it
+// with ONE funnel shift, v_alignbit(hi, lo, 2 (column & 15)): a dword of 16 positions x {is-1, is-4}.  (Round 3 kept the two planes in
+// separate dwords: 4 shifts + 2 ands + 2 or per lane and feature to cut the windows out, and every lane redid the address arithmetic of
+// every feature — 30 VALU instructions per lane and feature at 0.92 of the issue slots)
+// The top level ("pair stream", read by k_coarse_bits): the flat linear memories [label][phase][position] as one pair {is-1 dword, is-4
+// dword} per 32 consecutive arena bytes, so the reference's reads that run from one plane into the next stay what they are.
+// carry-save adder: two v_bitop3_b32 (gfx950's ternary logic op; truth tables with a = 0xF0, b = 0xCC, c = 0xAA: parity 0x96, majority 0xE8)
 static __device__ __forceinline__ void csa(uint32_t& sum, uint32_t& carry, uint32_t a, uint32_t b, uint32_t c) {
-    const uint32_t t = a ^ b;
-    carry = (a & b) | (t & c);
-    sum = t ^ c;
+    const uint32_t s = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+    sum = s;
 }
-// eight 1-bit inputs into {ones, twos, fours} + a bit-sliced counter of the eights (6 levels: counts up to 511)
-static __device__ __forceinline__ void add8(const uint32_t (&x)[8], uint32_t& ones, uint32_t& twos, uint32_t& fours, uint32_t (&hi)[6]) {
+// eight 1-bit inputs into {ones, twos, fours}; returns the carry of weight 8 (7 carry-save adders = 14 v_bitop3)
+static __device__ __forceinline__ uint32_t add8(const uint32_t (&x)[8], uint32_t& ones, uint32_t& twos, uint32_t& fours) {
     uint32_t ta, tb, fa, fb, e;
     csa(ones, ta, ones, x[0], x[1]);
     csa(ones, tb, ones, x[2], x[3]);
@@ -930,10 +940,36 @@ static __device__ __forceinline__ void add8(const uint32_t (&x)[8], uint32_t& on
     csa(ones, tb, ones, x[6], x[7]);
     csa(twos, fb, twos, ta, tb);
     csa(fours, e, fours, fa, fb);
+    return e;
+}
+// Counter of kN bits per position: c[0..3] = ones, twos, fours, eights, c[4..] = 16s and up.  Two carries of weight 8 (16 features) enter
+// through one more adder and ONE ripple of the sixteens (Harley-Seal: 2.5 operations per input instead of 3.25 with a ripple per 8).
+template <int kN>
+static __device__ __forceinline__ void add_eights2(uint32_t (&c)[kN], uint32_t e1, uint32_t e2) {
+    uint32_t k16;
+    csa(c[3], k16, c[3], e1, e2);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const uint32_t t = hi[k] & e; hi[k] ^= e; e = t; }
+    for (int k = 4; k < kN; ++k) { const uint32_t t = c[k] & k16; c[k] ^= k16; k16 = t; }
+}
+template <int kN>
+static __device__ __forceinline__ void add_eights1(uint32_t (&c)[kN], uint32_t e1) {
+    uint32_t k16 = c[3] & e1;
+    c[3] ^= e1;
+#pragma unroll
+    for (int k = 4; k < kN; ++k) { const uint32_t t = c[k] & k16; c[k] ^= k16; k16 = t; }
 }
 
+// 4 response bytes -> 8 bits, cell k at bits 2k (is 1 = bit 0 of the byte) and 2k + 1 (is 4 = bit 2 of the byte); the multiply gathers the
+// four 2-bit fields into the top byte (partial products land on distinct bits: no carries)
+static __device__ __forceinline__ uint32_t pack4(uint32_t d) {
+    const uint32_t e = d & 0x05050505u;
+    const uint32_t t = (e | (e >> 1)) & 0x03030303u;
+    return (t * 0x01041040u) >> 24;
+}
+static __device__ __forceinline__ uint32_t pack16(const uint4& v) { return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24); }
+
+// Strip records from the strip bytes (the front end writes the records itself when nothing reads the bytes: frontend.hip, bits_rows_body;
+// this kernel serves the banks and geometries that keep the byte planes — a fallback launch of k_local may follow — and the tests of both).
 __global__ void __launch_bounds__(256)
 k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;             // record = ((plane * NS + s) * Hd + row)
@@ -943,17 +979,27 @@ k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
     const uint4 a = *reinterpret_cast<const uint4*>(src);
     uint4 b = make_uint4(0, 0, 0, 0);
     if (s + 1 < (uint32_t)NS) b = *reinterpret_cast<const uint4*>(src + (size_t)Hd * 16);      // the next strip of this row
-    auto four = [](uint32_t d, int sh) -> uint32_t { return ((((d >> sh) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };   // bit sh of 4 bytes -> 4 bits
-    auto bits = [&](const uint4& v, int sh) -> uint32_t { return four(v.x, sh) | (four(v.y, sh) << 4) | (four(v.z, sh) << 8) | (four(v.w, sh) << 12); };
     uint2 r;
-    r.x = bits(a, 0) | (bits(b, 0) << 16);                           // response 1 = bit 0, response 4 = bit 2 of the byte
-    r.y = bits(a, 2) | (bits(b, 2) << 16);
+    r.x = pack16(a);
+    r.y = pack16(b);
     *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (sm_off0 >> 1) + (size_t)i * 8) = r;
 }
 
-__global__ void __launch_bounds__(256)
+// Refinement on strip records (LL.cpp:1855-1938, similarityLocal :1366-1428).  8 lanes per candidate — lane j owns window rows 2j and 2j + 1,
+// ONE 16-byte load = their two records —, 8 candidates per wave, one feature per candidate and load instruction: a wave load serves 8
+// (candidate, feature) pairs.  Per 16 features a lane fetches two feature words and forms, ONCE for its group, their record offsets (window
+// origin, strip carry) and shift amounts; the group's lanes pick them up with two ds_bpermute per feature and add only their own row term.
+// Per lane and feature: 1 add, 2 v_alignbit, 5 adder operations (two dwords x 2.5).  Counters of kN = 4 + kHi bits: kHi = 5 serves entries
+// of up to 511 features, kHi = 10 up to 16383 (the reference allows 8191 per modality, LL.cpp:1291, 1816).
+// All pyramid levels below the top are walked here (LL.cpp:1855: level by level, dropping a candidate as soon as it falls below the
+// threshold); a candidate whose windows leave their planes at some level (oversized template, features outside the frame) is marked in
+// `todo` and left, from the top, to k_local's per-candidate path.
+template <int kHi, int kWaves>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restrict__ entries, const uint32_t* __restrict__ feat_word,
-             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, uint32_t zero_off) {
+             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots) {
+    constexpr int kN = 4 + kHi;                                     // counter bits per plane
+    constexpr int kS = kN + 3;                                      // bits of n1 + 4 n4
     __shared__ unsigned long long s_acc[kMaxBatch][2];
     __shared__ uint32_t s_cnt[kMaxBatch];
     const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
@@ -980,10 +1026,8 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         const uint32_t tsize = dedupe_slots_for(s_cnt[f], dedupe_cap_slots);
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) table[i] = ~0ull;
     }
-    const LevelGeom lv = g.lv[0];
-    const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
-    const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-    const uint32_t HS8 = (uint32_t)Hd * 8u;
+    const int src0 = (lane & ~7) << 2;                              // ds_bpermute address of the group's first lane
+    const uint32_t rowoff = 16u * (uint32_t)j;                      // records of rows 2j, 2j + 1 behind the window's first row
     for (int fr = f_lo; fr < f_hi; ++fr) {
         const FrameSlot& F = fb.f[fr];
         const BufRsrc bits = make_rsrc(B.bits[fr]);
@@ -995,89 +1039,150 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
             if (valid) cd = F.cands[ci];
             const int work = cd.work;
             const int pyr = work_pyramids[work];
-            const TemplEntry e = entries[(size_t)pyr * g.levels];
-            // LL.cpp:1871-1880 (the clamp) and 1380-1381 (window origin), exactly as k_local
-            const int max_x = W - e.width - border, max_y = H - e.height - border;
-            int x = cd.x * 2 + 1, y = cd.y * 2 + 1;
-            x = x > border ? x : border;  y = y > border ? y : border;
-            x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
-            const int gx = x / T - 8, gy = y / T - 8;
-            const int off_x = gx * T, off_y = gy * T;
-            const bool all_in = e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 &&
-                                ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= Hd);
-            const bool fast = valid && all_in;
-            if (valid && j == 0) F.todo[ci] = fast ? 0 : 1;         // the others (oversized templates, features outside the frame) go to k_local's per-candidate path
-            const int nf = e.nf, nfp = fast ? (int)e.nf_padded : 0;
-            int nmax = nfp;
+            int mx = cd.x, my = cd.y;
+            float sim = cd.score;
+            bool alive = valid, leave = false;                      // leave: k_local's per-candidate path takes this candidate (from the top)
+            uint32_t evals = 0, bytes = 0;
+            for (int l = g.levels - 2; l >= 0; --l) {
+                const LevelGeom& lv = g.lv[l];
+                const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
+                const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+                const uint32_t HS8 = (uint32_t)Hd * 8u;
+                const uint32_t zero_off = (lv.sm_off[1] + 8u * (uint32_t)(T * T) * ((uint32_t)lv.NS * (uint32_t)Hd * 16u)) >> 1;   // the level's all-zero plane
+                const TemplEntry e = entries[(size_t)pyr * g.levels + l];
+                // LL.cpp:1871-1880 (the clamp) and 1380-1381 (window origin), exactly as k_local
+                const int max_x = W - e.width - border, max_y = H - e.height - border;
+                int x = mx * 2 + 1, y = my * 2 + 1;
+                x = x > border ? x : border;  y = y > border ? y : border;
+                x = x < max_x ? x : max_x;    y = y < max_y ? y : max_y;
+                const int gx = x / T - 8, gy = y / T - 8;
+                const int off_x = gx * T, off_y = gy * T;
+                const bool all_in = e.min_x >= 0 && e.min_y >= 0 && gx >= 0 && gy >= 0 &&
+                                    ((e.max_x + off_x) / T + 16 <= Wd) && ((e.max_y + off_y) / T + 16 <= Hd);
+                const bool want = alive && !leave;
+                if (want && !all_in) leave = true;
+                const bool run = want && all_in;
+                const int nf = e.nf, nfp = run ? (int)e.nf_padded : 0;
+                int nmax = nfp;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
-            nmax = __builtin_amdgcn_readfirstlane(nmax);
-            const uint32_t K = (uint32_t)(((gx >> 4) * Hd + gy + 2 * j) * 8);
-            const int gxl = gx & 15;
-            uint32_t ones1 = 0, twos1 = 0, fours1 = 0, hi1[6] = {0, 0, 0, 0, 0, 0};
-            uint32_t ones4 = 0, twos4 = 0, fours4 = 0, hi4[6] = {0, 0, 0, 0, 0, 0};
-            const uint32_t* fw = feat_word + e.feat_start;
-            for (int f0 = 0; f0 < nmax; f0 += kFeatBatch) {
-                const bool on = f0 < nfp;                           // this candidate still has features (uniform over its 8 lanes)
-                const uint32_t wv = on ? fw[f0 + j] : 0u;           // lane j of the group fetches word f0 + j; the group shares them below
-                uint4 v[kFeatBatch];
-                uint32_t sh[kFeatBatch];
+                for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
+                nmax = __builtin_amdgcn_readfirstlane(nmax);
+                const uint32_t Kbase = (uint32_t)(((gx >> 4) * Hd + gy) * 8);
+                const uint32_t gxl = (uint32_t)(gx & 15);
+                const uint32_t* fw = feat_word + e.feat_start;
+                uint32_t cA[kN], cB[kN];                            // bit-sliced counters of rows 2j / 2j + 1: even bits count the 1s, odd bits the 4s
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) {
-                    const uint32_t w = (uint32_t)__shfl((int)wv, (lane & ~7) + u, 64);
-                    const uint32_t sum = (w & 15u) + (uint32_t)gxl;
-                    sh[u] = sum & 15u;
-                    const uint32_t off = on ? ((w & ~15u) >> 1) + K + (sum >= 16u ? HS8 : 0u) : zero_off;
-                    v[u] = ld_buf16(bits, off, 0u);                // rows 2j, 2j + 1: {is-1, is-4} of 32 cells each
+                for (int k = 0; k < kN; ++k) { cA[k] = 0; cB[k] = 0; }
+                // lane j fetches the words of features f0 + 2j, f0 + 2j + 1 (entries start at multiples of 8 words, f0 is a multiple of 16)
+                auto fetch = [&](int f0) -> uint2 {
+                    uint2 w = make_uint2(0u, 0u);
+                    if (f0 + 2 * j < nfp) w = *reinterpret_cast<const uint2*>(fw + f0 + 2 * j);
+                    return w;
+                };
+                // a feature word (base0 | column class, lm_kernels.h) -> offset of its first record in the bit arena, 2 x the window's cell inside it
+                auto prep = [&](uint32_t w, bool on, uint32_t& off, uint32_t& s2) {
+                    s2 = ((w & 15u) + gxl) << 1;
+                    const uint32_t o = ((w & ~15u) >> 1) + Kbase + ((s2 >> 5) ? HS8 : 0u);
+                    off = on ? o : zero_off;                        // beyond this candidate's features (or no candidate): the zero plane
+                };
+                uint32_t offx = 0, offy = 0, sx = 0, sy = 0;
+                auto batch = [&](int half, uint32_t& eA, uint32_t& eB) {           // features 8 half .. 8 half + 7 of the current 16
+                    uint4 v[8];
+                    uint32_t sh[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int src = src0 + 4 * (4 * half + (u >> 1));          // the lane that fetched feature 8 half + u
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? offy : offx));
+                        sh[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? sy : sx));
+                        v[u] = ld_buf16(bits, o + rowoff, 0u);      // rows 2j, 2j + 1: 32 cells x 2 bits each
+                    }
+                    uint32_t xa[8], xb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xa[u] = __builtin_amdgcn_alignbit(v[u].y, v[u].x, sh[u]);      // 16 window cells of row 2j: bits 2c (is 1), 2c + 1 (is 4)
+                        xb[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].z, sh[u]);      // ... of row 2j + 1
+                    }
+                    eA = add8(xa, cA[0], cA[1], cA[2]);
+                    eB = add8(xb, cB[0], cB[1], cB[2]);
+                };
+                uint2 wn = fetch(0);
+                for (int f0 = 0; f0 < nmax; f0 += 16) {
+                    const uint2 w = wn;
+                    const bool on = f0 + 2 * j < nfp;
+                    wn = fetch(f0 + 16);                            // the next 16 words while these are worked on
+                    prep(w.x, on, offx, sx);
+                    prep(w.y, on, offy, sy);
+                    uint32_t e1A, e1B;
+                    batch(0, e1A, e1B);
+                    if (f0 + 8 < nmax) {                            // wave-uniform
+                        uint32_t e2A, e2B;
+                        batch(1, e2A, e2B);
+                        add_eights2<kN>(cA, e1A, e2A);
+                        add_eights2<kN>(cB, e1B, e2B);
+                    } else {
+                        add_eights1<kN>(cA, e1A);
+                        add_eights1<kN>(cB, e1B);
+                    }
                 }
-                uint32_t x1[kFeatBatch], x4[kFeatBatch];
+                // Once per candidate and level: the two rows of the lane side by side — bit 2c = row 2j, bit 2c + 1 = row 2j + 1 of window
+                // column c —, S = n1 + 4 n4 bit-sliced, the lane's maximum by a descent from the top bit, its FIRST position in raster order.
+                uint32_t S[kS], carry = 0;
+                {
+                    uint32_t n1[kN], n4[kN];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) {
-                    x1[u] = ((v[u].x >> sh[u]) & 0xFFFFu) | ((v[u].z >> sh[u]) << 16);
-                    x4[u] = ((v[u].y >> sh[u]) & 0xFFFFu) | ((v[u].w >> sh[u]) << 16);
+                    for (int k = 0; k < kN; ++k) {
+                        n1[k] = (cA[k] & 0x55555555u) | ((cB[k] << 1) & 0xAAAAAAAAu);
+                        n4[k] = ((cA[k] >> 1) & 0x55555555u) | (cB[k] & 0xAAAAAAAAu);
+                    }
+                    S[0] = n1[0]; S[1] = n1[1];
+#pragma unroll
+                    for (int k = 2; k < kS; ++k) {
+                        const uint32_t a = k < kN ? n1[k] : 0u, b = k - 2 < kN ? n4[k - 2] : 0u;
+                        csa(S[k], carry, a, b, carry);
+                    }
                 }
-                add8(x1, ones1, twos1, fours1, hi1);
-                add8(x4, ones4, twos4, fours4, hi4);
-            }
-            // S = n1 + 4 n4, bit-sliced (12 bits: <= 511 + 4 x 511), then the lane's maximum and its first position
-            const uint32_t n1[9] = {ones1, twos1, fours1, hi1[0], hi1[1], hi1[2], hi1[3], hi1[4], hi1[5]};
-            const uint32_t n4[9] = {ones4, twos4, fours4, hi4[0], hi4[1], hi4[2], hi4[3], hi4[4], hi4[5]};
-            uint32_t S[12], carry = 0;
-            S[0] = n1[0]; S[1] = n1[1];
+                uint32_t mask = 0xFFFFFFFFu, val = 0;
 #pragma unroll
-            for (int k = 2; k < 12; ++k) {
-                const uint32_t a = k < 9 ? n1[k] : 0u, b = k - 2 < 9 ? n4[k - 2] : 0u;
-                csa(S[k], carry, a, b, carry);
-            }
-            uint32_t mask = 0xFFFFFFFFu, val = 0;
-#pragma unroll
-            for (int k = 11; k >= 0; --k) {
-                const uint32_t t = mask & S[k];
-                if (t) { mask = t; val |= 1u << k; }
-            }
-            const uint32_t first = (uint32_t)__ffs((int)mask) - 1u;           // lowest position index of the lane's maximum; index = 32 j + bit
-            uint32_t key = (val << 8) | (255u - (32u * (uint32_t)j + first));
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
-            const int raw = (int)(key >> 8);
-            int br = -1, bc = -1;                               // LL.cpp:1910-1911
-            float best = 0.f;
-            if (raw > 0) {
-                const int idx = 255 - (int)(key & 0xFF);
-                br = idx >> 4; bc = idx & 15;
-                best = score_of(raw, nf);
-            }
-            if (fast && j == 0) {
-                if (ci < cap) {
-                    Candidate m;
-                    m.x = (x / T - 8 + bc) * T + offset;        // LL.cpp:1930-1931
-                    m.y = (y / T - 8 + br) * T + offset;
-                    m.score = best;
-                    m.work = best < threshold ? -1 : work;      // LL.cpp:1935
-                    F.matches_dev[ci] = m;
+                for (int k = kS - 1; k >= 0; --k) {
+                    const uint32_t t = mask & S[k];
+                    if (t) { mask = t; val |= 1u << k; }
                 }
-                atomicAdd(&s_acc[fr][0], 1ull);
-                atomicAdd(&s_acc[fr][1], 256ull * (unsigned long long)nf);
+                const uint32_t upper = mask & 0x55555555u;           // positions of row 2j attaining the maximum come first in raster order
+                const uint32_t pick = upper ? upper : mask;
+                const uint32_t bitp = (uint32_t)__ffs((int)pick) - 1u;
+                const uint32_t pos = ((2u * (uint32_t)j + (bitp & 1u)) << 4) + (bitp >> 1);   // row * 16 + column
+                uint32_t key = (val << 8) | (255u - pos);
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
+                const int raw = (int)(key >> 8);
+                int br = -1, bc = -1;                               // LL.cpp:1910-1911
+                float best = 0.f;
+                if (raw > 0) {
+                    const int idx = 255 - (int)(key & 0xFF);
+                    br = idx >> 4; bc = idx & 15;
+                    best = score_of(raw, nf);
+                }
+                if (run) {
+                    ++evals;
+                    bytes += 256u * (uint32_t)nf;                   // algorithmic response bytes of this 16x16 evaluation
+                    sim = best;
+                    mx = (x / T - 8 + bc) * T + offset;             // LL.cpp:1930-1931
+                    my = (y / T - 8 + br) * T + offset;
+                    if (sim < threshold) alive = false;             // LL.cpp:1935
+                }
+            }
+            if (valid && j == 0) {
+                F.todo[ci] = leave ? 1 : 0;
+                if (!leave) {
+                    if (ci < cap) {
+                        Candidate m;
+                        m.x = mx; m.y = my; m.score = sim;
+                        m.work = alive ? work : -1;
+                        F.matches_dev[ci] = m;
+                    }
+                    atomicAdd(&s_acc[fr][0], (unsigned long long)evals);
+                    atomicAdd(&s_acc[fr][1], (unsigned long long)bytes);
+                }
             }
         }
     }
@@ -1095,45 +1200,53 @@ void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream
 }
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       hipStream_t s) {
-    const LevelGeom& lv = g.lv[0];
-    const uint32_t splane = (uint32_t)lv.NS * (uint32_t)lv.Hd * 16u;
-    const uint32_t zero_off = (lv.sm_off[1] + 8u * (uint32_t)(lv.T * lv.T) * splane) >> 1;      // the all-zero plane, in bit-arena offsets
-    hipLaunchKernelGGL(k_local_bits, dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap,
-                       dedupe_cap_slots, zero_off);
+                       int max_features, hipStream_t s) {
+    if (max_features > kBitsSmallMax)
+        hipLaunchKernelGGL((k_local_bits<10, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves >= 6)
+        hipLaunchKernelGGL((k_local_bits<5, 6>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves == 5)
+        hipLaunchKernelGGL((k_local_bits<5, 5>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else
+        hipLaunchKernelGGL((k_local_bits<5, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
 }
 
-#ifdef LM_COARSE_BITS
-// ---- Bit-plane coarse pass (make CBITS=1 + LM_COARSE_BITS=1; NOT in the default library: written after the round's GPU time was spent,
-// compiled and modelled — profiles/bitplane_coarse_model.py equals the byte evaluation — but never run on a GPU).  The top level's flat
-// linear memories as ONE pair stream {is-1 dword, is-4 dword} per 32 arena bytes (k_pack_top); a template's map is walked 32 positions
-// per lane: a feature's load = two consecutive pairs per lane (16 bytes) at pair index (offset >> 5) + lane, funnel-shifted by
-// offset & 31 — the offset is wave-uniform, so both are scalar —, i.e. ONE wave load per feature and 2048 positions instead of one
-// per 1008 (and 38 live lanes at VGA).  Sums bit-sliced as in k_local_bits; the threshold test is a bit-sliced comparison with the
-// smallest raw sum that passes, so integers are formed only for the hits.  No tile planning (the bit-plane refinement needs none).
+// ---- Coarse pass on the pair stream (LL.cpp:1284-1354 similarity + :1835-1852 scan).  A wave per template, a lane = 32 consecutive
+// positions of the template's map: a feature's load = two consecutive pairs per lane (16 bytes) at pair index (offset >> 5) + lane,
+// funnel-shifted by offset & 31 — the offset is wave-uniform, so both are scalar —, i.e. ONE wave load per feature and 2048 positions
+// (the byte kernel: one per 1008 positions and 16 bytes per position and lane).  Sums bit-sliced as in k_local_bits; the threshold test is
+// a bit-sliced comparison with the smallest raw sum that passes, so integers are formed only for the hits.  The workgroup's 4 templates
+// reserve their candidate slots with ONE atomic on the frame's counter (same-address atomics serialise in the L2: 2000 per frame cost
+// the byte kernel 16 us).  No tiles: the bit-plane refinement needs none.
 __global__ void __launch_bounds__(256)
 k_pack_top(TopBits B, uint32_t byte0, uint32_t npairs) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= npairs) return;
     const uint8_t* src = B.lm[blockIdx.y] + byte0 + (size_t)i * 32;
     const uint4 a = *reinterpret_cast<const uint4*>(src), b = *reinterpret_cast<const uint4*>(src + 16);
-    auto four = [](uint32_t d, int sh) -> uint32_t { return ((((d >> sh) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+    auto four = [](uint32_t d, int sh) -> uint32_t { return ((((d >> sh) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };   // bit sh of 4 bytes -> 4 bits
     auto bits = [&](const uint4& v, int sh) -> uint32_t { return four(v.x, sh) | (four(v.y, sh) << 4) | (four(v.z, sh) << 8) | (four(v.w, sh) << 12); };
     uint2 r;
-    r.x = bits(a, 0) | (bits(b, 0) << 16);
+    r.x = bits(a, 0) | (bits(b, 0) << 16);                           // response 1 = bit 0, response 4 = bit 2 of the byte
     r.y = bits(a, 2) | (bits(b, 2) << 16);
     *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (size_t)i * 8) = r;
 }
 
+template <int kHi>
 __global__ void __launch_bounds__(256)
 k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
               const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0) {
+    constexpr int kN = 4 + kHi, kS = kN + 3;
+    __shared__ uint32_t s_tot[4];
+    __shared__ unsigned long long s_base;
     const FrameSlot& F = fb.f[blockIdx.y];
     Candidate* __restrict__ cands = F.cands;
     unsigned long long* __restrict__ counters = F.counters;
     const int lane = threadIdx.x & 63;
-    const int work = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));   // a wave per template
-    if (work >= num_work) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int work_raw = (int)blockIdx.x * 4 + wave;                       // a wave per template
+    const bool live = work_raw < num_work;
+    const int work = live ? work_raw : num_work - 1;                       // idle waves of the last workgroup shadow a real template and emit nothing
     const int pyr = work_pyramids[work];
     const TemplEntry e = entries[(size_t)pyr * levels + level];
     const int nf = e.nf, nfp = e.nf_padded;
@@ -1145,61 +1258,82 @@ k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, con
     const int limit = tp < npos ? tp : npos;                                // positions that carry sums
     // the smallest raw sum whose score passes (score_of is monotone in raw): LL.cpp:1844 `> threshold`
     int rmin = (int)(threshold * (float)(4 * nf) / 100.f);
-    if (rmin < 0) rmin = 0;
+    if (!(rmin >= 0)) rmin = 0;
+    if (rmin > 4 * nf + 1) rmin = 4 * nf + 1;
     while (rmin > 0 && score_of(rmin, nf) > threshold) --rmin;
     while (rmin <= 4 * nf && !(score_of(rmin, nf) > threshold)) ++rmin;
+    const bool zero_passes = score_of(0, nf) > threshold;
     const BufRsrc bits = make_rsrc(B.bits[blockIdx.y]);
-    for (int P0 = 0; P0 < npos; P0 += 2048) {
+    for (int P0 = 0; P0 < npos; P0 += 2048) {                               // (the same number of passes for every wave of the workgroup)
         const int pos0 = P0 + 32 * lane;                                    // first position of this lane
-        uint32_t ones1 = 0, twos1 = 0, fours1 = 0, hi1[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t ones4 = 0, twos4 = 0, fours4 = 0, hi4[6] = {0, 0, 0, 0, 0, 0};
-        if (P0 < limit && nfp > 0 && pos0 < limit) {                        // (lanes beyond the map sit the loads out)
-            for (int f = 0; f < nfp; f += kFeatBatch) {
-                uint4 v[kFeatBatch];
-                uint32_t sh[kFeatBatch];
+        uint32_t c1[kN], c4[kN];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) {
+        for (int k = 0; k < kN; ++k) { c1[k] = 0; c4[k] = 0; }
+        if (live && P0 < limit && nfp > 0 && pos0 < limit) {                // (lanes beyond the map sit the loads out)
+            auto batch = [&](int f, uint32_t& e1, uint32_t& e4) {
+                uint4 v[8];
+                uint32_t sh[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
                     const uint32_t ob = (uint32_t)fo[f + u] - byte0 + (uint32_t)P0;      // wave-uniform -> SMEM / SALU
                     sh[u] = ob & 31u;
                     v[u] = ld_buf16(bits, (uint32_t)lane * 8u, (ob >> 5) * 8u);          // pairs q + lane and q + lane + 1
                 }
-                uint32_t x1[kFeatBatch], x4[kFeatBatch];
+                uint32_t x1[8], x4[8];
 #pragma unroll
-                for (int u = 0; u < kFeatBatch; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     x1[u] = __builtin_amdgcn_alignbit(v[u].z, v[u].x, sh[u]);            // bits [s, s + 32) of {is-1 of pair q + lane + 1 : pair q + lane}
                     x4[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].y, sh[u]);
                 }
-                add8(x1, ones1, twos1, fours1, hi1);
-                add8(x4, ones4, twos4, fours4, hi4);
+                e1 = add8(x1, c1[0], c1[1], c1[2]);
+                e4 = add8(x4, c4[0], c4[1], c4[2]);
+            };
+            for (int f = 0; f < nfp; f += 16) {
+                uint32_t a1, a4;
+                batch(f, a1, a4);
+                if (f + 8 < nfp) {
+                    uint32_t b1, b4;
+                    batch(f + 8, b1, b4);
+                    add_eights2<kN>(c1, a1, b1);
+                    add_eights2<kN>(c4, a4, b4);
+                } else {
+                    add_eights1<kN>(c1, a1);
+                    add_eights1<kN>(c4, a4);
+                }
             }
         }
-        const uint32_t n1[9] = {ones1, twos1, fours1, hi1[0], hi1[1], hi1[2], hi1[3], hi1[4], hi1[5]};
-        const uint32_t n4[9] = {ones4, twos4, fours4, hi4[0], hi4[1], hi4[2], hi4[3], hi4[4], hi4[5]};
-        uint32_t S[12], carry = 0;
-        S[0] = n1[0]; S[1] = n1[1];
+        uint32_t S[kS], carry = 0;
+        S[0] = c1[0]; S[1] = c1[1];
 #pragma unroll
-        for (int k = 2; k < 12; ++k) csa(S[k], carry, k < 9 ? n1[k] : 0u, k - 2 < 9 ? n4[k - 2] : 0u, carry);
+        for (int k = 2; k < kS; ++k) csa(S[k], carry, k < kN ? c1[k] : 0u, k - 2 < kN ? c4[k - 2] : 0u, carry);
         uint32_t gt = 0, eq = 0xFFFFFFFFu;                                  // S >= rmin, bit-sliced
 #pragma unroll
-        for (int k = 11; k >= 0; --k) {
+        for (int k = kS - 1; k >= 0; --k) {
             if ((rmin >> k) & 1) eq &= S[k];                                // wave-uniform
             else { gt |= eq & S[k]; eq &= ~S[k]; }
         }
-        uint32_t hit_mask = rmin < 4096 ? (gt | eq) : 0u;
+        uint32_t hit_mask = rmin < (1 << kS) ? (gt | eq) : 0u;
         // positions at or beyond the template's position count hold zero sums (LL.cpp:1299-1309): they are hits only if zero passes
-        const int live = limit - pos0;                                      // positions of this lane that carry sums
-        const uint32_t summed = live >= 32 ? 0xFFFFFFFFu : (live > 0 ? (1u << live) - 1u : 0u);
+        const int sums = limit - pos0;                                      // positions of this lane that carry sums
+        const uint32_t summed = sums >= 32 ? 0xFFFFFFFFu : (sums > 0 ? (1u << sums) - 1u : 0u);
         const int inmap = npos - pos0;
         const uint32_t mapped = inmap >= 32 ? 0xFFFFFFFFu : (inmap > 0 ? (1u << inmap) - 1u : 0u);
-        const bool zero_passes = score_of(0, nf) > threshold;
         hit_mask = (hit_mask & summed) | (zero_passes ? (mapped & ~summed) : 0u);
+        if (!live) hit_mask = 0;
         int total;
         const int before = wave_excl_scan(__popc(hit_mask), lane, total);
+        // one atomic per workgroup and pass
+        if (lane == 0) s_tot[wave] = (uint32_t)total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long all = (unsigned long long)s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            s_base = all ? atomicAdd(&counters[0], all) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long slot = s_base + (unsigned long long)before;
+        for (int w = 0; w < wave; ++w) slot += s_tot[w];
+        __syncthreads();                                                    // s_tot / s_base are rewritten by the next pass
         if (total > 0) {                                                    // wave-uniform
-            unsigned long long wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&counters[0], (unsigned long long)total);
-            wbase = bcast_u64(wbase, 0);
-            unsigned long long slot = wbase + (unsigned long long)before;
             uint32_t m = hit_mask;
             while (m) {
                 const int b = __ffs((int)m) - 1;
@@ -1208,7 +1342,7 @@ k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, con
                     int raw = 0;
                     if ((summed >> b) & 1u) {
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) raw |= (int)((S[k] >> b) & 1u) << k;
+                        for (int k = 0; k < kS; ++k) raw |= (int)((S[k] >> b) & 1u) << k;
                     }
                     const int jpos = pos0 + b;
                     const int cy = jpos / Wd, cx = jpos - cy * Wd;
@@ -1226,13 +1360,16 @@ void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, 
     hipLaunchKernelGGL(k_pack_top, dim3((npairs + 255) / 256, nb), dim3(256), 0, s, B, byte0, npairs);
 }
 void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, hipStream_t s) {
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s) {
     if (num_work <= 0 || fb.nb <= 0) return;
     const int level = g.levels - 1;
-    hipLaunchKernelGGL(k_coarse_bits, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
-                       work_pyramids, num_work, threshold, cap, byte0);
+    if (max_features <= kBitsSmallMax)
+        hipLaunchKernelGGL(k_coarse_bits<5>, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+                           work_pyramids, num_work, threshold, cap, byte0);
+    else
+        hipLaunchKernelGGL(k_coarse_bits<10>, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+                           work_pyramids, num_work, threshold, cap, byte0);
 }
-#endif  // LM_COARSE_BITS
 
 void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
                   const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,

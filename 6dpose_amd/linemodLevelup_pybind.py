@@ -501,7 +501,7 @@ class Detector:
         _check(self._lib.lm_detector_set_batch_queue(self._h, int(batches)))
 
     def setAsyncCollect(self, on: bool) -> None:
-        """Streamed frames: prepare the result lists on the library's collector thread (default) or inside collect() (lm_detector_set_async_collect)."""
+        """Streamed frames: prepare the result lists on a collector thread of the library instead of inside collect() (lm_detector_set_async_collect; off by default, LM_ASYNC_COLLECT=1 turns it on)."""
         _check(self._lib.lm_detector_set_async_collect(self._h, 1 if on else 0))
 
     def hostProfile(self, reset: bool = True) -> dict:
@@ -519,6 +519,26 @@ class Detector:
         f.argtypes = [ctypes.c_void_p]
         f.restype = ctypes.c_int
         return bool(f(self._h))
+
+    _REFINE = {"bits": 0, "tiles": 1, "single": 2}
+    _COARSE = {"bits": 0, "bytes": 1}
+
+    def setPaths(self, refine: str = "bits", coarse: str = "bits") -> None:
+        """lm_detector_set_paths: which kernels serve the refinement ("bits" = k_local_bits, "tiles" / "single" = k_local with / without
+        tiles) and the coarse pass ("bits" = k_coarse_bits, "bytes" = k_coarse).  Results do not depend on it."""
+        f = self._lib.lm_detector_set_paths
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        f.restype = ctypes.c_int
+        _check(f(self._h, self._REFINE[refine], self._COARSE[coarse]))
+
+    def getPaths(self):
+        """lm_detector_get_paths: (refine, coarse) the current bank and frame geometry actually use, as the names of setPaths (valid after a match)."""
+        f = self._lib.lm_detector_get_paths
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        f.restype = ctypes.c_int
+        r, c = ctypes.c_int(), ctypes.c_int()
+        _check(f(self._h, ctypes.byref(r), ctypes.byref(c)))
+        return ({v: k for k, v in self._REFINE.items()}[r.value], {v: k for k, v in self._COARSE.items()}[c.value])
 
     def getBatch(self) -> int:
         return int(self._lib.lm_detector_get_batch(self._h))

@@ -262,6 +262,15 @@ int lm_detector_host_profile(lm_detector *d, double *out8, int reset);
 /* 1 when the local refinement (similarityLocal, LL.cpp:1366-1428) of the current bank and frame geometry runs on bit planes
  * (kernel k_local_bits), 0 when on byte planes (k_local): which kernel a profile of the match shows.  Valid after a match. */
 int lm_detector_refines_on_bit_planes(const lm_detector *d);
+/* Which kernels serve similarity (LL.cpp:1284-1354) and similarityLocal (LL.cpp:1366-1428).  Results never depend on it; tests and
+ * measurements use it to run every path against the oracle in one process.
+ *   refine: 0 = bit planes (k_local_bits; default, any pyramid with a level below the top), 1 = byte strip planes with tiles (k_local),
+ *           2 = byte planes, every candidate on its own (k_local without tiles).
+ *   coarse: 0 = bit planes (k_coarse_bits; default, used when the refinement runs on bit planes too), 1 = byte linear memories (k_coarse).
+ * Refused with frames in flight.  lm_detector_get_paths reports what the current bank and frame geometry actually use (valid after a
+ * match): refine 0 / 1 / 2 and coarse 0 / 1 as above. */
+int lm_detector_set_paths(lm_detector *d, int refine, int coarse);
+int lm_detector_get_paths(const lm_detector *d, int *refine, int *coarse);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity

@@ -1,5 +1,6 @@
-"""Design model (CPU, numpy) of the bit-plane refinement DESIGN.md section 8 plans: response memories as two 1-bit planes per (label, phase)
-instead of one byte plane, 32-cell strips at a stride of 16, a 16 x 16 window = 8 lanes x (2 rows x 32 positions), sums kept bit-sliced.
+"""Model (CPU, numpy) of the bit-plane refinement of DESIGN.md section 3.6 as built in round 4 (match.hip: k_pack_bits, k_local_bits): two bits
+per response cell instead of a byte, 32-cell strip records at a stride of 16, a 16 x 16 window = 8 lanes x (2 rows x 16 positions x {is 1,
+is 4}), one funnel shift per row and feature, sums kept bit-sliced (Harley-Seal, 16 features per trip).
 Checks, on the bench workload (frame 1 of bench.noisy_frames, planted bank, every `STEP`-th template): the lane-level emulation gives
 the SAME (best raw sum, first position attaining it) as a direct evaluation of the byte response maps for every coarse candidate, and the
 records it keeps equal the oracle's (match_oracle.c) for those templates.  Test infrastructure / design aid: imports oracle/.
@@ -24,8 +25,20 @@ H0, W0 = pyr[0][0].shape
 Hd, Wd = H0 // T0, W0 // T0
 R = [[lo.response_np(lo.spread_np(pyr[l][m], T[l])) for m in range(2)] for l in range(2)]        # [level][mod][label][H][W], values 0 / 1 / 4
 
-# ---- the bit-plane memories of level 0: rec[mod][label][phase][strip][row] = is1 bits of cells [16 s, 16 s + 32) | is4 bits << 32 ----
+# ---- the strip records of level 0 (match.hip, k_pack_bits): rec[mod][label][phase][strip][row] = 64 bits, cell c of [16 s, 16 s + 32) at
+# bits 2c (response is 1) and 2c + 1 (response is 4) ----
 NS = (Wd + 15) // 16
+def pack4(d):
+    """4 response bytes (one uint32) -> 8 bits, exactly the kernel's multiply trick."""
+    e = d & np.uint32(0x05050505)
+    t = (e | (e >> np.uint32(1))) & np.uint32(0x03030303)
+    return ((t.astype(np.uint64) * np.uint64(0x01041040)) & np.uint64(0xFFFFFFFF)).astype(np.uint32) >> np.uint32(24)
+def pack16(bytes16):
+    """[..., 16] response bytes -> uint32: 16 cells x 2 bits."""
+    d = bytes16.reshape(bytes16.shape[:-1] + (4, 4)).astype(np.uint32)
+    d = d[..., 0] | (d[..., 1] << np.uint32(8)) | (d[..., 2] << np.uint32(16)) | (d[..., 3] << np.uint32(24))
+    q = pack4(d)
+    return q[..., 0] | (q[..., 1] << np.uint32(8)) | (q[..., 2] << np.uint32(16)) | (q[..., 3] << np.uint32(24))
 def build_records():
     rec = np.zeros((2, 8, T0 * T0, NS, Hd), np.uint64)
     for m in range(2):
@@ -36,52 +49,85 @@ def build_records():
                     cells = plane[:, py, :, px]                                      # [Hd][Wd]
                     pad = np.zeros((Hd, NS * 16 + 32), np.uint8); pad[:, :Wd] = cells
                     for s in range(NS):
+                        lo = pack16(pad[:, 16 * s:16 * s + 16]); hi = pack16(pad[:, 16 * s + 16:16 * s + 32])
+                        rec[m, lab, py * T0 + px, s, :] = lo.astype(np.uint64) | (hi.astype(np.uint64) << np.uint64(32))
+                        # the definition: bit 2c = (cell == 1), bit 2c + 1 = (cell == 4)
                         seg = pad[:, 16 * s:16 * s + 32]
-                        w = (1 << np.arange(32, dtype=np.uint64))
-                        is1 = ((seg == 1).astype(np.uint64) * w).sum(axis=1)
-                        is4 = ((seg == 4).astype(np.uint64) * w).sum(axis=1)
-                        rec[m, lab, py * T0 + px, s, :] = is1 | (is4 << np.uint64(32))
+                        w = (np.uint64(1) << (2 * np.arange(32, dtype=np.uint64)))
+                        want = ((seg == 1).astype(np.uint64) * w).sum(axis=1) + ((seg == 4).astype(np.uint64) * (w << np.uint64(1))).sum(axis=1)
+                        assert np.array_equal(rec[m, lab, py * T0 + px, s, :], want)
     return rec
 t0 = time.time()
 REC = build_records()
 print("bit-plane memories of level 0: %.2f MB (byte planes: %.2f MB), built in %.1f s" % (REC.nbytes / 1e6, 2 * 8 * T0 * T0 * Wd * Hd / 1e6, time.time() - t0))
 
-def add_bitsliced(cnt, x):
-    """cnt: list of uint32 arrays (bit k of every position's counter), x: uint32 array of 0/1 per position.  Ripple-carry add of one bit."""
-    carry = x
-    for k in range(len(cnt)):
-        t = cnt[k] & carry
-        cnt[k] = cnt[k] ^ carry
-        carry = t
-    assert not carry.any()
+def csa(a, b, c):
+    return a ^ b ^ c, (a & b) | (a & c) | (b & c)
+def add8(x, c):
+    """eight dwords into c[0..2] (ones, twos, fours); returns the carry of weight 8 (match.hip add8)."""
+    c[0], ta = csa(c[0], x[0], x[1]); c[0], tb = csa(c[0], x[2], x[3]); c[1], fa = csa(c[1], ta, tb)
+    c[0], ta = csa(c[0], x[4], x[5]); c[0], tb = csa(c[0], x[6], x[7]); c[1], fb = csa(c[1], ta, tb)
+    c[2], e = csa(c[2], fa, fb)
+    return e
+def add_eights(c, e1, e2):
+    c[3], k16 = csa(c[3], e1, e2)
+    for k in range(4, len(c)):
+        t = c[k] & k16; c[k] = c[k] ^ k16; k16 = t
+    assert not k16.any()
 
+KN = 9
 def refine_bitplanes(gx, gy, F):
-    """One candidate, window origin (gx, gy) in cells, F = [nf][4] (x, y, label, mod).  8 lanes, lane j = rows 2j, 2j + 1; returns (raw, index)."""
-    KB = 10
-    n1 = [np.zeros(8, np.uint32) for _ in range(KB)]
-    n4 = [np.zeros(8, np.uint32) for _ in range(KB)]
+    """One candidate, window origin (gx, gy) in cells, F = [nf][4] (x, y, label, mod).  8 lanes, lane j = rows 2j, 2j + 1; returns (raw, index).
+    The lane-level algorithm of k_local_bits<5>: 16 features per trip, counters of 9 bits, rows side by side at the end."""
+    cA = [np.zeros(8, np.uint32) for _ in range(KN)]
+    cB = [np.zeros(8, np.uint32) for _ in range(KN)]
     lanes = np.arange(8)
-    for fx, fy, lab, m in F:
+    nfp = (len(F) + 7) // 8 * 8
+    zero = np.zeros(8, np.uint32)
+    def window(fx, fy, lab, m):
         cx, cy = fx // T0, fy // T0
         ph = (fy % T0) * T0 + (fx % T0)
-        x0, y0 = gx + cx, gy + cy
-        s, o = x0 >> 4, x0 & 15
-        r0 = REC[m, lab, ph, s, y0 + 2 * lanes]                  # the lane's 16-byte load: two consecutive row records
-        r1 = REC[m, lab, ph, s, y0 + 2 * lanes + 1]
-        def win(r, sh):                                            # 16 cells from bit o of the plane at bit `sh`
-            return ((r >> np.uint64(sh + o)) & np.uint64(0xFFFF)).astype(np.uint32)
-        x1 = win(r0, 0) | (win(r1, 0) << np.uint32(16))
-        x4 = win(r0, 32) | (win(r1, 32) << np.uint32(16))
-        add_bitsliced(n1, x1)
-        add_bitsliced(n4, x4)
-    # integers once per candidate: raw(position) = n1 + 4 n4; key = raw << 8 | 255 - index (first strict maximum in raster order)
+        s2 = ((cx & 15) + (gx & 15)) << 1                        # prep(): 2 x (column class + window column), bit 5 = strip carry
+        s = (cx >> 4) + (gx >> 4) + (s2 >> 5)
+        r0 = REC[m, lab, ph, s, cy + gy + 2 * lanes]               # the lane's 16-byte load: two consecutive row records
+        r1 = REC[m, lab, ph, s, cy + gy + 2 * lanes + 1]
+        sh = np.uint64(s2 & 31)                                    # v_alignbit(hi, lo, s2): 32 bits from bit s2 & 31 of the record
+        return ((r0 >> sh) & np.uint64(0xFFFFFFFF)).astype(np.uint32), ((r1 >> sh) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    for f0 in range(0, nfp, 16):
+        es = []
+        for half in range(2):
+            if f0 + 8 * half >= nfp: break
+            xa, xb = [], []
+            for u in range(8):
+                f = f0 + 8 * half + u
+                if f < len(F): a, b = window(*F[f])
+                else: a, b = zero, zero                            # padding features read the zero plane
+                xa.append(a); xb.append(b)
+            es.append((add8(xa, cA), add8(xb, cB)))
+        if len(es) == 2:
+            add_eights(cA, es[0][0], es[1][0]); add_eights(cB, es[0][1], es[1][1])
+        else:
+            add_eights(cA, es[0][0], zero); add_eights(cB, es[0][1], zero)
+    M = np.uint32(0x55555555); M2 = np.uint32(0xAAAAAAAA)
+    n1 = [(cA[k] & M) | ((cB[k] << np.uint32(1)) & M2) for k in range(KN)]
+    n4 = [((cA[k] >> np.uint32(1)) & M) | (cB[k] & M2) for k in range(KN)]
+    S = [n1[0], n1[1]]; carry = np.zeros(8, np.uint32)
+    for k in range(2, KN + 3):
+        a = n1[k] if k < KN else zero
+        b = n4[k - 2] if k - 2 < KN else zero
+        sk, carry = csa(a, b, carry)
+        S.append(sk)
     best = 0
     for j in range(8):
-        for b in range(32):
-            v1 = sum(((int(n1[k][j]) >> b) & 1) << k for k in range(KB))
-            v4 = sum(((int(n4[k][j]) >> b) & 1) << k for k in range(KB))
-            idx = (2 * j + (b >> 4)) * 16 + (b & 15)
-            best = max(best, ((v1 + 4 * v4) << 8) | (255 - idx))
+        mask, val = 0xFFFFFFFF, 0
+        for k in range(KN + 2, -1, -1):
+            t = mask & int(S[k][j])
+            if t: mask = t; val |= 1 << k
+        upper = mask & 0x55555555
+        pick = upper if upper else mask
+        bitp = (pick & -pick).bit_length() - 1
+        pos = ((2 * j + (bitp & 1)) << 4) + (bitp >> 1)
+        best = max(best, (val << 8) | (255 - pos))
     return best >> 8, 255 - (best & 0xFF)
 
 def refine_bytes(gx, gy, F):

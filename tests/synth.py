@@ -93,7 +93,7 @@ def _finish(all_feats, all_wh):
 
 
 def make_random_bank(seed: int, n: int, W: int = 640, H: int = 480, nfeat: Sequence[int] = (150, 75)):
-    """n template pyramids with uniform random features (levels = len(nfeat))."""
+    """n template pyramids with uniform random features (levels = len(nfeat); an entry of nfeat is a count per modality or a (colour, normals) pair)."""
     rng = np.random.default_rng(seed)
     scale = W / 640.0
     all_feats, all_wh = [], []
@@ -104,7 +104,8 @@ def make_random_bank(seed: int, n: int, W: int = 640, H: int = 480, nfeat: Seque
             wl, hl = max(2, w >> l), max(2, h >> l)
             mods = []
             for m in range(2):
-                f = np.stack([rng.integers(0, wl + 1, nf), rng.integers(0, hl + 1, nf), rng.integers(0, 8, nf)], 1)
+                nfm = nf[m] if isinstance(nf, (tuple, list)) else nf          # (colour, normals) or one count for both
+                f = np.stack([rng.integers(0, wl + 1, nfm), rng.integers(0, hl + 1, nfm), rng.integers(0, 8, nfm)], 1)
                 mods.append(f)
             lv.append(mods)
         f, wh = _crop_pack(lv)
@@ -137,14 +138,15 @@ def make_planted_bank(seed: int, n: int, quant_pyr: Sequence[Tuple[np.ndarray, n
             xl, yl, wl, hl = x0 >> l, y0 >> l, max(2, w >> l), max(2, h >> l)
             mods = []
             for m in range(2):
+                nfm = nf[m] if isinstance(nf, (tuple, list)) else nf          # (colour, normals) or one count for both
                 box = labs[l][m][yl:yl + hl + 1, xl:xl + wl + 1]
                 ys, xs = np.nonzero(box >= 0)
-                if len(ys) < nf:
+                if len(ys) < nfm:
                     ok = False
                     break
-                sel = rng.choice(len(ys), nf, replace=False)
+                sel = rng.choice(len(ys), nfm, replace=False)
                 lab = box[ys[sel], xs[sel]].copy()
-                flip = rng.uniform(0, 1, nf) < label_noise
+                flip = rng.uniform(0, 1, nfm) < label_noise
                 lab[flip] = rng.integers(0, 8, int(flip.sum()))
                 mods.append(np.stack([xs[sel] + xl, ys[sel] + yl, lab], 1))
             if not ok:

@@ -44,6 +44,29 @@ def as_multiset(rec, names):
     return sorted(zip(*[rec[n].tolist() for n in names]))
 
 
+# every kernel path of the matcher (Detector.setPaths: refinement, coarse pass); results may never depend on it
+PATHS = [("bits", "bits"), ("bits", "bytes"), ("tiles", "bytes"), ("single", "bytes")]
+
+
+def detector_on(lm, paths, *args, **kw):
+    det = lm.Detector(*args, **kw)
+    det.setPaths(*paths)
+    return det
+
+
+def expect_paths(det, paths, tiles_possible=True, levels=2):
+    """After a match: the kernels in use are the ones the case asked for — a test must not compare a path with itself."""
+    refine, coarse = paths
+    if levels < 2:
+        want = ("single", "bytes")
+    elif refine == "tiles" and not tiles_possible:
+        want = ("single", "bytes")
+    else:
+        want = (refine, coarse)
+    assert det.getPaths() == want, (det.getPaths(), want)
+    assert det.refinesOnBitPlanes() == (want[0] == "bits")
+
+
 # ---------------------------------------------------------------------------------------------
 # front end: quantised maps and linear memories, byte for byte
 # ---------------------------------------------------------------------------------------------
@@ -177,13 +200,14 @@ def test_gpu_equals_the_reference_lines(lm):
                     assert np.array_equal(got[a], rfin[b]), (case["name"], req, a)
 
 
+@pytest.mark.parametrize("paths", PATHS, ids=["-".join(p) for p in PATHS])
 @pytest.mark.parametrize("bank,nfeat", [("127", 127), ("63", 63)])
-def test_match_fixture_banks(lm, bank, nfeat):
+def test_match_fixture_banks(lm, bank, nfeat, paths):
     rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
     fmt = os.path.join(GOLDEN, "bank" + bank + "_%s.yaml.gz")
     od = lo.OracleDetector(nfeat, [5, 8])
     od.readClasses(["06_template"], fmt)
-    det = lm.Detector(nfeat, [5, 8], device=0)
+    det = detector_on(lm, paths, nfeat, [5, 8], device=0)
     det.readClasses(["06_template"], fmt)
     assert det.numTemplates("06_template") == 89 and det.classIds() == ["06_template"]
     # bank round trip: what the product parsed equals what the oracle parsed
@@ -196,6 +220,7 @@ def test_match_fixture_banks(lm, bank, nfeat):
         lms, sizes = od.linear_memories(rgb, dep)
         raw = od.match_raw(lms, sizes, thr, ["06_template"])
         same_records(got, lo.canonical_sort_unique(raw))
+        expect_paths(det, paths)
         tm = det.lastTimings()
         assert tm["coarse_candidates"] == od.last_stats["coarse_candidates"]
         assert tm["matches_pre_unique"] == len(raw)
@@ -221,16 +246,27 @@ def test_match_planted_and_random_banks(lm, W, H, T, nfeat, n, thr):
     pyr = od.quantize_pyramid(rgb, dep)
     planted = synth.make_planted_bank(21, n, [(p[0], p[1]) for p in pyr], T, nfeat)
     random = synth.make_random_bank(22, n // 2, W, H, nfeat)
-    det = lm.Detector(nfeat[0], T, device=0)
-    det.addClassPacked("planted", *planted)
-    det.addClassPacked("random", *random)
     ra, sa = oracle_matches(od, rgb, dep, planted, T, thr, 0)
     rb, sb = oracle_matches(od, rgb, dep, random, T, thr, 1)
     assert sa["coarse_candidates"] > n, "planted bank must exercise the refinement"
     want = lo.canonical_sort_unique(np.concatenate([ra, rb]))
+    for paths in PATHS[1:]:                                       # the byte paths (the default, bit planes everywhere, follows with the further checks)
+        dp = detector_on(lm, paths, nfeat[0], T, device=0)
+        dp.addClassPacked("planted", *planted)
+        dp.addClassPacked("random", *random)
+        same_records(dp.matchArray([rgb, dep], thr, ["planted", "random"]), want)
+        expect_paths(dp, paths, tiles_possible=len(T) == 2, levels=len(T))
+        tmp_ = dp.lastTimings()
+        assert tmp_["coarse_candidates"] == sa["coarse_candidates"] + sb["coarse_candidates"]
+        assert tmp_["local_evals"] == sa["local_evals"] + sb["local_evals"]
+    det = lm.Detector(nfeat[0], T, device=0)
+    det.addClassPacked("planted", *planted)
+    det.addClassPacked("random", *random)
     got = det.matchArray([rgb, dep], thr, ["planted", "random"])
     same_records(got, want)
+    expect_paths(det, PATHS[0], levels=len(T))                   # three levels too: every level below the top on bit planes
     assert det.lastTimings()["coarse_candidates"] == sa["coarse_candidates"] + sb["coarse_candidates"]
+    assert det.lastTimings()["local_evals"] == sa["local_evals"] + sb["local_evals"]
     # class order given by the caller; unknown classes are skipped; empty list = sorted class order
     got2 = det.matchArray([rgb, dep], thr, ["random", "nope", "planted"])
     rb2, ra2 = rb.copy(), ra.copy()
@@ -281,7 +317,11 @@ def test_match_edge_cases(lm):
     det.addClassPacked("hand", *bank)
     for thr in (10.0, 50.0, 100.0, 0.0):
         want, _ = oracle_matches(od, rgb, dep, bank, T, thr, 0)
-        same_records(det.matchArray([rgb, dep], thr, ["hand"]), lo.canonical_sort_unique(want))
+        for paths in PATHS:                                     # (bit planes: the oversized and out-of-frame templates take k_local's per-candidate path in a second launch)
+            det.setPaths(*paths)
+            same_records(det.matchArray([rgb, dep], thr, ["hand"]), lo.canonical_sort_unique(want))
+            expect_paths(det, paths)
+    det.setPaths("bits", "bits")
     # candidate-buffer growth path: threshold 0 on a bigger bank overflows the initial capacity? (count only)
     assert det.lastTimings()["matches_pre_unique"] == len(want)
     # invalid banks are rejected like the reference's CV_Asserts
@@ -293,89 +333,120 @@ def test_match_edge_cases(lm):
         det.addClassPacked("hand", *bank)               # class already present
 
 
-def test_tile_refinement_is_exact(lm):
-    """The default refinement groups the candidates of a template whose coarse cells are neighbours into tiles (planned by
-    k_coarse, the shared window region summed once per tile in k_local).  It must give the records of the per-candidate kernel
-    (LM_TILES=0, the round-1 path) AND of the oracle — pre-unique multiset, evaluation count and algorithmic bytes included — on
-    a planted bank (clusters of neighbouring candidates), a random one (isolated candidates), with templates planted against the
-    frame border (clamped windows stay singles), with oversized templates on the slow path, at low thresholds (dense tiles),
-    and with frames in flight."""
+def test_refinement_paths_are_exact(lm):
+    """Four kernel paths serve Detector.match — bit planes for both passes (k_coarse_bits + k_local_bits, the default), bit-plane refinement
+    behind the byte coarse pass, the byte strip planes with tiles (candidates of a template whose coarse cells are neighbours, planned
+    by k_coarse, summed once per tile in k_local) and every candidate on its own (round 1).  Each must give the records of the oracle
+    and of the others — pre-unique multiset, evaluation count and algorithmic bytes included — on a planted bank (clusters of
+    neighbouring candidates), a random one (isolated candidates), with templates planted against the frame border (clamped windows),
+    with oversized templates on the slow path, at low thresholds, and with frames in flight; `getPaths` proves which kernels ran."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
     rgb, dep = synth.make_frame(5, W, H)
     od = lo.OracleDetector(nfeat[0], T)
     pyr = od.quantize_pyramid(rgb, dep)
     banks = {"planted": synth.make_planted_bank(17, 300, [(p[0], p[1]) for p in pyr], T, nfeat), "random": synth.make_random_bank(18, 200, W, H, nfeat)}
-    tiled = lm.Detector(nfeat[0], T, device=0)
-    os.environ["LM_TILES"] = "0"
-    try:
-        plain = lm.Detector(nfeat[0], T, device=0)
-    finally:
-        del os.environ["LM_TILES"]
-    for d in (plain, tiled):
+    dets = {}
+    for paths in PATHS:
+        d = detector_on(lm, paths, nfeat[0], T, device=0)
         for c, b in banks.items():
             d.addClassPacked(c, *b)
         d.setFrame([rgb, dep])
+        dets[paths] = d
+    plain = dets[("single", "bytes")]
     names = ["x", "y", "similarity", "class_index", "template_id"]
     for thr, ids in ((75.0, ["planted"]), (60.0, ["random", "planted"]), (88.0, []), (45.0, ["planted"])):
         a = plain.matchResident(thr, ids)
-        b = tiled.matchResident(thr, ids)
-        assert len(a) > 0 and a.tobytes() == b.tobytes(), (thr, ids, len(a), len(b))
-        ta, tb = plain.lastTimings(), tiled.lastTimings()
-        assert ta["coarse_candidates"] == tb["coarse_candidates"]
-        assert ta["local_evals"] == tb["local_evals"] and ta["matches_pre_unique"] == tb["matches_pre_unique"] and ta["local_bytes"] == tb["local_bytes"]
+        ta = plain.lastTimings()
         ra = plain.matchResident(thr, ids, sort_unique=False)
-        rb = tiled.matchResident(thr, ids, sort_unique=False)
-        assert as_multiset(ra, names) == as_multiset(rb, names)
+        assert len(a) > 0
+        for paths in PATHS[:3]:
+            d = dets[paths]
+            b = d.matchResident(thr, ids)
+            expect_paths(d, paths)
+            assert a.tobytes() == b.tobytes(), (paths, thr, ids, len(a), len(b))
+            tb = d.lastTimings()
+            assert ta["coarse_candidates"] == tb["coarse_candidates"], paths
+            assert ta["local_evals"] == tb["local_evals"] and ta["matches_pre_unique"] == tb["matches_pre_unique"] and ta["local_bytes"] == tb["local_bytes"], paths
+            rb = d.matchResident(thr, ids, sort_unique=False)
+            assert as_multiset(ra, names) == as_multiset(rb, names), paths
         if thr >= 60.0:                                           # ... and the oracle itself
             order = ids if ids else sorted(banks)
             raws = []
             for ci, c in enumerate(order):
                 raw, _ = oracle_matches(od, rgb, dep, banks[c], T, thr, ci)
                 raws.append(raw)
-            same_records(b, lo.canonical_sort_unique(np.concatenate(raws)))
-    for k in range(7):                                          # pipelined, slots reused
-        tiled.submit(75.0, ["planted"])
-        if k >= 2:
-            assert tiled.collect().tobytes() == plain.matchResident(75.0, ["planted"]).tobytes()
-    tiled.collect(); tiled.collect()
-    # other tileable geometries: T = {2, 4} and {8, 16} (coarse cells again 4 fine cells apart), a small and a non-square frame
-    for (W2, H2, T2, nf2, thr2) in ((320, 240, [2, 4], (64, 32), 65.0), (640, 480, [8, 16], (64, 32), 60.0), (384, 272, [4, 8], (96, 48), 65.0)):
-        rgb2, dep2 = synth.make_frame(23, W2, H2, 24)
-        od2 = lo.OracleDetector(nf2[0], T2)
-        p2 = od2.quantize_pyramid(rgb2, dep2)
-        b2 = synth.make_planted_bank(29, 150, [(p[0], p[1]) for p in p2], T2, nf2)
-        d2 = lm.Detector(nf2[0], T2, device=0)
-        d2.addClassPacked("o", *b2)
-        raw2, st2 = oracle_matches(od2, rgb2, dep2, b2, T2, thr2)
-        assert st2["coarse_candidates"] > 150
-        same_records(d2.matchArray([rgb2, dep2], thr2, ["o"]), lo.canonical_sort_unique(raw2))
-        assert d2.lastTimings()["coarse_candidates"] == st2["coarse_candidates"]
-    # the reference's default geometry T = {5, 8} (Detector(), LL.cpp:1663-1692: every fixture bank): the windows of neighbouring coarse
-    # cells lie 16 / 5 level-0 cells apart - 3, 3, 3, 3, 4, ... - and the tiles carry those steps; also T = {6, 8} (steps 2 and 3) and
-    # {3, 4}.  Tiled == per-candidate path == oracle, statistics included; T = {4, 16} (8 cells apart) is not tiled and still exact.
-    for (T5, nf5, thr5, seed5) in (([5, 8], (63, 31), 70.0, 19), ([5, 8], (127, 63), 60.0, 20), ([6, 8], (64, 32), 65.0, 21), ([3, 4], (64, 32), 65.0, 22),
-                                   ([4, 16], (64, 32), 60.0, 23)):
-        W5, H5 = (640, 480) if T5[0] not in (3, 6) else (768, 480)
-        rgb5, dep5 = synth.make_frame(5, W5, H5)
+            same_records(a, lo.canonical_sort_unique(np.concatenate(raws)))
+    want75 = plain.matchResident(75.0, ["planted"]).tobytes()
+    for paths in PATHS[:3]:                                     # pipelined, slots reused
+        d = dets[paths]
+        for k in range(7):
+            d.submit(75.0, ["planted"])
+            if k >= 2:
+                assert d.collect().tobytes() == want75, paths
+        d.collect(); d.collect()
+    # other geometries: T = {2, 4} and {8, 16} (coarse cells again 4 fine cells apart), a small and a non-square frame; the reference's
+    # default T = {5, 8} (Detector(), LL.cpp:1663-1692: every fixture bank): the windows of neighbouring coarse cells lie 16 / 5 level-0
+    # cells apart - 3, 3, 3, 3, 4, ... - and the tiles carry those steps; T = {6, 8} (steps 2 and 3), {3, 4}; T = {4, 16} (8 cells apart) is
+    # not tiled.  Every path == oracle, statistics included.
+    for (W5, H5, T5, nf5, thr5, seed5) in ((320, 240, [2, 4], (64, 32), 65.0, 29), (640, 480, [8, 16], (64, 32), 60.0, 29), (384, 272, [4, 8], (96, 48), 65.0, 29),
+                                           (640, 480, [5, 8], (63, 31), 70.0, 19), (640, 480, [5, 8], (127, 63), 60.0, 20), (768, 480, [6, 8], (64, 32), 65.0, 21),
+                                           (768, 480, [3, 4], (64, 32), 65.0, 22), (640, 480, [4, 16], (64, 32), 60.0, 23)):
+        rgb5, dep5 = synth.make_frame(5 if T5[0] in (3, 5, 6) or T5 == [4, 16] else 23, W5, H5, 40 if W5 >= 640 else 24)
         od5 = lo.OracleDetector(nf5[0], T5)
         p5 = od5.quantize_pyramid(rgb5, dep5)
         b5 = synth.make_planted_bank(seed5, 160, [(p[0], p[1]) for p in p5], T5, nf5)
         raw, st5 = oracle_matches(od5, rgb5, dep5, b5, T5, thr5)
         want5 = lo.canonical_sort_unique(raw)
-        assert len(want5) > 0
+        assert len(want5) > 0 and st5["coarse_candidates"] > 100
         stats = []
-        for tiles_on in ("1", "0"):
-            os.environ["LM_TILES"] = tiles_on
-            try:
-                d5 = lm.Detector(nf5[0], T5, device=0)
-            finally:
-                del os.environ["LM_TILES"]
+        for paths in PATHS:
+            d5 = detector_on(lm, paths, nf5[0], T5, device=0)
             d5.addClassPacked("o", *b5)
             same_records(d5.matchArray([rgb5, dep5], thr5, ["o"]), want5)
+            expect_paths(d5, paths, tiles_possible=T5 != [4, 16])
             tm5 = d5.lastTimings()
             assert tm5["coarse_candidates"] == st5["coarse_candidates"]
             stats.append((tm5["local_evals"], tm5["local_bytes"], tm5["matches_pre_unique"]))
-        assert stats[0] == stats[1], (T5, stats)
+        assert len(set(stats)) == 1 and stats[0][0] == st5["local_evals"], (T5, stats)
+
+
+def test_feature_count_boundaries_and_mixed_banks(lm):
+    """The bit-sliced counters of the bit-plane kernels hold 511 features per template entry (both modalities of a pyramid level) in their
+    small instantiation; larger entries — the reference allows 8191 per modality (LL.cpp:1291, 1816) — take the 14-bit one.  Banks at the
+    boundary (511 / 512 features per level-0 entry), a bank mixing small and large templates, one with 2150-feature entries, and a
+    three-level pyramid with a 600-feature middle level: every kernel path equals the oracle, statistics included."""
+    W, H = 640, 480
+    rgb, dep = synth.make_frame(31, W, H, 40)
+    cases = [
+        ("511", [4, 8], [((256, 255), (128, 127))], 80, 72.0),
+        ("512", [4, 8], [((256, 256), (128, 128))], 80, 72.0),
+        ("mixed", [4, 8], [((150, 150), (75, 75)), ((128, 500), (64, 250))], 60, 72.0),
+        ("big", [4, 8], [((150, 2000), (75, 1000))], 40, 75.0),
+        ("3level", [4, 4, 8], [((64, 64), (100, 500), (64, 250))], 60, 72.0),   # (a colour template below 64 features would put the level on the reference's 8-bit path, which asserts <= 63 for the normals too: LL.cpp:1457)
+    ]
+    for name, T, specs, n, thr in cases:
+        od = lo.OracleDetector(64, T)
+        pyr = od.quantize_pyramid(rgb, dep)
+        banks = [synth.make_planted_bank(40 + k, n, [(p[0], p[1]) for p in pyr], T, nf) for k, nf in enumerate(specs)]
+        raws, cands, evals = [], 0, 0
+        for ci, b in enumerate(banks):
+            raw, st = oracle_matches(od, rgb, dep, b, T, thr, ci)
+            raws.append(raw); cands += st["coarse_candidates"]; evals += st["local_evals"]
+        want = lo.canonical_sort_unique(np.concatenate(raws))
+        assert len(want) > 0 and cands > n, name
+        for paths in PATHS:
+            det = detector_on(lm, paths, 64, T, device=0)
+            for ci, b in enumerate(banks):
+                det.addClassPacked("c%d" % ci, *b)
+            same_records(det.matchArray([rgb, dep], thr, ["c%d" % ci for ci in range(len(banks))]), want)
+            expect_paths(det, paths, tiles_possible=len(T) == 2, levels=len(T))
+            tm = det.lastTimings()
+            assert (tm["coarse_candidates"], tm["local_evals"]) == (cands, evals), (name, paths)
+            # streamed in a batch of four: the same lists
+            for _ in range(4):
+                det.submitFrame([rgb, dep], thr, ["c%d" % ci for ci in range(len(banks))])
+            for _ in range(4):
+                same_records(det.collect(), want)
 
 
 def test_sharded_equals_unsharded_on_one_device(lm):
@@ -681,13 +752,15 @@ def test_config1_size_2k_templates_bit_exact(lm):
     od = lo.OracleDetector(nfeat[0], T)
     pyr = od.quantize_pyramid(rgb, dep)
     bank = synth.make_planted_bank(1234, n, [(p[0], p[1]) for p in pyr], T, nfeat)
-    det = lm.Detector(nfeat[0], T, device=0)
-    det.addClassPacked("obj", *bank)
     want, st = oracle_matches(od, rgb, dep, bank, T, 75.0)
-    got = det.matchArray([rgb, dep], 75.0, ["obj"])
-    same_records(got, lo.canonical_sort_unique(want))
-    tm = det.lastTimings()
-    assert tm["coarse_candidates"] == st["coarse_candidates"] and tm["local_evals"] == st["local_evals"]
+    for paths in PATHS[::-1]:                                     # every kernel path at the bench's size; the default (bit planes) last and kept
+        det = detector_on(lm, paths, nfeat[0], T, device=0)
+        det.addClassPacked("obj", *bank)
+        got = det.matchArray([rgb, dep], 75.0, ["obj"])
+        same_records(got, lo.canonical_sort_unique(want))
+        expect_paths(det, paths)
+        tm = det.lastTimings()
+        assert tm["coarse_candidates"] == st["coarse_candidates"] and tm["local_evals"] == st["local_evals"], paths
     hi = det.matchArray([rgb, dep], 85.0, ["obj"])
     key = lambda r: set(zip(r["x"].tolist(), r["y"].tolist(), r["similarity"].tolist(), r["template_id"].tolist()))
     assert key(hi) <= key(got) and all(hi["similarity"] >= 85.0)
