@@ -1395,7 +1395,9 @@ static int bits_grid(lm_detector* d, int nb) {
 // nearest-neighbour pyramid, pyrDown to the next level} per level, then the linear memories of every level), every stage ONE launch
 // that carries the jobs of all frames of the batch.  Frame b keeps its intermediates in level_bufs(b, l) and writes the arenas of its
 // own result slot.  7 launches per frame (round 2's per-slot graph) -> 3 per batch.
-static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) {
+// direct_low / direct_top: nothing will read the byte planes of the levels below the top / of the top level — the bit planes are written
+// straight from the quantised maps by one k_fe_bits launch at the end (frontend.hip) and the byte planes not at all.
+static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, bool direct_low, bool direct_top) {
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
     int rc;
@@ -1415,6 +1417,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
     auto flush = [&]() { if (st.njobs) launch_fe_stage(st, s); st.njobs = 0; };
     auto room = [&](int jobs) { if (st.njobs + jobs > kFeMaxJobs) flush(); };
     auto build_lm_jobs = [&](int l) {                        // linear memories of level l of every frame (its quantised maps are complete)
+        if (l < L - 1 ? direct_low : direct_top) return;    // bit planes only: fe_bits_jobs below
         for (int b = 0; b < nb; ++b) {
             const int arena = (first + b) % lm_detector::kSlots;
             const lm_detector::Slot& sl = d->slot[arena];
@@ -1450,6 +1453,32 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s) 
     }
     build_lm_jobs(L - 1);
     flush();
+    if (direct_low || direct_top) {                      // the bit planes of every frame in one launch
+        st.njobs = 0;
+        auto flush_bits = [&]() { if (st.njobs) launch_fe_bits(st, s); st.njobs = 0; };
+        for (int b = 0; b < nb; ++b) {
+            const int arena = (first + b) % lm_detector::kSlots;
+            const lm_detector::Slot& sl = d->slot[arena];
+            for (int l = 0; l < L; ++l) {
+                const bool top = l == L - 1;
+                if (top ? !direct_top : !direct_low) continue;
+                LevelBufs& B = d->level_bufs(b, l);
+                const LevelGeom& lv = d->geom.lv[l];
+                const uint8_t* quant[2] = {B.ang.p, B.nrm.p};
+                const uint8_t* mask[2] = {sl.have_mask[0] ? d->lvl[l].mask[0].p : nullptr, sl.have_mask[1] ? d->lvl[l].mask[1].p : nullptr};
+                if (st.njobs + 1 > kFeMaxJobs) flush_bits();
+                if (top) {
+                    const uint32_t bit0[2] = {lv.lm_off[0] - d->cbits_byte0, lv.lm_off[1] - d->cbits_byte0};
+                    fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T);
+                } else {
+                    uint8_t* bits[2] = {d->bits_arena[arena].p + (lv.sm_off[0] >> 1), d->bits_arena[arena].p + (lv.sm_off[1] >> 1)};
+                    fe_job_bits_rows(st.job[st.njobs++], quant, mask, bits, B.W, B.H, lv.T);
+                }
+            }
+        }
+        flush_bits();
+    }
+    d->fe_bytes_low = !direct_low; d->fe_bytes_top = !direct_top;
     d->last_arena = first;                               // read_stage: the maps of level_bufs(0, .) belong to the batch's first frame
     HIP_TRY(hipGetLastError());
     return LM_OK;
@@ -1612,7 +1641,18 @@ int lm_launch_pending(lm_detector* d) {
         if (ring >= 0) HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0));
     }
     HIP_TRY(hipEventRecord(lead.ev[0], s));
-    if ((rc = run_frontend_batch(d, first, nb, s))) return rc;
+    const bool cbits = cbits_active(d, num_work);
+    // The front end writes the bit planes directly where nothing reads the byte planes: below the top when no candidate can leave its planes
+    // (then k_local never runs behind k_local_bits), at the top level when the coarse pass runs on the pair stream.
+    bool direct_low = knobs().fe_bits && d->fe_direct && bits && d->bits_all_in, direct_top = knobs().fe_bits && d->fe_direct && cbits;
+    for (int l = 0; l + 1 < d->geom.levels; ++l) direct_low = direct_low && fe_bits_rows_possible(d->geom.lv[l].W, d->geom.lv[l].T);
+    if (direct_top)                                      // the pair stream is OR-ed together: it has to be zero (k_local_bits leaves it so; k_pack_top and first use do not)
+        for (int b = 0; b < nb; ++b) {
+            const int si = (first + b) % lm_detector::kSlots;
+            if (!d->cbits_clean[si]) HIP_TRY(hipMemsetAsync(d->cbits_arena[si].p, 0, (size_t)d->cbits_npairs * 8, s));
+            d->cbits_clean[si] = true;
+        }
+    if ((rc = run_frontend_batch(d, first, nb, s, direct_low, direct_top))) return rc;
     BitsBatch bb{};
     FrameBatch fb_rest = fb;                                  // for k_local's per-candidate path on what k_local_bits leaves (todo = 1)
     if (bits) {
@@ -1622,16 +1662,19 @@ int lm_launch_pending(lm_detector* d) {
             fb.f[b].todo = fb_rest.f[b].todo = d->d_todo.p + (size_t)d->buf_cand_cap * si;
             fb_rest.f[b].tiles = d->d_tiles.p + (size_t)tile_cap * si;   // non-null: "only the candidates marked todo"; no tile was planned
         }
-        for (int l = 0; l + 1 < d->geom.levels; ++l) launch_pack_bits(bb, nb, d->geom.lv[l], s);
+        if (!direct_low)
+            for (int l = 0; l + 1 < d->geom.levels; ++l) launch_pack_bits(bb, nb, d->geom.lv[l], s);
     }
     TopBits tb{};
-    const bool cbits = cbits_active(d, num_work);
     if (cbits) {
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
             tb.lm[b] = d->lm_arena[si].p; tb.bits[b] = d->cbits_arena[si].p;
+            if (direct_top && !d->fe_keep_top) bb.top_clear[b] = d->cbits_arena[si].p;   // zeroed again by k_local_bits, after k_coarse_bits has read it
+            else d->cbits_clean[si] = false;
         }
-        launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
+        if (direct_top && !d->fe_keep_top) bb.top_clear_units = (d->cbits_npairs * 8u + 15u) / 16u;
+        if (!direct_top) launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
     }
     HIP_TRY(hipEventRecord(lead.ev[1], s));
     HIP_TRY(hipEventRecord(lead.fe_done, s));
@@ -2223,6 +2266,16 @@ extern "C" int lm_detector_set_paths(lm_detector* d, int refine, int coarse) {
     return LM_OK;
 }
 
+extern "C" int lm_detector_set_direct_bits(lm_detector* d, int on) {
+    if (!d) return lm_set_error(LM_ERR_INVALID, "null detector");
+    if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them first");
+    int rc = lm_launch_pending(d);
+    if (rc) return rc;
+    d->fe_direct = on != 0;
+    d->fe_keep_top = on == 2;       // tests: the pair stream stays readable after the match (lm_detector_read_stage kind 5) and is cleared before the next frame instead
+    return LM_OK;
+}
+
 extern "C" int lm_detector_get_paths(const lm_detector* d, int* refine, int* coarse) {
     if (!d || !refine || !coarse) return lm_set_error(LM_ERR_INVALID, "null argument");
     if (d->bank_dirty) return lm_set_error(LM_ERR_INVALID, "no match yet: the paths follow from the bank and the frame geometry");
@@ -2305,7 +2358,7 @@ extern "C" int lm_detector_last_timings(const lm_detector* d, lm_timings* t) {
 }
 
 extern "C" int64_t lm_detector_read_stage(lm_detector* d, int level, int kind, uint8_t* dst, int64_t capacity) {
-    if (!d || level < 0 || level >= d->pyramid_levels || kind < 0 || kind > 3) return lm_set_error(LM_ERR_INVALID, "bad argument");
+    if (!d || level < 0 || level >= d->pyramid_levels || kind < 0 || kind > 5) return lm_set_error(LM_ERR_INVALID, "bad argument");
     if (d->fW <= 0) return lm_set_error(LM_ERR_INVALID, "no frame processed yet");
     const LevelBufs& b = d->lvl[level];
     const LevelGeom& lv = d->geom.lv[level];
@@ -2315,12 +2368,31 @@ extern "C" int64_t lm_detector_read_stage(lm_detector* d, int level, int kind, u
         case 0: src = b.ang.p; size = (int64_t)b.W * b.H; break;
         case 1: src = b.nrm.p; size = (int64_t)b.W * b.H; break;
         case 2: src = d->lm_arena[d->last_arena].p + lv.lm_off[0]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
-        default: src = d->lm_arena[d->last_arena].p + lv.lm_off[1]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+        case 3: src = d->lm_arena[d->last_arena].p + lv.lm_off[1]; size = (int64_t)8 * lv.T * lv.T * lv.Wd * lv.Hd; break;
+        case 4:       // strip records of a level below the top, colour block then normal block (what k_local_bits reads)
+            if (level == d->pyramid_levels - 1) return lm_set_error(LM_ERR_INVALID, "the top level has no strip records");
+            src = d->bits_arena[d->last_arena].p + (lv.sm_off[0] >> 1); size = (int64_t)2 * 8 * lv.T * lv.T * lv.NS * lv.Hd * 8; break;
+        default:      // pair stream of the top level (what k_coarse_bits reads)
+            if (level != d->pyramid_levels - 1) return lm_set_error(LM_ERR_INVALID, "only the top level has a pair stream");
+            src = d->cbits_arena[d->last_arena].p; size = (int64_t)d->cbits_npairs * 8; break;
     }
     if (dst && capacity > 0) {
         if (hipSetDevice(d->device) != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipSetDevice failed");
         (void)hipStreamSynchronize(d->stream);
         (void)hipStreamSynchronize(d->mstream);
+        if ((kind == 2 || kind == 3) && (level == d->pyramid_levels - 1 ? !d->fe_bytes_top : !d->fe_bytes_low)) {
+            // the last front end wrote this level's bit planes only: build its byte planes now, from the quantised maps it left
+            if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them first");
+            const LevelBufs& q = d->level_bufs(0, level);
+            const lm_detector::Slot& sl = d->slot[d->last_arena];
+            const bool strips = level < d->pyramid_levels - 1;
+            const uint8_t* quant[2] = {q.ang.p, q.nrm.p};
+            const uint8_t* mask[2] = {sl.have_mask[0] ? b.mask[0].p : nullptr, sl.have_mask[1] ? b.mask[1].p : nullptr};
+            uint8_t* lmp[2] = {d->lm_arena[d->last_arena].p + lv.lm_off[0], d->lm_arena[d->last_arena].p + lv.lm_off[1]};
+            uint8_t* smp[2] = {strips ? d->sm_arena[d->last_arena].p + lv.sm_off[0] : nullptr, strips ? d->sm_arena[d->last_arena].p + lv.sm_off[1] : nullptr};
+            launch_build_lm(quant, mask, lmp, smp, q.W, q.H, lv.T, d->stream);
+            (void)hipStreamSynchronize(d->stream);
+        }
         hipError_t e = hipMemcpy(dst, src, (size_t)std::min(size, capacity), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return lm_set_error(LM_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
     }

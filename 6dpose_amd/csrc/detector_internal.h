@@ -175,6 +175,10 @@ struct lm_detector {
     // level below the top (default), 1 = byte strip planes with tiles (round 2-3's k_local), 2 = byte planes, every candidate on its own
     // (round 1).  coarse: 0 = pair stream when the refinement runs on bit planes (default), 1 = byte linear memories (k_coarse).
     int refine_mode = 0, coarse_mode = 0;
+    bool fe_direct = true;                          // lm_detector_set_direct_bits: the front end writes bit planes directly where nothing reads the bytes (0: bytes + k_pack_bits / k_pack_top)
+    bool fe_keep_top = false;                       // lm_detector_set_direct_bits(d, 2)
+    bool fe_bytes_low = true, fe_bytes_top = true;  // did the last front end write the byte planes of the levels below the top / of the top level (read_stage builds them on demand otherwise)
+    bool cbits_clean[kSlots] = {};                  // the slot's pair stream is all zero (what the front end's OR-ing writer needs)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
     int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)

@@ -20,7 +20,14 @@ void upload_normal_lut(const uint8_t lut400[400]) {
 
 // n / d by a multiplier the host prepares (lm_kernels.h, FeJob): exact while n * d < 2^32; m = 0 stands for d = 1
 static __host__ __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
-static __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m) { return m ? __umulhi(n, m) : n; }   // n / d for n * d < 2^32
+// n / d with m = div_magic(d) = ceil(2^32 / d): umulhi(n, m) is floor(n / d) or one more (the excess n e / (d 2^32), e = m d - 2^32 < d, stays
+// below 1 for every 32-bit n), so one comparison makes it exact for ANY n — an 8000 x 6000 frame puts n d past 2^32, where the bare product
+// was wrong for the last blocks of a job.
+static __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m, uint32_t d) {
+    if (!m) return n;
+    const uint32_t q = __umulhi(n, m);
+    return q - (q * d > n ? 1u : 0u);
+}
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -418,8 +425,8 @@ static __device__ __forceinline__ void build_lm_body(const int bx, const int by,
     int phase = by;                                      // r_start*T + c_start
     int npos = Wd * Hd;
     if (idx >= npos) return;
-    int ry = (int)fast_div((uint32_t)idx, m_wd), rx = idx - ry * Wd;
-    int rs = (int)fast_div((uint32_t)phase, m_t), cs = phase - rs * T;
+    int ry = (int)fast_div((uint32_t)idx, m_wd, (uint32_t)Wd), rx = idx - ry * Wd;
+    int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
     int y = ry * T + rs, x = rx * T + cs;
     const uint32_t v = spread_or(J, x, y, W, H, T);
     uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
@@ -445,8 +452,8 @@ static __device__ __forceinline__ void build_lm_body4(const int bx, const int by
     const int phase = by;
     const int npos = Wd * Hd;
     if (idx >= npos) return;                             // whole quads: npos is a multiple of 4
-    const int ry = (int)fast_div((uint32_t)idx, m_wd), rx = idx - ry * Wd;
-    const int rs = (int)fast_div((uint32_t)phase, m_t), cs = phase - rs * T;
+    const int ry = (int)fast_div((uint32_t)idx, m_wd, (uint32_t)Wd), rx = idx - ry * Wd;
+    const int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
     const int y = ry * T + rs, x = rx * T + cs;
     const uint32_t v = spread_or(J, x, y, W, H, T);
     const int lane = (int)threadIdx.x & 63, k4 = lane & 3, q0 = lane & ~3;
@@ -483,8 +490,90 @@ __global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T, hipStream_t s) {
     int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
-    LmJob j0{quant[0], mask[0], lm[0], strips[0]}, j1{quant[1], mask[1], lm[1], strips[1]};
+    LmJob j0{quant[0], mask[0], lm[0], strips[0], nullptr, 0u}, j1{quant[1], mask[1], lm[1], strips[1], nullptr, 0u};
     hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS, div_magic((uint32_t)Wd), div_magic((uint32_t)T));
+}
+
+// ---- the bit planes written directly -------------------------------------------------------------------------------
+// When nothing reads the byte planes of a level (bit-plane kernels for both passes, every window inside its plane) the linear-memory
+// stage does not write them at all: 8 response bytes per position and encoding (flat + strip-major: 9.8 MB per VGA frame at level 0)
+// become 2 bits per position and label (2.5 MB), and k_pack_bits / k_pack_top disappear from the batch.
+//
+// Strip records of a level below the top (match.hip: per plane row and 16-column strip 64 bits, cell c of [16 s, 16 s + 32) at bits 2c =
+// "response is 1" and 2c + 1 = "response is 4").  A workgroup takes R rows of one (modality, phase): every thread ORs the T x T
+// pixels of a few cells (spread) and leaves {neighbour bits & ~own bits | own bits << 8} per cell in LDS — response 4 iff the label's own
+// bit is set, 1 iff only a neighbouring label's is (LL.cpp:1121) —; then one thread per (label, row, strip) gathers the label's two bits of
+// its 32 cells into a record.  Rows fastest in the thread order: the records of a strip's R rows are R x 8 contiguous bytes.
+constexpr int kBitsCells = 1152;              // 16-bit cell words of a workgroup's rows in LDS: R x (16 NS + 16) <= this (VGA level 0: 6 x 176)
+static __host__ __device__ inline int fe_bits_rows(int Wd) { const int wp = ((Wd + 15) / 16) * 16 + 16; const int r = kBitsCells / wp; return r < 8 ? r : 8; }
+
+static __device__ __forceinline__ void bits_rows_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS, uint32_t m_wd,
+                                                      uint32_t m_t) {
+    __shared__ uint16_t s_cells[kBitsCells];
+    const int Wp = NS * 16 + 16, R = fe_bits_rows(Wd);
+    const int phase = by, ry0 = bx * R;
+    const int rows = Hd - ry0 < R ? Hd - ry0 : R;
+    const int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
+    for (int i = (int)threadIdx.x; i < rows * Wp; i += 256) {
+        const int r = i / Wp, rx = i - r * Wp;                            // (Wp: a handful of values per frame size; rows * Wp <= 1152)
+        uint32_t w = 0;
+        if (rx < Wd) {
+            const uint32_t v = spread_or(J, rx * T + cs, (ry0 + r) * T + rs, W, H, T);
+            const uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
+            w = (adj & ~v) | (v << 8);
+        }
+        s_cells[i] = (uint16_t)w;
+    }
+    __syncthreads();
+    const size_t splane1 = (size_t)NS * Hd * 8;                           // one (label, phase) plane of records
+    uint8_t* out = J.bits + (size_t)phase * splane1;
+    for (int i = (int)threadIdx.x; i < 8 * rows * NS; i += 256) {
+        const int r = i % rows, q = i / rows, st = q % NS, label = q / NS;
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(s_cells + r * Wp + 16 * st);     // 32 cells = 16 dwords of two cells each
+        uint32_t lo = 0, hi = 0;
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            // bits label and 8 + label of two cells -> {is 1, is 4, is 1, is 4}
+            lo |= (((((cw[k] >> label) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * k);
+            hi |= (((((cw[8 + k] >> label) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * k);
+        }
+        *reinterpret_cast<uint2*>(out + (size_t)label * T * T * splane1 + ((size_t)st * Hd + ry0 + r) * 8) = make_uint2(lo, hi);
+    }
+}
+
+// The pair stream of the top level (match.hip: {is-1 dword, is-4 dword} per 32 consecutive bytes of the flat arena).  One thread per
+// (phase, position) as in the byte stage; a wave's 64 consecutive positions of a label's plane are 64 consecutive bits of the stream at an
+// arbitrary bit offset (planes are not multiples of 32 positions): the ballots are shifted into place and OR-ed into the three dwords
+// they touch.  The stream was zeroed by a job of the batch's first launch (fe_job_zero).
+static __device__ __forceinline__ void top_bits_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, uint32_t m_wd, uint32_t m_t) {
+    const int idx = bx * 256 + (int)threadIdx.x;
+    const int phase = by, npos = Wd * Hd;
+    const bool in = idx < npos;
+    uint32_t v = 0;
+    if (in) {
+        const int ry = (int)fast_div((uint32_t)idx, m_wd, (uint32_t)Wd), rx = idx - ry * Wd;
+        const int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
+        v = spread_or(J, rx * T + cs, ry * T + rs, W, H, T);
+    }
+    const uint32_t one = (((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu) & ~v;
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t idx0 = (uint32_t)(idx - lane);                         // the wave's first position (wave-uniform)
+    uint32_t* stream = reinterpret_cast<uint32_t*>(J.bits);               // pair p: stream[2 p] = is 1, stream[2 p + 1] = is 4
+    const int plane = lane >= 3, k = lane - 3 * plane;                    // lanes 0..5 carry the three dwords of the two planes
+#pragma unroll
+    for (int ori = 0; ori < 8; ++ori) {
+        const unsigned long long m1 = __ballot(in && ((one >> ori) & 1u)), m4 = __ballot(in && ((v >> ori) & 1u));
+        if ((m1 | m4) == 0ull) continue;                                  // wave-uniform
+        const uint32_t fo = J.top_bit0 + (uint32_t)(ori * T * T + phase) * (uint32_t)npos + idx0;   // flat position of the wave's first bit, from the stream's start
+        const uint32_t sh = fo & 31u, p0 = fo >> 5;
+        const unsigned long long m = plane ? m4 : m1;
+        const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+        uint32_t val;
+        if (k == 0) val = lo << sh;
+        else if (k == 1) val = sh ? (lo >> (32u - sh)) | (hi << sh) : hi;
+        else val = sh ? hi >> (32u - sh) : 0u;
+        if (lane < 6 && val) atomicOr(stream + 2 * (size_t)(p0 + (uint32_t)k) + (uint32_t)plane, val);
+    }
 }
 
 // ---- several independent front-end jobs in ONE launch ---------------------------------------------------------------------
@@ -503,8 +592,8 @@ k_fe_stage(FeStage st, int total) {
         while (j + 1 < st.njobs && blk >= st.job[j + 1].first) ++j;
         const FeJob& J = st.job[j];
         const int local = blk - J.first;
-        const int bz = (int)fast_div((uint32_t)local, J.m_gxgy), rem = local - bz * J.gx * J.gy;
-        const int by = (int)fast_div((uint32_t)rem, J.m_gx), bx = rem - by * J.gx;
+        const int bz = (int)fast_div((uint32_t)local, J.m_gxgy, (uint32_t)(J.gx * J.gy)), rem = local - bz * J.gx * J.gy;
+        const int by = (int)fast_div((uint32_t)rem, J.m_gx, (uint32_t)J.gx), bx = rem - by * J.gx;
         switch (J.kind) {
             case kFeColour: color_quant_body(bx, by, (const uint8_t*)J.in, (float*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.f); break;
             case kFeNormals: normals_median_body(bx, by, (const uint16_t*)J.in, (uint8_t*)J.out0, (uint8_t*)J.out1, J.W, J.H, J.a, J.b); break;
@@ -517,6 +606,24 @@ k_fe_stage(FeStage st, int total) {
             default: break;
         }
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next tile reuses the bodies' LDS
+    }
+}
+
+// The bit-plane jobs of a batch (strip records of every level below the top, pair stream of the top level: bits_rows_body, top_bits_body)
+// in a launch of their own, the last of the front end: inside k_fe_stage they would cost the colour chain a wave of occupancy (95 VGPRs
+// against 79).  Same job table, same persistent walk.
+__global__ void __launch_bounds__(256)
+k_fe_bits(FeStage st, int total) {
+    for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
+        int j = 0;
+        while (j + 1 < st.njobs && blk >= st.job[j + 1].first) ++j;
+        const FeJob& J = st.job[j];
+        const int local = blk - J.first;
+        const int bz = (int)fast_div((uint32_t)local, J.m_gxgy, (uint32_t)(J.gx * J.gy)), rem = local - bz * J.gx * J.gy;
+        const int by = (int)fast_div((uint32_t)rem, J.m_gx, (uint32_t)J.gx), bx = rem - by * J.gx;
+        if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
+        else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
+        if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
 }
 
@@ -540,9 +647,24 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
                      int W, int H, int T) {
     j = FeJob{}; j.kind = kFeBuildLm; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
-    j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0]}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1]};
+    j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0], nullptr, 0u}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1], nullptr, 0u};
 }
-void launch_fe_stage(FeStage& st, hipStream_t s) {
+// strip records of a level below the top, written directly (bits[m]: the level's record block of modality m inside the bit arena)
+bool fe_bits_rows_possible(int W, int T) { return fe_bits_rows(W / T) >= 1; }
+void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T) {
+    j = FeJob{}; j.kind = kFeBitsRows; j.a = T; j.W = W; j.H = H;
+    j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
+    const int R = fe_bits_rows(j.Wd);
+    j.gx = (j.Hd + R - 1) / R; j.gy = T * T; j.gz = 2;
+    j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, bits[0], 0u}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, bits[1], 0u};
+}
+// pair stream of the top level, written directly; bit0[m] = flat arena offset of modality m's block less the stream's first byte
+void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T) {
+    j = FeJob{}; j.kind = kFeTopBits; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
+    j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
+    j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, stream, bit0[0]}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, stream, bit0[1]};
+}
+static int fe_prepare(FeStage& st) {                             // drops empty jobs, lays the jobs' blocks out on one flat index; returns the number of blocks
     int total = 0, n = 0;
     for (int i = 0; i < st.njobs; ++i) {
         const int blocks = st.job[i].gx * st.job[i].gy * st.job[i].gz;
@@ -552,15 +674,26 @@ void launch_fe_stage(FeStage& st, hipStream_t s) {
         ++n;
     }
     st.njobs = n;
+    return total;
+}
+static int fe_cus() {                                                // CUs of the CURRENT device (a process may drive several)
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)) cus[dev] = 256;
+    return cus[dev];
+}
+void launch_fe_stage(FeStage& st, hipStream_t s) {
+    const int total = fe_prepare(st);
     if (total <= 0) return;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
     const int per_cu = knobs().fe_wgs_per_cu;
-    const int grid = per_cu > 0 ? std::min(total, cus * per_cu) : total;
+    const int grid = per_cu > 0 ? std::min(total, fe_cus() * per_cu) : total;
     hipLaunchKernelGGL(k_fe_stage, dim3(grid), dim3(256), 0, s, st, total);
+}
+void launch_fe_bits(FeStage& st, hipStream_t s) {
+    const int total = fe_prepare(st);
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_fe_bits, dim3(std::min(total, fe_cus() * 8)), dim3(256), 0, s, st, total);
 }
 
 }  // namespace lm

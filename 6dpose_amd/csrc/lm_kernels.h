@@ -20,8 +20,9 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
                      int W, int H, int T, hipStream_t s);
 
 // several independent jobs of the front end in one launch (frontend.hip, k_fe_stage)
-struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
-enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm };
+struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips;
+               uint8_t* bits; uint32_t top_bit0; };   // bits: the bit planes written directly (strip records of the level / the top level's pair stream); top_bit0: see fe_job_top_bits
+enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits };
 struct FeJob {
     int kind, gx, gy, gz, first;          // job kind, its block grid, its first flat block index (set by launch_fe_stage)
     const void* in; void* out0; void* out1;
@@ -34,15 +35,21 @@ struct FeJob {
     int Wd, Hd;                           // build_lm: decimated size
     LmJob lm[2];                          // build_lm: [0] colour, [1] normals
 };
-constexpr int kFeMaxJobs = 24;            // 3 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
+constexpr int kFeMaxJobs = 20;            // 3-4 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
 struct FeStage { int njobs; FeJob job[kFeMaxJobs]; };
+static_assert(sizeof(FeStage) + 16 <= 4096, "FeStage is passed by value: kernel arguments are limited to 4 KB");
 void fe_job_colour(FeJob& j, const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq);
 void fe_job_normals(FeJob& j, const uint16_t* depth, uint8_t* raw, uint8_t* med, int W, int H, int dist_thr, int diff_thr);
 void fe_job_pyrdown(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
 void fe_job_nn_down2(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
 void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T);
+// the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip)
+bool fe_bits_rows_possible(int W, int T);     // the level's rows fit the stage's LDS
+void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T);
+void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T);
 void launch_fe_stage(FeStage& st, hipStream_t s);
+void launch_fe_bits(FeStage& st, hipStream_t s);      // a launch of bit-plane jobs only (fe_job_bits_rows, fe_job_top_bits)
 
 // ---- matching (match.hip): reference A8-A11, LL.cpp:1284-1428, 1788-1941 ----
 struct LevelGeom {        // one pyramid level of the current frame
@@ -121,7 +128,8 @@ struct FrameBatch {
 // Bit planes (match.hip).  Levels below the top: per frame of a batch the strip arena the records are packed from
 // (launch_pack_bits; the front end writes them itself when nothing reads the strip bytes) and its bit arena — the strip arena's layout at
 // half the offsets: per plane row and strip an 8-byte record of 32 cells x {is 1, is 4} instead of a 16-byte row.
-struct BitsBatch { const uint8_t* strips[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
+struct BitsBatch { const uint8_t* strips[kMaxBatch]; uint8_t* bits[kMaxBatch];
+                   uint8_t* top_clear[kMaxBatch]; uint32_t top_clear_units; };   // != 0: k_local_bits zeroes 16 x units bytes of every frame's pair stream (the front end ORs the next frame into it)
 constexpr int kBitsSmallMax = 511;            // features per template entry the 9-bit counters hold; larger entries (<= 16383) take the 14-bit instantiation
 void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s);
 // Every level below the top: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path (windows leaving their planes);

@@ -1026,6 +1026,11 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         const uint32_t tsize = dedupe_slots_for(s_cnt[f], dedupe_cap_slots);
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) table[i] = ~0ull;
     }
+    // The pair stream k_coarse_bits has just read is zeroed for the slot's next frame: the front end ORs it together (frontend.hip, top_bits_body)
+    if (B.top_clear_units)
+        for (int f = 0; f < nb; ++f)
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < B.top_clear_units; i += gridDim.x * blockDim.x)
+                reinterpret_cast<uint4*>(B.top_clear[f])[i] = make_uint4(0u, 0u, 0u, 0u);
     const int src0 = (lane & ~7) << 2;                              // ds_bpermute address of the group's first lane
     const uint32_t rowoff = 16u * (uint32_t)j;                      // records of rows 2j, 2j + 1 behind the window's first row
     for (int fr = f_lo; fr < f_hi; ++fr) {

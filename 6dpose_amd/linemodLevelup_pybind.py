@@ -523,13 +523,18 @@ class Detector:
     _REFINE = {"bits": 0, "tiles": 1, "single": 2}
     _COARSE = {"bits": 0, "bytes": 1}
 
-    def setPaths(self, refine: str = "bits", coarse: str = "bits") -> None:
+    def setPaths(self, refine: str = "bits", coarse: str = "bits", direct: bool = True) -> None:
         """lm_detector_set_paths: which kernels serve the refinement ("bits" = k_local_bits, "tiles" / "single" = k_local with / without
-        tiles) and the coarse pass ("bits" = k_coarse_bits, "bytes" = k_coarse).  Results do not depend on it."""
+        tiles) and the coarse pass ("bits" = k_coarse_bits, "bytes" = k_coarse); lm_detector_set_direct_bits: the front end writes the
+        bit planes itself (direct) or byte linear memories that a second kernel packs.  Results do not depend on any of it."""
         f = self._lib.lm_detector_set_paths
         f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         f.restype = ctypes.c_int
         _check(f(self._h, self._REFINE[refine], self._COARSE[coarse]))
+        g = self._lib.lm_detector_set_direct_bits
+        g.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        g.restype = ctypes.c_int
+        _check(g(self._h, int(direct)))          # True / False; 2 = direct and the top level's bit planes stay readable (tests)
 
     def getPaths(self):
         """lm_detector_get_paths: (refine, coarse) the current bank and frame geometry actually use, as the names of setPaths (valid after a match)."""
@@ -704,7 +709,7 @@ class Detector:
 
     def readStage(self, level: int, kind: int) -> np.ndarray:
         """Device intermediates of the last front end run (tests): kind 0/1 quantised colour/normal,
-        2/3 linear memories colour/normal."""
+        2/3 linear memories colour/normal, 4 strip records of a level below the top, 5 pair stream of the top level (bit planes)."""
         n = _check(self._lib.lm_detector_read_stage(self._h, level, kind, None, 0))
         buf = np.zeros(n, np.uint8)
         _check(self._lib.lm_detector_read_stage(self._h, level, kind, _ptr(buf), n))

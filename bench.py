@@ -665,8 +665,9 @@ def pmc_live(kernel, args, timeout=120):
             cols = [c[1] for c in con.execute("pragma table_info('counters_collection')")]
             name_col = "kernel_name" if "kernel_name" in cols else "name"
             # exactly this kernel: "k_local(" must not pick up "k_local_bits(" (demangled names), nor "7k_localE" "12k_local_bitsE" (mangled ones)
-            rows = con.execute("select counter_name, dispatch_id, sum(value) from counters_collection where %s like ? or %s like ? group by counter_name, dispatch_id"
-                               % (name_col, name_col), ("%" + kernel + "(%", "%%%d%sE%%" % (len(kernel), kernel))).fetchall()
+            rows = con.execute("select counter_name, dispatch_id, sum(value) from counters_collection where %s like ? or %s like ? or %s like ? or %s like ? "
+                               "group by counter_name, dispatch_id" % ((name_col,) * 4),
+                               ("%" + kernel + "(%", "%" + kernel + "<%", "%%%d%sE%%" % (len(kernel), kernel), "%%%d%sI%%" % (len(kernel), kernel))).fetchall()
             con.close()
             per = {}
             for cname, _disp, val in rows:

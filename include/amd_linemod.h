@@ -271,12 +271,23 @@ int lm_detector_refines_on_bit_planes(const lm_detector *d);
  * match): refine 0 / 1 / 2 and coarse 0 / 1 as above. */
 int lm_detector_set_paths(lm_detector *d, int refine, int coarse);
 int lm_detector_get_paths(const lm_detector *d, int *refine, int *coarse);
+/* The response maps of spread / computeResponseMaps / linearize (LL.cpp:1026-1243) as bit planes straight from the quantised images
+ * (default, on = 1: wherever the kernels in use read only bit planes, the byte linear memories are not written at all) or as the
+ * reference's byte linear memories first, packed into bit planes by a second kernel (on = 0).  on = 2: like 1, but the top level's
+ * bit planes stay readable after the match (lm_detector_read_stage kind 5; tests).  Results never depend on it. */
+int lm_detector_set_direct_bits(lm_detector *d, int on);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 
 /* Test/diagnostic access to the device-resident intermediates of the last front end run (parity
  * tests compare them byte-for-byte with the oracle).  kind: 0 quantised colour, 1 quantised
  * normals (W_l*H_l bytes each), 2 linear memories colour, 3 linear memories normals
- * (8*W_l*H_l bytes each).  Copies min(capacity, size) bytes, returns the full size. */
+ * (8*W_l*H_l bytes each; built on demand when the last match ran on bit planes only), 4 the strip
+ * records of a level below the top (colour block, normal block: [label][phase][strip][row] 8-byte
+ * records of 32 cells x {response is 1, response is 4}), 5 the pair stream of the top level ({is-1
+ * dword, is-4 dword} per 32 bytes of the flat linear memories, both modality blocks with their zero
+ * tails) — 4 and 5 only after a match that used them (k_local_bits / k_coarse_bits; a stream the front
+ * end wrote directly is cleared by the match unless lm_detector_set_direct_bits(d, 2) was set).
+ * Copies min(capacity, size) bytes, returns the full size. */
 int64_t lm_detector_read_stage(lm_detector *d, int level, int kind, uint8_t *dst, int64_t capacity);
 
 /* Canonical merge of match lists gathered from several ranks (LL.cpp:1771-1776 semantics, A12).

@@ -5,7 +5,7 @@
 # The profiled command is bench.py's roofline leg alone (--roofline-only): every k_local / k_coarse / k_fe_stage / k_dedupe dispatch
 # of the run but the set-up probe is one of the launches bench.py's `roofline` object describes (frames_per_launch frames each).
 set -u
-OUT=${1:-gpurun_out/pmc}; TAG=${2:-r03}; KERNELS=${3:-k_local_bits,k_local,k_coarse,k_fe_stage,k_pack_bits,k_dedupe}
+OUT=${1:-gpurun_out/pmc}; TAG=${2:-r03}; KERNELS=${3:-k_local_bits,k_coarse_bits,k_fe_stage,k_fe_bits,k_dedupe,k_local,k_coarse,k_pack_bits,k_pack_top}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp

@@ -15,7 +15,8 @@ def main(pattern, out=None, kernels=("k_local_bits", "k_local", "k_coarse")):
                            % (name_col, name_col)).fetchall()
         for kname, cname, _disp, val in rows:
             for k in kernels:
-                if (k + "(") in kname or ("%d%sE" % (len(k), k)) in kname:           # exactly this kernel, demangled or mangled name ("k_local(" is not "k_local_bits(")
+                # exactly this kernel, demangled or mangled name, plain or a template instantiation ("k_local(" is not "k_local_bits<5, 4>(")
+                if any(t in kname for t in (k + "(", k + "<", "%d%sE" % (len(k), k), "%d%sI" % (len(k), k))):
                     acc[k][cname].append(val)
     lines = []
     for k in kernels:

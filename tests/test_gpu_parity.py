@@ -45,7 +45,8 @@ def as_multiset(rec, names):
 
 
 # every kernel path of the matcher (Detector.setPaths: refinement, coarse pass); results may never depend on it
-PATHS = [("bits", "bits"), ("bits", "bytes"), ("tiles", "bytes"), ("single", "bytes")]
+PATHS = [("bits", "bits"), ("bits", "bytes"), ("tiles", "bytes"), ("single", "bytes"),
+         ("bits", "bits", False)]        # ... and the bit planes packed from byte linear memories instead of written by the front end itself
 
 
 def detector_on(lm, paths, *args, **kw):
@@ -56,7 +57,7 @@ def detector_on(lm, paths, *args, **kw):
 
 def expect_paths(det, paths, tiles_possible=True, levels=2):
     """After a match: the kernels in use are the ones the case asked for — a test must not compare a path with itself."""
-    refine, coarse = paths
+    refine, coarse = paths[:2]
     if levels < 2:
         want = ("single", "bytes")
     elif refine == "tiles" and not tiles_possible:
@@ -116,6 +117,85 @@ def test_frontend_masks(lm):
         n = 8 * qc.size
         assert np.array_equal(det.readStage(l, 2), lo.build_linear_memories(np.where(a > 0, qc, 0).astype(np.uint8), T[l])[:n])
         assert np.array_equal(det.readStage(l, 3), lo.build_linear_memories(np.where(b > 0, qn, 0).astype(np.uint8), T[l])[:n])
+
+
+def _strip_records(lm_flat, T, Wd, Hd):
+    """numpy statement of the strip records (match.hip): [label][phase][strip][row] uint64, cell c of [16 s, 16 s + 32) of the row at bits
+    2c (response is 1) and 2c + 1 (response is 4), from a flat linear memory [8][T*T][Hd*Wd]."""
+    NS = (Wd + 15) // 16
+    planes = lm_flat[:8 * T * T * Wd * Hd].reshape(8, T * T, Hd, Wd)
+    pad = np.zeros((8, T * T, Hd, NS * 16 + 32), np.uint8)
+    pad[..., :Wd] = planes
+    w1 = np.uint64(1) << (2 * np.arange(32, dtype=np.uint64))
+    out = np.zeros((8, T * T, NS, Hd), np.uint64)
+    for s in range(NS):
+        seg = pad[..., 16 * s:16 * s + 32]
+        out[:, :, s, :] = ((seg == 1).astype(np.uint64) * w1).sum(axis=-1) + ((seg == 4).astype(np.uint64) * (w1 << np.uint64(1))).sum(axis=-1)
+    return out
+
+
+def _pair_stream(lm_colour, lm_normal, T, Wd, Hd, npairs):
+    """numpy statement of the top level's pair stream: {is-1 dword, is-4 dword} per 32 bytes of the two modality blocks (zero tails included)."""
+    block = npairs * 16
+    flat = np.zeros(2 * block, np.uint8)
+    n = 8 * T * T * Wd * Hd
+    flat[:n] = lm_colour[:n]; flat[block:block + n] = lm_normal[:n]
+    g = flat.reshape(npairs, 32)
+    w = np.uint32(1) << np.arange(32, dtype=np.uint32)
+    out = np.zeros((npairs, 2), np.uint32)
+    out[:, 0] = ((g == 1).astype(np.uint32) * w).sum(axis=1); out[:, 1] = ((g == 4).astype(np.uint32) * w).sum(axis=1)
+    return out
+
+
+@pytest.mark.parametrize("case", ["T48", "T58", "3level", "1280", "small_T24", "masked"])
+def test_bit_planes_equal_the_packed_linear_memories(lm, case):
+    """The encodings the bit-plane kernels read — strip records of every level below the top, pair stream of the top level —
+    bit for bit against a numpy packing of the ORACLE's linear memories, both as written directly by the front end (k_fe_bits) and as packed
+    from the byte planes (k_pack_bits / k_pack_top)."""
+    W, H, T = {"T48": (640, 480, [4, 8]), "T58": (640, 480, [5, 8]), "3level": (640, 480, [4, 4, 8]), "1280": (1280, 960, [4, 8]),
+               "small_T24": (320, 240, [2, 4]), "masked": (640, 480, [4, 8])}[case]
+    rgb, dep = synth.make_frame(61, W, H, 40 if W <= 640 else 80)
+    masks = []
+    if case == "masked":
+        yy, xx = np.mgrid[0:H, 0:W]
+        masks = [((xx // 37 + yy // 29) % 3 != 0).astype(np.uint8) * 255, ((xx // 23 + yy // 41) % 4 != 0).astype(np.uint8) * 255]
+    nfeat = tuple(64 >> l for l in range(len(T)))
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    bank = synth.make_planted_bank(62, 12, [(p[0], p[1]) for p in pyr], T, nfeat)
+    lms, mk = [], list(masks)
+    for l, p in enumerate(pyr):
+        if masks and l > 0:
+            mk = [lo.nn_down2(m) for m in mk]                 # the masks follow the pyramid by nearest neighbour (LL.cpp:573-578, 874-879)
+        q = [np.where(mk[m] > 0, p[m], 0).astype(np.uint8) if masks else p[m] for m in range(2)]
+        lms.append([lo.build_linear_memories(q[0], T[l]), lo.build_linear_memories(q[1], T[l])])
+    L = len(T)
+    seen = []
+    for direct in (2, False):
+        det = lm.Detector(nfeat[0], T, device=0)
+        det.setPaths("bits", "bits", direct)
+        det.addClassPacked("o", *bank)
+        det.setFrame([rgb, dep], masks)
+        det.matchResident(70.0, ["o"])
+        assert det.getPaths() == ("bits", "bits")
+        got = []
+        for l in range(L - 1):
+            Wd, Hd = (W >> l) // T[l], (H >> l) // T[l]
+            NS = (Wd + 15) // 16
+            rec = det.readStage(l, 4).view(np.uint64).reshape(2, 8, T[l] * T[l], NS, Hd)
+            for m in range(2):
+                assert np.array_equal(rec[m], _strip_records(lms[l][m], T[l], Wd, Hd)), (case, direct, "strip records", l, m)
+            got.append(rec.tobytes())
+        Wd, Hd = (W >> (L - 1)) // T[-1], (H >> (L - 1)) // T[-1]
+        ps = det.readStage(L - 1, 5).view(np.uint32).reshape(-1, 2)
+        assert np.array_equal(ps, _pair_stream(lms[L - 1][0], lms[L - 1][1], T[-1], Wd, Hd, len(ps))), (case, direct, "pair stream")
+        got.append(ps.tobytes())
+        seen.append(got)
+        # and the stream is usable again: the next match clears what this one kept
+        if not masks:
+            raw, _ = oracle_matches(od, rgb, dep, bank, T, 70.0)
+            same_records(det.matchArray([rgb, dep], 70.0, ["o"]), lo.canonical_sort_unique(raw))
+    assert seen[0] == seen[1]
 
 
 def test_precondition_errors_like_cv_assert(lm):
@@ -200,7 +280,7 @@ def test_gpu_equals_the_reference_lines(lm):
                     assert np.array_equal(got[a], rfin[b]), (case["name"], req, a)
 
 
-@pytest.mark.parametrize("paths", PATHS, ids=["-".join(p) for p in PATHS])
+@pytest.mark.parametrize("paths", PATHS, ids=["-".join(map(str, p)) for p in PATHS])
 @pytest.mark.parametrize("bank,nfeat", [("127", 127), ("63", 63)])
 def test_match_fixture_banks(lm, bank, nfeat, paths):
     rgb, dep = load_bgr("0000_rgb.png"), load_u16("0000_dep.png")
@@ -250,7 +330,7 @@ def test_match_planted_and_random_banks(lm, W, H, T, nfeat, n, thr):
     rb, sb = oracle_matches(od, rgb, dep, random, T, thr, 1)
     assert sa["coarse_candidates"] > n, "planted bank must exercise the refinement"
     want = lo.canonical_sort_unique(np.concatenate([ra, rb]))
-    for paths in PATHS[1:]:                                       # the byte paths (the default, bit planes everywhere, follows with the further checks)
+    for paths in PATHS[1:]:                                       # every other path (the default, bit planes everywhere, follows with the further checks)
         dp = detector_on(lm, paths, nfeat[0], T, device=0)
         dp.addClassPacked("planted", *planted)
         dp.addClassPacked("random", *random)
@@ -359,7 +439,9 @@ def test_refinement_paths_are_exact(lm):
         ta = plain.lastTimings()
         ra = plain.matchResident(thr, ids, sort_unique=False)
         assert len(a) > 0
-        for paths in PATHS[:3]:
+        for paths in PATHS:
+            if paths == ("single", "bytes"):
+                continue
             d = dets[paths]
             b = d.matchResident(thr, ids)
             expect_paths(d, paths)
@@ -377,7 +459,7 @@ def test_refinement_paths_are_exact(lm):
                 raws.append(raw)
             same_records(a, lo.canonical_sort_unique(np.concatenate(raws)))
     want75 = plain.matchResident(75.0, ["planted"]).tobytes()
-    for paths in PATHS[:3]:                                     # pipelined, slots reused
+    for paths in PATHS:                                         # pipelined, slots reused
         d = dets[paths]
         for k in range(7):
             d.submit(75.0, ["planted"])
