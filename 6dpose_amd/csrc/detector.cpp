@@ -31,9 +31,7 @@ int lm_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* lm_last_error(void) { return g_err.c_str(); }
-static void collector_main(lm_detector* d);
-static void collector_stop(lm_detector* d);
-static void copier_stop(lm_detector* d);
+static void pool_stop(lm_detector* d);
 extern "C" const char* lm_version(void) { return "amd-linemod 0.1 (gfx950)"; }
 // Binds the calling thread to the CPUs next to `device` (its PCI function's local_cpulist in sysfs): pinned staging buffers are then
 // allocated, filled and read by the copy engine on the GPU's own NUMA node.  On a two-socket host a process that happens to start on
@@ -185,6 +183,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (knobs().batch_queue > 0) d->keep_queued = knobs().batch_queue;
     if (knobs().launch_slack_us > 0) d->launch_slack_ms = knobs().launch_slack_us * 1e-3f;
     if (const char* ac = getenv("LM_ASYNC_COLLECT")) d->async_collect = ac[0] && ac[0] != '0';
+    if (const char* ht = getenv("LM_HOST_THREADS")) d->pool.threads = std::max(0, std::min(8, atoi(ht)));
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
@@ -202,8 +201,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)lm_launch_pending(d);
-    collector_stop(d);
-    copier_stop(d);
+    pool_stop(d);
     for (auto& sl : d->slot) { free(sl.prep); sl.prep = nullptr; }
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
@@ -211,7 +209,7 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     d->frame_rgb.release(); d->frame_depth.release(); d->nrm_raw.release();
     for (int i = 0; i < lm_detector::kSlots; ++i) {
         if (d->ingest.pinned[i]) (void)hipHostFree(d->ingest.pinned[i]);
-        d->ingest.d_rgb[i].release(); d->ingest.d_depth[i].release();
+        d->ingest.d_rgb[i].release();
         if (d->ingest.t0[i]) (void)hipEventDestroy(d->ingest.t0[i]);
         if (d->ingest.t1[i]) (void)hipEventDestroy(d->ingest.t1[i]);
     }
@@ -1754,21 +1752,6 @@ int lm_launch_pending(lm_detector* d) {
         d->queued.push_back({d->n_launched, first, nb, t, idle});
     }
     d->n_launched += (uint64_t)nb;
-    // streamed frames: the collector thread prepares their result lists as soon as the batch has finished
-    if (d->async_collect && !d->reference_order && lead.ring >= 0 && num_work > 0) {
-        lm_detector::Collector& C = d->collector;
-        for (int b = 0; b < nb; ++b) {
-            lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
-            sl.ready.store(0, std::memory_order_relaxed);
-            sl.prep_queued = true;
-        }
-        {
-            std::lock_guard<std::mutex> lk(C.mu);
-            if (!C.started) { C.stop = false; C.th = std::thread(collector_main, d); C.started = true; }
-            C.jobs.emplace_back(first, nb);
-        }
-        C.cv_work.notify_one();
-    }
     return LM_OK;
 }
 
@@ -1809,97 +1792,97 @@ static size_t canonical_list_of(const lm_detector::Slot& sl, uint64_t nd, lm_mat
     return n;
 }
 
-static void collector_main(lm_detector* d) {
-    (void)hipSetDevice(d->device);
-    lm_detector::Collector& C = d->collector;
+// ---- helper threads of the streamed path (detector_internal.h, HostPool): no HIP calls on them ----
+static void pool_main(lm_detector* d) {
+    lm_detector::HostPool& P = d->pool;
     for (;;) {
-        std::pair<int, int> job;
-        {
-            std::unique_lock<std::mutex> lk(C.mu);
-            C.cv_work.wait(lk, [&] { return C.stop || !C.jobs.empty(); });
-            if (C.jobs.empty()) return;                  // stop requested and nothing left
-            job = C.jobs.front();
-            C.jobs.pop_front();
-        }
-        const int first = job.first, nb = job.second;
-        // the batch's last kernel (its leader's event); errors surface in lm_collect_frame.  Polled, not hipEventSynchronize: a thread
-        // blocked inside the runtime's wait made every HIP call of the submitting thread take ~0.1 ms (0.30 ms per submit_frame)
-        for (;;) {
-            const hipError_t q = hipEventQuery(d->slot[first].done);
-            if (q != hipErrorNotReady) break;
-            for (int i = 0; i < 200; ++i) __builtin_ia32_pause();       // ~3-5 us between queries
-        }
-        (void)hipGetLastError();
-        for (int b = 0; b < nb; ++b) {
-            lm_detector::Slot& sl = d->slot[(first + b) % lm_detector::kSlots];
-            int state = 2;
-            sl.prep = nullptr; sl.prep_n = 0;
-            const unsigned long long* hc = sl.h_counters;
-            if (sl.num_work > 0 && hc[0] <= sl.cand_cap && hc[0] <= sl.match_cap && hc[1] <= hc[0]) {
-                sl.prep_n = canonical_list_of(sl, hc[1], &sl.prep, &sl.prep_collect_ms, &sl.prep_merge_ms);
-                if (sl.prep) state = 1;
-            }
-            sl.ready.store(state, std::memory_order_release);
-        }
-        { std::lock_guard<std::mutex> lk(C.mu); }
-        C.cv_done.notify_all();
-    }
-}
-
-static void copier_main(lm_detector* d) {
-    lm_detector::CopyHelper& H = d->copier;
-    uint64_t last = 0;
-    for (;;) {
+        std::function<void()> job;
         int spins = 0;
-        while (H.seq.load(std::memory_order_acquire) == last) {
-            if (H.stop.load(std::memory_order_acquire)) return;
-            if (++spins < 40000) { __builtin_ia32_pause(); continue; }          // ~0.5 ms of spinning, then sleep
-            std::unique_lock<std::mutex> lk(H.mu);
-            H.asleep.store(1, std::memory_order_seq_cst);
-            H.cv.wait(lk, [&] { return H.stop.load() || H.seq.load(std::memory_order_seq_cst) != last; });
-            H.asleep.store(0, std::memory_order_seq_cst);
+        for (;;) {
+            if (P.posted.load(std::memory_order_acquire) > 0) {
+                std::lock_guard<std::mutex> lk(P.mu);
+                if (!P.jobs.empty()) { job = std::move(P.jobs.front()); P.jobs.pop_front(); P.posted.fetch_sub(1, std::memory_order_acq_rel); break; }
+            }
+            if (++spins < 30000) { __builtin_ia32_pause(); continue; }          // ~0.3 ms of spinning, then sleep
+            std::unique_lock<std::mutex> lk(P.mu);
+            if (P.stop) return;
+            P.asleep.fetch_add(1, std::memory_order_seq_cst);
+            P.cv.wait(lk, [&] { return P.stop || !P.jobs.empty(); });
+            P.asleep.fetch_sub(1, std::memory_order_seq_cst);
+            if (P.stop && P.jobs.empty()) return;
             spins = 0;
         }
-        last = H.seq.load(std::memory_order_acquire);
-        memcpy(H.dst, H.src, H.bytes);
-        H.done.store(last, std::memory_order_release);
+        job();
     }
 }
-
-static void copier_stop(lm_detector* d) {
-    lm_detector::CopyHelper& H = d->copier;
-    if (!H.started) return;
-    { std::lock_guard<std::mutex> lk(H.mu); H.stop.store(true, std::memory_order_release); }
-    H.cv.notify_all();
-    if (H.th.joinable()) H.th.join();
-    H.started = false;
+static bool pool_ready(lm_detector* d) {
+    lm_detector::HostPool& P = d->pool;
+    if (P.threads <= 0) return false;
+    if (!P.started) {
+        P.stop = false;
+        for (int i = 0; i < P.threads; ++i) P.th.emplace_back(pool_main, d);
+        P.started = true;
+    }
+    return true;
+}
+static void pool_post(lm_detector* d, std::function<void()> job) {
+    lm_detector::HostPool& P = d->pool;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.jobs.push_back(std::move(job));
+        P.posted.fetch_add(1, std::memory_order_seq_cst);
+    }
+    if (P.asleep.load(std::memory_order_seq_cst) > 0) P.cv.notify_one();
+}
+static void pool_stop(lm_detector* d) {
+    lm_detector::HostPool& P = d->pool;
+    if (!P.started) return;
+    { std::lock_guard<std::mutex> lk(P.mu); P.stop = true; }
+    P.cv.notify_all();
+    for (auto& t : P.th) if (t.joinable()) t.join();
+    P.th.clear();
+    P.started = false;
 }
 
-// dst <- src split over the caller's thread (first part) and the helper (rest)
-static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
-    lm_detector::CopyHelper& H = d->copier;
-    const bool same_a = a == dst, same_b = b == dst + na;           // zero-copy: the caller filled lm_detector_ingest_buffer's pointers
-    if (same_a || same_b || na + nb < (1u << 19)) {                  // small frames: one thread
+// dst <- a, dst_b <- b (the two images of a frame), cut into slices for the caller's thread and the helpers
+static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t na, uint8_t* dst_b, const uint8_t* b, size_t nb) {
+    const bool same_a = a == dst, same_b = b == dst_b;              // zero-copy: the caller filled lm_detector_ingest_buffer's pointers
+    if (same_a || same_b || na + nb < (1u << 19) || !pool_ready(d)) {   // small frames: one thread
         if (!same_a) memcpy(dst, a, na);
-        if (!same_b) memcpy(dst + na, b, nb);
+        if (!same_b) memcpy(dst_b, b, nb);
         return;
     }
-    if (!H.started) { H.stop.store(false); H.th = std::thread(copier_main, d); H.started = true; }
-    H.src = b; H.dst = dst + na; H.bytes = nb;
-    const uint64_t job = H.seq.load(std::memory_order_relaxed) + 1;
-    H.seq.store(job, std::memory_order_seq_cst);      // seq_cst on both sides: the store may not pass the load of `asleep` (the helper would sleep on a posted job)
-    if (H.asleep.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(H.mu); H.cv.notify_one(); }
-    memcpy(dst, a, na);
-    while (H.done.load(std::memory_order_acquire) != job) __builtin_ia32_pause();
+    const int parts = d->pool.threads + 1;
+    const size_t total = na + nb, per = ((total + (size_t)parts - 1) / (size_t)parts + 4095) & ~(size_t)4095;
+    auto copy_range = [=](size_t lo, size_t hi) {                   // bytes [lo, hi) of the two images taken as one run
+        if (lo < na) memcpy(dst + lo, a + lo, std::min(hi, na) - lo);
+        if (hi > na) { const size_t l2 = std::max(lo, na); memcpy(dst_b + (l2 - na), b + (l2 - na), hi - l2); }
+    };
+    std::atomic<int> left{0};
+    int posted = 0;
+    for (int p = 1; p < parts; ++p) {
+        const size_t lo = std::min(total, per * (size_t)p), hi = std::min(total, per * (size_t)(p + 1));
+        if (lo >= hi) break;
+        left.fetch_add(1, std::memory_order_relaxed);
+        ++posted;
+        std::atomic<int>* lp = &left;
+        pool_post(d, [=]() { copy_range(lo, hi); lp->fetch_sub(1, std::memory_order_release); });
+    }
+    copy_range(0, std::min(total, per));
+    while (left.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    (void)posted;
 }
 
-static void collector_stop(lm_detector* d) {
-    lm_detector::Collector& C = d->collector;
-    if (!C.started) return;
-    { std::lock_guard<std::mutex> lk(C.mu); C.stop = true; }
-    C.cv_work.notify_all();
-    if (C.th.joinable()) C.th.join();
-    C.started = false;
+// The canonical list of a finished frame on a helper thread (its records are in pinned memory: the caller has seen the batch's event)
+static void prepare_list_job(lm_detector::Slot* sl) {
+    int state = 2;
+    sl->prep = nullptr; sl->prep_n = 0;
+    const unsigned long long* hc = sl->h_counters;
+    if (sl->num_work > 0 && hc[0] <= sl->cand_cap && hc[0] <= sl->match_cap && hc[1] <= hc[0]) {
+        sl->prep_n = canonical_list_of(*sl, hc[1], &sl->prep, &sl->prep_collect_ms, &sl->prep_merge_ms);
+        if (sl->prep) state = 1;
+    }
+    sl->ready.store(state, std::memory_order_release);
 }
 
 // Wait for the oldest frame in flight and turn its records into lm_match.  Returns 1 when a buffer
@@ -1918,13 +1901,9 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     lm_match* prepared = nullptr;
     size_t prepared_n = 0;
     bool have_prepared = false;
-    if (sl.prep_queued) {                               // the collector thread owns the slot until it has marked it ready
-        if (sl.ready.load(std::memory_order_acquire) == 0) {
-            for (int spin = 0; spin < 2000 && sl.ready.load(std::memory_order_acquire) == 0; ++spin) __builtin_ia32_pause();
-            if (sl.ready.load(std::memory_order_acquire) == 0) {
-                std::unique_lock<std::mutex> lk(d->collector.mu);
-                d->collector.cv_done.wait(lk, [&] { return sl.ready.load(std::memory_order_acquire) != 0; });
-            }
+    if (sl.prep_queued) {                               // a helper thread owns the slot until it has marked it ready (a job of ~35 us, posted when the batch's first frame was collected)
+        for (int spin = 0; sl.ready.load(std::memory_order_acquire) == 0; ++spin) {
+            if (spin < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
         }
         have_prepared = sl.ready.load(std::memory_order_acquire) == 1;
         prepared = sl.prep; prepared_n = sl.prep_n;
@@ -1954,6 +1933,17 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     }
     HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
+    // The batch has finished: the records of ALL its frames are in pinned memory.  The helper threads prepare the lists of the later frames
+    // while this thread does this frame's (sort_unique = 1, the Detector.match list, is what a stream asks for frame after frame).
+    if (sort_unique == 1 && d->async_collect && !d->reference_order && sl.leader == slot_index && sl.batch_n > 1 && sl.num_work > 0 && pool_ready(d))
+        for (int b = 1; b < sl.batch_n; ++b) {
+            lm_detector::Slot& later = d->slot[(slot_index + b) % lm_detector::kSlots];
+            if (!later.pending || !later.launched || later.leader != slot_index || later.prep_queued) continue;
+            later.ready.store(0, std::memory_order_relaxed);
+            later.prep_queued = true;
+            lm_detector::Slot* lp = &later;
+            pool_post(d, [lp]() { prepare_list_job(lp); });
+        }
     {
         const double now = host_seconds(t2), dry_at = now + 1e-3 * later_ms();
         if (batch_head && blocked) {
@@ -2154,15 +2144,17 @@ static int ingest_entry(lm_detector* d, int r, size_t n) {
         HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
         for (int i = 0; i < lm_detector::kSlots; ++i) { HIP_TRY(hipEventCreate(&g.t0[i])); HIP_TRY(hipEventCreate(&g.t1[i])); }
     }
-    if (g.pinned_bytes[r] < n * 5) {
+    g.depth_off = (n * 3 + 15) & ~(size_t)15;                       // the depth image behind the colour image, 16-byte aligned (host entry and device entry alike)
+    const size_t bytes = g.depth_off + n * 2;
+    if (g.pinned_bytes[r] < bytes) {
         if (g.pinned[r]) (void)hipHostFree(g.pinned[r]);
         g.pinned[r] = nullptr; g.pinned_bytes[r] = 0;
-        HIP_TRY(hipHostMalloc(&g.pinned[r], n * 5, hipHostMallocDefault));
-        g.pinned_bytes[r] = n * 5;
+        HIP_TRY(hipHostMalloc(&g.pinned[r], bytes, hipHostMallocDefault));
+        g.pinned_bytes[r] = bytes;
     }
     int rc;
-    if ((rc = g.d_rgb[r].ensure(n * 3))) return rc;
-    if ((rc = g.d_depth[r].ensure(n))) return rc;
+    if ((rc = g.d_rgb[r].ensure(bytes))) return rc;
+    g.d_depth[r] = reinterpret_cast<uint16_t*>(g.d_rgb[r].p + g.depth_off);
     return LM_OK;
 }
 
@@ -2190,7 +2182,7 @@ extern "C" int lm_detector_ingest_buffer(lm_detector* d, int width, int height, 
     const size_t n = (size_t)width * height;
     if ((rc = ingest_entry(d, r, n))) return rc;
     *rgb = (uint8_t*)d->ingest.pinned[r];
-    *depth = (uint16_t*)((uint8_t*)d->ingest.pinned[r] + n * 3);
+    *depth = (uint16_t*)((uint8_t*)d->ingest.pinned[r] + d->ingest.depth_off);
     return LM_OK;
 }
 
@@ -2208,23 +2200,22 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     lm_detector::Ingest& g = d->ingest;
     uint8_t* st = (uint8_t*)g.pinned[r];
     const auto tp0 = std::chrono::steady_clock::now();
-    staged_copy(d, st, rgb, n * 3, (const uint8_t*)depth, n * 2);  // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
+    staged_copy(d, st, rgb, n * 3, st + g.depth_off, (const uint8_t*)depth, n * 2);  // zero-copy when the caller filled lm_detector_ingest_buffer's pointers
     const auto tp1 = std::chrono::steady_clock::now();
     if (g.reader[r]) {                                            // a resident re-match of the entry's previous frame may still read it (another slot's front end)
         HIP_TRY(hipStreamWaitEvent(g.stream, g.reader[r], 0));
         g.reader[r] = nullptr;
     }
     HIP_TRY(hipEventRecord(g.t0[r], g.stream));
-    HIP_TRY(hipMemcpyAsync(g.d_rgb[r].p, st, n * 3, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.d_depth[r].p, st + n * 3, n * 2, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_rgb[r].p, st, g.depth_off + n * 2, hipMemcpyHostToDevice, g.stream));   // colour + depth: one copy (two cost the copy engine a second set-up: 0.061 -> ~0.05 ms, and the host a call)
     HIP_TRY(hipEventRecord(g.t1[r], g.stream));                   // the batch's front end waits for it (lm_launch_pending)
-    d->cur_rgb = g.d_rgb[r].p; d->cur_depth = g.d_depth[r].p;
+    d->cur_rgb = g.d_rgb[r].p; d->cur_depth = g.d_depth[r];
     d->have_mask[0] = d->have_mask[1] = false;
     d->last_h2d_ms = 0.f;
     d->frame_valid = true;
     const uint64_t before = d->n_submitted;
     const auto tp2 = std::chrono::steady_clock::now();
-    rc = slot_begin(d, threshold, class_ids, num_class_ids, g.d_rgb[r].p, g.d_depth[r].p, d->have_mask, r);
+    rc = slot_begin(d, threshold, class_ids, num_class_ids, g.d_rgb[r].p, g.d_depth[r], d->have_mask, r);
     if (rc) return rc;
     if (d->n_submitted == before + 1) g.used[r] = true;
     const auto tp3 = std::chrono::steady_clock::now();

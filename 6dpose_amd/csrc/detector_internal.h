@@ -4,6 +4,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -208,35 +209,28 @@ struct lm_detector {
     double last_submit_at = 0.0;                    // lm_detector_submit_frame: host clock of the previous call,
     float submit_gap_ms = 0.f;                      // moving average of the gap between calls (0 = no second call yet: treated as sparse),
     float launch_cost_ms = 0.1f;                    // and of the host time one lm_launch_pending takes
-    // Collector thread (streamed frames): waits for a launched batch on the host and turns each frame's records into the canonical
-    // Detector::match list (conversion, sort, unique: ~45 us per frame at 2k templates) while the caller's thread submits the next
-    // frames; lm_detector_collect then only hands the list over.  One per detector, started with the first streamed batch.
-    struct Collector {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv_work, cv_done;
-        std::deque<std::pair<int, int>> jobs;       // (first slot, frames) of launched batches, in launch order
-        bool stop = false, started = false;
-    } collector;
-    // Staging copy of a streamed frame: the caller's thread copies the colour image, a helper thread the depth image (1.5 MB at VGA:
-    // 40 us on one core, the largest item of the host's per-frame work).  The helper spins for a while after a job (a stream hands it
-    // one every ~150 us) and sleeps on the condition variable otherwise.
-    struct CopyHelper {
-        std::thread th;
+    // Helper threads of the streamed path (one pool per detector, started with the first job; LM_HOST_THREADS, default 3, 0 = none).  They
+    // never call into the HIP runtime — a second thread inside the runtime made every HIP call of the calling thread take ~0.1 ms (round 3:
+    // the collector thread that waited on events) — and do two things:
+    //   * the staging copy of a streamed frame (1.5 MB at VGA: 40 us on one core) in slices, beside the caller's own slice;
+    //   * the canonical result lists: frames are launched in batches, so when the collect of a batch's first frame has seen the batch's
+    //     event, the records of ALL its frames are in pinned memory — the helpers convert, sort and unique the lists of the later frames
+    //     (30-35 us each at 2k templates) while the caller's thread does the first one; the later collects only hand their lists over.
+    // A helper spins for ~0.3 ms after a job (a stream hands them one every few tens of us) and sleeps on the condition variable otherwise.
+    struct HostPool {
+        std::vector<std::thread> th;
         std::mutex mu;
         std::condition_variable cv;
-        std::atomic<uint64_t> seq{0}, done{0};
-        std::atomic<int> asleep{0};
-        const void* src = nullptr;
-        void* dst = nullptr;
-        size_t bytes = 0;
-        std::atomic<bool> stop{false};
-        bool started = false;
-    } copier;
+        std::deque<std::function<void()>> jobs;
+        std::atomic<int> posted{0};                 // jobs in the queue
+        std::atomic<int> asleep{0};                 // helpers waiting on cv
+        bool stop = false, started = false;
+        int threads = 3;
+    } pool;
     // host-side wall time of the streamed path, accumulated (lm_detector_host_profile): [0] frames, [1] staging copy, [2] H2D enqueue,
     // [3] slot bookkeeping, [4] batch launches, [5] collect: waiting for the GPU, [6] record conversion, [7] canonical sort + unique
     double host_prof[8] = {};
-    bool async_collect = false;                     // lm_detector_set_async_collect / LM_ASYNC_COLLECT=1 (measured: pays only when the host thread is the bottleneck)
+    bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0: the lists of a batch's later frames are prepared by the helper threads
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's
     // pinned buffer (or written there by the caller: lm_detector_ingest_buffer), copied to the entry's device buffers on a
@@ -246,8 +240,9 @@ struct lm_detector {
         hipStream_t stream = nullptr;
         void* pinned[kSlots] = {};
         size_t pinned_bytes[kSlots] = {};
-        DevBuf<uint8_t> d_rgb[kSlots];
-        DevBuf<uint16_t> d_depth[kSlots];
+        DevBuf<uint8_t> d_rgb[kSlots];                 // colour image, then (16-byte aligned) the depth image: ONE upload per frame, the pinned entry has the same layout
+        uint16_t* d_depth[kSlots] = {};                // = d_rgb + depth_off
+        size_t depth_off = 0;
         hipEvent_t t0[kSlots] = {}, t1[kSlots] = {};   // timing of the H2D (copy stream)
         bool used[kSlots] = {};                        // the slot's frame came in through the ring (lm_timings.h2d_ms from t0/t1)
         hipEvent_t reader[kSlots] = {};                // front end (of another slot: a resident re-match of the streamed frame) that still reads the entry

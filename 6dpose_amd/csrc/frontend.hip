@@ -514,21 +514,33 @@ static __device__ __forceinline__ void bits_rows_body(const int bx, const int by
     const int phase = by, ry0 = bx * R;
     const int rows = Hd - ry0 < R ? Hd - ry0 : R;
     const int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
-    for (int i = (int)threadIdx.x; i < rows * Wp; i += 256) {
-        const int r = i / Wp, rx = i - r * Wp;                            // (Wp: a handful of values per frame size; rows * Wp <= 1152)
-        uint32_t w = 0;
-        if (rx < Wd) {
+    // every thread's cells (<= kBitsCells / 256, rounded up) at once: their pixel loads are all in flight together
+    constexpr int kPer = (kBitsCells + 255) / 256;
+    const float inv_wp = 1.0f / (float)Wp;
+    uint32_t w[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        const int r = (int)(((float)i + 0.5f) * inv_wp), rx = i - r * Wp;      // exact: i < 2048, Wp >= 32
+        w[k] = 0;
+        if (i < rows * Wp && rx < Wd) {
             const uint32_t v = spread_or(J, rx * T + cs, (ry0 + r) * T + rs, W, H, T);
             const uint32_t adj = ((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu;
-            w = (adj & ~v) | (v << 8);
+            w[k] = (adj & ~v) | (v << 8);
         }
-        s_cells[i] = (uint16_t)w;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < rows * Wp) s_cells[i] = (uint16_t)w[k];
     }
     __syncthreads();
     const size_t splane1 = (size_t)NS * Hd * 8;                           // one (label, phase) plane of records
     uint8_t* out = J.bits + (size_t)phase * splane1;
+    const float inv_rows = 1.0f / (float)rows, inv_ns = 1.0f / (float)NS;
     for (int i = (int)threadIdx.x; i < 8 * rows * NS; i += 256) {
-        const int r = i % rows, q = i / rows, st = q % NS, label = q / NS;
+        const int q = (int)(((float)i + 0.5f) * inv_rows), r = i - q * rows;   // (small integers: the float quotients are exact)
+        const int label = (int)(((float)q + 0.5f) * inv_ns), st = q - label * NS;
         const uint32_t* cw = reinterpret_cast<const uint32_t*>(s_cells + r * Wp + 16 * st);     // 32 cells = 16 dwords of two cells each
         uint32_t lo = 0, hi = 0;
 #pragma unroll 2
@@ -691,6 +703,15 @@ void launch_fe_stage(FeStage& st, hipStream_t s) {
     hipLaunchKernelGGL(k_fe_stage, dim3(grid), dim3(256), 0, s, st, total);
 }
 void launch_fe_bits(FeStage& st, hipStream_t s) {
+    if (knobs().fe_bits_split) {                          // LM_FE_BITS_SPLIT=1 (measurements): the strip-record jobs and the pair-stream jobs as two launches
+        for (int kind : {kFeBitsRows, kFeTopBits}) {
+            FeStage part{};
+            for (int i = 0; i < st.njobs; ++i) if (st.job[i].kind == kind) part.job[part.njobs++] = st.job[i];
+            const int total = fe_prepare(part);
+            if (total > 0) hipLaunchKernelGGL(k_fe_bits, dim3(std::min(total, fe_cus() * 8)), dim3(256), 0, s, part, total);
+        }
+        return;
+    }
     const int total = fe_prepare(st);
     if (total <= 0) return;
     hipLaunchKernelGGL(k_fe_bits, dim3(std::min(total, fe_cus() * 8)), dim3(256), 0, s, st, total);

@@ -337,6 +337,10 @@ def main():
             tlog["n"] += 1
         last["n"] = len(out)
 
+    # ... and the gate on the streamed path itself (world 1: the timed loop's submit / collect with the same number of frames in flight)
+    if parity is not None:
+        parity["stream"] = stream_gate(det, host_frame, classes, banks[classes[0]], args.templates, PIPELINE_DEPTH)
+
     def run(nsteps, resident=False, first=0):
         inflight = 0
         for k in range(first, first + nsteps):
@@ -629,6 +633,38 @@ def parity_gate(det, frames, bank, classes, n_templates, n_frames=2):
         out["ok"] = out["ok"] and ok
     if not out["ok"]:
         sys.stderr.write("bench.py: PARITY GATE FAILED - GPU matches differ from the CPU oracle: %s\n" % json.dumps(out["frames"]))
+        sys.exit(3)
+    return out
+
+
+def stream_gate(det, host_frame, classes, bank, n_templates, depth, steps=(0, 1, 6, 11)):
+    """The same comparison for the path the number is measured on: host frames through lm_detector_submit_frame, `depth` in flight, the
+    library's batching (several frames per kernel launch, frame -> XCD affinity) — the lists collect() returns for a few steps of one
+    stream against the oracle's lists for exactly those (stamped) frames.  Exits without a number on a mismatch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    od = lo.OracleDetector(NFEAT[0], T_LEVELS)
+    pb = lo.PackedBank(n_templates, 2, *bank)
+    n = max(steps) + 1
+    kept, got, infl = {}, [], 0
+    for k in range(n):
+        rgb, dep = host_frame(k)
+        if k in steps:
+            kept[k] = (rgb.copy(), dep.copy())                # the pool frame is stamped again by later steps
+        det.submitFrame((rgb, dep), THRESHOLD, classes)
+        infl += 1
+        if infl == depth:
+            got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
+    while infl:
+        got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
+    out = {"ok": True, "steps": [], "frames_in_flight": depth}
+    for k in steps:
+        want, _, st, _, _, _ = oracle_matches(od, lo, pb, kept[k][0], kept[k][1], THRESHOLD)
+        ok = same_records(got[k][0], want)
+        out["steps"].append({"step": k, "matches": int(len(want)), "gpu_matches": int(len(got[k][0])), "frames_in_its_launch": int(got[k][1]), "equal": bool(ok)})
+        out["ok"] = out["ok"] and ok
+    if not out["ok"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED on the streamed path - collect() differs from the CPU oracle: %s\n" % json.dumps(out["steps"]))
         sys.exit(3)
     return out
 
