@@ -184,6 +184,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (knobs().launch_slack_us > 0) d->launch_slack_ms = knobs().launch_slack_us * 1e-3f;
     if (const char* ac = getenv("LM_ASYNC_COLLECT")) d->async_collect = ac[0] && ac[0] != '0';
     if (const char* ht = getenv("LM_HOST_THREADS")) d->pool.threads = std::max(0, std::min(8, atoi(ht)));
+    if (const char* sw = getenv("LM_SPIN_WAIT_US")) d->spin_wait_us = std::max(0, atoi(sw));
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
@@ -1467,7 +1468,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
                 if (st.njobs + 1 > kFeMaxJobs) flush_bits();
                 if (top) {
                     const uint32_t bit0[2] = {lv.lm_off[0] - d->cbits_byte0, lv.lm_off[1] - d->cbits_byte0};
-                    fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T);
+                    fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T, d->fe_top_atomic);
                 } else {
                     uint8_t* bits[2] = {d->bits_arena[arena].p + (lv.sm_off[0] >> 1), d->bits_arena[arena].p + (lv.sm_off[1] >> 1)};
                     fe_job_bits_rows(st.job[st.njobs++], quant, mask, bits, B.W, B.H, lv.T);
@@ -1644,7 +1645,9 @@ int lm_launch_pending(lm_detector* d) {
     // (then k_local never runs behind k_local_bits), at the top level when the coarse pass runs on the pair stream.
     bool direct_low = knobs().fe_bits && d->fe_direct && bits && d->bits_all_in, direct_top = knobs().fe_bits && d->fe_direct && cbits;
     for (int l = 0; l + 1 < d->geom.levels; ++l) direct_low = direct_low && fe_bits_rows_possible(d->geom.lv[l].W, d->geom.lv[l].T);
-    if (direct_top)                                      // the pair stream is OR-ed together: it has to be zero (k_local_bits leaves it so; k_pack_top and first use do not)
+    const LevelGeom& topl = d->geom.lv[d->geom.levels - 1];
+    const bool top_ored = direct_top && (d->fe_top_atomic || !fe_top_bits_aligned(topl.W, topl.H, topl.T));   // (else whole dwords are stored: nothing to clear)
+    if (top_ored)                                        // the pair stream is OR-ed together: it has to be zero (k_local_bits leaves it so; k_pack_top and first use do not)
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
             if (!d->cbits_clean[si]) HIP_TRY(hipMemsetAsync(d->cbits_arena[si].p, 0, (size_t)d->cbits_npairs * 8, s));
@@ -1668,10 +1671,10 @@ int lm_launch_pending(lm_detector* d) {
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
             tb.lm[b] = d->lm_arena[si].p; tb.bits[b] = d->cbits_arena[si].p;
-            if (direct_top && !d->fe_keep_top) bb.top_clear[b] = d->cbits_arena[si].p;   // zeroed again by k_local_bits, after k_coarse_bits has read it
+            if (top_ored && !d->fe_keep_top) bb.top_clear[b] = d->cbits_arena[si].p;     // zeroed again by k_local_bits, after k_coarse_bits has read it
             else d->cbits_clean[si] = false;
         }
-        if (direct_top && !d->fe_keep_top) bb.top_clear_units = (d->cbits_npairs * 8u + 15u) / 16u;
+        if (top_ored && !d->fe_keep_top) bb.top_clear_units = (d->cbits_npairs * 8u + 15u) / 16u;
         if (!direct_top) launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
     }
     HIP_TRY(hipEventRecord(lead.ev[1], s));
@@ -1930,6 +1933,19 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
             int rc = lm_launch_pending(d);
             if (rc) return rc;
         }
+    }
+    // Poll before blocking: hipEventSynchronize puts the thread to sleep on an interrupt, and waking up costs tens of microseconds —
+    // once per batch, on the stream's critical path whenever host and GPU run at about the same pace.  A batch takes 0.2-0.5 ms, so the
+    // thread spins on the event for up to 2 ms (LM_SPIN_WAIT_US; 0 = block at once) and only then blocks.
+    if (d->spin_wait_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(d->spin_wait_us);
+        for (;;) {
+            const hipError_t q = hipEventQuery(lead.done);
+            if (q != hipErrorNotReady) break;
+            if (std::chrono::steady_clock::now() >= until) break;
+            for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+        }
+        (void)hipGetLastError();
     }
     HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
@@ -2226,7 +2242,11 @@ extern "C" int lm_detector_submit_frame(lm_detector* d, const uint8_t* rgb, cons
     {   // how fast the frames arrive (moving average of the gap between submits; a pause counts as 10 ms)
         const double t = host_seconds(tp3);
         if (d->last_submit_at > 0.0) {
-            const float gap = (float)std::min(10.0, (t - d->last_submit_at) * 1e3);
+            float gap = (float)std::min(10.0, (t - d->last_submit_at) * 1e3);
+            // one long gap is a pause, not a change of pace: a tight loop that stops to synchronise (the fence between a warm-up and a timed
+            // region, a caller that drains the pipeline now and then) must not look like a camera for its next few frames — they would go
+            // out one frame per launch, 0.3 ms of GPU time each.  A stream that has really slowed down is told apart within four frames (the average grows by a quarter per frame).
+            if (d->submit_gap_ms > 0.f) gap = std::min(gap, 2.f * d->submit_gap_ms);
             d->submit_gap_ms = d->submit_gap_ms > 0.f ? 0.75f * d->submit_gap_ms + 0.25f * gap : gap;
         }
         d->last_submit_at = t;
@@ -2263,7 +2283,8 @@ extern "C" int lm_detector_set_direct_bits(lm_detector* d, int on) {
     int rc = lm_launch_pending(d);
     if (rc) return rc;
     d->fe_direct = on != 0;
-    d->fe_keep_top = on == 2;       // tests: the pair stream stays readable after the match (lm_detector_read_stage kind 5) and is cleared before the next frame instead
+    d->fe_keep_top = (on & 2) != 0;  // tests: the pair stream stays readable after the match (lm_detector_read_stage kind 5) and is cleared before the next frame instead
+    d->fe_top_atomic = (on & 4) != 0; // tests: the OR-ing writer of the pair stream also where whole dwords could be stored
     return LM_OK;
 }
 

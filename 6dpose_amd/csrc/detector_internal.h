@@ -177,7 +177,7 @@ struct lm_detector {
     // (round 1).  coarse: 0 = pair stream when the refinement runs on bit planes (default), 1 = byte linear memories (k_coarse).
     int refine_mode = 0, coarse_mode = 0;
     bool fe_direct = true;                          // lm_detector_set_direct_bits: the front end writes bit planes directly where nothing reads the bytes (0: bytes + k_pack_bits / k_pack_top)
-    bool fe_keep_top = false;                       // lm_detector_set_direct_bits(d, 2)
+    bool fe_keep_top = false, fe_top_atomic = false; // lm_detector_set_direct_bits(d, 2 / 4)
     bool fe_bytes_low = true, fe_bytes_top = true;  // did the last front end write the byte planes of the levels below the top / of the top level (read_stage builds them on demand otherwise)
     bool cbits_clean[kSlots] = {};                  // the slot's pair stream is all zero (what the front end's OR-ing writer needs)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
@@ -230,6 +230,7 @@ struct lm_detector {
     // host-side wall time of the streamed path, accumulated (lm_detector_host_profile): [0] frames, [1] staging copy, [2] H2D enqueue,
     // [3] slot bookkeeping, [4] batch launches, [5] collect: waiting for the GPU, [6] record conversion, [7] canonical sort + unique
     double host_prof[8] = {};
+    int spin_wait_us = 2000;                        // LM_SPIN_WAIT_US: lm_detector_collect polls the batch's event this long before it blocks in hipEventSynchronize
     bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0: the lists of a batch's later frames are prepared by the helper threads
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's

@@ -588,6 +588,36 @@ static __device__ __forceinline__ void top_bits_body(const int bx, const int by,
     }
 }
 
+// The same when the label planes start on 64-position boundaries of the stream (T * T * positions a multiple of 64: T = 8, or T = 4 with an
+// even number of... any grid whose T^2 W_d H_d is): one thread per bit of a label's T * T * positions planes taken as ONE run — phase and
+// position follow from the bit index —, a wave = 64 consecutive bits of that run in EVERY label's block, so its ballots are whole dwords:
+// lane `label` stores the two pairs {is 1, is 4} x 2 with one 16-byte store.  No atomics, nothing to zero beforehand.
+static __device__ __forceinline__ void top_bits_aligned_body(const int bx, const LmJob& J, int W, int H, int T, int Wd, int Hd, uint32_t m_wd, uint32_t m_t, uint32_t m_np) {
+    const int npos = Wd * Hd, run = T * T * npos;
+    const int b = bx * 256 + (int)threadIdx.x;
+    const bool in = b < run;
+    uint32_t v = 0;
+    if (in) {
+        const int phase = (int)fast_div((uint32_t)b, m_np, (uint32_t)npos), idx = b - phase * npos;
+        const int ry = (int)fast_div((uint32_t)idx, m_wd, (uint32_t)Wd), rx = idx - ry * Wd;
+        const int rs = (int)fast_div((uint32_t)phase, m_t, (uint32_t)T), cs = phase - rs * T;
+        v = spread_or(J, rx * T + cs, ry * T + rs, W, H, T);
+    }
+    const uint32_t one = (((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu) & ~v;
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t b0 = (uint32_t)(b - lane);                             // the wave's first bit of the run (a multiple of 64)
+    uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int ori = 0; ori < 8; ++ori) {
+        const unsigned long long m1 = __ballot(in && ((one >> ori) & 1u)), m4 = __ballot(in && ((v >> ori) & 1u));
+        if (lane == ori) mine = make_uint4((uint32_t)m1, (uint32_t)m4, (uint32_t)(m1 >> 32), (uint32_t)(m4 >> 32));
+    }
+    if (lane < 8 && b0 < (uint32_t)run) {
+        const uint32_t pair = (J.top_bit0 + (uint32_t)lane * (uint32_t)run + b0) >> 5;                  // even: the label's block and b0 are multiples of 64 positions
+        *reinterpret_cast<uint4*>(J.bits + (size_t)pair * 8) = mine;
+    }
+}
+
 // ---- several independent front-end jobs in ONE launch ---------------------------------------------------------------------
 // The seven kernels of a frame are small (5-17 us) and dependent kernels on a queue start ~7 us apart, so the front end is
 // mostly launch latency.  The jobs that do not depend on each other share a launch: stage k = {colour chain of level k,
@@ -635,6 +665,7 @@ k_fe_bits(FeStage st, int total) {
         const int by = (int)fast_div((uint32_t)rem, J.m_gx, (uint32_t)J.gx), bx = rem - by * J.gx;
         if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
         else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
+        else if (J.kind == kFeTopBitsAligned) top_bits_aligned_body(bx, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t, J.m_np);
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
 }
@@ -671,11 +702,16 @@ void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* co
     j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, bits[0], 0u}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, bits[1], 0u};
 }
 // pair stream of the top level, written directly; bit0[m] = flat arena offset of modality m's block less the stream's first byte
-void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T) {
+void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T, bool force_atomic) {
     j = FeJob{}; j.kind = kFeTopBits; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
     j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, stream, bit0[0]}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, stream, bit0[1]};
+    if (fe_top_bits_aligned(W, H, T) && !force_atomic) {    // whole dwords per wave: no atomics, nothing to clear
+        const int npos = j.Wd * j.Hd;
+        j.kind = kFeTopBitsAligned; j.gx = (T * T * npos + 255) / 256; j.gy = 1; j.m_np = div_magic((uint32_t)npos);
+    }
 }
+bool fe_top_bits_aligned(int W, int H, int T) { return ((long)T * T * (W / T) * (H / T)) % 64 == 0; }
 static int fe_prepare(FeStage& st) {                             // drops empty jobs, lays the jobs' blocks out on one flat index; returns the number of blocks
     int total = 0, n = 0;
     for (int i = 0; i < st.njobs; ++i) {
@@ -706,7 +742,7 @@ void launch_fe_bits(FeStage& st, hipStream_t s) {
     if (knobs().fe_bits_split) {                          // LM_FE_BITS_SPLIT=1 (measurements): the strip-record jobs and the pair-stream jobs as two launches
         for (int kind : {kFeBitsRows, kFeTopBits}) {
             FeStage part{};
-            for (int i = 0; i < st.njobs; ++i) if (st.job[i].kind == kind) part.job[part.njobs++] = st.job[i];
+            for (int i = 0; i < st.njobs; ++i) if ((st.job[i].kind == kFeBitsRows) == (kind == kFeBitsRows)) part.job[part.njobs++] = st.job[i];
             const int total = fe_prepare(part);
             if (total > 0) hipLaunchKernelGGL(k_fe_bits, dim3(std::min(total, fe_cus() * 8)), dim3(256), 0, s, part, total);
         }

@@ -22,7 +22,7 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
 // several independent jobs of the front end in one launch (frontend.hip, k_fe_stage)
 struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips;
                uint8_t* bits; uint32_t top_bit0; };   // bits: the bit planes written directly (strip records of the level / the top level's pair stream); top_bit0: see fe_job_top_bits
-enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits };
+enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits, kFeTopBitsAligned };
 struct FeJob {
     int kind, gx, gy, gz, first;          // job kind, its block grid, its first flat block index (set by launch_fe_stage)
     const void* in; void* out0; void* out1;
@@ -31,7 +31,7 @@ struct FeJob {
     // Divisions by run-time values cost ~25 instructions each on the GPU and the bodies are short: the quotients a block / thread needs
     // (flat block index -> job-local (bx, by, bz); linear-memory index -> (row, column); phase -> (row, column) inside the T x T cell)
     // come from multipliers the host prepares: n / d = umulhi(n, m), m = ceil(2^32 / d), exact while n * d < 2^32 (m = 0 stands for d = 1).
-    uint32_t m_gx, m_gxgy, m_wd, m_t;
+    uint32_t m_gx, m_gxgy, m_wd, m_t, m_np;  // (m_np: positions of a plane, the aligned pair-stream writer)
     int Wd, Hd;                           // build_lm: decimated size
     LmJob lm[2];                          // build_lm: [0] colour, [1] normals
 };
@@ -47,7 +47,10 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
 // the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip)
 bool fe_bits_rows_possible(int W, int T);     // the level's rows fit the stage's LDS
 void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T);
-void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T);
+// (the writer of whole dwords when the label planes start on 64-position boundaries — fe_top_bits_aligned —, else, or when forced, the one that ORs
+// shifted ballots into a stream that must be zero beforehand)
+void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T, bool force_atomic);
+bool fe_top_bits_aligned(int W, int H, int T);
 void launch_fe_stage(FeStage& st, hipStream_t s);
 void launch_fe_bits(FeStage& st, hipStream_t s);      // a launch of bit-plane jobs only (fe_job_bits_rows, fe_job_top_bits)
 

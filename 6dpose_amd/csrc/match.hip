@@ -1237,8 +1237,8 @@ k_pack_top(TopBits B, uint32_t byte0, uint32_t npairs) {
     *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (size_t)i * 8) = r;
 }
 
-template <int kHi>
-__global__ void __launch_bounds__(256)
+template <int kHi, int kWaves>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
               const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0) {
     constexpr int kN = 4 + kHi, kS = kN + 3;
@@ -1368,11 +1368,14 @@ void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom&
                         const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s) {
     if (num_work <= 0 || fb.nb <= 0) return;
     const int level = g.levels - 1;
-    if (max_features <= kBitsSmallMax)
-        hipLaunchKernelGGL(k_coarse_bits<5>, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+    if (max_features > kBitsSmallMax)
+        hipLaunchKernelGGL((k_coarse_bits<10, 5>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+                           work_pyramids, num_work, threshold, cap, byte0);
+    else if (knobs().cbits_waves >= 8)
+        hipLaunchKernelGGL((k_coarse_bits<5, 8>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
                            work_pyramids, num_work, threshold, cap, byte0);
     else
-        hipLaunchKernelGGL(k_coarse_bits<10>, dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
+        hipLaunchKernelGGL((k_coarse_bits<5, 6>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off,
                            work_pyramids, num_work, threshold, cap, byte0);
 }
 

@@ -366,6 +366,7 @@ def main():
         torch.cuda.synchronize()
 
     primed = {"live": False, "resident": False}
+    rank_times = {"dt": None}
 
     def timed(nsteps, warmup, resident=False):
         # one-time set-up, before the W warm-up steps: every slot of the result ring (lm_detector_max_in_flight() = 16) allocates its
@@ -390,6 +391,9 @@ def main():
             for q in keys:
                 acc[q] += getattr(tlog["buf"][i], q)
         if world > 1:
+            each = [None] * world                          # every rank's own time of the region: the line reports min / max besides the MAX the contract asks for,
+            dist.all_gather_object(each, float(dt))        # so that the first run on a real node shows at once whether one rank (one GPU, one NUMA node) lags
+            rank_times["dt"] = each
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -432,6 +436,7 @@ def main():
         st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14); sys.stderr.write(st.getvalue())
     dt = timed(args.steps, args.warmup)              # THE timed region: a new host frame per step, H2D included
     n_final = last["n"]
+    per_rank_ms = [t / K * 1e3 for t in rank_times["dt"]] if rank_times["dt"] else None
     mean = {k: acc[k] / K for k in keys}
     host_mean = {q: host_t[q] / K * 1e3 for q in host_t}
     total_templates = args.templates * n_obj
@@ -449,7 +454,7 @@ def main():
             # or k_local alone when the bank / geometry keeps the byte planes)
             kname, kms, kbytes, kpipe = ("k_local_bits" if det.refinesOnBitPlanes() else "k_local"), excl["local_ms"], excl["local_bytes"], mean["local_ms"]
         else:
-            kname, kms, kbytes, kpipe = "k_coarse", excl["coarse_ms"], excl["coarse_bytes"], mean["coarse_ms"]
+            kname, kms, kbytes, kpipe = ("k_coarse_bits" if det.getPaths()[1] == "bits" else "k_coarse"), excl["coarse_ms"], excl["coarse_bytes"], mean["coarse_ms"]
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         gbps = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         if world == 1 and not strong:
@@ -476,6 +481,8 @@ def main():
                        "ranks_observed": (dist.get_world_size() if use_dist else 1), "backend": (backend if use_dist else None),
                        "exchange": exchange_mode, "exchange_capacity": (ex.capacity if ex is not None else None),
                        "templates_per_rank": templates_per_rank, "unsharded_check": unsharded,
+                       "ms_per_step_per_rank": ({"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms} if per_rank_ms else None),
+                       "exchange_host_ms_per_step_rank0": ({"gather": host_mean["gather"], "merge": host_mean["merge"]} if world > 1 else None),
                        "pipeline_depth": PIPELINE_DEPTH, "frames_per_launch_max": BATCH, "batches_kept_queued": args.batch_queue,
                        "frames_per_launch_mean_timed": mean["batch_frames"],
                        "setup_before_warmup": "16 frames through the ingest ring (each of the library's 16 result slots allocates its pinned staging "
@@ -489,8 +496,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": kms, "frames_per_launch": BATCH,
-                         "kernel_ms_covers": ("the events bracket the refinement of a batch: k_local_bits and the (nearly empty) k_local launch that takes the candidates "
-                                              "it leaves; kernel_us_profiled below is k_local_bits alone" if kname == "k_local_bits" else "one k_local launch"),
+                         "kernel_ms_covers": ("the events bracket the refinement of a batch: k_local_bits (and, for banks whose candidates can leave their planes, the k_local "
+                                              "launch that takes those; none at this workload)" if kname == "k_local_bits" else "one launch of the kernel"),
                          "convention": "ALGORITHMIC bytes (SURVEY 8d: one byte per response read the reference performs) per launch / kernel time, "
                                        "against the HBM peak as BASELINE.json's metric asks.  The linear memories are cache-resident, so this is not "
                                        "physical HBM traffic (see `traffic`); the ceilings that physically bound the kernel are below",
@@ -531,44 +538,68 @@ def main():
         # PMC counters of the dominant kernel, measured NOW: separate rocprofv3 --pmc passes over `bench.py --roofline-only` (the
         # same launches as the roofline leg above), corrected as MI355X_MICROARCH.md (HBM) prescribes.  Without rocprofv3 (or with
         # --no-pmc) the numbers of the last committed pass (profiles/roofline_traffic.json) are quoted and labelled as such.
-        pm = None if (args.no_pmc or args.no_extras or world != 1 or strong) else pmc_live(kname, args)
+        paths = det.getPaths()
+        k_refine = "k_local_bits" if paths[0] == "bits" else "k_local"
+        k_coarse_name = "k_coarse_bits" if paths[1] == "bits" else "k_coarse"
+        pm_all = None if (args.no_pmc or args.no_extras or world != 1 or strong) else pmc_live((k_refine, k_coarse_name, "k_fe_stage", "k_fe_bits", "k_pack_bits", "k_pack_top", "k_dedupe"), args)
+        pm = pm_all.get(kname) if pm_all else None
         rf = out["roofline"]
+        rf["frac_is"] = ("ALGORITHMIC bytes over the HBM peak (SURVEY 8d's convention): NOT a physical fraction - the bit-plane kernels load 16 bytes where the "
+                         "reference reads 256, from L1 / L2 - and it exceeds 1.  What the kernel reaches of the ceilings that can bind it is `binding` (<= 1), "
+                         "per stage under `stages`")
         if pm is not None:
-            hbm = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0      # FETCH_SIZE / WRITE_SIZE are in KB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B
-            kcycles = pm["GRBM_GUI_ACTIVE"] / 8.0                                   # summed over the 8 XCDs
+            cz = ceilings_of(pm)
+            hbm = cz["hbm_bytes_per_dispatch"]      # FETCH_SIZE / WRITE_SIZE are in KB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)
+            pairs = kbytes / 256.0                   # (candidate, feature) pairs per launch: 256 algorithmic bytes each
+            lane_features = pairs / 8.0              # a wave instruction of k_local_bits serves 8 pairs (8 lanes per candidate)
             rf.update({
                 "traffic": hbm,
                 "traffic_source": "live: rocprofv3 --kernel-trace --pmc passes of `bench.py --roofline-only` run by this bench.py (FETCH_SIZE x2 + WRITE_SIZE, "
                                   "mean per %s dispatch of %d frames); memory-side (fabric) bytes, Infinity-Cache hits included" % (kname, BATCH),
-                "hbm_frac_physical": hbm / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None,
-                "l1_accesses_per_launch": pm["TCP_TOTAL_CACHE_ACCESSES_sum"],
-                "l1_pending_stall_cycles_per_launch": pm["TCP_PENDING_STALL_CYCLES_sum"],
-                "frac_of_tcp_cycles": ((pm["TCP_TOTAL_CACHE_ACCESSES_sum"] + pm["TCP_PENDING_STALL_CYCLES_sum"]) / (256.0 * kcycles)) if kcycles > 0 else None,
-                "l1_accesses_per_vmem_instruction": pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / pm["SQ_INSTS_VMEM_RD"] if pm["SQ_INSTS_VMEM_RD"] else None,
-                "bytes_loaded": pm["SQ_INSTS_VMEM_RD"] * 64 * 16,
-                "bytes_loaded_note": ("wave-level load instructions x 64 lanes x 16 B: an upper bound (k_local_bits: one 16-byte record load per 8 (candidate, feature) pairs, "
-                                      "plus a 4-byte feature-word load per 8 of those and the candidates' records)" if kname == "k_local_bits" else
-                                      "wave-level 16-byte load instructions x 64 lanes x 16 B: an upper bound (tiles keep 60 of 64 lanes busy)"),
-                "valu_issue_frac": (4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kcycles)) if kcycles > 0 else None,     # wave64 on 16-lane SIMDs: 4 cycles per instruction, 1024 SIMDs
-                "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None,
-                "insts_per_launch": {"salu": pm["SQ_INSTS_SALU"], "valu": pm["SQ_INSTS_VALU"], "vmem_rd": pm["SQ_INSTS_VMEM_RD"], "waves": pm["SQ_WAVES"]},
-                "kernel_us_profiled": kcycles / 2400.0,
-                # the load path itself: a 16-byte-per-lane wave load retires in ~31.5 CU cycles when its lines come from L2 and 23.5 when they
-                # all hit L1, whatever the alignment of the lanes' quads and whether a lane asks for 8 or 16 bytes
-                # (profiles/tcp_rotation_microbench.hip -> profiles/r03_tcp_rotation_microbench.txt)
-                "cu_cycles_per_wave_load": (256.0 * kcycles / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
-                "load_path": {"microbench_cycles_per_wave_load_l2_resident": LOAD_CYCLES_L2, "microbench_cycles_per_wave_load_l1_hits": LOAD_CYCLES_L1,
-                              "frac": (LOAD_CYCLES_L2 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kcycles)) if kcycles > 0 else None,
-                              "note": "frac = what the same number of wave loads costs in the micro-benchmark of the access pattern alone / the kernel's CU cycles: "
-                                      "the kernel runs at this fraction of the rate its load instructions can be retired at; fewer wave loads, not faster ones, is what is left"},
-                "what_bounds_it": ("k_local_bits reads the responses as two 1-bit planes (n1 + 4 n4 = the byte sum): a 16-byte wave load serves 8 (candidate, feature) "
-                                   "pairs, so `frac` (ALGORITHMIC response bytes / HBM peak) is far above 1 - 256 algorithmic bytes per pair are 16 loaded ones, from L2.  "
-                                   "The candidates are the vector L1 (frac_of_tcp_cycles, load_path.frac) and the VALU (valu_issue_frac: carry-save adders on bit-sliced "
-                                   "counters); hbm_frac_physical is the real HBM share" if kname == "k_local_bits" else
-                                   "the vector L1 (TCP): one 64-byte access per cycle and CU; accesses + cycles stalled on pending misses over the CU cycles of "
-                                   "the launch = frac_of_tcp_cycles.  `frac` (algorithmic bytes / HBM peak) exceeds 1 because the linear memories are "
-                                   "cache-resident and a tile's window region is loaded once for all its members; hbm_frac_physical is the real HBM share")})
-        else:
+                "binding": cz["binding"], "ceilings": cz["fractions"],
+                "hbm_frac_physical": cz["fractions"]["hbm"],
+                "kernel_us_profiled": cz["kernel_us_profiled"], "l2_hit_rate": cz["l2_hit_rate"],
+                "cu_cycles_per_wave_load": cz["cu_cycles_per_wave_load"], "l1_accesses_per_wave_load": cz["l1_accesses_per_wave_load"],
+                "insts_per_launch": {"salu": pm["SQ_INSTS_SALU"], "valu": pm["SQ_INSTS_VALU"], "vmem_rd": pm["SQ_INSTS_VMEM_RD"], "waves": pm["SQ_WAVES"]}})
+            if kname == "k_local_bits" and lane_features > 0:
+                per = pm["SQ_INSTS_VALU"] / lane_features
+                rf.update({
+                    "valu_per_lane_feature": per,
+                    "useful_valu_frac": USEFUL_ADDER_OPS_PER_LANE_FEATURE / per,
+                    "useful_valu_frac_with_window_shifts": (USEFUL_ADDER_OPS_PER_LANE_FEATURE + ALIGN_OPS_PER_LANE_FEATURE) / per,
+                    "useful_valu_note": "adder operations the bit-sliced sums need per lane and feature (5.0: ISA of the 16-feature loop body, DESIGN.md 3.6) over the "
+                                        "wave-level VALU instructions measured per lane and feature (SQ_INSTS_VALU / (pairs / 8)); round 3's kernel: 10 of 33",
+                    "what_bounds_it": "the vector L1: a wave load of k_local_bits is 8 candidates x 128 contiguous bytes at 8-byte alignment = ~22 64-byte accesses, and "
+                                      "accesses + miss stalls fill `ceilings.tcp` of the launch's CU cycles; the VALU (carry-save adders on bit-sliced counters) "
+                                      "is at `ceilings.valu` of its issue slots since the window shifts and the address arithmetic were cut (VERDICT r03 item 3)"})
+        # every stage of a frame with the ceiling that binds it, from the same PMC passes (one fraction <= 1 per stage, recomputable from profiles/r04_pmc.txt)
+        if pm_all:
+            B_FRONT = W * H * 3 + W * H * 2 + 8 * 2 * (W * H + (W // 2) * (H // 2))      # 1.54 MB in + 6.14 MB of linear memories (8 labels x 2 modalities x 2 levels) out per VGA frame
+            stages = {}
+            fe_us, fe_bytes = 0.0, 0.0
+            fe_parts = {}
+            for k in ("k_fe_stage", "k_fe_bits", "k_pack_bits", "k_pack_top"):
+                if k in pm_all:
+                    cz = ceilings_of(pm_all[k])
+                    n = pm_all[k]["dispatches"] / max(1, pm_all[k_refine]["dispatches"] if k_refine in pm_all else 1)     # dispatches of this kernel per batch
+                    fe_us += cz["kernel_us_profiled"] * n
+                    fe_bytes += cz["hbm_bytes_per_dispatch"] * n
+                    fe_parts[k] = {"dispatches_per_batch": n, "us_per_dispatch": cz["kernel_us_profiled"], "binding": cz["binding"], "ceilings": cz["fractions"]}
+            if fe_us > 0:
+                stages["frontend"] = {"kernels": fe_parts, "us_per_batch_profiled": fe_us, "ms_per_batch_events": excl["frontend_ms"],
+                                      "algorithmic_bytes_per_frame": B_FRONT,
+                                      "hbm_frac_algorithmic": B_FRONT * BATCH / (excl["frontend_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if excl["frontend_ms"] > 0 else None,
+                                      "traffic_bytes_per_batch": fe_bytes, "traffic_over_algorithmic": fe_bytes / (B_FRONT * BATCH),
+                                      "note": "the one stage that streams: a frame in, its response maps out.  With bit planes for both passes the maps leave as 2 bits per "
+                                              "cell (2.8 MB per frame) instead of bytes in two layouts (11 MB), so the traffic can fall below SURVEY 8(d)'s algorithmic figure"}
+            for stage, k, ms in (("coarse", k_coarse_name, excl["coarse_ms"]), ("refine", k_refine, excl["local_ms"])):
+                if k in pm_all:
+                    cz = ceilings_of(pm_all[k])
+                    stages[stage] = {"kernel": k, "ms_per_batch_events": ms, "us_per_dispatch_profiled": cz["kernel_us_profiled"], "binding": cz["binding"],
+                                     "ceilings": cz["fractions"], "l2_hit_rate": cz["l2_hit_rate"], "cu_cycles_per_wave_load": cz["cu_cycles_per_wave_load"],
+                                     "l1_accesses_per_wave_load": cz["l1_accesses_per_wave_load"]}
+            rf["stages"] = stages
+        if pm is None:
             traffic = os.path.join(ROOT, "profiles", "roofline_traffic.json")   # last committed PMC pass (profiles/pmc_run.sh)
             if os.path.exists(traffic):
                 try:
@@ -576,7 +607,7 @@ def main():
                     if tj.get("kernel") == kname:
                         rf["traffic"] = tj.get("hbm_bytes_per_launch")
                         rf["traffic_source"] = "NOT measured by this run - committed pass: " + str(tj.get("source"))
-                        for q in ("l1_accesses_per_launch", "frac_of_tcp_cycles", "hbm_frac_physical", "bytes_loaded", "frames_per_launch"):
+                        for q in ("binding", "ceilings", "hbm_frac_physical", "frames_per_launch"):
                             if q in tj:
                                 rf.setdefault(q if q != "frames_per_launch" else "traffic_frames_per_launch", tj[q])
                 except (OSError, ValueError):
@@ -671,13 +702,13 @@ def stream_gate(det, host_frame, classes, bank, n_templates, depth, steps=(0, 1,
 
 PMC_PASSES = (("FETCH_SIZE", "GRBM_GUI_ACTIVE"),
               ("WRITE_SIZE", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum"),
-              ("SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_WAVES", "TCC_HIT_sum", "TCC_MISS_sum"))
+              ("SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_WAVES", "TCC_HIT_sum", "TCC_MISS_sum"))      # (MI355X_MICROARCH.md, PMC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 
 
-def pmc_live(kernel, args, timeout=120):
-    """Mean per dispatch of `kernel` of the counters in PMC_PASSES, one rocprofv3 run per pass (SQ, TCC and TCP counters do not all
-    fit one pass; --kernel-trace + --pmc only, nothing else traced) over `python bench.py --roofline-only`.  None if rocprofv3 is not
-    there or a pass fails."""
+def pmc_live(kernels, args, timeout=150):
+    """{kernel: {"dispatches": n, counter: mean per dispatch}} of the counters in PMC_PASSES for every kernel of `kernels` that ran, one rocprofv3
+    run per pass (SQ, TCC and TCP counters do not all fit one pass; --kernel-trace + --pmc only, nothing else traced) over
+    `python bench.py --roofline-only`.  None if rocprofv3 is not there or a pass fails."""
     import glob
     import shutil
     import sqlite3
@@ -685,7 +716,7 @@ def pmc_live(kernel, args, timeout=120):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None
-    vals = {}
+    vals = {k: {} for k in kernels}
     tmp = tempfile.mkdtemp(prefix="lm_pmc_", dir="/tmp")
     try:
         env = dict(os.environ, TMPDIR="/tmp")
@@ -700,24 +731,54 @@ def pmc_live(kernel, args, timeout=120):
             con = sqlite3.connect(dbs[0])
             cols = [c[1] for c in con.execute("pragma table_info('counters_collection')")]
             name_col = "kernel_name" if "kernel_name" in cols else "name"
-            # exactly this kernel: "k_local(" must not pick up "k_local_bits(" (demangled names), nor "7k_localE" "12k_local_bitsE" (mangled ones)
-            rows = con.execute("select counter_name, dispatch_id, sum(value) from counters_collection where %s like ? or %s like ? or %s like ? or %s like ? "
-                               "group by counter_name, dispatch_id" % ((name_col,) * 4),
-                               ("%" + kernel + "(%", "%" + kernel + "<%", "%%%d%sE%%" % (len(kernel), kernel), "%%%d%sI%%" % (len(kernel), kernel))).fetchall()
+            rows = con.execute("select %s, counter_name, dispatch_id, sum(value) from counters_collection group by %s, counter_name, dispatch_id" % (name_col, name_col)).fetchall()
             con.close()
-            per = {}
-            for cname, _disp, val in rows:
-                per.setdefault(cname, []).append(val)
-            for cname, v in per.items():
-                vals[cname] = sum(v) / len(v)                # every dispatch of the leg serves frames_per_launch frames
+            per = {k: {} for k in kernels}
+            for kn, cname, _disp, val in rows:
+                for k in kernels:
+                    # exactly this kernel, demangled or mangled, plain or a template instantiation: "k_local(" is not "k_local_bits<5, 4>("
+                    if any(t in kn for t in (k + "(", k + "<", "%d%sE" % (len(k), k), "%d%sI" % (len(k), k))):
+                        per[k].setdefault(cname, []).append(val)
+            for k in kernels:
+                for cname, v in per[k].items():
+                    vals[k][cname] = sum(v) / len(v)
+                    vals[k]["dispatches"] = len(v)
         need = [c for grp in PMC_PASSES for c in grp]
-        if any(c not in vals for c in need):
-            return None
-        return vals
+        return {k: v for k, v in vals.items() if all(c in v for c in need)}
     except (OSError, subprocess.SubprocessError, sqlite3.Error):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# VALU instructions per lane and feature the bit-sliced sums need (ISA of k_local_bits' 16-feature loop body): two dwords x
+# 2.5 adder operations (7 carry-save adders per 8 inputs, one more per 16, a 5-level ripple per 16: 40 v_bitop3 per dword and 16 features)
+USEFUL_ADDER_OPS_PER_LANE_FEATURE = 5.0
+ALIGN_OPS_PER_LANE_FEATURE = 2.0      # + the two v_alignbit that cut the lane's two window rows out of their records
+
+
+def ceilings_of(pm):
+    """What a kernel's launch reached of each physical ceiling, from its PMC means (every fraction <= 1 by construction):
+    tcp = vector-L1 accesses (one 64-byte access per cycle and CU) + cycles stalled on pending misses over the launch's CU cycles;
+    valu = wave-level VALU instructions x 4 cycles over the SIMD cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle: profiles/r04_pmc.txt);
+    l2 = L2 requests x 128 B (an upper bound on the bytes they move) per second over the L2 peak; hbm = memory-side bytes per second over the HBM peak."""
+    kc = pm["GRBM_GUI_ACTIVE"] / 8.0
+    if kc <= 0:
+        return None
+    us = kc / 2400.0
+    hbm_bytes = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0
+    c = {"tcp": (pm["TCP_TOTAL_CACHE_ACCESSES_sum"] + pm["TCP_PENDING_STALL_CYCLES_sum"]) / (256.0 * kc),
+         "valu": 4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kc),
+         "l2": (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) * 128.0 / (us * 1e-6) / 1e9 / L2_PEAK_GBS,
+         "hbm": hbm_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    top = max(c, key=lambda q: c[q])
+    names = {"tcp": "vector L1 (TCP): accesses + miss-stall cycles over the launch's CU cycles", "valu": "VALU issue slots (4 cycles per wave instruction)",
+             "l2": "L2 bandwidth (requests x 128 B against %.1f TB/s)" % (L2_PEAK_GBS / 1e3), "hbm": "HBM bandwidth (memory-side bytes against %.0f TB/s)" % (HBM_PEAK_GBS / 1e3)}
+    return {"kernel_us_profiled": us, "dispatches_profiled": pm.get("dispatches"), "fractions": c, "binding": {"ceiling": names[top], "frac": c[top]},
+            "hbm_bytes_per_dispatch": hbm_bytes, "wave_loads": pm["SQ_INSTS_VMEM_RD"], "valu_insts": pm["SQ_INSTS_VALU"],
+            "cu_cycles_per_wave_load": (256.0 * kc / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
+            "l1_accesses_per_wave_load": (pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
+            "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None}
 
 
 def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=8, depth=8):

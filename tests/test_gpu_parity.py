@@ -150,8 +150,9 @@ def _pair_stream(lm_colour, lm_normal, T, Wd, Hd, npairs):
 @pytest.mark.parametrize("case", ["T48", "T58", "3level", "1280", "small_T24", "masked"])
 def test_bit_planes_equal_the_packed_linear_memories(lm, case):
     """The encodings the bit-plane kernels read — strip records of every level below the top, pair stream of the top level —
-    bit for bit against a numpy packing of the ORACLE's linear memories, both as written directly by the front end (k_fe_bits) and as packed
-    from the byte planes (k_pack_bits / k_pack_top)."""
+    bit for bit against a numpy packing of the ORACLE's linear memories, as written directly by the front end (k_fe_bits: strip records from
+    LDS cell words; the pair stream as whole dwords, or OR-ed together from shifted ballots) and as packed from the byte planes (k_pack_bits /
+    k_pack_top)."""
     W, H, T = {"T48": (640, 480, [4, 8]), "T58": (640, 480, [5, 8]), "3level": (640, 480, [4, 4, 8]), "1280": (1280, 960, [4, 8]),
                "small_T24": (320, 240, [2, 4]), "masked": (640, 480, [4, 8])}[case]
     rgb, dep = synth.make_frame(61, W, H, 40 if W <= 640 else 80)
@@ -171,7 +172,7 @@ def test_bit_planes_equal_the_packed_linear_memories(lm, case):
         lms.append([lo.build_linear_memories(q[0], T[l]), lo.build_linear_memories(q[1], T[l])])
     L = len(T)
     seen = []
-    for direct in (2, False):
+    for direct in (2, 6, False):                              # the front end's own writers (2: kept readable; 6: ... and the OR-ing writer of the top level forced), packed from bytes
         det = lm.Detector(nfeat[0], T, device=0)
         det.setPaths("bits", "bits", direct)
         det.addClassPacked("o", *bank)
@@ -195,7 +196,7 @@ def test_bit_planes_equal_the_packed_linear_memories(lm, case):
         if not masks:
             raw, _ = oracle_matches(od, rgb, dep, bank, T, 70.0)
             same_records(det.matchArray([rgb, dep], 70.0, ["o"]), lo.canonical_sort_unique(raw))
-    assert seen[0] == seen[1]
+    assert seen[0] == seen[1] == seen[2]
 
 
 def test_precondition_errors_like_cv_assert(lm):
