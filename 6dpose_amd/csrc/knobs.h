@@ -11,7 +11,7 @@ struct Knobs {
     int coarse_group = 4;          // LM_COARSE_GROUP: templates per workgroup of k_coarse (<= 4)
     int local_blocks = 0;          // LM_LOCAL_BLOCKS: grid of k_local (0 = default per CU count)
     int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default)
-    int serial = 1;                // LM_SERIAL: 1 = coarse / refinement / duplicate removal of every batch on ONE stream (default), 2 = the front end too, 0 = a stream per stage
+    int serial = 2;                // LM_SERIAL: 2 = every kernel of a batch on ONE stream (default), 1 = the front end on its own stream beside the matching of the batch before, 0 = a stream per stage
     int coarse_bits = 1;           // LM_COARSE_BITS=0: coarse pass on the byte linear memories (k_coarse) instead of on the pair stream (k_coarse_bits)
     int bitplanes = 1;             // LM_BITPLANES=0: refinement on the byte strip planes with tiles (round 2-3's kernel) instead of on bit planes
     int fe_bits = 1;               // LM_FE_BITS=0: the front end always writes the byte planes and k_pack_bits / k_pack_top pack them (1: bit planes directly when nothing reads the bytes)
