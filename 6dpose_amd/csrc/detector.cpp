@@ -1445,7 +1445,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
             LevelBufs& B = d->level_bufs(b, l);
             const uint8_t* src = l == 0 ? sl.in_rgb : B.rgb.p;
             room(3);
-            fe_job_colour(st.job[st.njobs++], src, B.mag.p, B.ang.p, B.W, B.H, thr_sq);                                          // LL.cpp:367-504
+            fe_job_colour(st.job[st.njobs++], src, nullptr /* magnitudes: addTemplate only */, B.ang.p, B.W, B.H, thr_sq);      // LL.cpp:367-504
             if (l == 0) fe_job_normals(st.job[st.njobs++], sl.in_depth, b == 0 ? d->nrm_raw.p : d->nrm_raw_x[b - 1].p, B.nrm.p, B.W, B.H,
                                        d->distance_threshold, d->difference_threshold);                                          // LL.cpp:729-819
             else fe_job_nn_down2(st.job[st.njobs++], d->level_bufs(b, l - 1).nrm.p, B.nrm.p, d->level_bufs(b, l - 1).W, d->level_bufs(b, l - 1).H);   // LL.cpp:857-880

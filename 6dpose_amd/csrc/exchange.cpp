@@ -114,12 +114,15 @@ extern "C" int lm_detector_exchange_merge_group_strided(lm_detector* d, uint64_t
     hipStream_t xs = d->xchg.stream;
     launch_exchange_merge_group(G, world, (uint32_t)capacity, xs, (uint32_t)(rank_stride_bytes / 4));   // merge + copy-out to the pinned buffers
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(d->xchg.done[(int)(first % lm_detector::kSlots)], xs));  // one event for the group: its first slot's
     for (int i = 0; i < n; ++i) {
+        // the group's completion on EVERY member slot's own event (a record is cheap): with one event on the first slot, that slot's next
+        // frame — 16 frames on — re-recorded it while the later members of this group were still uncollected, and their collect then waited
+        // for the newer group
         const int slot = (int)((first + (uint64_t)i) % lm_detector::kSlots);
+        HIP_TRY(hipEventRecord(d->xchg.done[slot], xs));
         d->xchg.state[slot] = 2;
         d->xchg.world[slot] = world;
-        d->xchg.done_slot[slot] = (int)(first % lm_detector::kSlots);
+        d->xchg.done_slot[slot] = slot;
     }
     return LM_OK;
 }

@@ -172,7 +172,7 @@ static __device__ __forceinline__ void color_quant_body(const int bx, const int 
             if (votes >= 5) res = (uint8_t)(1u << best);
         }
         const size_t o = (size_t)y * W + x;
-        mag[o] = m;
+        if (mag) mag[o] = m;                   // (null for the frames of a match: only addTemplate reads the magnitudes, LL.cpp:589-643)
         onehot[o] = res;
     }
 }

@@ -1012,7 +1012,7 @@ static __device__ __forceinline__ bool dedupe_first(unsigned long long* table, u
         } else expected = prev;                                     // left over from an earlier frame: free — claim it
     }
 }
-constexpr int kKeepBuf = 256;                                       // distinct records a workgroup collects in LDS before it reserves their places with one atomic
+constexpr int kKeepBuf = 32;                                        // distinct records a WAVE collects in LDS before it reserves their places with one atomic
 
 template <int kHi, int kWaves, bool kInline>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
@@ -1023,9 +1023,8 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
     constexpr int kS = kN + 3;                                      // bits of n1 + 4 n4
     __shared__ unsigned long long s_acc[kMaxBatch][2];
     __shared__ uint32_t s_cnt[kMaxBatch];
-    __shared__ Candidate s_keep[kInline ? kKeepBuf : 1];
-    __shared__ uint32_t s_nkeep, s_nalive, s_bad;
-    __shared__ unsigned long long s_base;
+    __shared__ Candidate s_keep[kInline ? 4 : 1][kInline ? kKeepBuf : 1];   // per wave of the workgroup
+    __shared__ uint32_t s_bad;
     const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
     const int nb = fb.nb;
     // frame -> XCD affinity as in k_local
@@ -1061,16 +1060,35 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         const FrameSlot& F = fb.f[fr];
         const BufRsrc bits = make_rsrc(B.bits[fr]);
         const uint32_t nc = s_cnt[fr], ngroups = (nc + 7u) >> 3;
-        if (kInline) {
-            if (threadIdx.x == 0) { s_nkeep = 0; s_nalive = 0; s_bad = 0; }
-            __syncthreads();
-        }
-        // (kInline: every wave of the workgroup makes the same number of trips — the barriers of flush_keep — and sits a trip out when its group is past the end)
+        // kInline: a wave collects the distinct records of its candidates in its own LDS rows and reserves their places in the frame's list with ONE
+        // atomic per flush (no workgroup barrier inside the loop: four waves waiting for each other cost more than k_dedupe saved)
         const uint32_t wave_in_block = threadIdx.x >> 6;
-        for (uint32_t g0 = w_first - wave_in_block; g0 < ngroups; g0 += w_step) {
-            const uint32_t gi = g0 + wave_in_block;
+        uint32_t wkeep = 0, walive = 0;                             // wave-uniform
+        auto flush_keep = [&]() {
+            if (wkeep == 0 && walive == 0) return;
+            unsigned long long base = 0;
+            if (lane == 0) {
+                if (wkeep) base = atomicAdd(&F.counters[1], (unsigned long long)wkeep);
+                if (walive) atomicAdd(&F.counters[2], (unsigned long long)walive);
+            }
+            base = bcast_u64(base, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((uint32_t)lane < wkeep) {
+                const Candidate c = s_keep[wave_in_block][lane];
+                const unsigned long long at = base + (unsigned long long)lane;
+                F.distinct[at] = c;
+                if (F.distinct_keys) {                              // the record as a sort key for the multi-GPU exchange
+                    const int cls = work_cls[c.work], tid = work_tid[c.work];
+                    F.distinct_keys[at] = xchg_make_key(c.x, c.y, c.score, cls, tid);
+                    if (!xchg_key_fits(c.x, c.y, cls, tid)) s_bad = 1;
+                }
+            }
+            wkeep = 0; walive = 0;
+        };
+        if (kInline && threadIdx.x == 0) s_bad = 0;
+        for (uint32_t gi = w_first; gi < ngroups; gi += w_step) {
             const uint32_t ci = gi * 8u + (uint32_t)grp;
-            const bool valid = gi < ngroups && ci < nc;
+            const bool valid = ci < nc;
             Candidate cd{0, 0, 0.f, 0};
             if (valid) cd = F.cands[ci];
             const int work = cd.work;
@@ -1207,47 +1225,32 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
                     if (sim < threshold) alive = false;             // LL.cpp:1935
                 }
             }
+            bool keep = false, live = false;
+            Candidate m{0, 0, 0.f, -1};
             if (valid && j == 0) {
                 F.todo[ci] = leave ? 1 : 0;
                 if (!leave) {
-                    Candidate m;
                     m.x = mx; m.y = my; m.score = sim;
                     m.work = alive ? work : -1;
                     if (ci < cap) F.matches_dev[ci] = m;
                     atomicAdd(&s_acc[fr][0], (unsigned long long)evals);
                     atomicAdd(&s_acc[fr][1], (unsigned long long)bytes);
                     if (kInline && alive && ci < cap) {             // the duplicate removal of k_dedupe, here
-                        atomicAdd(&s_nalive, 1u);
-                        if (dedupe_first(F.dedupe_table, F.dedupe_mask, F.dedupe_gen, work, mx, my)) s_keep[atomicAdd(&s_nkeep, 1u)] = m;
+                        live = true;
+                        keep = dedupe_first(F.dedupe_table, F.dedupe_mask, F.dedupe_gen, work, mx, my);
                     }
                 }
             }
-            if (kInline) {                                          // flush when the next trip (<= 32 records) might not fit
-                __syncthreads();
-                if (s_nkeep + 32u > (uint32_t)kKeepBuf || g0 + w_step >= ngroups) {
-                    const uint32_t n = s_nkeep;
-                    if (threadIdx.x == 0) {
-                        s_base = n ? atomicAdd(&F.counters[1], (unsigned long long)n) : 0ull;
-                        if (s_nalive) atomicAdd(&F.counters[2], (unsigned long long)s_nalive);
-                    }
-                    __syncthreads();
-                    if (threadIdx.x < n) {
-                        const Candidate c = s_keep[threadIdx.x];
-                        const unsigned long long at = s_base + threadIdx.x;
-                        F.distinct[at] = c;
-                        if (F.distinct_keys) {                      // the record as a sort key for the multi-GPU exchange
-                            const int cls = work_cls[c.work], tid = work_tid[c.work];
-                            F.distinct_keys[at] = xchg_make_key(c.x, c.y, c.score, cls, tid);
-                            if (!xchg_key_fits(c.x, c.y, cls, tid)) s_bad = 1;
-                        }
-                    }
-                    __syncthreads();
-                    if (threadIdx.x == 0) { s_nkeep = 0; s_nalive = 0; }
-                    __syncthreads();
-                }
+            if (kInline) {
+                const unsigned long long mk = __ballot(keep), ml = __ballot(live);
+                if (keep) s_keep[wave_in_block][wkeep + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = m;
+                wkeep += (uint32_t)__popcll(mk); walive += (uint32_t)__popcll(ml);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (wkeep + 8u > (uint32_t)kKeepBuf) flush_keep();  // the next trip (<= 8 records) might not fit
             }
         }
         if (kInline) {
+            flush_keep();
             // this workgroup is done with frame fr: the last one to say so publishes the frame's counts and resets its working counters (k_dedupe's
             // epilogue).  The counter atomics are performed at the device's coherence point, so all the ticket needs is that this workgroup's own
             // memory operations have completed (records to pinned memory included).

@@ -83,6 +83,7 @@ class DeviceExchange:
         self.stream = torch.cuda.ExternalStream(detector.exchangeStream(), device=self.dev)
         self.slots = lm.load_library().lm_detector_max_in_flight()
         self.queue = []                 # numbers of the frames submitted whose exchange is not enqueued yet
+        self.group = None
         self._alloc(capacity)
 
     def _alloc(self, capacity: int):
@@ -92,8 +93,18 @@ class DeviceExchange:
         if nbytes == 0:
             raise ValueError("capacity must be a power of two in [256, %d]" % lm.load_library().lm_exchange_max_capacity())
         self.block_bytes = nbytes
-        # one send / receive buffer per GROUP of frames in flight: the blocks of up to `group` consecutive frames travel in ONE all-gather
-        self.group = max(1, min(self.det.getBatch(), self.slots))
+        # one send / receive buffer per GROUP of frames in flight: the blocks of up to `group` consecutive frames travel in ONE all-gather.
+        # The group size has to be the SAME on every rank (it sets the size and the number of the collectives): the smallest getBatch() of
+        # all ranks, agreed once (a rank with another LM_FRAME_BATCH / setBatch would otherwise hang the all-gather: ADVICE r03); a later
+        # setBatch() on the detector changes the kernel batches, not the exchange groups.
+        if getattr(self, "group", None) is None:
+            g = max(1, min(self.det.getBatch(), self.slots))
+            if self.collective:
+                import torch.distributed as dist
+                t = torch.tensor([g], dtype=torch.int32, device=self.dev if self.device_collective else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group_handle)
+                g = int(t.item())
+            self.group = g
         self.sets = self.slots // self.group + 2
         self.send = [torch.zeros(nbytes * self.group, dtype=torch.uint8, device=self.dev) for _ in range(self.sets)]
         self.recv = [torch.zeros(nbytes * self.group * self.world, dtype=torch.uint8, device=self.dev) for _ in range(self.sets)]

@@ -339,7 +339,7 @@ def main():
 
     # ... and the gate on the streamed path itself (world 1: the timed loop's submit / collect with the same number of frames in flight)
     if parity is not None:
-        parity["stream"] = stream_gate(det, host_frame, classes, banks[classes[0]], args.templates, PIPELINE_DEPTH)
+        parity["stream"] = stream_gate(det, host_frame, classes, banks[classes[0]], args.templates, PIPELINE_DEPTH, args.batch_queue)
 
     def run(nsteps, resident=False, first=0):
         inflight = 0
@@ -617,7 +617,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(noisy_frames(N_FRAMES), banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         if world == 1 and not strong and not args.no_extras:
-            out["extras"]["strong_scaling_reference"] = strong_reference(det, quant, frames, args.templates)
+            out["extras"]["strong_scaling_reference"] = strong_reference(det, quant, frames, args.templates, steps=max(20, args.steps), depth=PIPELINE_DEPTH)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out))
@@ -668,7 +668,7 @@ def parity_gate(det, frames, bank, classes, n_templates, n_frames=2):
     return out
 
 
-def stream_gate(det, host_frame, classes, bank, n_templates, depth, steps=(0, 1, 6, 11)):
+def stream_gate(det, host_frame, classes, bank, n_templates, depth, batch_queue, steps=(0, 1, 6, 11)):
     """The same comparison for the path the number is measured on: host frames through lm_detector_submit_frame, `depth` in flight, the
     library's batching (several frames per kernel launch, frame -> XCD affinity) — the lists collect() returns for a few steps of one
     stream against the oracle's lists for exactly those (stamped) frames.  Exits without a number on a mismatch."""
@@ -678,6 +678,7 @@ def stream_gate(det, host_frame, classes, bank, n_templates, depth, steps=(0, 1,
     pb = lo.PackedBank(n_templates, 2, *bank)
     n = max(steps) + 1
     kept, got, infl = {}, [], 0
+    det.setBatchQueue(0)                                      # full batches only: the gate must see frames that SHARE their launches, whatever the pace estimate says this early
     for k in range(n):
         rgb, dep = host_frame(k)
         if k in steps:
@@ -688,6 +689,7 @@ def stream_gate(det, host_frame, classes, bank, n_templates, depth, steps=(0, 1,
             got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
     while infl:
         got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
+    det.setBatchQueue(batch_queue)
     out = {"ok": True, "steps": [], "frames_in_flight": depth}
     for k in steps:
         want, _, st, _, _, _ = oracle_matches(od, lo, pb, kept[k][0], kept[k][1], THRESHOLD)
@@ -825,7 +827,7 @@ def sparse_threshold_run(det, frames, classes, n_templates, steps=30):
             "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "frontend_ms": tm.get("frontend_ms")}
 
 
-def strong_reference(det0, quant, frames, per_object, steps=20):
+def strong_reference(det0, quant, frames, per_object, steps=20, depth=8):
     """The N=1 point of the strong-scaling curve (`--scaling strong`: 8 objects x 2000 templates on ONE GPU), so that the
     "x at 8 GPUs over 1 GPU when sharding >= 16k templates" ratio of BASELINE.json can be formed from two bench lines."""
     import linemodLevelup_pybind as lm
@@ -837,8 +839,8 @@ def strong_reference(det0, quant, frames, per_object, steps=20):
         det.addClassPacked(cid, *synth.make_planted_bank(1234 + o, per_object, quant, T_LEVELS, NFEAT))
         classes.append(cid)
     total = per_object * STRONG_OBJECTS
-    dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps)
-    return {"templates_total": total, "ms_per_step": dt * 1e3, "value": total * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
+    dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps, warmup=16, depth=depth)
+    return {"templates_total": total, "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": depth, "value": total * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
             "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "coarse_candidates": tm.get("coarse_candidates"),
             "note": "same live-stream loop as the headline (host frame per step), `python bench.py --scaling strong` gives the same number as a bench line"}
 

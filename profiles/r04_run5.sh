@@ -24,7 +24,7 @@ PY
 run default X=1 --
 run no_inline LM_INLINE_DEDUPE=0 --
 run batch8 X=1 -- --batch 8
-run batch6 LM_BENCH_DEPTH=12 -- --batch 6
+run batch8_serial1 LM_SERIAL=1 -- --batch 8
 run batch8_noinline LM_INLINE_DEDUPE=0 -- --batch 8
 } 2>&1 | tee $OUT/bench_ab.txt
 tail -3 $OUT/bench_tmp.err
