@@ -1508,7 +1508,6 @@ static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, Fra
     F.counters = d->d_counters.p + (size_t)kCounterWords * si;
     F.matches_dev = d->d_matches_dev.p + (size_t)cc * si;
     F.dedupe_table = d->d_hash.p + dedupe_table_slots(cc) * (size_t)si;
-    F.dedupe_mask = (uint32_t)(dedupe_table_slots(cc) - 1); F.dedupe_gen = d->dedupe_gen[si];
     F.distinct_keys = d->d_distinct_keys.p + (size_t)cc * si;
     F.final_dev = d->d_final.p + 8 * (size_t)si;
     F.matches = nullptr;                                  // (k_local no longer stores the raw records into host memory: 16-byte PCIe writes per candidate)
@@ -1550,8 +1549,6 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
         if ((rc = d->d_cands.ensure((size_t)cc * K))) return rc;            // per result slot: coarse(k+1) runs beside local(k)
         if ((rc = d->d_matches_dev.ensure((size_t)cc * K))) return rc;
         if ((rc = d->d_hash.ensure(dedupe_table_slots(cc) * K))) return rc;   // one table per result slot
-        HIP_TRY(hipMemset(d->d_hash.p, 0xFF, dedupe_table_slots(cc) * K * sizeof(unsigned long long)));   // all free (generation 0xFFF is never a frame's)
-        for (int k = 0; k < K; ++k) d->dedupe_gen[k] = 0;
         if ((rc = d->d_distinct_keys.ensure((size_t)cc * K))) return rc;
         d->buf_cand_cap = cc;
     }
@@ -1638,16 +1635,6 @@ int lm_launch_pending(lm_detector* d) {
     FrameBatch fb{};
     fb.nb = nb;
     int rc;
-    // k_local_bits removes the duplicates itself (no k_dedupe launch) when it is the only refinement launch: every candidate inside its planes
-    const bool inline_dedupe = bits && d->bits_all_in && knobs().inline_dedupe && num_work > 0;
-    if (inline_dedupe)
-        for (int b = 0; b < nb; ++b) {                       // a new generation for the slot's hash table; after 4094 of them the table starts over
-            const int si = (first + b) % lm_detector::kSlots;
-            if (++d->dedupe_gen[si] > 4094u) {
-                HIP_TRY(hipMemsetAsync(d->d_hash.p + dedupe_table_slots(d->buf_cand_cap) * (size_t)si, 0xFF, dedupe_table_slots(d->buf_cand_cap) * sizeof(unsigned long long), d->mstream));
-                d->dedupe_gen[si] = 1;
-            }
-        }
     for (int b = 0; b < nb; ++b)
         if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
     hipStream_t ms = d->mstream, s = knobs().serial >= 2 ? ms : d->stream;
@@ -1726,7 +1713,7 @@ int lm_launch_pending(lm_detector* d) {
         // the hash tables k_dedupe uses
         if (bits) {
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
-                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, inline_dedupe, d->d_work_cls.p, d->d_work_tid.p, ms);
+                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms);
             if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
                 launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
@@ -1739,7 +1726,6 @@ int lm_launch_pending(lm_detector* d) {
     };
     // exact duplicates out (they never survive std::unique): distinct records + counts to the slots' pinned memory
     auto enqueue_dedupe = [&](hipStream_t st) -> int {
-        if (inline_dedupe) return LM_OK;                      // done by k_local_bits
         if (num_work > 0)
             launch_dedupe(fb, d->buf_cand_cap, dedupe_table_slots(d->buf_cand_cap), d->d_work_cls.p, d->d_work_tid.p, d->num_cus * 2, st);
         else

@@ -180,7 +180,6 @@ struct lm_detector {
     bool fe_keep_top = false, fe_top_atomic = false; // lm_detector_set_direct_bits(d, 2 / 4)
     bool fe_bytes_low = true, fe_bytes_top = true;  // did the last front end write the byte planes of the levels below the top / of the top level (read_stage builds them on demand otherwise)
     hipEvent_t resident_reader = nullptr;           // front end (event of its batch) that reads the resident frame buffers: lm_detector_select_frame's copy waits for it
-    uint32_t dedupe_gen[kSlots] = {};               // generation of the slot's hash table entries (k_local_bits removing the duplicates itself)
     bool cbits_clean[kSlots] = {};                  // the slot's pair stream is all zero (what the front end's OR-ing writer needs)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list

@@ -116,9 +116,7 @@ struct FrameSlot {                            // device pointers of ONE frame of
     unsigned long long* counters;             // [kCounterWords] working counters, zero between frames
     Candidate* matches;                       // unused (round 2: a pinned host copy of matches_dev written by k_local; the host now fetches matches_dev when asked)
     Candidate* matches_dev;                   // [cap] refined records in HBM, one per candidate (duplicate removal, on-device NMS, exchange)
-    unsigned long long* dedupe_table;         // open-addressing table of the duplicate removal (k_dedupe, or k_local_bits itself)
-    uint32_t dedupe_gen, dedupe_mask;         // k_local_bits removing the duplicates itself: entries carry the frame's generation (1 .. 4094) in their top 12 bits,
-                                              // so the table (dedupe_mask + 1 slots) is never emptied — an entry of another generation is a free slot
+    unsigned long long* dedupe_table;         // open-addressing table of k_dedupe
     Candidate* distinct;                      // [cap] records without exact duplicates, pinned host memory
     ulonglong2* distinct_keys;                // the same as 128-bit exchange keys (HBM), may be null
     unsigned long long* final_dev;            // [8] published counts of the finished frame (HBM): candidates, distinct, alive, key overflow
@@ -139,11 +137,9 @@ constexpr int kBitsSmallMax = 511;            // features per template entry the
 void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s);
 // Every level below the top: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path (windows leaving their planes);
 // max_features = the largest nf of the bank's entries below the top level.
-// inline_dedupe: the kernel also does k_dedupe's work (distinct records to pinned memory, their exchange keys, the published counts, the reset
-// of the working counters) — only when no second refinement launch follows (work_cls / work_tid: class position and template id per work item)
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       int max_features, bool inline_dedupe, const int32_t* work_cls, const int32_t* work_tid, hipStream_t s);
+                       int max_features, hipStream_t s);
 // Coarse pass on bit planes: per frame of a batch the flat arena and the pair stream of bytes [byte0, byte0 + 32 npairs) of it (the top
 // level's blocks of both modalities with their zero tails): launch_pack_top packs it from the bytes, the front end writes it directly when
 // nothing reads the top level's bytes (frontend.hip, top_bits_body: the stream must be zero before).

@@ -994,37 +994,14 @@ k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
 // All pyramid levels below the top are walked here (LL.cpp:1855: level by level, dropping a candidate as soon as it falls below the
 // threshold); a candidate whose windows leave their planes at some level (oversized template, features outside the frame) is marked in
 // `todo` and left, from the top, to k_local's per-candidate path.
-// Duplicate removal inside the refinement (kInline): a record is kept iff it is the first (work item, x, y) of its frame in the slot's hash
-// table.  Entries carry the frame's generation in their top 12 bits, so nothing empties the table: an entry of another generation is free.
-static __device__ __forceinline__ bool dedupe_first(unsigned long long* table, uint32_t mask, uint32_t gen, int work, int x, int y) {
-    if ((uint32_t)work >= (1u << 20) || x < -32768 || x > 32767 || y < -32768 || y > 32767) return true;   // cannot be keyed: kept (std::unique decides on the host)
-    const unsigned long long body = ((unsigned long long)(uint32_t)work << 32) | ((uint32_t)(x & 0xFFFF) << 16) | (uint32_t)(y & 0xFFFF);
-    const unsigned long long key = ((unsigned long long)gen << 52) | body;
-    uint32_t slot = (uint32_t)((body * 0x9E3779B97F4A7C15ull) >> 40) & mask;
-    unsigned long long expected = ~0ull;
-    for (;;) {                                                      // the table has >= 2 x the candidate capacity: never full
-        const unsigned long long prev = atomicCAS(&table[slot], expected, key);
-        if (prev == expected) return true;                          // claimed a free slot
-        if ((uint32_t)(prev >> 52) == gen) {                        // a record of this frame
-            if (prev == key) return false;
-            slot = (slot + 1) & mask;
-            expected = ~0ull;
-        } else expected = prev;                                     // left over from an earlier frame: free — claim it
-    }
-}
-constexpr int kKeepBuf = 32;                                        // distinct records a WAVE collects in LDS before it reserves their places with one atomic
-
-template <int kHi, int kWaves, bool kInline>
+template <int kHi, int kWaves>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restrict__ entries, const uint32_t* __restrict__ feat_word,
-             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots,
-             const int32_t* __restrict__ work_cls, const int32_t* __restrict__ work_tid) {
+             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots) {
     constexpr int kN = 4 + kHi;                                     // counter bits per plane
     constexpr int kS = kN + 3;                                      // bits of n1 + 4 n4
     __shared__ unsigned long long s_acc[kMaxBatch][2];
     __shared__ uint32_t s_cnt[kMaxBatch];
-    __shared__ Candidate s_keep[kInline ? 4 : 1][kInline ? kKeepBuf : 1];   // per wave of the workgroup
-    __shared__ uint32_t s_bad;
     const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
     const int nb = fb.nb;
     // frame -> XCD affinity as in k_local
@@ -1043,7 +1020,7 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         s_acc[threadIdx.x][0] = 0; s_acc[threadIdx.x][1] = 0;
     }
     __syncthreads();
-    for (int f = 0; f < nb && !kInline; ++f) {                      // k_dedupe's hash table, emptied here like k_local does
+    for (int f = 0; f < nb; ++f) {                                  // k_dedupe's hash table, emptied here like k_local does
         unsigned long long* table = fb.f[f].dedupe_table;
         if (!table) continue;
         const uint32_t tsize = dedupe_slots_for(s_cnt[f], dedupe_cap_slots);
@@ -1060,32 +1037,6 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         const FrameSlot& F = fb.f[fr];
         const BufRsrc bits = make_rsrc(B.bits[fr]);
         const uint32_t nc = s_cnt[fr], ngroups = (nc + 7u) >> 3;
-        // kInline: a wave collects the distinct records of its candidates in its own LDS rows and reserves their places in the frame's list with ONE
-        // atomic per flush (no workgroup barrier inside the loop: four waves waiting for each other cost more than k_dedupe saved)
-        const uint32_t wave_in_block = threadIdx.x >> 6;
-        uint32_t wkeep = 0, walive = 0;                             // wave-uniform
-        auto flush_keep = [&]() {
-            if (wkeep == 0 && walive == 0) return;
-            unsigned long long base = 0;
-            if (lane == 0) {
-                if (wkeep) base = atomicAdd(&F.counters[1], (unsigned long long)wkeep);
-                if (walive) atomicAdd(&F.counters[2], (unsigned long long)walive);
-            }
-            base = bcast_u64(base, 0);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if ((uint32_t)lane < wkeep) {
-                const Candidate c = s_keep[wave_in_block][lane];
-                const unsigned long long at = base + (unsigned long long)lane;
-                F.distinct[at] = c;
-                if (F.distinct_keys) {                              // the record as a sort key for the multi-GPU exchange
-                    const int cls = work_cls[c.work], tid = work_tid[c.work];
-                    F.distinct_keys[at] = xchg_make_key(c.x, c.y, c.score, cls, tid);
-                    if (!xchg_key_fits(c.x, c.y, cls, tid)) s_bad = 1;
-                }
-            }
-            wkeep = 0; walive = 0;
-        };
-        if (kInline && threadIdx.x == 0) s_bad = 0;
         for (uint32_t gi = w_first; gi < ngroups; gi += w_step) {
             const uint32_t ci = gi * 8u + (uint32_t)grp;
             const bool valid = ci < nc;
@@ -1225,65 +1176,23 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
                     if (sim < threshold) alive = false;             // LL.cpp:1935
                 }
             }
-            bool keep = false, live = false;
-            Candidate m{0, 0, 0.f, -1};
             if (valid && j == 0) {
                 F.todo[ci] = leave ? 1 : 0;
                 if (!leave) {
-                    m.x = mx; m.y = my; m.score = sim;
-                    m.work = alive ? work : -1;
-                    if (ci < cap) F.matches_dev[ci] = m;
+                    if (ci < cap) {
+                        Candidate m;
+                        m.x = mx; m.y = my; m.score = sim;
+                        m.work = alive ? work : -1;
+                        F.matches_dev[ci] = m;
+                    }
                     atomicAdd(&s_acc[fr][0], (unsigned long long)evals);
                     atomicAdd(&s_acc[fr][1], (unsigned long long)bytes);
-                    if (kInline && alive && ci < cap) {             // the duplicate removal of k_dedupe, here
-                        live = true;
-                        keep = dedupe_first(F.dedupe_table, F.dedupe_mask, F.dedupe_gen, work, mx, my);
-                    }
                 }
             }
-            if (kInline) {
-                const unsigned long long mk = __ballot(keep), ml = __ballot(live);
-                if (keep) s_keep[wave_in_block][wkeep + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = m;
-                wkeep += (uint32_t)__popcll(mk); walive += (uint32_t)__popcll(ml);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (wkeep + 8u > (uint32_t)kKeepBuf) flush_keep();  // the next trip (<= 8 records) might not fit
-            }
-        }
-        if (kInline) {
-            flush_keep();
-            // this workgroup is done with frame fr: the last one to say so publishes the frame's counts and resets its working counters (k_dedupe's
-            // epilogue).  The counter atomics are performed at the device's coherence point, so all the ticket needs is that this workgroup's own
-            // memory operations have completed (records to pinned memory included).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned long long* counters = F.counters;
-                if (s_bad) atomicOr(&counters[3], 1ull);
-                if (s_acc[fr][0] != 0) {                            // the statistics of this frame, before the ticket
-                    unsigned long long* st = counters + 8 + 2 * (blockIdx.x & (kStatShards - 1));
-                    atomicAdd(st, s_acc[fr][0]);
-                    atomicAdd(st + 1, s_acc[fr][1]);
-                    s_acc[fr][0] = 0;
-                }
-                const unsigned long long serving = (f_hi - f_lo == 1 && nb > 1) ? (unsigned long long)(gridDim.x >> 3) * (unsigned long long)(8 / nb) : (unsigned long long)gridDim.x;
-                if (atomicAdd(&counters[7], 1ull) == serving - 1ull) {
-                    const unsigned long long c0 = atomicAdd(&counters[0], 0ull);
-                    const unsigned long long nd = atomicAdd(&counters[1], 0ull), na = atomicAdd(&counters[2], 0ull), bad = atomicAdd(&counters[3], 0ull);
-                    unsigned long long ev = 0, lb = 0;
-                    for (int q = 0; q < kStatShards; ++q) { ev += atomicAdd(&counters[8 + 2 * q], 0ull); lb += atomicAdd(&counters[9 + 2 * q], 0ull); }
-                    const unsigned long long ncand = c0 & kCandMask;
-                    F.final_dev[0] = ncand; F.final_dev[1] = nd; F.final_dev[2] = na; F.final_dev[3] = bad;
-                    F.final_host[0] = ncand; F.final_host[1] = nd; F.final_host[2] = na; F.final_host[3] = bad;
-                    F.final_host[4] = c0 >> kCandBits;
-                    F.final_host[5] = ev; F.final_host[6] = lb;
-                    for (int q = 0; q < kCounterWords; ++q) counters[q] = 0;
-                }
-            }
-            __syncthreads();
         }
     }
     __syncthreads();
-    if (!kInline && (int)threadIdx.x < nb && s_acc[threadIdx.x][0] != 0) {
+    if ((int)threadIdx.x < nb && s_acc[threadIdx.x][0] != 0) {
         unsigned long long* st = fb.f[threadIdx.x].counters + 8 + 2 * (blockIdx.x & (kStatShards - 1));
         atomicAdd(st, s_acc[threadIdx.x][0]);
         atomicAdd(st + 1, s_acc[threadIdx.x][1]);
@@ -1296,14 +1205,15 @@ void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream
 }
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       int max_features, bool inline_dedupe, const int32_t* work_cls, const int32_t* work_tid, hipStream_t s) {
-#define LM_LAUNCH_LOCAL_BITS(HI, WAVES, INL) \
-    hipLaunchKernelGGL((k_local_bits<HI, WAVES, INL>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, \
-                       dedupe_cap_slots, work_cls, work_tid)
-    if (max_features > kBitsSmallMax) { if (inline_dedupe) LM_LAUNCH_LOCAL_BITS(10, 4, true); else LM_LAUNCH_LOCAL_BITS(10, 4, false); }
-    else if (knobs().bits_waves == 5) { if (inline_dedupe) LM_LAUNCH_LOCAL_BITS(5, 5, true); else LM_LAUNCH_LOCAL_BITS(5, 5, false); }
-    else { if (inline_dedupe) LM_LAUNCH_LOCAL_BITS(5, 4, true); else LM_LAUNCH_LOCAL_BITS(5, 4, false); }
-#undef LM_LAUNCH_LOCAL_BITS
+                       int max_features, hipStream_t s) {
+    if (max_features > kBitsSmallMax)
+        hipLaunchKernelGGL((k_local_bits<10, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves >= 6)
+        hipLaunchKernelGGL((k_local_bits<5, 6>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves == 5)
+        hipLaunchKernelGGL((k_local_bits<5, 5>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else
+        hipLaunchKernelGGL((k_local_bits<5, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
 }
 
 // ---- Coarse pass on the pair stream (LL.cpp:1284-1354 similarity + :1835-1852 scan).  A wave per template, a lane = 32 consecutive
