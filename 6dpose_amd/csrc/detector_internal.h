@@ -183,7 +183,7 @@ struct lm_detector {
     bool cbits_clean[kSlots] = {};                  // the slot's pair stream is all zero (what the front end's OR-ing writer needs)
     uint64_t n_submitted = 0, n_collected = 0, n_launched = 0;
     // frames submitted but not launched yet: slots pend_first .. pend_first + pend_n - 1 (modulo kSlots), same threshold and work list
-    int batch_max = 4;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch)
+    int batch_max = 8;                              // frames per launch in stream mode (lm_detector_set_batch, LM_FRAME_BATCH; <= kMaxBatch).  8 since round 4: 0.074 against 0.089 ms per frame over 200 steps, the same at 20 (profiles/r04_stream_ab.txt)
     int pend_first = 0, pend_n = 0;
     float pend_threshold = 0.f;
     // Launched batches the GPU may still be working on, oldest first.  When does a streamed frame that does not fill its batch go

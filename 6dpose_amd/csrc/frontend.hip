@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) k_build_lm(LmJob j0, LmJob j1, int W, int
 void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T, hipStream_t s) {
     int Wd = W / T, Hd = H / T, NS = (Wd + 15) / 16;
-    LmJob j0{quant[0], mask[0], lm[0], strips[0], nullptr, 0u}, j1{quant[1], mask[1], lm[1], strips[1], nullptr, 0u};
+    LmJob j0{quant[0], mask[0], lm[0], strips[0]}, j1{quant[1], mask[1], lm[1], strips[1]};
     hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS, div_magic((uint32_t)Wd), div_magic((uint32_t)T));
 }
 
@@ -536,7 +536,7 @@ static __device__ __forceinline__ void bits_rows_body(const int bx, const int by
     }
     __syncthreads();
     const size_t splane1 = (size_t)NS * Hd * 8;                           // one (label, phase) plane of records
-    uint8_t* out = J.bits + (size_t)phase * splane1;
+    uint8_t* out = J.lm + (size_t)phase * splane1;
     const float inv_rows = 1.0f / (float)rows, inv_ns = 1.0f / (float)NS;
     for (int i = (int)threadIdx.x; i < 8 * rows * NS; i += 256) {
         const int q = (int)(((float)i + 0.5f) * inv_rows), r = i - q * rows;   // (small integers: the float quotients are exact)
@@ -570,13 +570,14 @@ static __device__ __forceinline__ void top_bits_body(const int bx, const int by,
     const uint32_t one = (((v << 1) | (v >> 7) | (v >> 1) | (v << 7)) & 0xFFu) & ~v;
     const int lane = (int)threadIdx.x & 63;
     const uint32_t idx0 = (uint32_t)(idx - lane);                         // the wave's first position (wave-uniform)
-    uint32_t* stream = reinterpret_cast<uint32_t*>(J.bits);               // pair p: stream[2 p] = is 1, stream[2 p + 1] = is 4
+    uint32_t* stream = reinterpret_cast<uint32_t*>(J.lm);                 // pair p: stream[2 p] = is 1, stream[2 p + 1] = is 4
+    const uint32_t top_bit0 = (uint32_t)reinterpret_cast<uintptr_t>(J.strips);
     const int plane = lane >= 3, k = lane - 3 * plane;                    // lanes 0..5 carry the three dwords of the two planes
 #pragma unroll
     for (int ori = 0; ori < 8; ++ori) {
         const unsigned long long m1 = __ballot(in && ((one >> ori) & 1u)), m4 = __ballot(in && ((v >> ori) & 1u));
         if ((m1 | m4) == 0ull) continue;                                  // wave-uniform
-        const uint32_t fo = J.top_bit0 + (uint32_t)(ori * T * T + phase) * (uint32_t)npos + idx0;   // flat position of the wave's first bit, from the stream's start
+        const uint32_t fo = top_bit0 + (uint32_t)(ori * T * T + phase) * (uint32_t)npos + idx0;   // flat position of the wave's first bit, from the stream's start
         const uint32_t sh = fo & 31u, p0 = fo >> 5;
         const unsigned long long m = plane ? m4 : m1;
         const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
@@ -613,8 +614,8 @@ static __device__ __forceinline__ void top_bits_aligned_body(const int bx, const
         if (lane == ori) mine = make_uint4((uint32_t)m1, (uint32_t)m4, (uint32_t)(m1 >> 32), (uint32_t)(m4 >> 32));
     }
     if (lane < 8 && b0 < (uint32_t)run) {
-        const uint32_t pair = (J.top_bit0 + (uint32_t)lane * (uint32_t)run + b0) >> 5;                  // even: the label's block and b0 are multiples of 64 positions
-        *reinterpret_cast<uint4*>(J.bits + (size_t)pair * 8) = mine;
+        const uint32_t pair = ((uint32_t)reinterpret_cast<uintptr_t>(J.strips) + (uint32_t)lane * (uint32_t)run + b0) >> 5;                  // even: the label's block and b0 are multiples of 64 positions
+        *reinterpret_cast<uint4*>(J.lm + (size_t)pair * 8) = mine;
     }
 }
 
@@ -690,7 +691,7 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
                      int W, int H, int T) {
     j = FeJob{}; j.kind = kFeBuildLm; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
-    j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0], nullptr, 0u}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1], nullptr, 0u};
+    j.lm[0] = LmJob{quant[0], mask[0], lm[0], strips[0]}; j.lm[1] = LmJob{quant[1], mask[1], lm[1], strips[1]};
 }
 // strip records of a level below the top, written directly (bits[m]: the level's record block of modality m inside the bit arena)
 bool fe_bits_rows_possible(int W, int T) { return fe_bits_rows(W / T) >= 1; }
@@ -699,13 +700,13 @@ void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* co
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
     const int R = fe_bits_rows(j.Wd);
     j.gx = (j.Hd + R - 1) / R; j.gy = T * T; j.gz = 2;
-    j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, bits[0], 0u}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, bits[1], 0u};
+    j.lm[0] = LmJob{quant[0], mask[0], bits[0], nullptr}; j.lm[1] = LmJob{quant[1], mask[1], bits[1], nullptr};
 }
 // pair stream of the top level, written directly; bit0[m] = flat arena offset of modality m's block less the stream's first byte
 void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T, bool force_atomic) {
     j = FeJob{}; j.kind = kFeTopBits; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
-    j.lm[0] = LmJob{quant[0], mask[0], nullptr, nullptr, stream, bit0[0]}; j.lm[1] = LmJob{quant[1], mask[1], nullptr, nullptr, stream, bit0[1]};
+    j.lm[0] = LmJob{quant[0], mask[0], stream, reinterpret_cast<uint8_t*>((uintptr_t)bit0[0])}; j.lm[1] = LmJob{quant[1], mask[1], stream, reinterpret_cast<uint8_t*>((uintptr_t)bit0[1])};
     if (fe_top_bits_aligned(W, H, T) && !force_atomic) {    // whole dwords per wave: no atomics, nothing to clear
         const int npos = j.Wd * j.Hd;
         j.kind = kFeTopBitsAligned; j.gx = (T * T * npos + 255) / 256; j.gy = 1; j.m_np = div_magic((uint32_t)npos);

@@ -20,8 +20,9 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
                      int W, int H, int T, hipStream_t s);
 
 // several independent jobs of the front end in one launch (frontend.hip, k_fe_stage)
-struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips;
-               uint8_t* bits; uint32_t top_bit0; };   // bits: the bit planes written directly (strip records of the level / the top level's pair stream); top_bit0: see fe_job_top_bits
+struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
+// (the bit-plane jobs reuse the two output slots — 24 jobs of a batch of 8 frames must fit the 4 KB of kernel arguments —: `lm` = the strip
+// records of the level / the top level's pair stream, `strips` = for the pair stream the flat position of the modality's block in it, as an integer)
 enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits, kFeTopBitsAligned };
 struct FeJob {
     int kind, gx, gy, gz, first;          // job kind, its block grid, its first flat block index (set by launch_fe_stage)
@@ -35,7 +36,7 @@ struct FeJob {
     int Wd, Hd;                           // build_lm: decimated size
     LmJob lm[2];                          // build_lm: [0] colour, [1] normals
 };
-constexpr int kFeMaxJobs = 20;            // 3-4 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
+constexpr int kFeMaxJobs = 24;            // 3-4 jobs per frame of a batch (stage 1), kMaxLevels per frame in the last stage: the struct is a kernel argument (< 4 KB)
 struct FeStage { int njobs; FeJob job[kFeMaxJobs]; };
 static_assert(sizeof(FeStage) + 16 <= 4096, "FeStage is passed by value: kernel arguments are limited to 4 KB");
 void fe_job_colour(FeJob& j, const uint8_t* rgb, float* mag, uint8_t* onehot, int W, int H, float thr_sq);

@@ -492,7 +492,7 @@ class Detector:
         _check(self._lib.lm_detector_flush(self._h))
 
     def setBatch(self, frames: int) -> None:
-        """Frames per kernel launch in stream mode, 1..8 (lm_detector_set_batch; default 4 or LM_FRAME_BATCH).  Results do not depend on it."""
+        """Frames per kernel launch in stream mode, 1..8 (lm_detector_set_batch; default 8 or LM_FRAME_BATCH).  Results do not depend on it."""
         _check(self._lib.lm_detector_set_batch(self._h, int(frames)))
 
     def setBatchQueue(self, batches: int) -> None:

@@ -238,7 +238,7 @@ int lm_detector_set_reference_order(lm_detector *d, int on);
  *
  * Frames per launch: a 2k-template bank does not fill the chip, so consecutive streamed frames share their kernel launches —
  * the frame's upload starts at once, its front end / coarse pass / refinement / duplicate removal are launched together with
- * those of the following frames once lm_detector_get_batch() (default 4, LM_FRAME_BATCH, lm_detector_set_batch 1..8) frames
+ * those of the following frames once lm_detector_get_batch() (default 8, LM_FRAME_BATCH, lm_detector_set_batch 1..8) frames
  * with the same threshold and class list are waiting, or when lm_detector_flush or a lm_detector_collect that needs one of them
  * is called — or at once while the GPU has fewer than lm_detector_set_batch_queue (default 2, LM_BATCH_QUEUE; 0 = always wait for
  * a full batch) launched batches still to finish: the GPU never idles waiting for a batch to fill, the first frames of a stream go

@@ -800,7 +800,7 @@ def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
     want65 = [det.matchArray(list(f), 65.0, ["o"]) for f in frames[:3]]
     det.addClassPacked("p", *synth.make_planted_bank(72, 40, [(p[0], p[1]) for p in pyr], T, nfeat))
     want_po = [det.matchArray(list(f), 70.0, ["p", "o"]) for f in frames[:3]]
-    assert det.getBatch() == 4
+    assert det.getBatch() == 8
     for nbatch in (1, 2, 3, 4, 5, 8, 4):
         det.setBatch(nbatch)
         det.setBatchQueue(0 if nbatch != 4 else 2)                 # 0: full batches only (deterministic sizes); 2 = default: early launches while the GPU's queue is short
@@ -824,7 +824,7 @@ def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
             assert det.collect().tobytes() == e.tobytes(), (nbatch, "mixed", k)
     with pytest.raises(RuntimeError):
         det.setBatch(9)
-    det.setBatch(4)
+    det.setBatch(8)
 
 
 def test_config1_size_2k_templates_bit_exact(lm):
