@@ -1614,6 +1614,11 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 static bool partial_batch_due(lm_detector* d, double at) {
     if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
     if (d->n_launched == d->n_collected) return true;
+    // ... or everything launched has FINISHED on the GPU (collected or not): frames are waiting and the GPU is idle.  The start of a stream
+    // used to lose ~0.15 ms here: frame 0 went out alone, finished after 0.2-0.3 ms, and the frames behind it waited for a full batch of
+    // eight.  (One event query per submit while a batch is pending; a tight loop cannot get stuck on one-frame batches through this rule:
+    // a lone frame keeps the GPU busy for 0.15-0.2 ms, three submits' worth of host time.)
+    if (batches_queued(d) == 0) return true;
     if (d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms) return false;   // (0: no second submit yet — sparse until shown otherwise)
     if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;

@@ -15,7 +15,7 @@ det.setFrame(list(frames[0])); det.matchResident(75.0, ["_probe"])
 quant = [(det.readStage(l, 0).reshape(H >> l, W >> l), det.readStage(l, 1).reshape(H >> l, W >> l)) for l in range(2)]
 det.addClassPacked("obj", *synth.make_planted_bank(1234, 2000, quant, bench.T_LEVELS, bench.NFEAT))
 cls = ["obj"]
-depth = int(os.environ.get("DEPTH", "12"))
+depth = int(os.environ.get("DEPTH", "16"))
 def tm(det):
     t = det.lastTimings()
     return "%d fe%.0f co%.0f lo%.0f tot%.0f" % (t["batch_frames"], t["frontend_ms"] * 1e3, t["coarse_ms"] * 1e3, t["local_ms"] * 1e3, t["total_ms"] * 1e3)
