@@ -1237,7 +1237,7 @@ k_pack_top(TopBits B, uint32_t byte0, uint32_t npairs) {
     *reinterpret_cast<uint2*>(B.bits[blockIdx.y] + (size_t)i * 8) = r;
 }
 
-template <int kHi, int kWaves, bool kDeep>
+template <int kHi, int kWaves>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
               const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0) {
@@ -1293,40 +1293,8 @@ k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, con
                 e1 = add8(x1, c1[0], c1[1], c1[2]);
                 e4 = add8(x4, c4[0], c4[1], c4[2]);
             };
-            // kDeep: the loads of both halves of a 16-feature trip are issued before the first is used — the pass is bound by the latency of its
-            // 19 dependent load batches per template (vector L1 at 0.46, VALU at 0.45 of their ceilings), so 10 round trips instead of 19
-            auto loads = [&](int f, uint4 (&v)[8], uint32_t (&sh)[8]) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t ob = (uint32_t)fo[f + u] - byte0 + (uint32_t)P0;      // wave-uniform -> SMEM / SALU
-                    sh[u] = ob & 31u;
-                    v[u] = ld_buf16(bits, (uint32_t)lane * 8u, (ob >> 5) * 8u);          // pairs q + lane and q + lane + 1
-                }
-            };
-            auto sums = [&](const uint4 (&v)[8], const uint32_t (&sh)[8], uint32_t& e1, uint32_t& e4) {
-                uint32_t x1[8], x4[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    x1[u] = __builtin_amdgcn_alignbit(v[u].z, v[u].x, sh[u]);
-                    x4[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].y, sh[u]);
-                }
-                e1 = add8(x1, c1[0], c1[1], c1[2]);
-                e4 = add8(x4, c4[0], c4[1], c4[2]);
-            };
             for (int f = 0; f < nfp; f += 16) {
                 uint32_t a1, a4;
-                if (kDeep && f + 8 < nfp) {
-                    uint4 va[8], vb[8];
-                    uint32_t sa[8], sb[8];
-                    loads(f, va, sa);
-                    loads(f + 8, vb, sb);
-                    uint32_t b1, b4;
-                    sums(va, sa, a1, a4);
-                    sums(vb, sb, b1, b4);
-                    add_eights2<kN>(c1, a1, b1);
-                    add_eights2<kN>(c4, a4, b4);
-                    continue;
-                }
                 batch(f, a1, a4);
                 if (f + 8 < nfp) {
                     uint32_t b1, b4;
@@ -1400,12 +1368,11 @@ void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom&
                         const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s) {
     if (num_work <= 0 || fb.nb <= 0) return;
     const int level = g.levels - 1;
-#define LM_LAUNCH_COARSE_BITS(HI, WAVES, DEEP) \
-    hipLaunchKernelGGL((k_coarse_bits<HI, WAVES, DEEP>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off, \
+#define LM_LAUNCH_COARSE_BITS(HI, WAVES) \
+    hipLaunchKernelGGL((k_coarse_bits<HI, WAVES>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off, \
                        work_pyramids, num_work, threshold, cap, byte0)
-    if (max_features > kBitsSmallMax) LM_LAUNCH_COARSE_BITS(10, 5, false);
-    else if (knobs().cbits_deep) LM_LAUNCH_COARSE_BITS(5, 5, true);
-    else LM_LAUNCH_COARSE_BITS(5, 6, false);
+    if (max_features > kBitsSmallMax) LM_LAUNCH_COARSE_BITS(10, 5);
+    else LM_LAUNCH_COARSE_BITS(5, 6);
 #undef LM_LAUNCH_COARSE_BITS
 }
 
