@@ -76,21 +76,26 @@ def add_eights(c, e1, e2):
     assert not k16.any()
 
 KN = 9
-def refine_bitplanes(gx, gy, F):
-    """One candidate, window origin (gx, gy) in cells, F = [nf][4] (x, y, label, mod).  8 lanes, lane j = rows 2j, 2j + 1; returns (raw, index).
-    The lane-level algorithm of k_local_bits<5>: 16 features per trip, counters of 9 bits, rows side by side at the end."""
-    cA = [np.zeros(8, np.uint32) for _ in range(KN)]
-    cB = [np.zeros(8, np.uint32) for _ in range(KN)]
-    lanes = np.arange(8)
+def refine_bitplanes(gx, gy, F, dys=(0,)):
+    """One unit, window origin (gx, gy) in cells, F = [nf][4] (x, y, label, mod).  Lane j = rows 2j, 2j + 1 behind gy.  dys = (0,): a single
+    candidate on 8 lanes; several entries: a VERTICAL RUN — candidates of one template in consecutive coarse rows of one coarse column, window
+    origins (gx, gy + dy) with 0 <= dy <= 16 — on 16 lanes: the rows are summed once, every member takes the maximum of its own 16 rows.
+    Returns (raw, index) per member.  The lane-level algorithm of k_local_bits<5>: 16 features per trip, 9-bit counters, rows side by side at the end."""
+    NL = 8 if len(dys) == 1 else 16
+    cA = [np.zeros(NL, np.uint32) for _ in range(KN)]
+    cB = [np.zeros(NL, np.uint32) for _ in range(KN)]
+    lanes = np.arange(NL)
+    active = 2 * lanes < max(dys) + 16                          # lanes beyond the run's last row load nothing
     nfp = (len(F) + 7) // 8 * 8
-    zero = np.zeros(8, np.uint32)
+    zero = np.zeros(NL, np.uint32)
     def window(fx, fy, lab, m):
         cx, cy = fx // T0, fy // T0
         ph = (fy % T0) * T0 + (fx % T0)
         s2 = ((cx & 15) + (gx & 15)) << 1                        # prep(): 2 x (column class + window column), bit 5 = strip carry
         s = (cx >> 4) + (gx >> 4) + (s2 >> 5)
-        r0 = REC[m, lab, ph, s, cy + gy + 2 * lanes]               # the lane's 16-byte load: two consecutive row records
-        r1 = REC[m, lab, ph, s, cy + gy + 2 * lanes + 1]
+        rows = np.where(active, cy + gy + 2 * lanes, 0)
+        r0 = np.where(active, REC[m, lab, ph, s, rows], np.uint64(0))       # the lane's 16-byte load: two consecutive row records
+        r1 = np.where(active, REC[m, lab, ph, s, np.minimum(rows + 1, Hd - 1)], np.uint64(0))
         sh = np.uint64(s2 & 31)                                    # v_alignbit(hi, lo, s2): 32 bits from bit s2 & 31 of the record
         return ((r0 >> sh) & np.uint64(0xFFFFFFFF)).astype(np.uint32), ((r1 >> sh) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     for f0 in range(0, nfp, 16):
@@ -111,24 +116,45 @@ def refine_bitplanes(gx, gy, F):
     M = np.uint32(0x55555555); M2 = np.uint32(0xAAAAAAAA)
     n1 = [(cA[k] & M) | ((cB[k] << np.uint32(1)) & M2) for k in range(KN)]
     n4 = [((cA[k] >> np.uint32(1)) & M) | (cB[k] & M2) for k in range(KN)]
-    S = [n1[0], n1[1]]; carry = np.zeros(8, np.uint32)
+    S = [n1[0], n1[1]]; carry = np.zeros(NL, np.uint32)
     for k in range(2, KN + 3):
         a = n1[k] if k < KN else zero
         b = n4[k - 2] if k - 2 < KN else zero
         sk, carry = csa(a, b, carry)
         S.append(sk)
-    best = 0
-    for j in range(8):
-        mask, val = 0xFFFFFFFF, 0
-        for k in range(KN + 2, -1, -1):
-            t = mask & int(S[k][j])
-            if t: mask = t; val |= 1 << k
-        upper = mask & 0x55555555
-        pick = upper if upper else mask
-        bitp = (pick & -pick).bit_length() - 1
-        pos = ((2 * j + (bitp & 1)) << 4) + (bitp >> 1)
-        best = max(best, (val << 8) | (255 - pos))
-    return best >> 8, 255 - (best & 0xFF)
+    out = []
+    for dy in dys:                                             # every member: its own 16 rows [dy, dy + 16) of the unit's rows
+        best = 0
+        for j in range(NL):
+            va, vb = dy <= 2 * j < dy + 16, dy <= 2 * j + 1 < dy + 16
+            mask = (0x55555555 if va else 0) | (0xAAAAAAAA if vb else 0)
+            if not mask: continue                              # (key 0 in the kernel)
+            val = 0
+            for k in range(KN + 2, -1, -1):
+                t = mask & int(S[k][j])
+                if t: mask = t; val |= 1 << k
+            upper = mask & 0x55555555
+            pick = upper if upper else mask
+            bitp = (pick & -pick).bit_length() - 1
+            pos = ((2 * j + (bitp & 1) - dy) << 4) + (bitp >> 1)
+            best = max(best, (val << 8) | (255 - pos))
+        out.append((best >> 8, 255 - (best & 0xFF)))
+    return out[0] if len(dys) == 1 else out
+
+def plan_runs(hit, run_max):
+    """The planner of k_coarse_bits: hit = [Hd1][Wd1] bool.  A hit is the k-th of the chain of hits directly above it; heads are those with
+    k % run_max == 0, a head's run = the hits directly below it, at most run_max in all.  Returns [(ax, ay, n)] for the heads (raster order)."""
+    units = []
+    for ay in range(hit.shape[0]):
+        for ax in range(hit.shape[1]):
+            if not hit[ay, ax]: continue
+            k = 0
+            while ay - k - 1 >= 0 and hit[ay - k - 1, ax]: k += 1
+            if k % run_max: continue
+            n = 1
+            while n < run_max and ay + n < hit.shape[0] and hit[ay + n, ax]: n += 1
+            units.append((ax, ay, n))
+    return units
 
 def refine_bytes(gx, gy, F):
     jj, ii = np.mgrid[0:16, 0:16]
@@ -143,6 +169,7 @@ Wd1, Hd1 = W1 // T1, H1 // T1
 off1 = T1 // 2 + (T1 % 2 - 1); off0 = T0 // 2 + (T0 % 2 - 1)
 border = 8 * T0
 ncand = nbad = 0
+nrun = nrun_members = nrun_bad = 0
 kept = []
 t0 = time.time()
 for t in range(0, 2000, STEP):
@@ -166,12 +193,16 @@ for t in range(0, 2000, STEP):
     F = np.concatenate([np.column_stack([f, np.full(len(f), m)]) for m, (f, _) in enumerate(fs)])
     nf0 = len(F)
     tw = max(fs[0][1][0], fs[1][1][0]); th = max(fs[0][1][1], fs[1][1][1])
-    for h in hits:
-        ay, ax = divmod(int(h), Wd1)
+    def origin(ax, ay):
         mx, my = ax * T1 + off1, ay * T1 + off1
         x = min(max(mx * 2 + 1, border), W0 - tw - border); y = min(max(my * 2 + 1, border), H0 - th - border)
-        gx, gy = x // T0 - 8, y // T0 - 8
+        return x, y, x // T0 - 8, y // T0 - 8
+    single = {}
+    for h in hits:
+        ay, ax = divmod(int(h), Wd1)
+        x, y, gx, gy = origin(ax, ay)
         a = refine_bitplanes(gx, gy, F)
+        single[(ax, ay)] = a
         b = refine_bytes(gx, gy, F)
         ncand += 1
         if a != b:
@@ -181,7 +212,25 @@ for t in range(0, 2000, STEP):
         sim = np.float32(raw) * np.float32(100.0) / np.float32(4 * nf0)
         if sim >= np.float32(THR):
             kept.append(((x // T0 - 8 + (idx & 15)) * T0 + off0, (y // T0 - 8 + (idx >> 4)) * T0 + off0, float(sim), t))
+    # vertical runs (k_coarse_bits plans them, k_local_bits serves a run with 16 lanes): every member's result equals its single evaluation
+    hitmap = np.zeros(Hd1 * Wd1, bool); hitmap[hits] = True
+    RUN_MAX = min(5, 1 + (8 * T0) // T1)
+    covered = 0
+    for ax, ay, n in plan_runs(hitmap.reshape(Hd1, Wd1), RUN_MAX):
+        covered += n
+        if n == 1: continue
+        _, _, gx, gy = origin(ax, ay)
+        dys = [origin(ax, ay + m)[3] - gy for m in range(n)]
+        assert all(origin(ax, ay + m)[2] == gx for m in range(n)) and all(0 <= d <= 16 for d in dys), (dys,)
+        res = refine_bitplanes(gx, gy, F, tuple(dys))
+        nrun += 1; nrun_members += n
+        for m in range(n):
+            if res[m] != single[(ax, ay + m)]:
+                nrun_bad += 1
+                if nrun_bad < 5: print("RUN MISMATCH template", t, (ax, ay), m, dys, res[m], single[(ax, ay + m)])
+    assert covered == len(hits)
 print("templates %d, candidates %d, bit-plane == byte evaluation: %s (%d mismatches), %.1f s" % (len(range(0, 2000, STEP)), ncand, nbad == 0, nbad, time.time() - t0))
+print("vertical runs %d with %d members: run evaluation == single evaluation: %s (%d mismatches)" % (nrun, nrun_members, nrun_bad == 0, nrun_bad))
 
 # the oracle's records for the same templates
 pb = lo.PackedBank(2000, 2, feat, off, wh)
