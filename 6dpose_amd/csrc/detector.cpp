@@ -221,7 +221,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& b : d->slot_depth) b.release();
     for (auto& l : d->lvl) { l.rgb.release(); l.mag.release(); l.ang.release(); l.nrm.release(); l.mask[0].release(); l.mask[1].release(); }
     d->d_entries.release(); d->d_feat_off.release(); d->d_feat_xy.release(); d->d_feat_word.release(); d->d_run_mask.release(); d->d_work.release();
-    d->d_singles.release(); d->d_runs.release();
     d->d_cands.release(); d->d_counters.release(); d->d_final.release(); d->d_matches_dev.release(); d->d_hash.release(); d->d_distinct_keys.release(); d->d_tiles.release(); d->d_todo.release(); d->d_work_cls.release(); d->d_work_tid.release();
     for (int l = 0; l < kMaxLevels; ++l) { d->train.mask[l].release(); d->train.lab[l].release(); d->train.hrun[l].release(); }
     d->train.user_mask.release();
@@ -978,8 +977,8 @@ static int upload_bank(lm_detector* d) {
                 for (size_t i = 0; i < recs.size();) {
                     size_t j = i;
                     while (j < recs.size() && recs[j].cls == recs[i].cls) ++j;
-                    // a run: <= kClassRunMax (even) features of one class, so that the packed-byte sums of the refinement cannot overflow
-                    for (size_t k = i; k < j; ++k) push_feat(recs[k].off, recs[k].xy, recs[k].base0, recs[k].cls, (k - i) % kClassRunMax == 0);
+                    // a run: <= kRunMax (even) features of one class, so that the packed-byte sums of the refinement cannot overflow
+                    for (size_t k = i; k < j; ++k) push_feat(recs[k].off, recs[k].xy, recs[k].base0, recs[k].cls, (k - i) % kRunMax == 0);
                     last_cls = recs[i].cls;
                     if (!top && ((j - i) & 1)) push_pad(last_cls);   // the refinement consumes features in same-class pairs
                     i = j;
@@ -1506,8 +1505,6 @@ static int frame_slot(lm_detector* d, int si, bool tiled, uint32_t tile_cap, Fra
     F.cands = d->d_cands.p + (size_t)cc * si;
     F.tiles = tiled ? d->d_tiles.p + (size_t)tile_cap * si : nullptr;
     F.todo = tiled ? d->d_todo.p + (size_t)cc * si : nullptr;
-    F.singles = d->d_singles.p ? d->d_singles.p + (size_t)cc * si : nullptr;
-    F.runs = d->d_runs.p ? d->d_runs.p + (size_t)(cc / 2) * si : nullptr;
     F.counters = d->d_counters.p + (size_t)kCounterWords * si;
     F.matches_dev = d->d_matches_dev.p + (size_t)cc * si;
     F.dedupe_table = d->d_hash.p + dedupe_table_slots(cc) * (size_t)si;
@@ -1553,8 +1550,6 @@ static int slot_begin(lm_detector* d, float threshold, const char* const* class_
         if ((rc = d->d_matches_dev.ensure((size_t)cc * K))) return rc;
         if ((rc = d->d_hash.ensure(dedupe_table_slots(cc) * K))) return rc;   // one table per result slot
         if ((rc = d->d_distinct_keys.ensure((size_t)cc * K))) return rc;
-        if ((rc = d->d_singles.ensure((size_t)cc * K))) return rc;          // unit lists of the bit-plane refinement (k_coarse_bits plans vertical runs)
-        if ((rc = d->d_runs.ensure((size_t)(cc / 2) * K))) return rc;
         d->buf_cand_cap = cc;
     }
     if (!d->d_counters.p) {                                                          // per result slot; zero from here on (see k_dedupe)
@@ -1708,17 +1703,10 @@ int lm_launch_pending(lm_detector* d) {
                 if (d->ingest.d_rgb[r].p && sl.in_rgb == d->ingest.d_rgb[r].p) d->ingest.reader[r] = lead.fe_done;
     }
     const uint32_t cap = std::min<uint32_t>(lead.match_cap, d->buf_cand_cap);
-    // Vertical runs (match.hip): planned by k_coarse_bits for two-level pyramids whose candidates all stay inside their planes (no second
-    // refinement launch) and whose coarse map one pass of the planner's bitmap holds; members' windows lie at most 16 rows behind the head's
-    int run_max = 0;
-    if (cbits && d->bits_all_in && d->use_runs && knobs().runs && d->geom.levels == 2 && d->geom.lv[1].Wd * d->geom.lv[1].Hd <= 2048) {
-        run_max = std::min(kRunMax, 1 + (8 * d->geom.lv[0].T) / d->geom.lv[1].T);
-        if (run_max < 2) run_max = 0;
-    }
     auto enqueue_coarse = [&](hipStream_t st) -> int {
         HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
-        if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, run_max, st);
+        if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, st);
         else launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
         HIP_TRY(hipEventRecord(lead.ev[3], st));
         return LM_OK;
@@ -1730,7 +1718,7 @@ int lm_launch_pending(lm_detector* d) {
         // the hash tables k_dedupe uses
         if (bits) {
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
-                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, run_max >= 2, ms);
+                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms);
             if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
                 launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
@@ -2050,7 +2038,6 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.matches_pre_unique = (int64_t)nm;
     tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
     tm.batch_frames = sl.batch_n;
-    tm.refine_runs = sl.num_work > 0 ? (int32_t)hc[7] : 0;
     if (hipEventElapsedTime(&tm.frontend_ms, lead.ev[0], lead.ev[1]) != hipSuccess ||
         hipEventElapsedTime(&tm.coarse_ms, lead.ev[2], lead.ev[3]) != hipSuccess ||
         hipEventElapsedTime(&tm.local_ms, lead.ev[5], lead.ev[4]) != hipSuccess ||
@@ -2314,7 +2301,6 @@ extern "C" int lm_detector_set_direct_bits(lm_detector* d, int on) {
     d->fe_direct = on != 0;
     d->fe_keep_top = (on & 2) != 0;  // tests: the pair stream stays readable after the match (lm_detector_read_stage kind 5) and is cleared before the next frame instead
     d->fe_top_atomic = (on & 4) != 0; // tests: the OR-ing writer of the pair stream also where whole dwords could be stored
-    d->use_runs = (on & 8) == 0;      // tests / measurements: bit 3 = no vertical runs in the bit-plane refinement
     return LM_OK;
 }
 

@@ -121,9 +121,6 @@ struct lm_detector {
     DevBuf<Candidate> d_matches_dev;                // HBM copy of the refined records (on-device NMS / top-K, duplicate removal)
     DevBuf<unsigned long long> d_hash;              // open-addressing table of k_dedupe
     DevBuf<TileRec> d_tiles;                        // per result slot: the tiles k_coarse planned (cand_cap / 2 records each)
-    DevBuf<uint32_t> d_singles;                     // per result slot: candidate slots the bit-plane refinement takes one by one (k_coarse_bits planning vertical runs)
-    DevBuf<RunRec> d_runs;                          // per result slot: vertical runs (cand_cap / 2 records)
-    bool use_runs = true;                           // lm_detector_set_direct_bits bit 3 clears it
     DevBuf<uint8_t> d_todo;                         // per result slot: 1 = candidate that no tile serves (refined on its own)
     bool use_tiles = true;                          // LM_TILES=0: every candidate on its own (the round-1 refinement)
     bool reference_order = false;                   // lm_detector_set_reference_order / LM_REFERENCE_ORDER=1: match() returns the reference's own permutation (sort_unique 3)

@@ -108,20 +108,12 @@ constexpr int kCounterWords = 64;             // working counters per result slo
                                               // [2] alive, [3] key overflow, [7] block ticket of k_dedupe, [8 + 2 s], [9 + 2 s]: 16x16 evaluations /
                                               // their algorithmic bytes of the refinement, shard s = block & (kStatShards - 1)
 constexpr int kStatShards = 16;
-// Vertical runs (match.hip): the coarse hits of a template in consecutive coarse rows of ONE coarse column have the same
-// window column and window rows a few cells apart, so k_local_bits sums the rows of such a run once (16 lanes = up to 32 rows) and every
-// member takes the maximum of its own 16.  k_coarse_bits plans them: every candidate is either in the frame's list of singles or a member of
-// exactly one run.
-constexpr int kRunMax = 5;                    // members of a run: 16 + 4 x 4 rows = the 32 rows of 16 lanes
-struct RunRec { uint32_t slot[kRunMax]; uint32_t n; uint32_t pad[2]; };   // candidate slots of the members, top to bottom
 struct FrameSlot {                            // device pointers of ONE frame of a batch
     const uint8_t* lm_arena;                  // linear memories (flat) of the frame
     const uint8_t* sm_arena;                  // strip-major copy (levels below the top)
     Candidate* cands;                         // [cand_cap] coarse candidates
     TileRec* tiles;                           // [tile_cap] or null
     uint8_t* todo;                            // [cand_cap] or null
-    uint32_t* singles;                        // [cand_cap] candidate slots refined on their own (k_coarse_bits planning runs: counters[4] of them), or null
-    RunRec* runs;                             // [cand_cap / 2] vertical runs (counters[5] of them), or null
     unsigned long long* counters;             // [kCounterWords] working counters, zero between frames
     Candidate* matches;                       // unused (round 2: a pinned host copy of matches_dev written by k_local; the host now fetches matches_dev when asked)
     Candidate* matches_dev;                   // [cap] refined records in HBM, one per candidate (duplicate removal, on-device NMS, exchange)
@@ -146,19 +138,17 @@ constexpr int kBitsSmallMax = 511;            // features per template entry the
 void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream_t s);
 // Every level below the top: todo[ci] = 1 for the candidates it leaves to launch_local's per-candidate path (windows leaving their planes);
 // max_features = the largest nf of the bank's entries below the top level.
-// use_lists: k_coarse_bits planned vertical runs — the work items are the frame's runs and singles lists instead of its candidates
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       int max_features, bool use_lists, hipStream_t s);
+                       int max_features, hipStream_t s);
 // Coarse pass on bit planes: per frame of a batch the flat arena and the pair stream of bytes [byte0, byte0 + 32 npairs) of it (the top
 // level's blocks of both modalities with their zero tails): launch_pack_top packs it from the bytes, the front end writes it directly when
 // nothing reads the top level's bytes (frontend.hip, top_bits_body: the stream must be zero before).
 struct TopBits { const uint8_t* lm[kMaxBatch]; uint8_t* bits[kMaxBatch]; };
 void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, hipStream_t s);
 // candidates only (no tiles); max_features = the largest nf of the bank's top-level entries
-// run_max >= 2: also plans vertical runs of up to run_max members (FrameSlot::singles / runs; maps of up to 2048 positions only — the caller checks)
 void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, int run_max, hipStream_t s);
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s);
 bool tile_plan_possible(const FrameGeom& g);
 size_t coarse_plan_lds_bytes(int Wd, int Hd);
 // Per frame of the batch: counters[0] = number of candidates produced (may exceed cap: nothing is written past cap); with tiles
@@ -176,7 +166,7 @@ void launch_coarse(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* e
 // scalar instruction per feature for the address (round 2: 9, and 8 for the run bookkeeping).
 // run_mask[f / 8] bit (f % 8): feature f starts a new class run (class change, or 62 features of one class: the packed-byte sums hold
 // 63 x 4).  Runs have even length and start at even indices (the per-candidate path loads same-class pairs).
-constexpr int kClassRunMax = 62;
+constexpr int kRunMax = 62;
 void launch_local(const FrameBatch& fb, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off, const uint32_t* feat_word,
                   const uint32_t* run_mask, const uint32_t* feat_xy, const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap,
                   uint32_t dedupe_cap_slots, uint32_t tile_cap, int grid_blocks, hipStream_t s);

@@ -16,7 +16,6 @@
 //             already redirected to the zero tail.  feat_xy[] = int16 x | int16 y << 16 is only
 //             read on the slow path of the refinement (bounds test of LL.cpp:1394).
 #include <algorithm>
-#include <type_traits>
 
 #include "knobs.h"
 #include "lm_kernels.h"
@@ -662,7 +661,7 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                             if (cur >= 0) flush(cur);
                             cur = (int)(c[u] & 15);
                         }
-                        r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // <= 62 x 4 per byte (host: runs of <= kClassRunMax)
+                        r8[0] += v[u].x; r8[1] += v[u].y; r8[2] += v[u].z; r8[3] += v[u].w;   // <= 62 x 4 per byte (host: runs of <= kRunMax)
                     }
 #pragma unroll
                     for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
@@ -838,7 +837,7 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
                                 if (cur >= 0) flush(cur);
                                 cur = (int)(c[2 * k] & 15);
                             }
-                            r8[0] += v[k].x; r8[1] += v[k].y; r8[2] += v[k].z; r8[3] += v[k].w;   // <= 31 x 4 per byte and half (host: runs of <= kClassRunMax)
+                            r8[0] += v[k].x; r8[1] += v[k].y; r8[2] += v[k].z; r8[3] += v[k].w;   // <= 31 x 4 per byte and half (host: runs of <= kRunMax)
                         }
 #pragma unroll
                         for (int u = 0; u < kFeatBatch; ++u) c[u] = cn[u];
@@ -998,30 +997,30 @@ k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
 template <int kHi, int kWaves>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restrict__ entries, const uint32_t* __restrict__ feat_word,
-             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int use_lists) {
+             const int32_t* __restrict__ work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots) {
     constexpr int kN = 4 + kHi;                                     // counter bits per plane
     constexpr int kS = kN + 3;                                      // bits of n1 + 4 n4
     __shared__ unsigned long long s_acc[kMaxBatch][2];
-    __shared__ uint32_t s_cnt[kMaxBatch], s_ns[kMaxBatch], s_nr[kMaxBatch];
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_cnt[kMaxBatch];
+    const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
     const int nb = fb.nb;
-    // frame -> XCD affinity as in k_local
+    // Frame -> XCD affinity as in k_local (an XCD's L2 holds ONE frame's planes), for ANY batch size up to 8: frame f is served by the workgroups of
+    // the XCDs x with x % nb == f — 8 / nb of them each when nb divides 8, else some frames get one XCD more than others.  (Round 3 fell back to
+    // dealing the items of all frames to all workgroups unless nb divided 8: a 5-frame launch — the first and last launches of a short stream —
+    // then cost 35 us per frame against 26 in an 8-frame launch.)
     int f_lo = 0, f_hi = nb;
     uint32_t w_first = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), w_step = gridDim.x * (blockDim.x >> 6);
-    if (nb > 1 && (8 % nb) == 0 && (gridDim.x & 7) == 0) {
-        const int per = 8 / nb, xcd = (int)(blockIdx.x & 7);
-        f_lo = xcd / per; f_hi = f_lo + 1;
+    if (nb > 1 && nb <= 8 && (gridDim.x & 7) == 0) {
+        const int xcd = (int)(blockIdx.x & 7);
+        f_lo = xcd % nb; f_hi = f_lo + 1;
+        const uint32_t mine = (uint32_t)((7 - f_lo) / nb + 1);      // XCDs serving this frame: f_lo, f_lo + nb, ...
         const uint32_t wpb = blockDim.x >> 6;
-        w_first = ((blockIdx.x >> 3) * (uint32_t)per + (uint32_t)(xcd % per)) * wpb + (threadIdx.x >> 6);
-        w_step = (gridDim.x >> 3) * (uint32_t)per * wpb;
+        w_first = ((blockIdx.x >> 3) * mine + (uint32_t)(xcd / nb)) * wpb + (threadIdx.x >> 6);
+        w_step = (gridDim.x >> 3) * mine * wpb;
     }
     if ((int)threadIdx.x < nb) {
-        const unsigned long long* cn = fb.f[threadIdx.x].counters;
-        const unsigned long long nc = cn[0] & kCandMask;
+        const unsigned long long nc = fb.f[threadIdx.x].counters[0] & kCandMask;
         s_cnt[threadIdx.x] = nc < cand_cap ? (uint32_t)nc : cand_cap;
-        // the lists k_coarse_bits planned (every candidate is in exactly one of them; none past the candidate capacity is listed)
-        s_ns[threadIdx.x] = use_lists ? (uint32_t)(cn[4] < cand_cap ? cn[4] : cand_cap) : 0u;
-        s_nr[threadIdx.x] = use_lists ? (uint32_t)(cn[5] < cand_cap / 2 ? cn[5] : cand_cap / 2) : 0u;
         s_acc[threadIdx.x][0] = 0; s_acc[threadIdx.x][1] = 0;
     }
     __syncthreads();
@@ -1036,200 +1035,15 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
         for (int f = 0; f < nb; ++f)
             for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < B.top_clear_units; i += gridDim.x * blockDim.x)
                 reinterpret_cast<uint4*>(B.top_clear[f])[i] = make_uint4(0u, 0u, 0u, 0u);
-
-    // One level of one UNIT: a candidate on kGroup = 8 lanes, or a vertical run of up to kRunMax candidates on kGroup = 16 (lane j = rows 2j, 2j + 1
-    // behind the unit's first window row; `rows` of them are needed).  Sums the responses of the unit's features over its rows; returns the
-    // bit-sliced S = n1 + 4 n4 of the lane's two rows side by side (bit 2c = row 2j, bit 2c + 1 = row 2j + 1 of window column c).
-    auto accumulate = [&](auto group_tag, const BufRsrc bits, const LevelGeom& lv, const TemplEntry& e, const bool run, const int gx, const int gy, const int rows,
-                          uint32_t (&S)[kS]) {
-        constexpr int kGroup = decltype(group_tag)::value;
-        const int j = lane & (kGroup - 1);
-        const int src0 = (lane & ~(kGroup - 1)) << 2;              // ds_bpermute address of the unit's first lane
-        const uint32_t rowoff = 16u * (uint32_t)j;                  // records of rows 2j, 2j + 1 behind the window's first row
-        const bool act = 2 * j < rows;                              // (a run of few members leaves its last lanes without rows: they load nothing)
-        const int T = lv.T, Hd = lv.Hd;
-        const uint32_t HS8 = (uint32_t)Hd * 8u;
-        const uint32_t zero_off = (lv.sm_off[1] + 8u * (uint32_t)(T * T) * ((uint32_t)lv.NS * (uint32_t)Hd * 16u)) >> 1;   // the level's all-zero plane
-        const int nfp = run ? (int)e.nf_padded : 0;
-        int nmax = nfp;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
-        nmax = __builtin_amdgcn_readfirstlane(nmax);
-        const uint32_t Kbase = (uint32_t)(((gx >> 4) * Hd + gy) * 8);
-        const uint32_t gxl = (uint32_t)(gx & 15);
-        const uint32_t* fw = feat_word + e.feat_start;
-        uint32_t cA[kN], cB[kN];                                    // bit-sliced counters of rows 2j / 2j + 1: even bits count the 1s, odd bits the 4s
-#pragma unroll
-        for (int k = 0; k < kN; ++k) { cA[k] = 0; cB[k] = 0; }
-        // lanes 0..7 of the unit fetch the words of features f0 + 2j, f0 + 2j + 1 (entries start at multiples of 8 words, f0 is a multiple of 16)
-        auto fetch = [&](int f0) -> uint2 {
-            uint2 w = make_uint2(0u, 0u);
-            if (j < 8 && f0 + 2 * j < nfp) w = *reinterpret_cast<const uint2*>(fw + f0 + 2 * j);
-            return w;
-        };
-        // a feature word (base0 | column class, lm_kernels.h) -> offset of its first record in the bit arena, 2 x the window's cell inside it
-        auto prep = [&](uint32_t w, bool on, uint32_t& off, uint32_t& s2) {
-            s2 = ((w & 15u) + gxl) << 1;
-            const uint32_t o = ((w & ~15u) >> 1) + Kbase + ((s2 >> 5) ? HS8 : 0u);
-            off = on ? o : zero_off;                                // beyond this unit's features (or no unit): the zero plane
-        };
-        uint32_t offx = 0, offy = 0, sx = 0, sy = 0;
-        auto batch = [&](int half, uint32_t& eA, uint32_t& eB) {   // features 8 half .. 8 half + 7 of the current 16
-            uint4 v[8];
-            uint32_t sh[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int src = src0 + 4 * (4 * half + (u >> 1));  // the lane that fetched feature 8 half + u
-                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? offy : offx));
-                sh[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? sy : sx));
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (kGroup == 8 || act) v[u] = ld_buf16(bits, o + rowoff, 0u);   // rows 2j, 2j + 1: 32 cells x 2 bits each
-            }
-            uint32_t xa[8], xb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                xa[u] = __builtin_amdgcn_alignbit(v[u].y, v[u].x, sh[u]);      // 16 window cells of row 2j: bits 2c (is 1), 2c + 1 (is 4)
-                xb[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].z, sh[u]);      // ... of row 2j + 1
-            }
-            eA = add8(xa, cA[0], cA[1], cA[2]);
-            eB = add8(xb, cB[0], cB[1], cB[2]);
-        };
-        uint2 wn = fetch(0);
-        for (int f0 = 0; f0 < nmax; f0 += 16) {
-            const uint2 w = wn;
-            const bool on = j < 8 && f0 + 2 * j < nfp;
-            wn = fetch(f0 + 16);                                    // the next 16 words while these are worked on
-            prep(w.x, on, offx, sx);
-            prep(w.y, on, offy, sy);
-            uint32_t e1A, e1B;
-            batch(0, e1A, e1B);
-            if (f0 + 8 < nmax) {                                    // wave-uniform
-                uint32_t e2A, e2B;
-                batch(1, e2A, e2B);
-                add_eights2<kN>(cA, e1A, e2A);
-                add_eights2<kN>(cB, e1B, e2B);
-            } else {
-                add_eights1<kN>(cA, e1A);
-                add_eights1<kN>(cB, e1B);
-            }
-        }
-        uint32_t n1[kN], n4[kN], carry = 0;
-#pragma unroll
-        for (int k = 0; k < kN; ++k) {
-            n1[k] = (cA[k] & 0x55555555u) | ((cB[k] << 1) & 0xAAAAAAAAu);
-            n4[k] = ((cA[k] >> 1) & 0x55555555u) | (cB[k] & 0xAAAAAAAAu);
-        }
-        S[0] = n1[0]; S[1] = n1[1];
-#pragma unroll
-        for (int k = 2; k < kS; ++k) {
-            const uint32_t a = k < kN ? n1[k] : 0u, b = k - 2 < kN ? n4[k - 2] : 0u;
-            csa(S[k], carry, a, b, carry);
-        }
-    };
-    // The maximum of S over the 16 window rows [dy, dy + 16) of a unit's rows and its FIRST position in raster order (row 2j before row 2j + 1,
-    // then the column): the lane's maximum by a descent from the top bit, the unit's by exchanges among its lanes.  Returns raw << 8 | 255 - index.
-    auto best_of = [&](auto group_tag, const uint32_t (&S)[kS], const int dy) -> uint32_t {
-        constexpr int kGroup = decltype(group_tag)::value;
-        const int j = lane & (kGroup - 1);
-        const int ra = 2 * j - dy, rb = ra + 1;                     // the lane's rows inside the window
-        uint32_t mask = ((ra >= 0 && ra < 16) ? 0x55555555u : 0u) | ((rb >= 0 && rb < 16) ? 0xAAAAAAAAu : 0u);
-        const bool any = mask != 0u;
-        uint32_t val = 0;
-#pragma unroll
-        for (int k = kS - 1; k >= 0; --k) {
-            const uint32_t t = mask & S[k];
-            if (t) { mask = t; val |= 1u << k; }
-        }
-        const uint32_t upper = mask & 0x55555555u;                   // positions of row 2j attaining the maximum come first in raster order
-        const uint32_t pick = upper ? upper : mask;
-        const uint32_t bitp = (uint32_t)__ffs((int)pick) - 1u;
-        const uint32_t pos = ((uint32_t)(ra + (int)(bitp & 1u)) << 4) + (bitp >> 1);   // row * 16 + column
-        uint32_t key = any ? ((val << 8) | (255u - pos)) : 0u;
-#pragma unroll
-        for (int o = 1; o < kGroup; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
-        return key;
-    };
-
+    const int src0 = (lane & ~7) << 2;                              // ds_bpermute address of the group's first lane
+    const uint32_t rowoff = 16u * (uint32_t)j;                      // records of rows 2j, 2j + 1 behind the window's first row
     for (int fr = f_lo; fr < f_hi; ++fr) {
         const FrameSlot& F = fb.f[fr];
         const BufRsrc bits = make_rsrc(B.bits[fr]);
-        // ---- vertical runs (two-level pyramids, every window inside its plane: k_coarse_bits plans them only then): 4 units of 16 lanes per wave
-        const uint32_t nruns = s_nr[fr];
-        for (uint32_t gi = w_first; gi < ((nruns + 3u) >> 2); gi += w_step) {
-            const uint32_t ui = gi * 4u + (uint32_t)(lane >> 4);
-            const bool valid = ui < nruns;
-            const int j = lane & 15;
-            RunRec r{};
-            if (valid) r = F.runs[ui];
-            const int n = valid ? (int)r.n : 0;
-            const LevelGeom& lv = g.lv[0];
-            const int T = lv.T, W = lv.W, H = lv.H;
-            const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-            Candidate cd{0, 0, 0.f, 0};
-            if (valid) cd = F.cands[r.slot[0]];
-            const int work = cd.work;
-            const TemplEntry e = entries[(size_t)work_pyramids[work] * g.levels];
-            const int max_x = W - e.width - border, max_y = H - e.height - border;
-            auto clamp_y = [&](int cy) { int y = cy * 2 + 1; y = y > border ? y : border; return y < max_y ? y : max_y; };   // LL.cpp:1871-1880
-            int x = cd.x * 2 + 1;
-            x = x > border ? x : border; x = x < max_x ? x : max_x;
-            const int y0 = clamp_y(cd.y);
-            const int gx = x / T - 8, gy0 = y0 / T - 8;
-            int dy[kRunMax];                                         // the members' window rows behind the first member's
-            dy[0] = 0;
-#pragma unroll
-            for (int m = 1; m < kRunMax; ++m) {
-                dy[m] = 0;
-                if (m < n) dy[m] = clamp_y(F.cands[r.slot[m]].y) / T - 8 - gy0;
-            }
-            int rows = 0;
-#pragma unroll
-            for (int m = 0; m < kRunMax; ++m) if (m < n) rows = dy[m] + 16;
-            uint32_t S[kS];
-            accumulate(std::integral_constant<int, 16>{}, bits, lv, e, valid, gx, gy0, rows, S);
-            int nmem = n;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmem, o, 64); nmem = t > nmem ? t : nmem; }
-            nmem = __builtin_amdgcn_readfirstlane(nmem);
-            const int nf = e.nf;
-#pragma unroll
-            for (int m = 0; m < kRunMax; ++m) {
-                if (m >= nmem) break;                               // wave-uniform
-                const uint32_t key = best_of(std::integral_constant<int, 16>{}, S, dy[m]);
-                if (m < n && j == 0) {
-                    const int raw = (int)(key >> 8);
-                    int br = -1, bc = -1;                           // LL.cpp:1910-1911
-                    float best = 0.f;
-                    if (raw > 0) {
-                        const int idx = 255 - (int)(key & 0xFF);
-                        br = idx >> 4; bc = idx & 15;
-                        best = score_of(raw, nf);
-                    }
-                    const uint32_t ci = r.slot[m];
-                    F.todo[ci] = 0;
-                    if (ci < cap) {
-                        Candidate out;
-                        out.x = (x / T - 8 + bc) * T + offset;      // LL.cpp:1930-1931
-                        out.y = (gy0 + dy[m] + br) * T + offset;   // (y / T - 8 of the member = gy0 + dy)
-                        out.score = best;
-                        out.work = best < threshold ? -1 : work;    // LL.cpp:1935
-                        F.matches_dev[ci] = out;
-                    }
-                }
-            }
-            if (valid && j == 0) {
-                atomicAdd(&s_acc[fr][0], (unsigned long long)n);
-                atomicAdd(&s_acc[fr][1], (unsigned long long)n * 256ull * (unsigned long long)nf);   // algorithmic response bytes: one 16x16 evaluation per member
-            }
-        }
-        // ---- single candidates: 8 units of 8 lanes per wave, every level below the top
-        const uint32_t nc = s_cnt[fr], nsingle = use_lists ? s_ns[fr] : nc;
-        for (uint32_t gi = w_first; gi < ((nsingle + 7u) >> 3); gi += w_step) {
-            const uint32_t ii = gi * 8u + (uint32_t)(lane >> 3);
-            const bool valid = ii < nsingle;
-            const int j = lane & 7;
-            uint32_t ci = ii;
-            if (use_lists) ci = valid ? F.singles[ii] : 0u;
+        const uint32_t nc = s_cnt[fr], ngroups = (nc + 7u) >> 3;
+        for (uint32_t gi = w_first; gi < ngroups; gi += w_step) {
+            const uint32_t ci = gi * 8u + (uint32_t)grp;
+            const bool valid = ci < nc;
             Candidate cd{0, 0, 0.f, 0};
             if (valid) cd = F.cands[ci];
             const int work = cd.work;
@@ -1242,6 +1056,8 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
                 const LevelGeom& lv = g.lv[l];
                 const int T = lv.T, W = lv.W, H = lv.H, Wd = lv.Wd, Hd = lv.Hd;
                 const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+                const uint32_t HS8 = (uint32_t)Hd * 8u;
+                const uint32_t zero_off = (lv.sm_off[1] + 8u * (uint32_t)(T * T) * ((uint32_t)lv.NS * (uint32_t)Hd * 16u)) >> 1;   // the level's all-zero plane
                 const TemplEntry e = entries[(size_t)pyr * g.levels + l];
                 // LL.cpp:1871-1880 (the clamp) and 1380-1381 (window origin), exactly as k_local
                 const int max_x = W - e.width - border, max_y = H - e.height - border;
@@ -1255,13 +1071,101 @@ k_local_bits(FrameBatch fb, BitsBatch B, FrameGeom g, const TemplEntry* __restri
                 const bool want = alive && !leave;
                 if (want && !all_in) leave = true;
                 const bool run = want && all_in;
-                uint32_t S[kS];
-                accumulate(std::integral_constant<int, 8>{}, bits, lv, e, run, gx, gy, 16, S);
-                const uint32_t key = best_of(std::integral_constant<int, 8>{}, S, 0);
+                const int nf = e.nf, nfp = run ? (int)e.nf_padded : 0;
+                int nmax = nfp;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
+                nmax = __builtin_amdgcn_readfirstlane(nmax);
+                const uint32_t Kbase = (uint32_t)(((gx >> 4) * Hd + gy) * 8);
+                const uint32_t gxl = (uint32_t)(gx & 15);
+                const uint32_t* fw = feat_word + e.feat_start;
+                uint32_t cA[kN], cB[kN];                            // bit-sliced counters of rows 2j / 2j + 1: even bits count the 1s, odd bits the 4s
+#pragma unroll
+                for (int k = 0; k < kN; ++k) { cA[k] = 0; cB[k] = 0; }
+                // lane j fetches the words of features f0 + 2j, f0 + 2j + 1 (entries start at multiples of 8 words, f0 is a multiple of 16)
+                auto fetch = [&](int f0) -> uint2 {
+                    uint2 w = make_uint2(0u, 0u);
+                    if (f0 + 2 * j < nfp) w = *reinterpret_cast<const uint2*>(fw + f0 + 2 * j);
+                    return w;
+                };
+                // a feature word (base0 | column class, lm_kernels.h) -> offset of its first record in the bit arena, 2 x the window's cell inside it
+                auto prep = [&](uint32_t w, bool on, uint32_t& off, uint32_t& s2) {
+                    s2 = ((w & 15u) + gxl) << 1;
+                    const uint32_t o = ((w & ~15u) >> 1) + Kbase + ((s2 >> 5) ? HS8 : 0u);
+                    off = on ? o : zero_off;                        // beyond this candidate's features (or no candidate): the zero plane
+                };
+                uint32_t offx = 0, offy = 0, sx = 0, sy = 0;
+                auto batch = [&](int half, uint32_t& eA, uint32_t& eB) {           // features 8 half .. 8 half + 7 of the current 16
+                    uint4 v[8];
+                    uint32_t sh[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int src = src0 + 4 * (4 * half + (u >> 1));          // the lane that fetched feature 8 half + u
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? offy : offx));
+                        sh[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)((u & 1) ? sy : sx));
+                        v[u] = ld_buf16(bits, o + rowoff, 0u);      // rows 2j, 2j + 1: 32 cells x 2 bits each
+                    }
+                    uint32_t xa[8], xb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xa[u] = __builtin_amdgcn_alignbit(v[u].y, v[u].x, sh[u]);      // 16 window cells of row 2j: bits 2c (is 1), 2c + 1 (is 4)
+                        xb[u] = __builtin_amdgcn_alignbit(v[u].w, v[u].z, sh[u]);      // ... of row 2j + 1
+                    }
+                    eA = add8(xa, cA[0], cA[1], cA[2]);
+                    eB = add8(xb, cB[0], cB[1], cB[2]);
+                };
+                uint2 wn = fetch(0);
+                for (int f0 = 0; f0 < nmax; f0 += 16) {
+                    const uint2 w = wn;
+                    const bool on = f0 + 2 * j < nfp;
+                    wn = fetch(f0 + 16);                            // the next 16 words while these are worked on
+                    prep(w.x, on, offx, sx);
+                    prep(w.y, on, offy, sy);
+                    uint32_t e1A, e1B;
+                    batch(0, e1A, e1B);
+                    if (f0 + 8 < nmax) {                            // wave-uniform
+                        uint32_t e2A, e2B;
+                        batch(1, e2A, e2B);
+                        add_eights2<kN>(cA, e1A, e2A);
+                        add_eights2<kN>(cB, e1B, e2B);
+                    } else {
+                        add_eights1<kN>(cA, e1A);
+                        add_eights1<kN>(cB, e1B);
+                    }
+                }
+                // Once per candidate and level: the two rows of the lane side by side — bit 2c = row 2j, bit 2c + 1 = row 2j + 1 of window
+                // column c —, S = n1 + 4 n4 bit-sliced, the lane's maximum by a descent from the top bit, its FIRST position in raster order.
+                uint32_t S[kS], carry = 0;
+                {
+                    uint32_t n1[kN], n4[kN];
+#pragma unroll
+                    for (int k = 0; k < kN; ++k) {
+                        n1[k] = (cA[k] & 0x55555555u) | ((cB[k] << 1) & 0xAAAAAAAAu);
+                        n4[k] = ((cA[k] >> 1) & 0x55555555u) | (cB[k] & 0xAAAAAAAAu);
+                    }
+                    S[0] = n1[0]; S[1] = n1[1];
+#pragma unroll
+                    for (int k = 2; k < kS; ++k) {
+                        const uint32_t a = k < kN ? n1[k] : 0u, b = k - 2 < kN ? n4[k - 2] : 0u;
+                        csa(S[k], carry, a, b, carry);
+                    }
+                }
+                uint32_t mask = 0xFFFFFFFFu, val = 0;
+#pragma unroll
+                for (int k = kS - 1; k >= 0; --k) {
+                    const uint32_t t = mask & S[k];
+                    if (t) { mask = t; val |= 1u << k; }
+                }
+                const uint32_t upper = mask & 0x55555555u;           // positions of row 2j attaining the maximum come first in raster order
+                const uint32_t pick = upper ? upper : mask;
+                const uint32_t bitp = (uint32_t)__ffs((int)pick) - 1u;
+                const uint32_t pos = ((2u * (uint32_t)j + (bitp & 1u)) << 4) + (bitp >> 1);   // row * 16 + column
+                uint32_t key = (val << 8) | (255u - pos);
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)key, o, 64); key = t > key ? t : key; }
                 const int raw = (int)(key >> 8);
                 int br = -1, bc = -1;                               // LL.cpp:1910-1911
                 float best = 0.f;
-                const int nf = e.nf;
                 if (raw > 0) {
                     const int idx = 255 - (int)(key & 0xFF);
                     br = idx >> 4; bc = idx & 15;
@@ -1305,12 +1209,15 @@ void launch_pack_bits(const BitsBatch& B, int nb, const LevelGeom& lv, hipStream
 }
 void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom& g, const TemplEntry* entries, const uint32_t* feat_word,
                        const int32_t* work_pyramids, uint32_t cand_cap, float threshold, uint32_t cap, uint32_t dedupe_cap_slots, int grid_blocks,
-                       int max_features, bool use_lists, hipStream_t s) {
-    const int lists = use_lists ? 1 : 0;
+                       int max_features, hipStream_t s) {
     if (max_features > kBitsSmallMax)
-        hipLaunchKernelGGL((k_local_bits<10, 3>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots, lists);
+        hipLaunchKernelGGL((k_local_bits<10, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves >= 6)
+        hipLaunchKernelGGL((k_local_bits<5, 6>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
+    else if (knobs().bits_waves == 5)
+        hipLaunchKernelGGL((k_local_bits<5, 5>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
     else
-        hipLaunchKernelGGL((k_local_bits<5, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots, lists);
+        hipLaunchKernelGGL((k_local_bits<5, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
 }
 
 // ---- Coarse pass on the pair stream (LL.cpp:1284-1354 similarity + :1835-1852 scan).  A wave per template, a lane = 32 consecutive
@@ -1337,12 +1244,10 @@ k_pack_top(TopBits B, uint32_t byte0, uint32_t npairs) {
 template <int kHi, int kWaves>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWaves, kWaves)))
 k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, const TemplEntry* __restrict__ entries, const int32_t* __restrict__ feat_off,
-              const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int run_max) {
+              const int32_t* __restrict__ work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0) {
     constexpr int kN = 4 + kHi, kS = kN + 3;
     __shared__ uint32_t s_tot[4];
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_hit[4][64], s_bef[4][64];                         // run planning (maps of <= 2048 positions): a template's hit bitmap, hits before each word
-    __shared__ uint32_t s_nsr[4][2], s_bsr[2];                              // singles / runs of each wave's template; the workgroup's first places in the frame's lists
     const FrameSlot& F = fb.f[blockIdx.y];
     Candidate* __restrict__ cands = F.cands;
     unsigned long long* __restrict__ counters = F.counters;
@@ -1437,7 +1342,6 @@ k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, con
         unsigned long long slot = s_base + (unsigned long long)before;
         for (int w = 0; w < wave; ++w) slot += s_tot[w];
         __syncthreads();                                                    // s_tot / s_base are rewritten by the next pass
-        const unsigned long long slot0 = slot - (unsigned long long)before;   // the template's first candidate slot
         if (total > 0) {                                                    // wave-uniform
             uint32_t m = hit_mask;
             while (m) {
@@ -1458,62 +1362,6 @@ k_coarse_bits(FrameBatch fb, TopBits B, LevelGeom lv, int level, int levels, con
                 ++slot;
             }
         }
-        if (run_max >= 2) {
-            // Vertical runs (lm_kernels.h, RunRec): a hit is the k-th of the chain of hits directly above it in its coarse column; the heads are
-            // those with k % run_max == 0, a head's run = the hits directly below it, at most run_max in all.  A head alone is a single.  The
-            // caller plans only when every window lies inside its plane (no candidate is left to k_local), so members differ in nothing but
-            // their window rows: same column (same clamp in x), rows 0 .. 16 cells behind the head's (the clamp in y only shortens the steps).
-            s_hit[wave][lane] = hit_mask; s_bef[wave][lane] = (uint32_t)before;
-            __syncthreads();
-            auto is_hit = [&](int q) -> bool { return q >= 0 && q < npos && ((s_hit[wave][q >> 5] >> (q & 31)) & 1u); };
-            auto slot_of = [&](int q) -> uint32_t { return (uint32_t)slot0 + s_bef[wave][q >> 5] + (uint32_t)__popc(s_hit[wave][q >> 5] & ((1u << (q & 31)) - 1u)); };
-            auto run_of = [&](int p) -> int {                               // 0: a member of the run of a head above it; else the length of the run p heads
-                int k = 0;
-                for (int q = p - Wd; is_hit(q); q -= Wd) ++k;
-                if (k % run_max) return 0;
-                int n = 1;
-                for (int q = p + Wd; n < run_max && is_hit(q); q += Wd) ++n;
-                return n;
-            };
-            uint32_t nsingle = 0, nrun = 0;
-            for (uint32_t m = hit_mask; m; m &= m - 1) {
-                const int n = run_of(pos0 + __ffs((int)m) - 1);
-                nsingle += n == 1; nrun += n >= 2;
-            }
-            int tot_s, tot_r;
-            const int bef_s = wave_excl_scan((int)nsingle, lane, tot_s), bef_r = wave_excl_scan((int)nrun, lane, tot_r);
-            if (lane == 0) { s_nsr[wave][0] = (uint32_t)tot_s; s_nsr[wave][1] = (uint32_t)tot_r; }
-            __syncthreads();
-            if (threadIdx.x < 2) {
-                const unsigned long long all = (unsigned long long)s_nsr[0][threadIdx.x] + s_nsr[1][threadIdx.x] + s_nsr[2][threadIdx.x] + s_nsr[3][threadIdx.x];
-                s_bsr[threadIdx.x] = all ? (uint32_t)atomicAdd(&counters[4 + threadIdx.x], all) : 0u;
-            }
-            __syncthreads();
-            uint32_t at_s = s_bsr[0] + (uint32_t)bef_s, at_r = s_bsr[1] + (uint32_t)bef_r;
-            for (int w = 0; w < wave; ++w) { at_s += s_nsr[w][0]; at_r += s_nsr[w][1]; }
-            for (uint32_t m = hit_mask; m; m &= m - 1) {
-                const int p = pos0 + __ffs((int)m) - 1;
-                const int n = run_of(p);
-                const uint32_t mine = slot_of(p);
-                if (n == 1) {
-                    // (an overflowing frame — more candidates than the buffers hold — is rerun with larger ones: its lists only have to stay inside their arrays)
-                    if (at_s < cap) F.singles[at_s] = mine < cap ? mine : 0u;
-                    ++at_s;
-                } else if (n >= 2) {
-                    RunRec r{};
-                    r.n = (uint32_t)n;
-                    bool fits = true;
-                    for (int k = 0; k < kRunMax; ++k) {
-                        r.slot[k] = k < n ? slot_of(p + k * Wd) : 0u;
-                        fits = fits && r.slot[k] < cap;
-                    }
-                    if (!fits) { r.n = 1u; r.slot[0] = 0u; }              // (overflow: see above)
-                    if (at_r < cap / 2) F.runs[at_r] = r;
-                    ++at_r;
-                }
-            }
-            __syncthreads();                                                // (the bitmaps are rewritten by the next pass: there is none for maps this small)
-        }
     }
 }
 
@@ -1521,13 +1369,12 @@ void launch_pack_top(const TopBits& B, int nb, uint32_t byte0, uint32_t npairs, 
     hipLaunchKernelGGL(k_pack_top, dim3((npairs + 255) / 256, nb), dim3(256), 0, s, B, byte0, npairs);
 }
 void launch_coarse_bits(const FrameBatch& fb, const TopBits& B, const FrameGeom& g, const TemplEntry* entries, const int32_t* feat_off,
-                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, int run_max, hipStream_t s) {
+                        const int32_t* work_pyramids, int num_work, float threshold, uint32_t cap, uint32_t byte0, int max_features, hipStream_t s) {
     if (num_work <= 0 || fb.nb <= 0) return;
     const int level = g.levels - 1;
 #define LM_LAUNCH_COARSE_BITS(HI, WAVES) \
     hipLaunchKernelGGL((k_coarse_bits<HI, WAVES>), dim3((num_work + 3) / 4, fb.nb), dim3(256), 0, s, fb, B, g.lv[level], level, g.levels, entries, feat_off, \
-                       work_pyramids, num_work, threshold, cap, byte0, run_max)
-    if (run_max > kRunMax) run_max = kRunMax;
+                       work_pyramids, num_work, threshold, cap, byte0)
     if (max_features > kBitsSmallMax) LM_LAUNCH_COARSE_BITS(10, 5);
     else LM_LAUNCH_COARSE_BITS(5, 6);
 #undef LM_LAUNCH_COARSE_BITS

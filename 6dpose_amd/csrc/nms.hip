@@ -348,7 +348,6 @@ k_dedupe(FrameBatch fb, uint32_t cap, uint32_t table_mask /*allocated slots - 1*
         final_host[0] = nc; final_host[1] = nd; final_host[2] = na; final_host[3] = bad;
         final_host[4] = atomicAdd(&counters[0], 0ull) >> kCandBits;                                       // tiles planned by k_coarse
         final_host[5] = evals; final_host[6] = lbytes;
-        final_host[7] = atomicAdd(&counters[5], 0ull);                                                    // vertical runs k_coarse_bits planned (0: none planned)
         for (int q = 0; q < kCounterWords; ++q) counters[q] = 0;
     }
 }

@@ -68,8 +68,7 @@ class Timings(ctypes.Structure):
                 ("matches_pre_unique", ctypes.c_int64), ("templates", ctypes.c_int64),
                 ("coarse_bytes", ctypes.c_int64), ("local_bytes", ctypes.c_int64),
                 ("host_submit_ms", ctypes.c_float), ("host_wait_ms", ctypes.c_float),
-                ("host_collect_ms", ctypes.c_float), ("host_merge_ms", ctypes.c_float), ("batch_frames", ctypes.c_int32),
-                ("refine_runs", ctypes.c_int32)]
+                ("host_collect_ms", ctypes.c_float), ("host_merge_ms", ctypes.c_float), ("batch_frames", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -70,7 +70,6 @@ typedef struct lm_timings {
     float host_merge_ms;   /* host wall time: canonical sort + unique (0 when not requested)  */
     int32_t batch_frames;  /* frames served by the launches the stage times above belong to (1 for a lone frame;
                             * lm_detector_submit_frame batches): per-frame device time = stage time / batch_frames */
-    int32_t refine_runs;   /* vertical runs of candidates whose shared window rows the bit-plane refinement summed once (0: every candidate on its own) */
 } lm_timings;
 
 const char *lm_last_error(void);
@@ -276,8 +275,7 @@ int lm_detector_get_paths(const lm_detector *d, int *refine, int *coarse);
  * (default, on = 1: wherever the kernels in use read only bit planes, the byte linear memories are not written at all) or as the
  * reference's byte linear memories first, packed into bit planes by a second kernel (on = 0).  Bit 1 (on = 2, 3): the top level's bit
  * planes stay readable after the match (lm_detector_read_stage kind 5; tests); bit 2 (on = 4 ...): the writer that ORs the top level's
- * planes together is used even where whole dwords can be stored (tests); bit 3 (on = 8 ...): the bit-plane refinement takes every candidate
- * on its own instead of summing the shared window rows of vertically neighbouring candidates once (tests).  Results never depend on it. */
+ * planes together is used even where whole dwords can be stored (tests).  Results never depend on it. */
 int lm_detector_set_direct_bits(lm_detector *d, int on);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 

@@ -212,7 +212,8 @@ for t in range(0, 2000, STEP):
         sim = np.float32(raw) * np.float32(100.0) / np.float32(4 * nf0)
         if sim >= np.float32(THR):
             kept.append(((x // T0 - 8 + (idx & 15)) * T0 + off0, (y // T0 - 8 + (idx >> 4)) * T0 + off0, float(sim), t))
-    # vertical runs (k_coarse_bits plans them, k_local_bits serves a run with 16 lanes): every member's result equals its single evaluation
+    # DESIGN STUDY, not in the product: vertical runs (a planner in k_coarse_bits, a run served by 16 lanes of k_local_bits) — every member's result equals
+    # its single evaluation.  Built and measured in round 4 (commit d8535ff): correct, 1.6 x fewer lane loads, but slower on the GPU (profiles/r04_stream_ab.txt)
     hitmap = np.zeros(Hd1 * Wd1, bool); hitmap[hits] = True
     RUN_MAX = min(5, 1 + (8 * T0) // T1)
     covered = 0

@@ -18,7 +18,6 @@ def test_refinement_model_equals_byte_evaluation_and_oracle():
     text = _run("bitplane_model.py", 100)
     assert "bit-plane == byte evaluation: True" in text, text
     assert "equal (as multisets): True" in text, text
-    assert "run evaluation == single evaluation: True" in text and "vertical runs 0 " not in text, text
 
 
 def test_coarse_model_equals_byte_evaluation():
