@@ -293,3 +293,33 @@ def test_nms_norms_and_nmsboxes_equal_the_oracle(lib):
     # test.cpp's use: 40x40 boxes at the match positions, threshold 0, overlap 0.4
     rects = np.array([[100, 100, 40, 40], [105, 100, 40, 40], [160, 100, 40, 40], [100, 130, 40, 40]], np.int32)
     assert mod.NMSBoxes(rects, np.array([90, 95, 80, 85], np.float32), 0.0, 0.4) == [1, 3, 2]   # by score: 95 kept, 90 overlaps it (IoU 0.78), 85 and 80 kept
+
+
+def test_magic_division_with_one_correction_is_exact():
+    """frontend.hip fast_div: q = umulhi(n, ceil(2^32 / d)) is floor(n / d) or one more for EVERY 32-bit n (the excess n e / (d 2^32) with
+    e = m d - 2^32 < d stays below 1), so `q - (q d > n)` is exact — also where n d passes 2^32 (8000 x 6000 frames: ADVICE r03; the bare
+    product was wrong there).  Checked here on the index ranges the front end divides (flat block index / blocks of a job, linear-memory
+    index / row length) up to 16384 x 16384 frames and on random 31-bit values."""
+    rng = np.random.default_rng(7)
+    def check(n, d):
+        n = np.asarray(n, np.uint64); d = np.uint64(d)
+        m = (np.uint64(1) << np.uint64(32)) // d + (np.uint64(1) if (np.uint64(1) << np.uint64(32)) % d else np.uint64(0))
+        q = (n * m) >> np.uint64(32)
+        q = q - (q * d > n).astype(np.uint64)
+        assert np.array_equal(q, n // d), (int(d),)
+        bare = (n * m) >> np.uint64(32)
+        return bool((bare != n // d).any())
+    wrong_without_correction = False
+    for W, H, T in ((640, 480, 4), (8000, 6000, 4), (12000, 9000, 4), (16384, 16384, 2), (16380, 16380, 4), (4096, 4096, 8)):
+        Wd, Hd = W // T, H // T
+        npos = Wd * Hd
+        idx = np.concatenate([np.arange(0, min(npos, 70000)), np.arange(max(0, npos - 70000), npos + 256), rng.integers(0, npos + 256, 50000)])
+        wrong_without_correction |= check(idx, Wd)
+        gx, gy = (npos + 255) // 256, T * T
+        blocks = gx * gy * 2
+        b = np.concatenate([np.arange(max(0, blocks - 70000), blocks), rng.integers(0, blocks, 50000)])
+        wrong_without_correction |= check(b, gx * gy)
+        wrong_without_correction |= check(b % (gx * gy), gx)
+    for d in (3, 5, 7, 160, 19200, 65535, 1 << 20):
+        wrong_without_correction |= check(rng.integers(0, 1 << 31, 200000), d)
+    assert wrong_without_correction, "the cases must include some the uncorrected product gets wrong"
