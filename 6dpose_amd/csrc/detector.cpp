@@ -184,7 +184,6 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     if (knobs().launch_slack_us > 0) d->launch_slack_ms = knobs().launch_slack_us * 1e-3f;
     if (const char* ac = getenv("LM_ASYNC_COLLECT")) d->async_collect = ac[0] && ac[0] != '0';
     if (const char* ht = getenv("LM_HOST_THREADS")) d->pool.threads = std::max(0, std::min(8, atoi(ht)));
-    if (const char* sw = getenv("LM_SPIN_WAIT_US")) d->spin_wait_us = std::max(0, atoi(sw));
     if (const char* tl = getenv("LM_TILES")) d->use_tiles = tl[0] && tl[0] != '0';
     if (const char* ro = getenv("LM_REFERENCE_ORDER")) d->reference_order = ro[0] && ro[0] != '0';
     {
@@ -1951,18 +1950,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
             if (rc) return rc;
         }
     }
-    // LM_SPIN_WAIT_US > 0 (experiment, off): poll before blocking — hipEventSynchronize puts the thread to sleep and waking up costs tens of
-    // microseconds once per batch.  Measured the other way round: 0.107 ms per frame polling against 0.092 blocking (profiles/r04_stream_ab.txt).
-    if (d->spin_wait_us > 0) {
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(d->spin_wait_us);
-        for (;;) {
-            const hipError_t q = hipEventQuery(lead.done);
-            if (q != hipErrorNotReady) break;
-            if (std::chrono::steady_clock::now() >= until) break;
-            for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
-        }
-        (void)hipGetLastError();
-    }
+    // (blocking wait: polling the event with hipEventQuery instead was slower, 0.107 against 0.092 ms per frame — profiles/r04_stream_ab.txt)
     HIP_TRY(hipEventSynchronize(lead.done));
     const auto t2 = std::chrono::steady_clock::now();
     // The batch has finished: the records of ALL its frames are in pinned memory.  The helper threads prepare the lists of the later frames

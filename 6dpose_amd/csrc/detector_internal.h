@@ -231,7 +231,6 @@ struct lm_detector {
     // host-side wall time of the streamed path, accumulated (lm_detector_host_profile): [0] frames, [1] staging copy, [2] H2D enqueue,
     // [3] slot bookkeeping, [4] batch launches, [5] collect: waiting for the GPU, [6] record conversion, [7] canonical sort + unique
     double host_prof[8] = {};
-    int spin_wait_us = 0;                           // LM_SPIN_WAIT_US: lm_detector_collect polls the batch's event this long before it blocks in hipEventSynchronize (measured: polling is SLOWER, 0.107 against 0.092 ms per frame — hipEventQuery in a loop gets in the way of the runtime's own threads)
     bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0: the lists of a batch's later frames are prepared by the helper threads
 
     // Live-stream ingest (lm_detector_submit_frame): one ring entry per result slot.  The host frame is staged in the entry's

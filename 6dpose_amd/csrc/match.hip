@@ -1212,10 +1212,6 @@ void launch_local_bits(const FrameBatch& fb, const BitsBatch& B, const FrameGeom
                        int max_features, hipStream_t s) {
     if (max_features > kBitsSmallMax)
         hipLaunchKernelGGL((k_local_bits<10, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
-    else if (knobs().bits_waves >= 6)
-        hipLaunchKernelGGL((k_local_bits<5, 6>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
-    else if (knobs().bits_waves == 5)
-        hipLaunchKernelGGL((k_local_bits<5, 5>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
     else
         hipLaunchKernelGGL((k_local_bits<5, 4>), dim3(grid_blocks), dim3(256), 0, s, fb, B, g, entries, feat_word, work_pyramids, cand_cap, threshold, cap, dedupe_cap_slots);
 }

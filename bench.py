@@ -7,13 +7,14 @@ templates·Mpixels matched/sec on 640x480 RGB-D).
 A *step* is one `Detector.match` of the reference driver loop (linemod_and_levelup_test.py:314-327,
 linemod_ros/detect.py:83-138) on a NEW host frame: the frame is handed over in host memory
 (lm_detector_submit_frame: pinned staging ring, H2D on a copy stream), then front end (quantise,
-spread, response, linearise) + coarse similarity over all templates + 16x16 refinement of every
-candidate + download, canonical sort and unique of the match records (+, for N>1, the all-gather of
-the per-rank records over RCCL and the merge on the device).  Four to six frames are in flight, so
-the upload of frame k+1 overlaps the matching of frame k — SURVEY §8(d): "t_frame = one match call
-with the bank resident, frame H2D included".  No frame is replayed from HBM: the host holds a pool of
-distinct noisy frames and every step stamps its number into the frame it submits.  The rate with the
-frames parked in HBM (round 1's headline) is reported under `extras.resident_replay`.
+spread, response, bit planes) + coarse similarity over all templates + 16x16 refinement of every
+candidate + duplicate removal + download, canonical sort and unique of the match records (+, for N>1,
+the all-gather of the per-rank records over RCCL and the merge on the device).  Sixteen frames are in
+flight and up to eight consecutive frames share their kernel launches, so the upload of later frames
+overlaps the matching of earlier ones — SURVEY §8(d): "t_frame = one match call with the bank resident,
+frame H2D included"; the per-call figures (frame resident / from host memory) are under
+`extras.synchronous_call` / `extras.pcie_inclusive`.  No frame is replayed from HBM: the host holds a
+pool of distinct noisy frames and every step stamps its number into the frame it submits.
 
 Workload (N=1): BASELINE configs[1] — 1 object x 2000 template pyramids, Detector(150,[4,8])
 (150+150 features at level 0, 75+75 at level 1), threshold 75, planted synthetic bank (tests/
@@ -27,14 +28,18 @@ rank; started plainly (`python bench.py --gpus N`) it re-executes itself under
 `python -m torch.distributed.run --standalone --nproc-per-node N`, one rank per GPU (on a box with
 fewer GPUs than ranks: LM_BENCH_BACKEND=gloo LM_BENCH_DEVICE=0 rehearses the path on one device).
 
-One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel (k_local or k_coarse):
-algorithmic response bytes per launch (sum nfeat*256 per 16x16 evaluation, resp.
-sum nfeat*template_positions per template) / that kernel's mean duration from HIP events on the
-detector's stream; peak = 8000 GB/s (HBM3E spec).  The same rate is also given against the L2
-(34.5 TB/s) and LDS (150 TB/s) ceilings of MI355X_MICROARCH.md, because the kernel's working set is
-cache-resident (`traffic` = fabric bytes from the PMC pass is a small fraction of the algorithmic
-bytes).  `cpu_baseline` times the oracle's SSE C port of the same matching step on the host (rank 0,
-N=1 only), single thread like the reference.
+Before anything is timed (N=1) the GPU's results must equal the CPU oracle's — the synchronous call on two
+frames AND the streamed path with shared launches on four steps — or the bench exits without a number.
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel (k_local_bits): `achieved` /
+`frac` = ALGORITHMIC response bytes per launch (sum nfeat*256 per 16x16 evaluation) / the
+kernel's mean duration from HIP events on its stream, against the HBM peak — the convention BASELINE.json
+asks for, labelled as NOT a physical fraction (the bit-plane kernels load 16 bytes where the reference
+reads 256, from L1 / L2, so it exceeds 1); `binding` = the ceiling that physically binds the kernel and the
+fraction of it the launch reaches (<= 1), `stages` = the same per stage of a frame (front end, coarse pass,
+refinement), `traffic` = HBM bytes — all from rocprofv3 --pmc passes this script runs itself over its own
+roofline leg.  `cpu_baseline` times the REFERENCE's own `Detector::match` lines (oracle/_ref, its flags,
+one thread like the reference) and the oracle's SSE port on the host (rank 0, N=1 only).
 """
 import argparse
 import json
