@@ -561,7 +561,8 @@ def main():
                 "traffic": hbm,
                 "traffic_source": "live: rocprofv3 --kernel-trace --pmc passes of `bench.py --roofline-only` run by this bench.py (FETCH_SIZE x2 + WRITE_SIZE, "
                                   "mean per %s dispatch of %d frames); memory-side (fabric) bytes, Infinity-Cache hits included" % (kname, BATCH),
-                "binding": cz["binding"], "ceilings": cz["fractions"],
+                "binding": cz["binding"], "ceilings": cz["fractions"], "tcp_accesses_per_cu_cycle_raw": cz["tcp_accesses_per_cu_cycle_raw"],
+                "tcp_miss_stall_cycles_per_cu_cycle": cz["tcp_miss_stall_cycles_per_cu_cycle"],
                 "hbm_frac_physical": cz["fractions"]["hbm"],
                 "kernel_us_profiled": cz["kernel_us_profiled"], "l2_hit_rate": cz["l2_hit_rate"],
                 "cu_cycles_per_wave_load": cz["cu_cycles_per_wave_load"], "l1_accesses_per_wave_load": cz["l1_accesses_per_wave_load"],
@@ -575,8 +576,9 @@ def main():
                     "useful_valu_note": "adder operations the bit-sliced sums need per lane and feature (5.0: ISA of the 16-feature loop body, DESIGN.md 3.6) over the "
                                         "wave-level VALU instructions measured per lane and feature (SQ_INSTS_VALU / (pairs / 8)); round 3's kernel: 10 of 33",
                     "what_bounds_it": "the vector L1: a wave load of k_local_bits is 8 candidates x 128 contiguous bytes at 8-byte alignment = ~22 64-byte accesses, and "
-                                      "accesses + miss stalls fill `ceilings.tcp` of the launch's CU cycles; the VALU (carry-save adders on bit-sliced counters) "
-                                      "is at `ceilings.valu` of its issue slots since the window shifts and the address arithmetic were cut (VERDICT r03 item 3)"})
+                                      "the TCP serves about one access per cycle (`ceilings.tcp`; raw ratio and miss-stall share beside it); the VALU (carry-save "
+                                      "adders on bit-sliced counters) is at `ceilings.valu` of its issue slots since the window shifts and the address arithmetic "
+                                      "were cut (VERDICT r03 item 3)"})
         # every stage of a frame with the ceiling that binds it, from the same PMC passes (one fraction <= 1 per stage, recomputable from profiles/r04_pmc.txt)
         if pm_all:
             B_FRONT = W * H * 3 + W * H * 2 + 8 * 2 * (W * H + (W // 2) * (H // 2))      # 1.54 MB in + 6.14 MB of linear memories (8 labels x 2 modalities x 2 levels) out per VGA frame
@@ -589,7 +591,8 @@ def main():
                     n = pm_all[k]["dispatches"] / max(1, pm_all[k_refine]["dispatches"] if k_refine in pm_all else 1)     # dispatches of this kernel per batch
                     fe_us += cz["kernel_us_profiled"] * n
                     fe_bytes += cz["hbm_bytes_per_dispatch"] * n
-                    fe_parts[k] = {"dispatches_per_batch": n, "us_per_dispatch": cz["kernel_us_profiled"], "binding": cz["binding"], "ceilings": cz["fractions"]}
+                    fe_parts[k] = {"dispatches_per_batch": n, "us_per_dispatch": cz["kernel_us_profiled"], "binding": cz["binding"], "ceilings": cz["fractions"],
+                                   "tcp_miss_stall_cycles_per_cu_cycle": cz["tcp_miss_stall_cycles_per_cu_cycle"]}
             if fe_us > 0:
                 stages["frontend"] = {"kernels": fe_parts, "us_per_batch_profiled": fe_us, "ms_per_batch_events": excl["frontend_ms"],
                                       "algorithmic_bytes_per_frame": B_FRONT,
@@ -601,7 +604,8 @@ def main():
                 if k in pm_all:
                     cz = ceilings_of(pm_all[k])
                     stages[stage] = {"kernel": k, "ms_per_batch_events": ms, "us_per_dispatch_profiled": cz["kernel_us_profiled"], "binding": cz["binding"],
-                                     "ceilings": cz["fractions"], "l2_hit_rate": cz["l2_hit_rate"], "cu_cycles_per_wave_load": cz["cu_cycles_per_wave_load"],
+                                     "ceilings": cz["fractions"], "tcp_accesses_per_cu_cycle_raw": cz["tcp_accesses_per_cu_cycle_raw"],
+                                     "tcp_miss_stall_cycles_per_cu_cycle": cz["tcp_miss_stall_cycles_per_cu_cycle"], "l2_hit_rate": cz["l2_hit_rate"], "cu_cycles_per_wave_load": cz["cu_cycles_per_wave_load"],
                                      "l1_accesses_per_wave_load": cz["l1_accesses_per_wave_load"]}
             rf["stages"] = stages
         if pm is None:
@@ -765,8 +769,10 @@ ALIGN_OPS_PER_LANE_FEATURE = 2.0      # + the two v_alignbit that cut the lane's
 
 
 def ceilings_of(pm):
-    """What a kernel's launch reached of each physical ceiling, from its PMC means (every fraction <= 1 by construction):
-    tcp = vector-L1 accesses (one 64-byte access per cycle and CU) + cycles stalled on pending misses over the launch's CU cycles;
+    """What a kernel's launch reached of each physical ceiling, from its PMC means:
+    tcp = vector-L1 (TCP) accesses per CU cycle — the TCP serves one 64-byte access per cycle (64 B x 256 CUs x ~2.25 GHz = the 36.9 TB/s
+          MI355X_MICROARCH.md gives for L2 + L1 reuse); the counter runs a few per cent past 1.0 on a saturated launch (1.01 measured), so the
+          fraction is capped at 1 and the raw ratio reported beside it; cycles stalled on pending misses are reported separately;
     valu = wave-level VALU instructions x 4 cycles over the SIMD cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle: profiles/r04_pmc.txt);
     l2 = L2 requests x 128 B (an upper bound on the bytes they move) per second over the L2 peak; hbm = memory-side bytes per second over the HBM peak."""
     kc = pm["GRBM_GUI_ACTIVE"] / 8.0
@@ -774,14 +780,16 @@ def ceilings_of(pm):
         return None
     us = kc / 2400.0
     hbm_bytes = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0
-    c = {"tcp": (pm["TCP_TOTAL_CACHE_ACCESSES_sum"] + pm["TCP_PENDING_STALL_CYCLES_sum"]) / (256.0 * kc),
+    tcp_raw = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kc)
+    c = {"tcp": min(1.0, tcp_raw),
          "valu": 4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kc),
          "l2": (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) * 128.0 / (us * 1e-6) / 1e9 / L2_PEAK_GBS,
          "hbm": hbm_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     top = max(c, key=lambda q: c[q])
-    names = {"tcp": "vector L1 (TCP): accesses + miss-stall cycles over the launch's CU cycles", "valu": "VALU issue slots (4 cycles per wave instruction)",
+    names = {"tcp": "vector L1 (TCP): 64-byte accesses per CU cycle (one per cycle = 36.9 TB/s over the chip)", "valu": "VALU issue slots (4 cycles per wave instruction)",
              "l2": "L2 bandwidth (requests x 128 B against %.1f TB/s)" % (L2_PEAK_GBS / 1e3), "hbm": "HBM bandwidth (memory-side bytes against %.0f TB/s)" % (HBM_PEAK_GBS / 1e3)}
     return {"kernel_us_profiled": us, "dispatches_profiled": pm.get("dispatches"), "fractions": c, "binding": {"ceiling": names[top], "frac": c[top]},
+            "tcp_accesses_per_cu_cycle_raw": tcp_raw, "tcp_miss_stall_cycles_per_cu_cycle": pm["TCP_PENDING_STALL_CYCLES_sum"] / (256.0 * kc),
             "hbm_bytes_per_dispatch": hbm_bytes, "wave_loads": pm["SQ_INSTS_VMEM_RD"], "valu_insts": pm["SQ_INSTS_VALU"],
             "cu_cycles_per_wave_load": (256.0 * kc / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
             "l1_accesses_per_wave_load": (pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / pm["SQ_INSTS_VMEM_RD"]) if pm["SQ_INSTS_VMEM_RD"] else None,
