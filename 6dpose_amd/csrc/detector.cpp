@@ -170,7 +170,7 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     else d->ingest.stream = nullptr;
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
     for (auto& sl : d->slot) {
-        for (auto& e : sl.ev) (void)hipEventCreate(&e);
+        for (auto& e : sl.ev) (void)hipEventCreateWithFlags(&e, knobs().stage_events == 2 ? hipEventDefault : hipEventDisableSystemFence);   // timing only: nobody synchronises on them, and a default record costs the queue a cache write-back + invalidate (5-6 us between two kernels; sl.done keeps the fence)
         (void)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&sl.fe_done, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&sl.local_done, hipEventDisableTiming);
@@ -1602,8 +1602,10 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 }
 
 // Should the frames waiting for their batch go out now?  `at` = host time the question is asked for.
-//   * nothing launched is still uncollected: the GPU is idle, the frame goes out (the first frame of a stream, a caller that
-//     collects every frame before the next);
+//   * nothing launched is still uncollected, or everything launched has finished: the GPU is idle, the waiting frames go out (the
+//     first frame of a stream, a caller that collects every frame before the next) — in a tight loop once LM_FIRST_BATCH (3) of them
+//     wait: the launch occupies the caller for two submits' worth of time and a lone frame costs the GPU twice a batched one
+//     (A/B at the driver's 20 steps: 0.1054 -> 0.0997 ms per frame, 200 steps unchanged; profiles/r04_stream_ab.txt);
 //   * the caller submits in a tight loop (frames arrive less than 2.5 launches' worth of host time apart): only full batches.  A
 //     launch costs the calling thread ~0.1 ms (seven kernel launches + events) whatever the batch size, so a stream of partial
 //     batches makes the HOST the bottleneck at the pace of one launch per frame, the GPU keeps up with it, looks about to run dry
@@ -1612,13 +1614,15 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 //   * frames arrive sparsely (a camera): the GPU-time model — launch when the GPU's estimated backlog is shorter than the slack.
 static bool partial_batch_due(lm_detector* d, double at) {
     if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
-    if (d->n_launched == d->n_collected) return true;
+    const bool tight = d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms;
+    const bool enough = !tight || d->pend_n >= knobs().first_batch;
+    if (d->n_launched == d->n_collected) return enough;
     // ... or everything launched has FINISHED on the GPU (collected or not): frames are waiting and the GPU is idle.  The start of a stream
     // used to lose ~0.15 ms here: frame 0 went out alone, finished after 0.2-0.3 ms, and the frames behind it waited for a full batch of
     // eight.  (One event query per submit while a batch is pending; a tight loop cannot get stuck on one-frame batches through this rule:
     // a lone frame keeps the GPU busy for 0.15-0.2 ms, three submits' worth of host time.)
-    if (batches_queued(d) == 0) return true;
-    if (d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms) return false;   // (0: no second submit yet — sparse until shown otherwise)
+    if (batches_queued(d) == 0) return enough;
+    if (tight) return false;                            // (submit_gap_ms 0: no second submit yet — sparse until shown otherwise)
     if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
 }
@@ -1643,15 +1647,22 @@ int lm_launch_pending(lm_detector* d) {
         if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
     hipStream_t ms = d->mstream, s = knobs().serial >= 2 ? ms : d->stream;
     // the frames' uploads (copy stream) before the front end
-    for (int b = 0; b < nb; ++b) {
+    for (int b = nb - 1; b >= 0; --b) {                       // (the copy stream is one in-order queue: the upload of the batch's last streamed frame covers the earlier ones)
         const int ring = d->slot[(first + b) % lm_detector::kSlots].ring;
-        if (ring >= 0) HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0));
+        if (ring < 0) continue;
+        if (hipEventQuery(d->ingest.t1[ring]) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0)); }   // (already there: nothing to wait for)
+        break;
     }
     if (s != d->stream) {
         // every kernel of the batch runs on the matching stream (LM_SERIAL=2): whatever was enqueued on `stream` before — a blocking upload, the
         // device-to-device copy of lm_detector_select_frame, the clearing of new arenas, a training view — comes first
-        HIP_TRY(hipEventRecord(d->ev[5], d->stream));
-        HIP_TRY(hipStreamWaitEvent(s, d->ev[5], 0));
+        // (nothing pending there — the steady state of a stream of uploaded frames — needs no ordering: a query instead of a record, a cross-queue wait
+        // and the barrier packet the GPU would process for it)
+        if (hipStreamQuery(d->stream) != hipSuccess) {
+            (void)hipGetLastError();                          // hipErrorNotReady is not an error
+            HIP_TRY(hipEventRecord(d->ev[5], d->stream));
+            HIP_TRY(hipStreamWaitEvent(s, d->ev[5], 0));
+        }
     }
     HIP_TRY(hipEventRecord(lead.ev[0], s));
     const bool cbits = cbits_active(d, num_work);
@@ -1691,8 +1702,14 @@ int lm_launch_pending(lm_detector* d) {
         if (top_ored && !d->fe_keep_top) bb.top_clear_units = (d->cbits_npairs * 8u + 15u) / 16u;
         if (!direct_top) launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
     }
+    // One queue for the whole batch (LM_SERIAL=2): the end of a stage IS the start of the next — one timing record between two kernels
+    // instead of two or three, and fe_done only when something outside the batch waits for this front end (a resident frame).
+    const bool one_queue = s == ms && knobs().stage_events != 2;
+    bool resident_in = false;
+    for (int b = 0; b < nb; ++b) resident_in = resident_in || d->slot[(first + b) % lm_detector::kSlots].ring < 0;
     HIP_TRY(hipEventRecord(lead.ev[1], s));
-    HIP_TRY(hipEventRecord(lead.fe_done, s));
+    if (!one_queue || resident_in) HIP_TRY(hipEventRecord(lead.fe_done, s));
+    lead.t_coarse0 = one_queue ? 1 : 2; lead.t_local0 = one_queue ? 3 : 5;
     for (int b = 0; b < nb; ++b)                              // the resident frame is read by this front end: the next lm_detector_select_frame copy waits for it
         if (d->slot[(first + b) % lm_detector::kSlots].ring < 0) d->resident_reader = lead.fe_done;
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1703,7 +1720,7 @@ int lm_launch_pending(lm_detector* d) {
     }
     const uint32_t cap = std::min<uint32_t>(lead.match_cap, d->buf_cand_cap);
     auto enqueue_coarse = [&](hipStream_t st) -> int {
-        HIP_TRY(hipEventRecord(lead.ev[2], st));
+        if (!one_queue) HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
         if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, st);
         else launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
@@ -1711,7 +1728,7 @@ int lm_launch_pending(lm_detector* d) {
         return LM_OK;
     };
     auto enqueue_match = [&]() -> int {
-        HIP_TRY(hipEventRecord(lead.ev[5], ms));
+        if (!one_queue) HIP_TRY(hipEventRecord(lead.ev[5], ms));
         // persistent refinement grid over the tiles and then the remaining candidates of every frame of the batch; the counts are
         // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
         // the hash tables k_dedupe uses
@@ -1752,7 +1769,7 @@ int lm_launch_pending(lm_detector* d) {
         if ((rc = enqueue_dedupe(d->xchg.stream))) return rc;
         HIP_TRY(hipEventRecord(lead.done, d->xchg.stream));
     } else {
-        HIP_TRY(hipStreamWaitEvent(ms, lead.fe_done, 0));
+        if (!one_queue) HIP_TRY(hipStreamWaitEvent(ms, lead.fe_done, 0));
         if ((rc = enqueue_coarse(ms))) return rc;
         if ((rc = enqueue_match())) return rc;
         if ((rc = enqueue_dedupe(ms))) return rc;
@@ -2027,8 +2044,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
     tm.batch_frames = sl.batch_n;
     if (hipEventElapsedTime(&tm.frontend_ms, lead.ev[0], lead.ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&tm.coarse_ms, lead.ev[2], lead.ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, lead.ev[5], lead.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, lead.ev[lead.t_coarse0], lead.ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, lead.ev[lead.t_local0], lead.ev[4]) != hipSuccess ||
         hipEventElapsedTime(&tm.total_ms, lead.ev[0], lead.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
         tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;
