@@ -1604,8 +1604,8 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 // Should the frames waiting for their batch go out now?  `at` = host time the question is asked for.
 //   * nothing launched is still uncollected, or everything launched has finished: the GPU is idle, the waiting frames go out (the
 //     first frame of a stream, a caller that collects every frame before the next) — in a tight loop once LM_FIRST_BATCH (3) of them
-//     wait: the launch occupies the caller for two submits' worth of time and a lone frame costs the GPU twice a batched one
-//     (A/B at the driver's 20 steps: 0.1054 -> 0.0997 ms per frame, 200 steps unchanged; profiles/r04_stream_ab.txt);
+//     wait, and once per burst: the launch occupies the caller for two submits' worth of time and a lone frame costs the GPU twice a
+//     batched one (A/B at the driver's 20 steps: 0.1054 -> 0.0997 ms per frame, 200 steps unchanged; profiles/r04_stream_ab.txt);
 //   * the caller submits in a tight loop (frames arrive less than 2.5 launches' worth of host time apart): only full batches.  A
 //     launch costs the calling thread ~0.1 ms (seven kernel launches + events) whatever the batch size, so a stream of partial
 //     batches makes the HOST the bottleneck at the pace of one launch per frame, the GPU keeps up with it, looks about to run dry
@@ -1614,15 +1614,20 @@ static float batch_ms_estimate(const lm_detector* d, int n) {
 //   * frames arrive sparsely (a camera): the GPU-time model — launch when the GPU's estimated backlog is shorter than the slack.
 static bool partial_batch_due(lm_detector* d, double at) {
     if (d->pend_n <= 0 || d->keep_queued <= 0) return false;
-    const bool tight = d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms;
-    const bool enough = !tight || d->pend_n >= knobs().first_batch;
-    if (d->n_launched == d->n_collected) return enough;
-    // ... or everything launched has FINISHED on the GPU (collected or not): frames are waiting and the GPU is idle.  The start of a stream
-    // used to lose ~0.15 ms here: frame 0 went out alone, finished after 0.2-0.3 ms, and the frames behind it waited for a full batch of
-    // eight.  (One event query per submit while a batch is pending; a tight loop cannot get stuck on one-frame batches through this rule:
-    // a lone frame keeps the GPU busy for 0.15-0.2 ms, three submits' worth of host time.)
-    if (batches_queued(d) == 0) return enough;
-    if (tight) return false;                            // (submit_gap_ms 0: no second submit yet — sparse until shown otherwise)
+    const bool tight = d->submit_gap_ms > 0.f && d->submit_gap_ms < 2.5f * d->launch_cost_ms;   // (submit_gap_ms 0: no second submit yet — sparse until shown otherwise)
+    const bool drained = d->n_launched == d->n_collected;
+    if (drained) d->early_batch_used = false;                  // nothing in flight: a new burst
+    if (tight) {
+        // ONE early batch per burst: the GPU is idle (nothing launched is unfinished), LM_FIRST_BATCH frames wait.  Not again until the pipeline has
+        // drained: with a host that needs longer for three submits + a launch than the GPU for three frames, every early batch would find the GPU idle
+        // again and the stream would settle on three frames per launch (one run in three of a 20-step series did: 0.154 instead of 0.100 ms per frame).
+        if (d->early_batch_used || d->pend_n < knobs().first_batch) return false;
+        if (!drained && batches_queued(d) != 0) return false;
+        d->early_batch_used = true;
+        return true;
+    }
+    // sparse: nothing launched is unfinished (collected or not) -> the GPU is idle, the frames go out; else the GPU-time model
+    if (drained || batches_queued(d) == 0) return true;
     if (batch_ms_estimate(d, d->pend_n) <= 0.f) return batches_queued(d) < d->keep_queued;
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
 }

@@ -31,6 +31,14 @@ static __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m, uint
 
 static __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Full adder on 32 bit positions at once (two v_bitop3_b32: parity 0x96, majority 0xE8).  The 3x3 majority vote of the colour chain and the
+// 5x5 median of the normals count, per pixel, how many taps of a window satisfy a predicate: with one byte per tap (a bit per predicate) and
+// four neighbouring pixels per word, a tree of these adders counts 8 predicates of 4 pixels at once.
+static __device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t& sum, uint32_t& carry) {
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+
 // ---- cv::phase(dx, dy, angle, true): OpenCV fastAtan2 polynomial (LL.cpp:423; Appendix A.3) -----
 static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -65,6 +73,7 @@ static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // for (blur and Sobel replicate the border: smoothed(clamp(p)), not a blur centred outside the image), which makes the
 // fused kernel bit-identical to running the stages as separate whole-image passes (the oracle does exactly that).
 constexpr int kCTX = 32, kCTY = 16;           // output tile
+constexpr int kQRowWords = (kCTX + 2 + 3) / 4;   // dwords per row of the vote's / the median's byte planes (34 and 36 bytes -> 9)
 static __device__ __forceinline__ void color_quant_body(const int bx, const int by, const uint8_t* __restrict__ rgb, float* __restrict__ mag,
                                                         uint8_t* __restrict__ onehot, int W, int H, float thr_sq) {
     // virtual coordinates: tile origin (x0, y0); halos: rgb 5, blurred 2, quantised 1.
@@ -74,8 +83,8 @@ static __device__ __forceinline__ void color_quant_body(const int bx, const int 
     __shared__ uint32_t s_rgb[kCTY + 10][kCTX + 10];
     __shared__ uint2 s_tmp[kCTY + 10][kCTX + 4];           // horizontal pass at columns clamp(x0-2 .. x0+TX+1), all halo rows: {R | B << 16, G}
     __shared__ uint32_t s_sm[kCTY + 4][kCTX + 4];           // smoothed at clamp(y0-2 ..), clamp(x0-2 ..), packed like s_rgb
-    __shared__ uint8_t s_q[kCTY + 2][kCTX + 2];             // 16-bin code & 7 at y0-1 .., x0-1 .. (0 outside the interior)
-    __shared__ float s_mag[kCTY][kCTX];
+    __shared__ uint32_t s_q4[(kCTY + 2) * kQRowWords];      // ONE-HOT of the 16-bin code & 7 at y0-1 .., x0-1 .. (bin 0 outside the interior), a byte per pixel, rows of kQRowWords dwords
+    __shared__ __attribute__((aligned(16))) float s_mag[kCTY][kCTX];
     const int x0 = bx * kCTX, y0 = by * kCTY, tid = threadIdx.x;
     const uint32_t w7[7] = {8, 28, 56, 72, 56, 28, 8};
     for (int i = tid; i < (kCTY + 10) * (kCTX + 10); i += 256) {
@@ -148,32 +157,46 @@ static __device__ __forceinline__ void color_quant_body(const int bx, const int 
                 q = (uint8_t)(iv & 7);
             }
         }
-        s_q[ty][tx] = q;
+        reinterpret_cast<uint8_t*>(s_q4)[ty * (kQRowWords * 4) + tx] = (uint8_t)(1u << q);
     }
     __syncthreads();
-    for (int i = tid; i < kCTY * kCTX; i += 256) {
-        const int ty = i / kCTX, tx = i - ty * kCTX;
-        const int y = y0 + ty, x = x0 + tx;
-        if (x >= W || y >= H) continue;
-        const float m = s_mag[ty][tx];
-        uint8_t res = 0;
-        if (x > 0 && y > 0 && x < W - 1 && y < H - 1 && m > thr_sq) {
-            uint32_t hist = 0;   // eight 4-bit counters (max 9 votes)
+    // hysteresisGradient's vote (LL.cpp:457-504): the orientation that at least 5 of the 9 pixels of the 3x3 window carry (a strict maximum of
+    // >= 5 votes of 9 is that orientation; fewer: nothing).  Four pixels per thread: the 9 taps are words of four one-hot bytes (two aligned
+    // reads + v_alignbyte per row), a carry-save tree counts all 8 orientations of the 4 pixels at once, count >= 5 <=> b3 | b2 & (b1 | b0).
+    // (Was: 9 byte reads + a packed histogram + an 8-way arg-max per pixel, 58 VALU; now ~12.)
+    if (tid < kCTY * kCTX / 4) {
+        const int ty = tid >> 3, c = tid & 7;
+        const int y = y0 + ty, x = x0 + 4 * c;
+        if (x < W && y < H) {
+            uint32_t sr[3], kr[3];
 #pragma unroll
-            for (int dy = 0; dy <= 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx <= 2; ++dx) hist += 1u << (4 * s_q[ty + dy][tx + dx]);
-            int best = -1, votes = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int v = (hist >> (4 * k)) & 15;
-                if (votes < v) { votes = v; best = k; }   // first strict maximum (LL.cpp:491)
+            for (int dy = 0; dy < 3; ++dy) {
+                const uint32_t lo = s_q4[(ty + dy) * kQRowWords + c], hi = s_q4[(ty + dy) * kQRowWords + c + 1];
+                full_add(lo, __builtin_amdgcn_alignbyte(hi, lo, 1), __builtin_amdgcn_alignbyte(hi, lo, 2), sr[dy], kr[dy]);
             }
-            if (votes >= 5) res = (uint8_t)(1u << best);
+            uint32_t b0, k3, u, k4;
+            full_add(sr[0], sr[1], sr[2], b0, k3);            // weight 1 done; weight 2: kr[0..2], k3
+            full_add(kr[0], kr[1], kr[2], u, k4);
+            const uint32_t b1 = u ^ k3, k5 = u & k3;          // weight 4: k4 k5
+            const uint32_t b2 = k4 ^ k5, b3 = k4 & k5;
+            const uint32_t win = b3 | (b2 & (b1 | b0));
+            const size_t o = (size_t)y * W + x;
+            const bool yin = y > 0 && y < H - 1;
+            uint32_t keep = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m = s_mag[ty][4 * c + q];
+                if (yin && x + q > 0 && x + q < W - 1 && m > thr_sq) keep |= 0xFFu << (8 * q);
+                if (mag && x + q < W) mag[o + q] = m;         // (null for the frames of a match: only addTemplate reads the magnitudes, LL.cpp:589-643)
+            }
+            const uint32_t res = win & keep;
+            if (x + 3 < W && ((reinterpret_cast<uintptr_t>(onehot) + o) & 3) == 0) *reinterpret_cast<uint32_t*>(onehot + o) = res;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (x + q < W) onehot[o + q] = (uint8_t)(res >> (8 * q));
+            }
         }
-        const size_t o = (size_t)y * W + x;
-        if (mag) mag[o] = m;                   // (null for the frames of a match: only addTemplate reads the magnitudes, LL.cpp:589-643)
-        onehot[o] = res;
     }
 }
 
@@ -289,37 +312,60 @@ static __device__ __forceinline__ uint8_t normal_at(const uint16_t* __restrict__
 
 static __device__ __forceinline__ void normals_median_body(const int bx, const int by, const uint16_t* __restrict__ depth, uint8_t* __restrict__ raw,
                                                            uint8_t* __restrict__ med, int W, int H, int dist_thr, int diff_thr) {
-    __shared__ uint8_t s_raw[kCTY + 4][kCTX + 4];
+    __shared__ uint32_t s_m[(kCTY + 4) * kQRowWords];        // a byte per pixel of the tile + 2: bit k = (rank of the raw normal <= k), rank 0 = none, k + 1 = 1 << k
     const int x0 = bx * kCTX, y0 = by * kCTY, tid = threadIdx.x;
     for (int i = tid; i < (kCTY + 4) * (kCTX + 4); i += 256) {
         const int ty = i / (kCTX + 4), tx = i - ty * (kCTX + 4);
         const int y = clampi(y0 - 2 + ty, 0, H - 1), x = clampi(x0 - 2 + tx, 0, W - 1);
         const uint8_t v = normal_at(depth, x, y, W, H, dist_thr, diff_thr);
-        s_raw[ty][tx] = v;
+        reinterpret_cast<uint8_t*>(s_m)[ty * (kQRowWords * 4) + tx] = (uint8_t)(0xFFu << (32 - __clz((int)v)));   // (__clz(0) = 32)
         if (ty >= 2 && ty < kCTY + 2 && tx >= 2 && tx < kCTX + 2 && y0 - 2 + ty < H && x0 - 2 + tx < W) raw[(size_t)y * W + x] = v;
     }
     __syncthreads();
-    for (int i = tid; i < kCTY * kCTX; i += 256) {
-        const int ty = i / kCTX, tx = i - ty * kCTX;
-        const int y = y0 + ty, x = x0 + tx;
-        if (x >= W || y >= H) continue;
-        unsigned long long cnt = 0;
+    // cv::medianBlur(5) of values that are 0 or one-hot = the 13th smallest of 25 ranks: median rank <= k <=> at least 13 taps have rank <= k.
+    // Four pixels per thread; a tap word holds the 8 predicates "rank <= k" of 4 neighbouring pixels, a carry-save tree (20 full + 2 half
+    // adders) counts them over the 25 taps, count >= 13 <=> b4 | b3 & b2 & (b1 | b0).  The predicates of a pixel are monotone in k, so its byte
+    // of the result is 0xFF << rank and the value 1 << (rank - 1) (0 for rank 0) is its lowest set bit (of the byte | 0x100) >> 1.
+    // (Was: 25 byte reads into packed 5-bit counters of a 64-bit word + a 9-step scan per pixel, 251 VALU; now ~26.)
+    if (tid < kCTY * kCTX / 4) {
+        const int ty = tid >> 3, c = tid & 7;
+        const int y = y0 + ty, x = x0 + 4 * c;
+        if (x < W && y < H) {
+            // a row at a time (five taps -> a 3-bit count: 2 full + 1 half adder), added into the bit-sliced total by a ripple adder: a few more
+            // operations than one tree over the 25 taps (62 against 44) but a dozen live registers instead of 30 — the tree cost k_fe_stage a wave of occupancy
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
 #pragma unroll
-        for (int dy = 0; dy <= 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx <= 4; ++dx) {
-                const uint32_t v = s_raw[ty + dy][tx + dx];
-                const int rank = v ? (32 - __clz(v)) : 0;     // 0 -> 0, 1<<k -> k+1
-                cnt += 1ull << (5 * rank);
+            for (int dy = 0; dy < 5; ++dy) {
+                const uint32_t lo = s_m[(ty + dy) * kQRowWords + c], hi = s_m[(ty + dy) * kQRowWords + c + 1];
+                uint32_t sa, ka, r0, kb;
+                full_add(lo, __builtin_amdgcn_alignbyte(hi, lo, 1), __builtin_amdgcn_alignbyte(hi, lo, 2), sa, ka);
+                full_add(sa, __builtin_amdgcn_alignbyte(hi, lo, 3), hi, r0, kb);
+                const uint32_t r1 = ka ^ kb, r2 = ka & kb;
+                if (dy == 0) { b0 = r0; b1 = r1; b2 = r2; }
+                else {
+                    const uint32_t k0 = b0 & r0; b0 ^= r0;
+                    uint32_t k1, k2;
+                    full_add(b1, r1, k0, b1, k1);
+                    full_add(b2, r2, k1, b2, k2);
+                    const uint32_t k3 = b3 & k2; b3 ^= k2;
+                    b4 ^= k3;
+                }
             }
-        int cum = 0, rank = 0;
+            const uint32_t ge = b4 | (b3 & b2 & (b1 | b0));
+            uint32_t out = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int c = (int)((cnt >> (5 * k)) & 31);
-            if (cum < 13 && cum + c >= 13) rank = k;
-            cum += c;
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t B = ((ge >> (8 * q)) & 0xFFu) | 0x100u;
+                out |= ((B & (0u - B)) >> 1) << (8 * q);
+            }
+            const size_t o = (size_t)y * W + x;
+            if (x + 3 < W && ((reinterpret_cast<uintptr_t>(med) + o) & 3) == 0) *reinterpret_cast<uint32_t*>(med + o) = out;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (x + q < W) med[o + q] = (uint8_t)(out >> (8 * q));
+            }
         }
-        med[(size_t)y * W + x] = rank ? (uint8_t)(1u << (rank - 1)) : 0;
     }
 }
 
@@ -628,7 +674,7 @@ static __device__ __forceinline__ void top_bits_aligned_body(const int bx, const
 // ~30 ns — with one workgroup per tile (10.8k for the first stage of four VGA frames) a CU held 1.3 workgroups on average and the
 // stage took as long as the dispatcher needed (42 us; profiles/r03_pmc.txt: 5 waves per CU).  A few workgroups per CU walk the
 // tiles instead (flat index + k * grid).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))   // 6 persistent workgroups per CU (knobs: fe_wgs_per_cu) = 6 waves per SIMD: at most 80 VGPRs
 k_fe_stage(FeStage st, int total) {
     for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
         int j = 0;

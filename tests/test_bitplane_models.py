@@ -23,3 +23,11 @@ def test_refinement_model_equals_byte_evaluation_and_oracle():
 def test_coarse_model_equals_byte_evaluation():
     text = _run("bitplane_coarse_model.py", 50)
     assert "bit-plane coarse pass == byte evaluation: True" in text, text
+
+
+def test_frontend_bitsliced_vote_and_median_equal_the_oracle():
+    """The carry-save window counts of the front end (3x3 majority vote, 5x5 median of one-hot normals) as a numpy model against the oracle."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "frontend_bitslice_model.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr[-2000:]
+    assert "bit-sliced vote == oracle hysteresis_gradient: True" in out.stdout
+    assert "bit-sliced median == median filter: True" in out.stdout
