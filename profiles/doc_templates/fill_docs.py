@@ -1,0 +1,67 @@
+import json, os, re, sys
+O=(sys.argv[1] if len(sys.argv)>1 else 'gpurun_out/r04final')+'/'
+def J(n):
+    return json.load(open(O+n))
+dflt=J('bench_default.json'); drv=J('bench_driver_flags.json'); s200=J('bench_steps200.json'); strong=J('bench_strong_n1_16k.json')
+reps=[ln.split()[-1] for ln in open(O+'driver_flags_repeats.txt') if 'ms/step' in ln]
+ex=dflt['extras']; rf=dflt['roofline']; cb=dflt['cpu_baseline']
+st=rf.get('stages',{})
+ks=open(O+'kernel_stats_roofline_leg.txt').read().splitlines()
+def kavg(name):
+    for ln in ks:
+        if name in ln:
+            p=ln.split()
+            return float(p[-9]), int(p[-11])
+    return None, 0
+rows={}
+for k in ('k_local_bits','k_fe_stage','k_coarse_bits','k_fe_bits','k_dedupe'):
+    rows[k]=kavg(k)
+nb=8
+fe_total=rows['k_fe_stage'][0]*2+rows['k_fe_bits'][0]
+kern="front end %.0f µs (`k_fe_stage` x 2: %.0f + `k_fe_bits` %.0f), `k_coarse_bits` %.0f, `k_local_bits` %.0f, `k_dedupe` %.0f → %.0f µs per frame (round 3, 4-frame launches: 140)" % (fe_total, rows['k_fe_stage'][0]*2, rows['k_fe_bits'][0], rows['k_coarse_bits'][0], rows['k_local_bits'][0], rows['k_dedupe'][0], (fe_total+rows['k_coarse_bits'][0]+rows['k_local_bits'][0]+rows['k_dedupe'][0])/nb)
+def stg(name):
+    d=st.get(name)
+    if not d: return name+': -'
+    if name=='frontend':
+        parts=['%s %s %.2f' % (k, 'TCP' if 'TCP' in v['binding']['ceiling'] else ('VALU' if 'VALU' in v['binding']['ceiling'] else 'other'), v['binding']['frac']) for k,v in d['kernels'].items()]
+        return 'front end: %s; traffic %.0f MB per batch = %.1f x the algorithmic %.1f MB' % (', '.join(parts), d['traffic_bytes_per_batch']/1e6, d['traffic_over_algorithmic'], d['algorithmic_bytes_per_frame']*nb/1e6)
+    b=d['binding']; c=d['ceilings']
+    return '%s (`%s`): **%.2f of the %s**; vector L1 %.2f (+ %.2f miss stalls), VALU %.2f, L2 %.2f, HBM %.3f' % (name, d['kernel'], b['frac'], 'vector-L1 access rate' if 'TCP' in b['ceiling'] else ('VALU issue slots' if 'VALU' in b['ceiling'] else b['ceiling']), c['tcp'], d['tcp_miss_stall_cycles_per_cu_cycle'], c['valu'], c['l2'], c['hbm'])
+stages='; '.join(stg(n) for n in ('frontend','coarse','refine'))
+roof='%.2f GB algorithmic per %d-frame launch / %.3f ms = %.1f TB/s = %.2f x the HBM peak by the §8(d) convention (NOT a physical fraction: the kernel loads 16 bytes where the reference reads 256); physically: **%.2f 64-byte vector-L1 accesses per CU cycle against the one per cycle the TCP serves** (reported as %.2f; %.1f accesses per wave load, %.1f CU cycles per wave load; %.2f of the cycles also stalled on pending misses), VALU %.2f of the issue slots (%.1f instructions per lane and feature, %.2f of them adder operations), L2 %.2f, HBM traffic %.0f MB per launch = %.3f of the peak' % (rf['algorithmic_bytes_per_launch']/1e9, rf['frames_per_launch'], rf['kernel_ms'], rf['achieved']/1e3, rf['frac'], rf['tcp_accesses_per_cu_cycle_raw'], rf['binding']['frac'], rf['l1_accesses_per_wave_load'], rf['cu_cycles_per_wave_load'], rf['tcp_miss_stall_cycles_per_cu_cycle'], rf['ceilings']['valu'], rf['valu_per_lane_feature'], rf['useful_valu_frac'], rf['ceilings']['l2'], rf['traffic']/1e6, rf['ceilings']['hbm'])
+icp=ex['icp']; pl=ex['pipeline']
+hp=open(O+'host_profile.txt').read().strip().splitlines() if __import__('os').path.exists(O+'host_profile.txt') else []
+host=(hp[-1].split('|')[1].strip() if hp else 'see r04_host_profile.txt')
+R={
+ 'R4_DRIVER_VALUE': '%.2f' % (drv['value']/1e6),
+ 'R4_DRIVER': '%.4f' % drv['ms_per_step'],
+ 'R4_REPEATS': ' / '.join(reps),
+ 'R4_50': '%.4f' % dflt['ms_per_step'],
+ 'R4_200': '%.4f' % s200['ms_per_step'],
+ 'R4_SYNC': '%.3f' % ex['synchronous_call']['ms_per_frame'],
+ 'R4_PCIE_VALUE': '%.2f' % (ex['pcie_inclusive']['value']/1e6),
+ 'R4_PCIE': '%.3f' % ex['pcie_inclusive']['ms_per_frame'],
+ 'R4_SPEEDUP': '%.0f (driver flags) / %.0f (50 steps)' % (drv['value']/cb['value'], dflt['value']/cb['value']),
+ 'R4_16K_ROW': '%.3f ms/frame = %.1f M templates·Mpx/s as `--scaling strong` bench line (`r04_bench_strong_n1_16k.json`; round 3: 0.756), %.3f in the extras leg of the default run (a second detector beside the first)' % (strong['ms_per_step'], strong['value']/1e6, ex['strong_scaling_reference']['ms_per_step']),
+ 'R4_16K': '%.3f' % strong['ms_per_step'],
+ 'R4_ICP_ROW': '%.2f ms device = %.0f k ICP iterations/s (unchanged since round 2); CPU: the oracle\'s numpy `pose_refine` %.0f iterations/s' % (icp['device_ms'], icp['icp_iters_per_sec_device']/1e3, icp.get('cpu_baseline',{}).get('icp_iters_per_sec',0)),
+ 'R4_ICP': '%.2f' % icp['device_ms'],
+ 'R4_PIPE_ROW': 'match %.2f + NMS %.2f + ICP %.2f = %.2f ms per frame (round 3: 2.15)' % (pl.get('match_ms',0), pl.get('nms_ms',0), pl['icp_ms'], pl['total_ms']),
+ 'R4_PIPE': '%.2f' % pl['total_ms'],
+ 'R4_SPARSE': 'threshold %.1f: %.3f ms/frame' % (ex['one_candidate_per_template']['threshold'], ex['one_candidate_per_template']['ms_per_frame']),
+ 'R4_FIXTURE': '%.3f ms/frame = %.1f M templates·Mpx/s (round 3: 0.299)' % (ex['real_fixture']['ms_per_frame'], ex['real_fixture']['value']/1e6),
+ 'R4_CPU': '%.1f k templates·Mpx/s (%.3f s/frame)** → GPU/CPU **%.0f x at the driver\'s flags, %.0f x at 50 steps**; the oracle\'s SSE port %.1f k; with the oracle\'s numpy quantisation included %.1f k; the port on all %d threads %.0f k (not what the reference does)' % (cb['value']/1e3, cb['seconds_per_frame'], drv['value']/cb['value'], dflt['value']/cb['value'], cb['port']['value']/1e3, cb['incl_quantisation']['value']/1e3, cb['all_cores_variant']['threads'], cb['all_cores_variant']['value']/1e3),
+ 'R4_TCPRAW': '%.2f' % rf['tcp_accesses_per_cu_cycle_raw'], 'R4_TCPSTALL': '%.2f' % rf['tcp_miss_stall_cycles_per_cu_cycle'], 'R4_VALUF': '%.2f' % rf['ceilings']['valu'], 'R4_L2F': '%.2f' % rf['ceilings']['l2'], 'R4_HBMF': '%.3f' % rf['ceilings']['hbm'],
+ 'R4_FE_MS': '%.2f' % (fe_total/1e3), 'R4_FE_SHARE': '%.0f µs per frame, %.0f %%' % (fe_total/nb, 100*fe_total/(fe_total+rows['k_coarse_bits'][0]+rows['k_local_bits'][0]+rows['k_dedupe'][0])),
+ 'R4_BATCH8': '%.2f' % ((fe_total+rows['k_coarse_bits'][0]+rows['k_local_bits'][0]+rows['k_dedupe'][0]+25)/1e3),
+ 'R4_CPUK': '%.1f' % (cb['value']/1e3),
+ 'R4_KERNELS': kern, 'R4_STAGES': stages, 'R4_ROOFLINE': roof, 'R4_HOST': host,
+}
+for p in ('README.md','DESIGN.md'):
+    s=open('os.path.join(os.path.dirname(os.path.abspath(__file__)), p + '.tmpl')).read()
+    for k in sorted(R, key=len, reverse=True):
+        s=s.replace(k, R[k])
+    left=re.findall(r'R4_[A-Z0-9_]+', s)
+    print(p, 'left:', set(left))
+    open(p,'w').write(s)
+print(json.dumps({k:R[k] for k in ('R4_DRIVER','R4_50','R4_200','R4_SYNC','R4_PCIE','R4_16K','R4_ICP','R4_PIPE')}))
