@@ -1,3 +1,4 @@
+"""Fills the R4_* placeholders of README.md.tmpl / DESIGN.md.tmpl (this directory) from ONE run of profiles/r04_final.sh and writes README.md / DESIGN.md at the repo root.\nUsage (repo root): python profiles/doc_templates/fill_docs.py gpurun_out/r04final"""
 import json, os, re, sys
 O=(sys.argv[1] if len(sys.argv)>1 else 'gpurun_out/r04final')+'/'
 def J(n):
@@ -58,7 +59,7 @@ R={
  'R4_KERNELS': kern, 'R4_STAGES': stages, 'R4_ROOFLINE': roof, 'R4_HOST': host,
 }
 for p in ('README.md','DESIGN.md'):
-    s=open('os.path.join(os.path.dirname(os.path.abspath(__file__)), p + '.tmpl')).read()
+    s=open(os.path.join(os.path.dirname(os.path.abspath(__file__)), p + '.tmpl')).read()
     for k in sorted(R, key=len, reverse=True):
         s=s.replace(k, R[k])
     left=re.findall(r'R4_[A-Z0-9_]+', s)
