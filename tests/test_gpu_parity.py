@@ -71,7 +71,7 @@ def expect_paths(det, paths, tiles_possible=True, levels=2):
 # ---------------------------------------------------------------------------------------------
 # front end: quantised maps and linear memories, byte for byte
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["fixture_T58", "synth_T48", "synth_small_T48", "synth_3level", "synth_1280"])
+@pytest.mark.parametrize("case", ["fixture_T58", "synth_T48", "synth_small_T48", "synth_3level", "synth_1280", "synth_100x96_T22", "synth_50x48_T2"])
 def test_frontend_stages_bit_exact(lm, case):
     if case == "fixture_T58":
         rgb, dep, T, nf = load_bgr("0000_rgb.png"), load_u16("0000_dep.png"), [5, 8], 127
@@ -81,6 +81,10 @@ def test_frontend_stages_bit_exact(lm, case):
         (rgb, dep), T, nf = synth.make_frame(5, 320, 240, 12), [4, 8], 64
     elif case == "synth_3level":
         (rgb, dep), T, nf = synth.make_frame(6, 640, 480), [4, 4, 8], 64
+    elif case == "synth_100x96_T22":                     # level 1 is 50 wide: rows that are not dword-aligned, tiles hanging over the right edge (the four-pixel stores of the vote / the median fall back to bytes)
+        (rgb, dep), T, nf = synth.make_frame(8, 100, 96, 10), [2, 2], 64
+    elif case == "synth_50x48_T2":
+        (rgb, dep), T, nf = synth.make_frame(8, 50, 48, 6), [2], 64
     else:
         (rgb, dep), T, nf = synth.make_frame(7, 1280, 960, 60), [4, 8], 150
     od = lo.OracleDetector(nf, T)
