@@ -1471,7 +1471,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
                 if (st.njobs + 1 > kFeMaxJobs) flush_bits();
                 if (top) {
                     const uint32_t bit0[2] = {lv.lm_off[0] - d->cbits_byte0, lv.lm_off[1] - d->cbits_byte0};
-                    fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T, d->fe_top_atomic);
+                    fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T, d->fe_top_mode);
                 } else {
                     uint8_t* bits[2] = {d->bits_arena[arena].p + (lv.sm_off[0] >> 1), d->bits_arena[arena].p + (lv.sm_off[1] >> 1)};
                     fe_job_bits_rows(st.job[st.njobs++], quant, mask, bits, B.W, B.H, lv.T);
@@ -1676,7 +1676,8 @@ int lm_launch_pending(lm_detector* d) {
     bool direct_low = knobs().fe_bits && d->fe_direct && bits && d->bits_all_in, direct_top = knobs().fe_bits && d->fe_direct && cbits;
     for (int l = 0; l + 1 < d->geom.levels; ++l) direct_low = direct_low && fe_bits_rows_possible(d->geom.lv[l].W, d->geom.lv[l].T);
     const LevelGeom& topl = d->geom.lv[d->geom.levels - 1];
-    const bool top_ored = direct_top && (d->fe_top_atomic || !fe_top_bits_aligned(topl.W, topl.H, topl.T));   // (else whole dwords are stored: nothing to clear)
+    const uint32_t top_bit0[2] = {topl.lm_off[0] - d->cbits_byte0, topl.lm_off[1] - d->cbits_byte0};
+    const bool top_ored = direct_top && fe_top_bits_kind(topl.W, topl.H, topl.T, top_bit0, d->fe_top_mode) == kFeTopBits;   // (else whole bytes / dwords are stored: nothing to clear)
     if (top_ored)                                        // the pair stream is OR-ed together: it has to be zero (k_local_bits leaves it so; k_pack_top and first use do not)
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
@@ -2310,7 +2311,7 @@ extern "C" int lm_detector_set_direct_bits(lm_detector* d, int on) {
     if (rc) return rc;
     d->fe_direct = on != 0;
     d->fe_keep_top = (on & 2) != 0;  // tests: the pair stream stays readable after the match (lm_detector_read_stage kind 5) and is cleared before the next frame instead
-    d->fe_top_atomic = (on & 4) != 0; // tests: the OR-ing writer of the pair stream also where whole dwords could be stored
+    d->fe_top_mode = (on & 4) ? 1 : ((on & 8) ? 2 : 0);   // tests: 4 = the OR-ing writer of the pair stream also where whole bytes / dwords could be stored, 8 = no pixel tiles (the whole-dword writer where the geometry allows it)
     return LM_OK;
 }
 

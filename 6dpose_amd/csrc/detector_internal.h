@@ -178,7 +178,8 @@ struct lm_detector {
     // (round 1).  coarse: 0 = pair stream when the refinement runs on bit planes (default), 1 = byte linear memories (k_coarse).
     int refine_mode = 0, coarse_mode = 0;
     bool fe_direct = true;                          // lm_detector_set_direct_bits: the front end writes bit planes directly where nothing reads the bytes (0: bytes + k_pack_bits / k_pack_top)
-    bool fe_keep_top = false, fe_top_atomic = false; // lm_detector_set_direct_bits(d, 2 / 4)
+    bool fe_keep_top = false;                       // lm_detector_set_direct_bits(d, 2)
+    int fe_top_mode = 0;                            // lm_detector_set_direct_bits(d, 4 / 8): which writer of the pair stream (fe_job_top_bits)
     bool fe_bytes_low = true, fe_bytes_top = true;  // did the last front end write the byte planes of the levels below the top / of the top level (read_stage builds them on demand otherwise)
     hipEvent_t resident_reader = nullptr;           // front end (event of its batch) that reads the resident frame buffers: lm_detector_select_frame's copy waits for it
     bool cbits_clean[kSlots] = {};                  // the slot's pair stream is all zero (what the front end's OR-ing writer needs)

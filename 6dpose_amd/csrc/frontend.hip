@@ -554,8 +554,7 @@ constexpr int kBitsCells = 1152;              // 16-bit cell words of a workgrou
 static __host__ __device__ inline int fe_bits_rows(int Wd) { const int wp = ((Wd + 15) / 16) * 16 + 16; const int r = kBitsCells / wp; return r < 8 ? r : 8; }
 
 static __device__ __forceinline__ void bits_rows_body(const int bx, const int by, const LmJob& J, int W, int H, int T, int Wd, int Hd, int NS, uint32_t m_wd,
-                                                      uint32_t m_t) {
-    __shared__ uint16_t s_cells[kBitsCells];
+                                                      uint32_t m_t, uint16_t* __restrict__ s_cells /* kBitsCells */) {
     const int Wp = NS * 16 + 16, R = fe_bits_rows(Wd);
     const int phase = by, ry0 = bx * R;
     const int rows = Hd - ry0 < R ? Hd - ry0 : R;
@@ -665,6 +664,101 @@ static __device__ __forceinline__ void top_bits_aligned_body(const int bx, const
     }
 }
 
+// The pair stream from pixel TILES (T = 4 or 8, W_d a multiple of 8, the stream's first bit on a byte boundary): a workgroup takes one
+// row of cells of one modality.  The 2T - 1 pixel rows its windows touch go to LDS as dwords of four pixels (masked, zero beyond the
+// image); the T x T OR of EVERY pixel position of the cell row is separable — along x on the dwords (v_alignbyte), along y on the result —
+// so the T x T positions of a cell (= the T x T phases of the linear memory, LL.cpp:1026-1243) share their loads and their ORs instead of
+// every (phase, cell) thread loading its own T x T pixels (16 unaligned dword loads for T = 8).  A unit = (phase, 8 neighbouring cells):
+// the 8 spread bytes (8 labels x 8 cells) are transposed as an 8 x 8 bit matrix, once for "own bit set" (response 4) and once for
+// "only a neighbouring label's" (response 1), which gives for each label the byte of its 8 cells: 16 byte stores, no ballots, no atomics,
+// nothing to clear.  (top_bits_aligned_body: 29.5 us per 8-frame batch at VGA — three times the cost per pixel of the level below.)
+constexpr int kTileWords = 23 * 178;             // LDS pool of k_fe_bits (16 KB): 15 + 8 rows of kTileRowWords dwords
+static_assert(kTileWords * 2 >= kBitsCells, "the pool holds bits_rows_body's cell words");
+constexpr int kTileRowWords = 178;            // dwords per staged pixel row: W / 4 + T / 4 <= this (T = 8: W <= 704; T = 4: the same bound)
+static __host__ __device__ inline bool fe_top_tile_fits(int W, int T) { return (T == 4 || T == 8) && (W / T) % 8 == 0 && W / 4 + T / 4 <= kTileRowWords; }
+
+static __device__ __forceinline__ unsigned long long transpose8x8(unsigned long long x) {      // byte i bit j <-> byte j bit i
+    unsigned long long t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+    return x;
+}
+
+template <int kT>
+static __device__ __forceinline__ void top_bits_tile_body(const int ry, const LmJob& J, int W, int H, int Wd, int Hd, uint32_t* __restrict__ s_tile) {
+    constexpr int kRows = 2 * kT - 1;
+    uint32_t* const s_px = s_tile;                       // the pixel rows (15 x kTileRowWords), then their OR along x (in place)
+    uint32_t* const s_sp = s_tile + 15 * kTileRowWords;  // row rs: the T x T OR of the windows that start in pixel row ry T + rs (8 x kTileRowWords)
+    const int RW = W / 4 + kT / 4, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t* q4 = reinterpret_cast<const uint32_t*>(J.quant);
+    const uint32_t* m4 = reinterpret_cast<const uint32_t*>(J.mask);
+    for (int r = wave; r < kRows; r += 4) {
+        const int y = ry * kT + r;
+        for (int cw = lane; cw < RW; cw += 64) {
+            uint32_t v = 0;
+            if (y < H && 4 * cw < W) {
+                v = q4[((size_t)y * W >> 2) + cw];
+                if (m4) {
+                    const uint32_t m = m4[((size_t)y * W >> 2) + cw];
+                    const uint32_t nz = ((((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u) >> 7;      // 1 per non-zero mask byte
+                    v &= nz * 0xFFu;
+                }
+            }
+            s_px[r * RW + cw] = v;
+        }
+    }
+    __syncthreads();
+    // OR of kT consecutive pixels, a wave per row: every lane reads its dwords before any lane of the wave overwrites them
+    for (int r = wave; r < kRows; r += 4) {
+        for (int c0 = 0; c0 < RW; c0 += 64) {
+            const int cw = c0 + lane;
+            uint32_t h = 0;
+            if (cw < RW) {
+                const uint32_t d0 = s_px[r * RW + cw], d1 = cw + 1 < RW ? s_px[r * RW + cw + 1] : 0u;
+                h = d0 | __builtin_amdgcn_alignbyte(d1, d0, 1) | __builtin_amdgcn_alignbyte(d1, d0, 2) | __builtin_amdgcn_alignbyte(d1, d0, 3);
+                if (kT == 8) {
+                    const uint32_t d2 = cw + 2 < RW ? s_px[r * RW + cw + 2] : 0u;
+                    h |= d1 | __builtin_amdgcn_alignbyte(d2, d1, 1) | __builtin_amdgcn_alignbyte(d2, d1, 2) | __builtin_amdgcn_alignbyte(d2, d1, 3);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (cw < RW) s_px[r * RW + cw] = h;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kT * RW; i += 256) {            // ... and of kT consecutive rows
+        const int rs = i / RW, cw = i - rs * RW;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < kT; ++k) v |= s_px[(rs + k) * RW + cw];
+        s_sp[i] = v;
+    }
+    __syncthreads();
+    const int G = Wd >> 3, npos = Wd * Hd, units = kT * kT * G;
+    const uint32_t run = (uint32_t)(kT * kT) * (uint32_t)npos, top_bit0 = (uint32_t)reinterpret_cast<uintptr_t>(J.strips);
+    const uint8_t* sp = reinterpret_cast<const uint8_t*>(s_sp);
+    for (int u = tid; u < units; u += 256) {
+        const int phase = u / G, g = u - phase * G;
+        const int rs = phase / kT, cs = phase - rs * kT;
+        unsigned long long v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v |= (unsigned long long)sp[rs * (RW * 4) + (8 * g + j) * kT + cs] << (8 * j);
+        const unsigned long long adj = ((v << 1) & 0xFEFEFEFEFEFEFEFEull) | ((v >> 7) & 0x0101010101010101ull) |
+                                       ((v >> 1) & 0x7F7F7F7F7F7F7F7Full) | ((v << 7) & 0x8080808080808080ull);
+        const unsigned long long t4 = transpose8x8(v), t1 = transpose8x8(adj & ~v);
+        const uint32_t b = top_bit0 + (uint32_t)phase * (uint32_t)npos + (uint32_t)(ry * Wd + 8 * g);    // bit position (label 0) from the stream's start: a multiple of 8
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const uint32_t bl = b + (uint32_t)l * run;
+            uint8_t* o = J.lm + (size_t)(bl >> 5) * 8 + ((bl >> 3) & 3u);
+            o[0] = (uint8_t)(t1 >> (8 * l));                   // the pair's "is 1" dword ...
+            o[4] = (uint8_t)(t4 >> (8 * l));                   // ... and its "is 4" dword
+        }
+    }
+}
+
 // ---- several independent front-end jobs in ONE launch ---------------------------------------------------------------------
 // The seven kernels of a frame are small (5-17 us) and dependent kernels on a queue start ~7 us apart, so the front end is
 // mostly launch latency.  The jobs that do not depend on each other share a launch: stage k = {colour chain of level k,
@@ -701,8 +795,9 @@ k_fe_stage(FeStage st, int total) {
 // The bit-plane jobs of a batch (strip records of every level below the top, pair stream of the top level: bits_rows_body, top_bits_body)
 // in a launch of their own, the last of the front end: inside k_fe_stage they would cost the colour chain a wave of occupancy (95 VGPRs
 // against 79).  Same job table, same persistent walk.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_fe_bits(FeStage st, int total) {
+    __shared__ uint32_t s_tile[kTileWords];                // one pool for the bodies (a block runs one of them): the cell words of bits_rows_body, the pixel tile of top_bits_tile_body
     for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
         int j = 0;
         while (j + 1 < st.njobs && blk >= st.job[j + 1].first) ++j;
@@ -710,9 +805,10 @@ k_fe_bits(FeStage st, int total) {
         const int local = blk - J.first;
         const int bz = (int)fast_div((uint32_t)local, J.m_gxgy, (uint32_t)(J.gx * J.gy)), rem = local - bz * J.gx * J.gy;
         const int by = (int)fast_div((uint32_t)rem, J.m_gx, (uint32_t)J.gx), bx = rem - by * J.gx;
-        if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t);
+        if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t, reinterpret_cast<uint16_t*>(s_tile));
         else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
         else if (J.kind == kFeTopBitsAligned) top_bits_aligned_body(bx, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t, J.m_np);
+        else if (J.kind == kFeTopBitsTile) { if (J.a == 8) top_bits_tile_body<8>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); else top_bits_tile_body<4>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); }
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
 }
@@ -749,16 +845,23 @@ void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* co
     j.lm[0] = LmJob{quant[0], mask[0], bits[0], nullptr}; j.lm[1] = LmJob{quant[1], mask[1], bits[1], nullptr};
 }
 // pair stream of the top level, written directly; bit0[m] = flat arena offset of modality m's block less the stream's first byte
-void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T, bool force_atomic) {
+int fe_top_bits_kind(int W, int H, int T, const uint32_t bit0[2], int mode) {
+    if (mode != 1 && mode != 2 && fe_top_tile_fits(W, T) && bit0[0] % 8 == 0 && bit0[1] % 8 == 0) return kFeTopBitsTile;
+    if (mode != 1 && ((long)T * T * (W / T) * (H / T)) % 64 == 0) return kFeTopBitsAligned;
+    return kFeTopBits;
+}
+void fe_job_top_bits(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* stream, const uint32_t bit0[2], int W, int H, int T, int mode) {
     j = FeJob{}; j.kind = kFeTopBits; j.a = T; j.gx = ((W / T) * (H / T) + 255) / 256; j.gy = T * T; j.gz = 2; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
     j.lm[0] = LmJob{quant[0], mask[0], stream, reinterpret_cast<uint8_t*>((uintptr_t)bit0[0])}; j.lm[1] = LmJob{quant[1], mask[1], stream, reinterpret_cast<uint8_t*>((uintptr_t)bit0[1])};
-    if (fe_top_bits_aligned(W, H, T) && !force_atomic) {    // whole dwords per wave: no atomics, nothing to clear
+    const int kind = fe_top_bits_kind(W, H, T, bit0, mode);
+    if (kind == kFeTopBitsTile) {                           // a workgroup per row of cells: whole bytes, no atomics, nothing to clear
+        j.kind = kFeTopBitsTile; j.gx = j.Hd; j.gy = 1;
+    } else if (kind == kFeTopBitsAligned) {                 // whole dwords per wave: no atomics, nothing to clear
         const int npos = j.Wd * j.Hd;
         j.kind = kFeTopBitsAligned; j.gx = (T * T * npos + 255) / 256; j.gy = 1; j.m_np = div_magic((uint32_t)npos);
     }
 }
-bool fe_top_bits_aligned(int W, int H, int T) { return ((long)T * T * (W / T) * (H / T)) % 64 == 0; }
 static int fe_prepare(FeStage& st) {                             // drops empty jobs, lays the jobs' blocks out on one flat index; returns the number of blocks
     int total = 0, n = 0;
     for (int i = 0; i < st.njobs; ++i) {

@@ -534,7 +534,7 @@ class Detector:
         g = self._lib.lm_detector_set_direct_bits
         g.argtypes = [ctypes.c_void_p, ctypes.c_int]
         g.restype = ctypes.c_int
-        _check(g(self._h, int(direct)))          # True / False; 2 = direct and the top level's bit planes stay readable (tests)
+        _check(g(self._h, int(direct)))          # True / False; tests: + 2 the top level's bit planes stay readable, + 4 / + 8 which writer of the top level (amd_linemod.h)
 
     def getPaths(self):
         """lm_detector_get_paths: (refine, coarse) the current bank and frame geometry actually use, as the names of setPaths (valid after a match)."""

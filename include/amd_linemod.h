@@ -274,8 +274,10 @@ int lm_detector_get_paths(const lm_detector *d, int *refine, int *coarse);
 /* The response maps of spread / computeResponseMaps / linearize (LL.cpp:1026-1243) as bit planes straight from the quantised images
  * (default, on = 1: wherever the kernels in use read only bit planes, the byte linear memories are not written at all) or as the
  * reference's byte linear memories first, packed into bit planes by a second kernel (on = 0).  Bit 1 (on = 2, 3): the top level's bit
- * planes stay readable after the match (lm_detector_read_stage kind 5; tests); bit 2 (on = 4 ...): the writer that ORs the top level's
- * planes together is used even where whole dwords can be stored (tests).  Results never depend on it. */
+ * planes stay readable after the match (lm_detector_read_stage kind 5; tests).  The top level has three writers — from pixel tiles (T = 4 or 8,
+ * a multiple of 8 cells per row: whole bytes), whole dwords per wave (T * T * cells a multiple of 64), ballots OR-ed into a zeroed stream — and
+ * the cheapest the geometry allows is used; bit 2 (on = 4 ...) forces the OR-ing writer, bit 3 (on = 8 ...) rules out the tiles (tests).
+ * Results never depend on it. */
 int lm_detector_set_direct_bits(lm_detector *d, int on);
 int lm_detector_last_timings(const lm_detector *d, lm_timings *t);
 

@@ -176,7 +176,7 @@ def test_bit_planes_equal_the_packed_linear_memories(lm, case):
         lms.append([lo.build_linear_memories(q[0], T[l]), lo.build_linear_memories(q[1], T[l])])
     L = len(T)
     seen = []
-    for direct in (2, 6, False):                              # the front end's own writers (2: kept readable; 6: ... and the OR-ing writer of the top level forced), packed from bytes
+    for direct in (2, 10, 6, False):                          # the front end's own writers (2: kept readable — pixel tiles where the geometry allows; 10: ... whole dwords per wave; 6: ... the OR-ing writer), packed from bytes
         det = lm.Detector(nfeat[0], T, device=0)
         det.setPaths("bits", "bits", direct)
         det.addClassPacked("o", *bank)
@@ -200,7 +200,7 @@ def test_bit_planes_equal_the_packed_linear_memories(lm, case):
         if not masks:
             raw, _ = oracle_matches(od, rgb, dep, bank, T, 70.0)
             same_records(det.matchArray([rgb, dep], 70.0, ["o"]), lo.canonical_sort_unique(raw))
-    assert seen[0] == seen[1] == seen[2]
+    assert seen[0] == seen[1] == seen[2] == seen[3]
 
 
 def test_precondition_errors_like_cv_assert(lm):
