@@ -1474,7 +1474,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
                     fe_job_top_bits(st.job[st.njobs++], quant, mask, d->cbits_arena[arena].p, bit0, B.W, B.H, lv.T, d->fe_top_mode);
                 } else {
                     uint8_t* bits[2] = {d->bits_arena[arena].p + (lv.sm_off[0] >> 1), d->bits_arena[arena].p + (lv.sm_off[1] >> 1)};
-                    fe_job_bits_rows(st.job[st.njobs++], quant, mask, bits, B.W, B.H, lv.T);
+                    fe_job_bits_rows(st.job[st.njobs++], quant, mask, bits, B.W, B.H, lv.T, d->fe_top_mode == 0);
                 }
             }
         }

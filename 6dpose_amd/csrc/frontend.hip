@@ -672,10 +672,11 @@ static __device__ __forceinline__ void top_bits_aligned_body(const int bx, const
 // the 8 spread bytes (8 labels x 8 cells) are transposed as an 8 x 8 bit matrix, once for "own bit set" (response 4) and once for
 // "only a neighbouring label's" (response 1), which gives for each label the byte of its 8 cells: 16 byte stores, no ballots, no atomics,
 // nothing to clear.  (top_bits_aligned_body: 29.5 us per 8-frame batch at VGA — three times the cost per pixel of the level below.)
-constexpr int kTileWords = 23 * 178;             // LDS pool of k_fe_bits (16 KB): 15 + 8 rows of kTileRowWords dwords
+constexpr int kTileWords = 6144;                 // LDS pool of k_fe_bits (24 KB; 6 workgroups per CU): the staged pixel rows / spread rows / records of the tile writers
 static_assert(kTileWords * 2 >= kBitsCells, "the pool holds bits_rows_body's cell words");
-constexpr int kTileRowWords = 178;            // dwords per staged pixel row: W / 4 + T / 4 <= this (T = 8: W <= 704; T = 4: the same bound)
-static __host__ __device__ inline bool fe_top_tile_fits(int W, int T) { return (T == 4 || T == 8) && (W / T) % 8 == 0 && W / 4 + T / 4 <= kTileRowWords; }
+static __host__ __device__ inline bool fe_top_tile_fits(int W, int T) { return (T == 4 || T == 8) && (W / T) % 8 == 0 && (3 * T - 1) * (W / 4 + T / 4) <= kTileWords; }
+static __host__ __device__ inline int fe_rows_block_rows(int NS, int T);
+static __host__ __device__ inline bool fe_rows_tile_fits(int W, int T) { return (T == 4 || T == 8) && W % 16 == 0 && fe_rows_block_rows(((W / T) + 15) / 16, T) > 0; }
 
 static __device__ __forceinline__ unsigned long long transpose8x8(unsigned long long x) {      // byte i bit j <-> byte j bit i
     unsigned long long t;
@@ -685,12 +686,12 @@ static __device__ __forceinline__ unsigned long long transpose8x8(unsigned long 
     return x;
 }
 
+// stages of the top level's tile writer: the 2T - 1 pixel rows of cell row ry as dwords (masked, zero beyond the image, RW dwords per row),
+// OR-ed along x in place, then along y into s_sp (row rs = the T x T OR of every window that starts in pixel row ry T + rs)
 template <int kT>
-static __device__ __forceinline__ void top_bits_tile_body(const int ry, const LmJob& J, int W, int H, int Wd, int Hd, uint32_t* __restrict__ s_tile) {
+static __device__ __forceinline__ void tile_spread(const int ry, const LmJob& J, int W, int H, int RW, uint32_t* __restrict__ s_px, uint32_t* __restrict__ s_sp) {
     constexpr int kRows = 2 * kT - 1;
-    uint32_t* const s_px = s_tile;                       // the pixel rows (15 x kTileRowWords), then their OR along x (in place)
-    uint32_t* const s_sp = s_tile + 15 * kTileRowWords;  // row rs: the T x T OR of the windows that start in pixel row ry T + rs (8 x kTileRowWords)
-    const int RW = W / 4 + kT / 4, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t* q4 = reinterpret_cast<const uint32_t*>(J.quant);
     const uint32_t* m4 = reinterpret_cast<const uint32_t*>(J.mask);
     for (int r = wave; r < kRows; r += 4) {
@@ -736,6 +737,17 @@ static __device__ __forceinline__ void top_bits_tile_body(const int ry, const Lm
         s_sp[i] = v;
     }
     __syncthreads();
+}
+// response 1 of a label = a neighbouring label's bit without its own (LL.cpp:1121), on four packed spread bytes
+static __device__ __forceinline__ uint32_t only_neighbours(uint32_t v) {
+    return (((v << 1) & 0xFEFEFEFEu) | ((v >> 7) & 0x01010101u) | ((v >> 1) & 0x7F7F7F7Fu) | ((v << 7) & 0x80808080u)) & ~v;
+}
+
+template <int kT>
+static __device__ __forceinline__ void top_bits_tile_body(const int ry, const LmJob& J, int W, int H, int Wd, int Hd, uint32_t* __restrict__ s_tile) {
+    const int RW = W / 4 + kT / 4, tid = (int)threadIdx.x;
+    uint32_t* const s_sp = s_tile + (2 * kT - 1) * RW;
+    tile_spread<kT>(ry, J, W, H, RW, s_tile, s_sp);
     const int G = Wd >> 3, npos = Wd * Hd, units = kT * kT * G;
     const uint32_t run = (uint32_t)(kT * kT) * (uint32_t)npos, top_bit0 = (uint32_t)reinterpret_cast<uintptr_t>(J.strips);
     const uint8_t* sp = reinterpret_cast<const uint8_t*>(s_sp);
@@ -756,6 +768,115 @@ static __device__ __forceinline__ void top_bits_tile_body(const int ry, const Lm
             o[0] = (uint8_t)(t1 >> (8 * l));                   // the pair's "is 1" dword ...
             o[4] = (uint8_t)(t4 >> (8 * l));                   // ... and its "is 4" dword
         }
+    }
+}
+
+// The strip records of a level below the top from pixel tiles (T = 4 or 8, rows of a multiple of 16 pixels).  A workgroup takes a block of
+// R = 16 (or 8) rows of cells of one modality and one pixel-row phase rs; records are [label][phase][strip][row], so R rows of a
+// (label, phase, strip) are R x 8 contiguous bytes.
+//   A. a wave per row of cells, a lane per four dwords of the row: over the T pixel rows of the windows, the OR of T consecutive pixels starting
+//      at each pixel (one 16-byte load + the one or two dwords behind it, masked, zero beyond the image) -> s_sp[row][dword], byte b = the
+//      T x T OR of the window at pixel 4 dword + b.  Nothing is staged: every pixel row is read once per phase rs, from L1 / L2.
+//   B. per column phase cs: a unit = (16 neighbouring cells, row): per cell the byte "only a neighbouring label's bit" and the byte "own bit" —
+//      rows 2c and 2c + 1 of a 32 x 8 bit matrix whose transpose is, per label, exactly the dword {is 1, is 4} x 16 cells of half a record
+//      (four 8 x 8 transposes; the interleave is free).  The halves go to LDS as records (half h = low dword of record h, high dword of
+//      record h - 1) and leave as 8-byte stores, rows fastest: a wave writes four whole 128-byte lines.
+// (bits_rows_body: every (phase, cell) thread loads its own T x T pixels and every record gathers 32 cells with multiplies: 37.7 us per
+// 8-frame batch at VGA.  The same tile arithmetic with each unit storing its 16 dwords straight to HBM was as slow: 5.4 M scattered dword stores.)
+static __host__ __device__ inline int fe_rows_block_rows(int NS, int T) {       // rows of cells per workgroup: the spread rows + the records of one cs fit the pool
+    for (int R = 16; R >= 8; R >>= 1)
+        if (R * 4 * T * (NS + 1) + 8 * NS * R * 2 <= kTileWords) return R;
+    return 0;
+}
+template <int kT>
+static __device__ __forceinline__ void bits_rows_block_body(const int blk, const int rs, const LmJob& J, int W, int H, int Wd, int Hd, int NS, uint32_t* __restrict__ s_tile) {
+    const int RW = (NS + 1) * 4 * kT, R = fe_rows_block_rows(NS, kT);       // dwords per spread row: the pixels of 16 NS + 16 cells
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, ry0 = blk * R;
+    uint32_t* const s_sp = s_tile;                                         // R x RW
+    uint2* const s_rec = reinterpret_cast<uint2*>(s_tile + R * RW);        // [label][strip][row]
+    const uint32_t* q4 = reinterpret_cast<const uint32_t*>(J.quant);
+    const uint32_t* m4 = reinterpret_cast<const uint32_t*>(J.mask);
+    const int W4 = W >> 2;
+    auto keep = [](uint32_t m) -> uint32_t { return (((((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u) >> 7) * 0xFFu; };   // 0xFF per non-zero mask byte
+    auto px = [&](int y, int cw) -> uint32_t {                             // four pixels of row y, masked; zero beyond the image
+        uint32_t v = 0;
+        if (cw < W4) {
+            v = q4[(size_t)y * W4 + cw];
+            if (m4) v &= keep(m4[(size_t)y * W4 + cw]);
+        }
+        return v;
+    };
+    for (int rr = wave; rr < R; rr += 4) {
+        const int ry = ry0 + rr;
+        if (ry >= Hd) break;                                               // (wave-uniform)
+        for (int qd = lane; 4 * qd < RW; qd += 64) {
+            uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+            for (int k = 0; k < kT; ++k) {
+                const int y = ry * kT + rs + k;
+                if (y >= H) continue;
+                uint32_t d[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                if (4 * qd < W4) {                                         // (rows are multiples of 16 pixels: a quad is inside or outside)
+                    const uint4 v = *reinterpret_cast<const uint4*>(q4 + (size_t)y * W4 + 4 * qd);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    if (m4) {
+                        const uint4 m = *reinterpret_cast<const uint4*>(m4 + (size_t)y * W4 + 4 * qd);
+                        d[0] &= keep(m.x); d[1] &= keep(m.y); d[2] &= keep(m.z); d[3] &= keep(m.w);
+                    }
+                }
+                d[4] = px(y, 4 * qd + 4);
+                if (kT == 8) d[5] = px(y, 4 * qd + 5);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] |= d[q] | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+                    if (kT == 8) acc[q] |= d[q + 1] | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 1) | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 2) | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 3);
+                }
+            }
+            *reinterpret_cast<uint4*>(s_sp + rr * RW + 4 * qd) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    const uint8_t* sp = reinterpret_cast<const uint8_t*>(s_sp);
+    const size_t splane1 = (size_t)NS * Hd * 8;                            // one (label, phase) plane of records
+    const int rows = Hd - ry0 < R ? Hd - ry0 : R;
+    for (int cs = 0; cs < kT; ++cs) {
+        for (int u = tid; u < (NS + 1) * R; u += 256) {
+            const int h = u / R, rr = u - h * R;                           // rows fastest
+            if (rr >= rows) continue;
+            const uint8_t* cell = sp + rr * (RW * 4) + (16 * h) * kT + cs; // the spread byte of cell 16 h + c sits kT bytes further per cell
+            unsigned long long t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = (uint32_t)cell[(4 * k) * kT] | ((uint32_t)cell[(4 * k + 1) * kT] << 8) | ((uint32_t)cell[(4 * k + 2) * kT] << 16) | ((uint32_t)cell[(4 * k + 3) * kT] << 24);
+                const uint32_t o = only_neighbours(v);
+                // rows of the bit matrix: o0 v0 o1 v1 | o2 v2 o3 v3
+                const uint32_t lo = __builtin_amdgcn_perm(v, o, 0x05010400u), hi = __builtin_amdgcn_perm(v, o, 0x07030602u);
+                t[k] = transpose8x8(((unsigned long long)hi << 32) | lo);  // byte l = label l: bits 2c, 2c + 1 of cells 4 k .. 4 k + 3
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                         // label l: bytes l of t[0..3]
+                const uint32_t a0 = (uint32_t)(t[0] >> (32 * half)), a1 = (uint32_t)(t[1] >> (32 * half)), a2 = (uint32_t)(t[2] >> (32 * half)), a3 = (uint32_t)(t[3] >> (32 * half));
+                const uint32_t p0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), p1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                const uint32_t q0 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), q1 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                const uint32_t w[4] = {__builtin_amdgcn_perm(q0, p0, 0x05040100u), __builtin_amdgcn_perm(q0, p0, 0x07060302u),
+                                       __builtin_amdgcn_perm(q1, p1, 0x05040100u), __builtin_amdgcn_perm(q1, p1, 0x07060302u)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l = 4 * half + q;
+                    if (h < NS) s_rec[(l * NS + h) * R + rr].x = w[q];
+                    if (h > 0) s_rec[(l * NS + h - 1) * R + rr].y = w[q];
+                }
+            }
+        }
+        __syncthreads();
+        const int phase = rs * kT + cs;
+        for (int i = tid; i < 8 * NS * R; i += 256) {
+            const int ls = i / R, rr = i - ls * R;                         // ls = label * NS + strip
+            if (rr >= rows) continue;
+            const int l = ls / NS, st = ls - l * NS;
+            *reinterpret_cast<uint2*>(J.lm + ((size_t)l * kT * kT + phase) * splane1 + ((size_t)st * Hd + ry0 + rr) * 8) = s_rec[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -797,7 +918,7 @@ k_fe_stage(FeStage st, int total) {
 // against 79).  Same job table, same persistent walk.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_fe_bits(FeStage st, int total) {
-    __shared__ uint32_t s_tile[kTileWords];                // one pool for the bodies (a block runs one of them): the cell words of bits_rows_body, the pixel tile of top_bits_tile_body
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[kTileWords];                // one pool for the bodies (a block runs one of them): the cell words of bits_rows_body, the pixel tile of top_bits_tile_body
     for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
         int j = 0;
         while (j + 1 < st.njobs && blk >= st.job[j + 1].first) ++j;
@@ -808,6 +929,7 @@ k_fe_bits(FeStage st, int total) {
         if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t, reinterpret_cast<uint16_t*>(s_tile));
         else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
         else if (J.kind == kFeTopBitsAligned) top_bits_aligned_body(bx, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t, J.m_np);
+        else if (J.kind == kFeBitsRowsTile) { if (J.a == 8) bits_rows_block_body<8>(bx, by, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); else bits_rows_block_body<4>(bx, by, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); }
         else if (J.kind == kFeTopBitsTile) { if (J.a == 8) top_bits_tile_body<8>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); else top_bits_tile_body<4>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); }
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
@@ -837,11 +959,15 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
 }
 // strip records of a level below the top, written directly (bits[m]: the level's record block of modality m inside the bit arena)
 bool fe_bits_rows_possible(int W, int T) { return fe_bits_rows(W / T) >= 1; }
-void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T) {
+void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T, bool tiles) {
     j = FeJob{}; j.kind = kFeBitsRows; j.a = T; j.W = W; j.H = H;
     j.Wd = W / T; j.Hd = H / T; j.m_wd = div_magic((uint32_t)j.Wd); j.m_t = div_magic((uint32_t)T);
     const int R = fe_bits_rows(j.Wd);
     j.gx = (j.Hd + R - 1) / R; j.gy = T * T; j.gz = 2;
+    if (tiles && fe_rows_tile_fits(W, T)) {                // a workgroup per block of rows of cells and pixel-row phase
+        const int Rb = fe_rows_block_rows((j.Wd + 15) / 16, T);
+        j.kind = kFeBitsRowsTile; j.gx = (j.Hd + Rb - 1) / Rb; j.gy = T;
+    }
     j.lm[0] = LmJob{quant[0], mask[0], bits[0], nullptr}; j.lm[1] = LmJob{quant[1], mask[1], bits[1], nullptr};
 }
 // pair stream of the top level, written directly; bit0[m] = flat arena offset of modality m's block less the stream's first byte
@@ -892,7 +1018,7 @@ void launch_fe_bits(FeStage& st, hipStream_t s) {
     if (knobs().fe_bits_split) {                          // LM_FE_BITS_SPLIT=1 (measurements): the strip-record jobs and the pair-stream jobs as two launches
         for (int kind : {kFeBitsRows, kFeTopBits}) {
             FeStage part{};
-            for (int i = 0; i < st.njobs; ++i) if ((st.job[i].kind == kFeBitsRows) == (kind == kFeBitsRows)) part.job[part.njobs++] = st.job[i];
+            for (int i = 0; i < st.njobs; ++i) if ((st.job[i].kind == kFeBitsRows || st.job[i].kind == kFeBitsRowsTile) == (kind == kFeBitsRows)) part.job[part.njobs++] = st.job[i];
             const int total = fe_prepare(part);
             if (total > 0) hipLaunchKernelGGL(k_fe_bits, dim3(std::min(total, fe_cus() * 8)), dim3(256), 0, s, part, total);
         }

@@ -23,7 +23,7 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
 struct LmJob { const uint8_t* quant; const uint8_t* mask; uint8_t* lm; uint8_t* strips; };
 // (the bit-plane jobs reuse the two output slots — 24 jobs of a batch of 8 frames must fit the 4 KB of kernel arguments —: `lm` = the strip
 // records of the level / the top level's pair stream, `strips` = for the pair stream the flat position of the modality's block in it, as an integer)
-enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits, kFeTopBitsAligned, kFeTopBitsTile };
+enum { kFeNone = 0, kFeColour, kFeNormals, kFePyrDown, kFeNnDown, kFeBuildLm, kFeBitsRows, kFeTopBits, kFeTopBitsAligned, kFeTopBitsTile, kFeBitsRowsTile };
 struct FeJob {
     int kind, gx, gy, gz, first;          // job kind, its block grid, its first flat block index (set by launch_fe_stage)
     const void* in; void* out0; void* out1;
@@ -47,7 +47,7 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
                      int W, int H, int T);
 // the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip)
 bool fe_bits_rows_possible(int W, int T);     // the level's rows fit the stage's LDS
-void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T);
+void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T, bool tiles);   // tiles: from pixel tiles where the geometry allows (T = 4 or 8, the row fits the LDS pool)
 // (the writer of whole dwords when the label planes start on 64-position boundaries — fe_top_bits_kind —, else, or when forced, the one that ORs
 // shifted ballots into a stream that must be zero beforehand)
 // mode: 0 = the cheapest writer the geometry allows (pixel tiles -> whole dwords per wave -> OR-ed ballots), 1 = the OR-ing writer, 2 = no tiles (tests)
