@@ -789,7 +789,8 @@ static __host__ __device__ inline int fe_rows_block_rows(int NS, int T) {       
     return 0;
 }
 template <int kT>
-static __device__ __forceinline__ void bits_rows_block_body(const int blk, const int rs, const LmJob& J, int W, int H, int Wd, int Hd, int NS, uint32_t* __restrict__ s_tile) {
+static __device__ __forceinline__ void bits_rows_block_body(const int blk, const int part, const int csn, const LmJob& J, int W, int H, int Wd, int Hd, int NS, uint32_t* __restrict__ s_tile) {
+    const int rs = part / (kT / csn), cs0 = (part - rs * (kT / csn)) * csn;        // a workgroup takes csn of the kT column phases of its row phase
     const int RW = (NS + 1) * 4 * kT, R = fe_rows_block_rows(NS, kT);       // dwords per spread row: the pixels of 16 NS + 16 cells
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, ry0 = blk * R;
     uint32_t* const s_sp = s_tile;                                         // R x RW
@@ -839,7 +840,7 @@ static __device__ __forceinline__ void bits_rows_block_body(const int blk, const
     const uint8_t* sp = reinterpret_cast<const uint8_t*>(s_sp);
     const size_t splane1 = (size_t)NS * Hd * 8;                            // one (label, phase) plane of records
     const int rows = Hd - ry0 < R ? Hd - ry0 : R;
-    for (int cs = 0; cs < kT; ++cs) {
+    for (int cs = cs0; cs < cs0 + csn; ++cs) {
         for (int u = tid; u < (NS + 1) * R; u += 256) {
             const int h = u / R, rr = u - h * R;                           // rows fastest
             if (rr >= rows) continue;
@@ -929,7 +930,7 @@ k_fe_bits(FeStage st, int total) {
         if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t, reinterpret_cast<uint16_t*>(s_tile));
         else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
         else if (J.kind == kFeTopBitsAligned) top_bits_aligned_body(bx, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t, J.m_np);
-        else if (J.kind == kFeBitsRowsTile) { if (J.a == 8) bits_rows_block_body<8>(bx, by, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); else bits_rows_block_body<4>(bx, by, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); }
+        else if (J.kind == kFeBitsRowsTile) { if (J.a == 8) bits_rows_block_body<8>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); else bits_rows_block_body<4>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); }
         else if (J.kind == kFeTopBitsTile) { if (J.a == 8) top_bits_tile_body<8>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); else top_bits_tile_body<4>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); }
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
@@ -966,7 +967,9 @@ void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* co
     j.gx = (j.Hd + R - 1) / R; j.gy = T * T; j.gz = 2;
     if (tiles && fe_rows_tile_fits(W, T)) {                // a workgroup per block of rows of cells and pixel-row phase
         const int Rb = fe_rows_block_rows((j.Wd + 15) / 16, T);
-        j.kind = kFeBitsRowsTile; j.gx = (j.Hd + Rb - 1) / Rb; j.gy = T;
+        const int k = knobs().fe_rows_cs;
+        j.b = (k == 1 || k == 2 || k == 4 || k == 8) && k <= T ? k : 2;      // column phases per workgroup (LM_FE_ROWS_CS; VGA level 0, per 8-frame batch: all four 23.7 us, two 21.1, one 25.9)
+        j.kind = kFeBitsRowsTile; j.gx = (j.Hd + Rb - 1) / Rb; j.gy = T * (T / j.b);
     }
     j.lm[0] = LmJob{quant[0], mask[0], bits[0], nullptr}; j.lm[1] = LmJob{quant[1], mask[1], bits[1], nullptr};
 }

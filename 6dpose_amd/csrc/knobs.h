@@ -18,6 +18,7 @@ struct Knobs {
     int fe_bits_split = 0;         // LM_FE_BITS_SPLIT=1: k_fe_bits as two launches (strip records, pair stream) so that a profile times them apart
     int stage_events = 1;          // LM_STAGE_EVENTS=2: round 3's stage timing (records with a system-scope fence, start and end of every stage), for A/B
     int first_batch = 3;           // LM_FIRST_BATCH: frames an idle GPU waits for before a partial batch goes out WHILE THE CALLER SUBMITS IN A TIGHT LOOP (collect / flush launch what is left; sparse streams: every frame at once)
+    int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
     int fe_wgs_per_cu = 6;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
     int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default)
@@ -50,6 +51,7 @@ inline const Knobs& knobs() {
         v.serial = geti("LM_SERIAL", v.serial);
         v.stage_events = geti("LM_STAGE_EVENTS", 1);
         v.first_batch = geti("LM_FIRST_BATCH", v.first_batch);
+        v.fe_rows_cs = geti("LM_FE_ROWS_CS", 0);
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
         v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
