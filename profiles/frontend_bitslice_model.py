@@ -1,4 +1,5 @@
-"""numpy model of the two bit-sliced window counts of the front end (csrc/frontend.hip, round 4): the 3x3 majority vote of
+"""numpy model of the bit-level tricks of the front end: the 8 x 8 bit-matrix transposes that turn per-cell response bytes into strip records
+(bits_rows_block_body), and the two bit-sliced window counts (csrc/frontend.hip, round 4): the 3x3 majority vote of
 hysteresisGradient (LL.cpp:457-504) and cv::medianBlur(5) of the quantised normals (LL.cpp:818).  A tap is a BYTE of predicates per pixel
 (the kernel packs four neighbouring pixels into a word: the operations are bitwise, so a byte array states the same algorithm), a tree of
 full adders counts the taps per predicate, a bit-sliced comparison picks the result.  `python profiles/frontend_bitslice_model.py` checks
@@ -60,6 +61,48 @@ def median5_bitsliced(raw):
     return ((B & (0 - B.astype(np.int64)).astype(np.uint32)) >> 1).astype(np.uint8)
 
 
+def transpose8x8(x):
+    """8 x 8 bit-matrix transpose of uint64 words (byte i bit j <-> byte j bit i): three shift-xor-mask steps (csrc/frontend.hip)."""
+    x = x.astype(np.uint64)
+    for sh, mask in ((7, 0x00AA00AA00AA00AA), (14, 0x0000CCCC0000CCCC), (28, 0x00000000F0F0F0F0)):
+        t = (x ^ (x >> np.uint64(sh))) & np.uint64(mask)
+        x = x ^ t ^ (t << np.uint64(sh))
+    return x
+
+
+def only_neighbours(v):
+    v = v.astype(np.uint32)
+    return ((((v << 1) & 0xFE) | ((v >> 7) & 0x01) | ((v >> 1) & 0x7F) | ((v << 7) & 0x80)) & ~v & 0xFF).astype(np.uint8)
+
+
+def half_records_by_transpose(spread16):
+    """spread16: (..., 16) spread bytes of 16 neighbouring cells -> (..., 8) dwords, label l: bit 2c = response 1, bit 2c + 1 = response 4
+    of cell c (bits_rows_block_body: rows 2c, 2c + 1 of a 32 x 8 bit matrix = the bytes o_c, v_c; four 8 x 8 transposes)."""
+    v = spread16.astype(np.uint64)
+    o = only_neighbours(spread16).astype(np.uint64)
+    out = np.zeros(spread16.shape[:-1] + (8,), np.uint32)
+    for k in range(4):
+        block = np.zeros(spread16.shape[:-1], np.uint64)
+        for i in range(4):
+            block |= o[..., 4 * k + i] << np.uint64(16 * i)
+            block |= v[..., 4 * k + i] << np.uint64(16 * i + 8)
+        t = transpose8x8(block)
+        for l in range(8):
+            out[..., l] |= (((t >> np.uint64(8 * l)) & np.uint64(0xFF)) << np.uint64(8 * k)).astype(np.uint32)
+    return out
+
+
+def half_records_direct(spread16):
+    v = spread16.astype(np.uint32)
+    o = only_neighbours(spread16).astype(np.uint32)
+    out = np.zeros(spread16.shape[:-1] + (8,), np.uint32)
+    for l in range(8):
+        for c in range(16):
+            out[..., l] |= ((o[..., c] >> l) & 1) << (2 * c)
+            out[..., l] |= ((v[..., c] >> l) & 1) << (2 * c + 1)
+    return out
+
+
 def main():
     import linemod_oracle as lo
     from scipy.ndimage import median_filter
@@ -84,9 +127,17 @@ def main():
         lab = np.where(rng.random((H, W)) < 0.35, rng.integers(0, 9, (H, W)), lab)
         raw = np.where(lab > 0, 1 << np.maximum(lab - 1, 0), 0).astype(np.uint8)
         ok_m = ok_m and np.array_equal(median5_bitsliced(raw), median_filter(raw, size=5, mode="nearest"))
+    sp = rng.integers(0, 256, (500, 16)).astype(np.uint8)
+    sp[rng.random(sp.shape) < 0.5] = 0
+    ok_t = np.array_equal(half_records_by_transpose(sp), half_records_direct(sp))
+    x = rng.integers(0, 2 ** 63, 64).astype(np.uint64)
+    bits = ((x[:, None, None] >> (np.arange(8, dtype=np.uint64)[None, :, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, None, :])) & np.uint64(1))
+    back = (bits.transpose(0, 2, 1).astype(np.uint64) << (np.arange(8, dtype=np.uint64)[None, :, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, None, :])).sum(axis=(1, 2)).astype(np.uint64)
+    ok_t = ok_t and np.array_equal(transpose8x8(x), back)
+    print("half records by 8x8 bit transposes == direct packing:", ok_t)
     print("bit-sliced vote == oracle hysteresis_gradient:", ok_v)
     print("bit-sliced median == median filter:", ok_m)
-    return 0 if ok_v and ok_m else 1
+    return 0 if ok_v and ok_m and ok_t else 1
 
 
 if __name__ == "__main__":

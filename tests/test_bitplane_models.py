@@ -31,3 +31,4 @@ def test_frontend_bitsliced_vote_and_median_equal_the_oracle():
     assert out.returncode == 0, out.stdout + out.stderr[-2000:]
     assert "bit-sliced vote == oracle hysteresis_gradient: True" in out.stdout
     assert "bit-sliced median == median filter: True" in out.stdout
+    assert "half records by 8x8 bit transposes == direct packing: True" in out.stdout
