@@ -13,6 +13,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "detector_internal.h"
 #include <sched.h>
@@ -1399,6 +1400,21 @@ static int bits_grid(lm_detector* d, int nb) {
 // own result slot.  7 launches per frame (round 2's per-slot graph) -> 3 per batch.
 // direct_low / direct_top: nothing will read the byte planes of the levels below the top / of the top level — the bit planes are written
 // straight from the quantised maps by one k_fe_bits launch at the end (frontend.hip) and the byte planes not at all.
+#ifdef LM_DIAG
+struct LaunchClock {                                          // LM_LAUNCH_PROF: host time of individual HIP calls of a batch launch
+    const char* name; double t0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit LaunchClock(const char* n) : name(n), t0(now()) {}
+    ~LaunchClock() {
+        static std::map<std::string, std::pair<double, long>> acc;
+        auto& a = acc[name]; a.first += now() - t0; ++a.second;
+        if (getenv("LM_LAUNCH_PROF") && a.second % 64 == 0) fprintf(stderr, "  call %-22s %.1f us (n=%ld)\n", name, 1e6 * a.first / a.second, a.second);
+    }
+};
+#define LM_CLOCK(n) LaunchClock lm_clock_##__LINE__(n)
+#else
+#define LM_CLOCK(n)
+#endif
 static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, bool direct_low, bool direct_top) {
     const int L = d->pyramid_levels;
     const float thr_sq = d->weak_threshold * d->weak_threshold;
@@ -1416,7 +1432,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
         if ((rc = d->nrm_raw_x[b - 1].ensure((size_t)d->fW * d->fH))) return rc;
     }
     FeStage st{};
-    auto flush = [&]() { if (st.njobs) launch_fe_stage(st, s); st.njobs = 0; };
+    auto flush = [&]() { if (st.njobs) { LM_CLOCK("launch_fe_stage"); launch_fe_stage(st, s); } st.njobs = 0; };
     auto room = [&](int jobs) { if (st.njobs + jobs > kFeMaxJobs) flush(); };
     auto build_lm_jobs = [&](int l) {                        // linear memories of level l of every frame (its quantised maps are complete)
         if (l < L - 1 ? direct_low : direct_top) return;    // bit planes only: fe_bits_jobs below
@@ -1457,7 +1473,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
     flush();
     if (direct_low || direct_top) {                      // the bit planes of every frame in one launch
         st.njobs = 0;
-        auto flush_bits = [&]() { if (st.njobs) launch_fe_bits(st, s); st.njobs = 0; };
+        auto flush_bits = [&]() { if (st.njobs) { LM_CLOCK("launch_fe_bits"); launch_fe_bits(st, s); } st.njobs = 0; };
         for (int b = 0; b < nb; ++b) {
             const int arena = (first + b) % lm_detector::kSlots;
             const lm_detector::Slot& sl = d->slot[arena];
@@ -1637,6 +1653,9 @@ static bool partial_batch_due(lm_detector* d, double at) {
 int lm_launch_pending(lm_detector* d) {
     const int nb = d->pend_n, first = d->pend_first;
     if (nb <= 0) return LM_OK;
+#ifdef LM_DIAG
+    const auto tp_launch0 = std::chrono::steady_clock::now();
+#endif
     HIP_TRY(hipSetDevice(d->device));
     d->pend_n = 0;
     lm_detector::Slot& lead = d->slot[first];
@@ -1684,7 +1703,15 @@ int lm_launch_pending(lm_detector* d) {
             if (!d->cbits_clean[si]) HIP_TRY(hipMemsetAsync(d->cbits_arena[si].p, 0, (size_t)d->cbits_npairs * 8, s));
             d->cbits_clean[si] = true;
         }
+#ifdef LM_DIAG
+    static double lp_t[6]; static long lp_n;
+    auto lp_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double lp0 = host_seconds(tp_launch0), lp1 = lp_now();
+#endif
     if ((rc = run_frontend_batch(d, first, nb, s, direct_low, direct_top))) return rc;
+#ifdef LM_DIAG
+    const double lp2 = lp_now();
+#endif
     BitsBatch bb{};
     FrameBatch fb_rest = fb;                                  // for k_local's per-candidate path on what k_local_bits leaves (todo = 1)
     if (bits) {
@@ -1728,8 +1755,10 @@ int lm_launch_pending(lm_detector* d) {
     auto enqueue_coarse = [&](hipStream_t st) -> int {
         if (!one_queue) HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
+        { LM_CLOCK("launch_coarse");
         if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, st);
         else launch_coarse(fb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, tile_cap, st);
+        }
         HIP_TRY(hipEventRecord(lead.ev[3], st));
         return LM_OK;
     };
@@ -1739,8 +1768,9 @@ int lm_launch_pending(lm_detector* d) {
         // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
         // the hash tables k_dedupe uses
         if (bits) {
+            { LM_CLOCK("launch_local_bits");
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
-                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms);
+                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms); }
             if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
                 launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
@@ -1753,8 +1783,10 @@ int lm_launch_pending(lm_detector* d) {
     };
     // exact duplicates out (they never survive std::unique): distinct records + counts to the slots' pinned memory
     auto enqueue_dedupe = [&](hipStream_t st) -> int {
-        if (num_work > 0)
+        if (num_work > 0) {
+            LM_CLOCK("launch_dedupe");
             launch_dedupe(fb, d->buf_cand_cap, dedupe_table_slots(d->buf_cand_cap), d->d_work_cls.p, d->d_work_tid.p, d->num_cus * 2, st);
+        }
         else
             for (int b = 0; b < nb; ++b) HIP_TRY(hipMemsetAsync(fb.f[b].final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
         return LM_OK;
@@ -1776,10 +1808,27 @@ int lm_launch_pending(lm_detector* d) {
         HIP_TRY(hipEventRecord(lead.done, d->xchg.stream));
     } else {
         if (!one_queue) HIP_TRY(hipStreamWaitEvent(ms, lead.fe_done, 0));
+#ifdef LM_DIAG
+        const double lp3 = lp_now();
+#endif
         if ((rc = enqueue_coarse(ms))) return rc;
+#ifdef LM_DIAG
+        const double lp4 = lp_now();
+#endif
         if ((rc = enqueue_match())) return rc;
+#ifdef LM_DIAG
+        const double lp5 = lp_now();
+#endif
         if ((rc = enqueue_dedupe(ms))) return rc;
-        HIP_TRY(hipEventRecord(lead.done, ms));
+        { LM_CLOCK("record done"); HIP_TRY(hipEventRecord(lead.done, ms)); }
+#ifdef LM_DIAG
+        const double lp6 = lp_now();
+        if (getenv("LM_LAUNCH_SERIES") && lp_n < 80) fprintf(stderr, "batch %ld nb %d: %.0f us (fe %.0f coarse %.0f refine %.0f dedupe %.0f)\n", lp_n, nb, 1e6 * (lp6 - lp0), 1e6 * (lp2 - lp1), 1e6 * (lp4 - lp3), 1e6 * (lp5 - lp4), 1e6 * (lp6 - lp5));
+        lp_t[0] += lp1 - lp0; lp_t[1] += lp2 - lp1; lp_t[2] += lp3 - lp2; lp_t[3] += lp4 - lp3; lp_t[4] += lp5 - lp4; lp_t[5] += lp6 - lp5; ++lp_n;
+        if (getenv("LM_LAUNCH_PROF") && lp_n % 32 == 0)
+            fprintf(stderr, "launch profile over %ld batches (us): waits+ev0 %.1f | front end %.1f | bits tables+ev1 %.1f | coarse %.1f | refine %.1f | dedupe+done %.1f\n", lp_n,
+                    1e6 * lp_t[0] / lp_n, 1e6 * lp_t[1] / lp_n, 1e6 * lp_t[2] / lp_n, 1e6 * lp_t[3] / lp_n, 1e6 * lp_t[4] / lp_n, 1e6 * lp_t[5] / lp_n);
+#endif
     }
     const auto now = std::chrono::steady_clock::now();
     for (int b = 0; b < nb; ++b) {
