@@ -1935,6 +1935,31 @@ static void pool_stop(lm_detector* d) {
     P.started = false;
 }
 
+// memcpy into a pinned staging buffer with non-temporal stores: the buffer is read next by the copy engine, not by a core, and a slice
+// (a few hundred KB) is below the size from which glibc's memcpy streams on its own — ordinary stores first READ every destination line
+// (read for ownership).  Falls back to memcpy for small or unaligned pieces and on hosts without AVX2.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64)), e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a); _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), c); _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), e);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+static void copy_staging(uint8_t* dst, const uint8_t* src, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && knobs().nt_copy;
+    if (avx2 && n >= 16384 && (reinterpret_cast<uintptr_t>(dst) & 31) == 0) copy_stream_avx2(dst, src, n);
+    else memcpy(dst, src, n);
+}
+#else
+static void copy_staging(uint8_t* dst, const uint8_t* src, size_t n) { memcpy(dst, src, n); }
+#endif
+
 // dst <- a, dst_b <- b (the two images of a frame), cut into slices for the caller's thread and the helpers
 static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t na, uint8_t* dst_b, const uint8_t* b, size_t nb) {
     const bool same_a = a == dst, same_b = b == dst_b;              // zero-copy: the caller filled lm_detector_ingest_buffer's pointers
@@ -1946,8 +1971,8 @@ static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t n
     const int parts = d->pool.threads + 1;
     const size_t total = na + nb, per = ((total + (size_t)parts - 1) / (size_t)parts + 4095) & ~(size_t)4095;
     auto copy_range = [=](size_t lo, size_t hi) {                   // bytes [lo, hi) of the two images taken as one run
-        if (lo < na) memcpy(dst + lo, a + lo, std::min(hi, na) - lo);
-        if (hi > na) { const size_t l2 = std::max(lo, na); memcpy(dst_b + (l2 - na), b + (l2 - na), hi - l2); }
+        if (lo < na) copy_staging(dst + lo, a + lo, std::min(hi, na) - lo);
+        if (hi > na) { const size_t l2 = std::max(lo, na); copy_staging(dst_b + (l2 - na), b + (l2 - na), hi - l2); }
     };
     std::atomic<int> left{0};
     int posted = 0;

@@ -19,6 +19,7 @@ struct Knobs {
     int stage_events = 1;          // LM_STAGE_EVENTS=2: round 3's stage timing (records with a system-scope fence, start and end of every stage), for A/B
     int first_batch = 3;           // LM_FIRST_BATCH: frames an idle GPU waits for before a partial batch goes out WHILE THE CALLER SUBMITS IN A TIGHT LOOP (collect / flush launch what is left; sparse streams: every frame at once)
     int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
+    int nt_copy = 1;               // LM_NT_COPY=0: the staging copy of a streamed frame with memcpy instead of non-temporal AVX2 stores
     int fe_wgs_per_cu = 6;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
     int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default)
@@ -51,6 +52,7 @@ inline const Knobs& knobs() {
         v.serial = geti("LM_SERIAL", v.serial);
         v.stage_events = geti("LM_STAGE_EVENTS", 1);
         v.first_batch = geti("LM_FIRST_BATCH", v.first_batch);
+        v.nt_copy = geti("LM_NT_COPY", 1);
         v.fe_rows_cs = geti("LM_FE_ROWS_CS", 0);
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
