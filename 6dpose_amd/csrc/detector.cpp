@@ -1782,10 +1782,15 @@ int lm_launch_pending(lm_detector* d) {
         return LM_OK;
     };
     // exact duplicates out (they never survive std::unique): distinct records + counts to the slots' pinned memory
+    // k_dedupe's grid per frame: a workgroup per 256 candidates of the LAST collected frame (the kernel strides over whatever the count turns out to
+    // be), between 64 and two per CU.  Every workgroup takes a ticket at the frame's counter and most of a 2-per-CU grid had nothing else to do:
+    // 31 -> 19.5 us per 8-frame batch at 16k candidates per frame (profiles/r04_stream_ab.txt).
+    const int dedupe_blocks = knobs().dedupe_blocks > 0 ? knobs().dedupe_blocks
+                                                        : std::max(64, std::min(d->num_cus * 2, (int)((d->ncand_hint + 255) / 256)));
     auto enqueue_dedupe = [&](hipStream_t st) -> int {
         if (num_work > 0) {
             LM_CLOCK("launch_dedupe");
-            launch_dedupe(fb, d->buf_cand_cap, dedupe_table_slots(d->buf_cand_cap), d->d_work_cls.p, d->d_work_tid.p, d->num_cus * 2, st);
+            launch_dedupe(fb, d->buf_cand_cap, dedupe_table_slots(d->buf_cand_cap), d->d_work_cls.p, d->d_work_tid.p, dedupe_blocks, st);
         }
         else
             for (int b = 0; b < nb; ++b) HIP_TRY(hipMemsetAsync(fb.f[b].final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
@@ -2118,6 +2123,7 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     else if (sort_unique == 0) { for (uint64_t i = 0; i < ncand; ++i) nm += hm[i].work >= 0; }
     else nm = hc[2];                                   // counted on the device by k_dedupe: no pass over the raw records
     tm.coarse_candidates = (int64_t)ncand;
+    d->ncand_hint = (uint64_t)ncand;
     tm.local_evals = (int64_t)evals;
     tm.local_bytes = (int64_t)lbytes;
     tm.matches_pre_unique = (int64_t)nm;

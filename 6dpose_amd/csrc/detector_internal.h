@@ -233,6 +233,7 @@ struct lm_detector {
     // host-side wall time of the streamed path, accumulated (lm_detector_host_profile): [0] frames, [1] staging copy, [2] H2D enqueue,
     // [3] slot bookkeeping, [4] batch launches, [5] collect: waiting for the GPU, [6] record conversion, [7] canonical sort + unique
     double host_prof[8] = {};
+    uint64_t ncand_hint = 0;                        // coarse candidates of the last collected frame: sizes k_dedupe's grid
     bool early_batch_used = false;                  // the burst's one early (partial) batch of a tight stream has gone out (partial_batch_due)
     bool async_collect = true;                      // lm_detector_set_async_collect / LM_ASYNC_COLLECT=0: the lists of a batch's later frames are prepared by the helper threads
 

@@ -10,7 +10,7 @@ namespace lm {
 struct Knobs {
     int coarse_group = 4;          // LM_COARSE_GROUP: templates per workgroup of k_coarse (<= 4)
     int local_blocks = 0;          // LM_LOCAL_BLOCKS: grid of k_local (0 = default per CU count)
-    int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default)
+    int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int serial = 2;                // LM_SERIAL: 2 = every kernel of a batch on ONE stream (default), 1 = the front end on its own stream beside the matching of the batch before, 0 = a stream per stage
     int coarse_bits = 1;           // LM_COARSE_BITS=0: coarse pass on the byte linear memories (k_coarse) instead of on the pair stream (k_coarse_bits)
     int bitplanes = 1;             // LM_BITPLANES=0: refinement on the byte strip planes with tiles (round 2-3's kernel) instead of on bit planes
@@ -20,10 +20,11 @@ struct Knobs {
     int first_batch = 3;           // LM_FIRST_BATCH: frames an idle GPU waits for before a partial batch goes out WHILE THE CALLER SUBMITS IN A TIGHT LOOP (collect / flush launch what is left; sparse streams: every frame at once)
     int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
     int nt_copy = 1;               // LM_NT_COPY=0: the staging copy of a streamed frame with memcpy instead of non-temporal AVX2 stores
+    int dedupe_blocks = 0;         // LM_DEDUPE_BLOCKS: workgroups per frame of k_dedupe (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int fe_wgs_per_cu = 6;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
-    int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default)
-    int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default)
+    int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
+    int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
     int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
     int icp_maxshift_late = 4;
@@ -52,6 +53,7 @@ inline const Knobs& knobs() {
         v.serial = geti("LM_SERIAL", v.serial);
         v.stage_events = geti("LM_STAGE_EVENTS", 1);
         v.first_batch = geti("LM_FIRST_BATCH", v.first_batch);
+        v.dedupe_blocks = geti("LM_DEDUPE_BLOCKS", 0);
         v.nt_copy = geti("LM_NT_COPY", 1);
         v.fe_rows_cs = geti("LM_FE_ROWS_CS", 0);
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
