@@ -890,7 +890,7 @@ static __device__ __forceinline__ void bits_rows_block_body(const int blk, const
 // ~30 ns — with one workgroup per tile (10.8k for the first stage of four VGA frames) a CU held 1.3 workgroups on average and the
 // stage took as long as the dispatcher needed (42 us; profiles/r03_pmc.txt: 5 waves per CU).  A few workgroups per CU walk the
 // tiles instead (flat index + k * grid).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))   // 6 persistent workgroups per CU (knobs: fe_wgs_per_cu) = 6 waves per SIMD: at most 80 VGPRs
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kFeWaves, kFeWaves)))   // kFeWaves persistent workgroups per CU (knobs: fe_wgs_per_cu) = as many waves per SIMD
 k_fe_stage(FeStage st, int total) {
     for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
         int j = 0;

@@ -5,6 +5,11 @@
 #pragma once
 #include <stdlib.h>
 
+#ifndef LM_FE_WAVES
+#define LM_FE_WAVES 7
+#endif
+constexpr int kFeWaves = LM_FE_WAVES;   // waves per SIMD = persistent workgroups per CU of k_fe_stage: 7 = 72 VGPRs, no spills (6: 78 VGPRs; 8: 64 VGPRs with 7 spilled).  k_fe_stage per launch, mean of the two of an 8-frame batch: 50.8 / 48.6 / 47.0 us at 6 / 7 / 8 (profiles/r04_stream_ab.txt)
+
 namespace lm {
 
 struct Knobs {
@@ -21,7 +26,7 @@ struct Knobs {
     int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
     int nt_copy = 1;               // LM_NT_COPY=0: the staging copy of a streamed frame with memcpy instead of non-temporal AVX2 stores
     int dedupe_blocks = 0;         // LM_DEDUPE_BLOCKS: workgroups per frame of k_dedupe (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
-    int fe_wgs_per_cu = 6;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
+    int fe_wgs_per_cu = kFeWaves;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
     int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
@@ -45,7 +50,7 @@ inline const Knobs& knobs() {
         v.frame_batch = geti("LM_FRAME_BATCH", 0);
         v.batch_queue = geti("LM_BATCH_QUEUE", 0);
         v.launch_slack_us = geti("LM_LAUNCH_SLACK_US", 0);
-        v.fe_wgs_per_cu = geti("LM_FE_WGS_PER_CU", 6);
+        v.fe_wgs_per_cu = geti("LM_FE_WGS_PER_CU", kFeWaves);
         v.bitplanes = geti("LM_BITPLANES", 1);
         v.coarse_bits = geti("LM_COARSE_BITS", 1);
         v.fe_bits = geti("LM_FE_BITS", 1);
