@@ -59,6 +59,7 @@ R={
  'R4_FE4': '%.3f' % (fe_total/2e3), 'R4_FE_TRAFFIC': ('%.0f MB per batch = %.1f x the algorithmic %.1f MB' % (st['frontend']['traffic_bytes_per_batch']/1e6, st['frontend']['traffic_over_algorithmic'], st['frontend']['algorithmic_bytes_per_frame']*nb/1e6)) if st.get('frontend') else '-',
  'R4_LOCAL4': '%.3f' % (rows['k_local_bits'][0]/2e3), 'R4_COARSE4': '%.3f' % (rows['k_coarse_bits'][0]/2e3),
  'R4_KSUM': '%.3f' % ((fe_total+rows['k_coarse_bits'][0]+rows['k_local_bits'][0]+rows['k_dedupe'][0])/nb/1e3),
+ 'R4_LOCALSHARE': '%.0f %%' % (100*rows['k_local_bits'][0]/(fe_total+rows['k_coarse_bits'][0]+rows['k_local_bits'][0]+rows['k_dedupe'][0])),
  'R4_KERNELS': kern, 'R4_STAGES': stages, 'R4_ROOFLINE': roof, 'R4_HOST': host,
 }
 for p in ('README.md','DESIGN.md'):
