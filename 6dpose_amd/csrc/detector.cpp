@@ -1389,9 +1389,13 @@ static int local_grid(lm_detector* d, int nb) {
 }
 
 // Grid of k_local_bits: a wave serves 8 candidates (~2k groups per frame at configs[1]); 4 workgroups per CU and frame of the batch.
+// Grid of k_local_bits: the workgroups the chip holds at once (4 waves per SIMD = 4 workgroups of 256 per CU), whatever the batch: the waves stride over
+// the items.  (Round 4 launched four times as many for batches of four and more frames; one wave per item and a dispatcher that has to place 4096
+// workgroups cost 3-4 %: 204-207 -> 197-199 us per 8-frame launch, profiles/r05_local_sharing/kernel_times_grid_sweep.txt.)
 static int bits_grid(lm_detector* d, int nb) {
+    (void)nb;
     if (knobs().local_blocks > 0) return knobs().local_blocks;
-    return d->num_cus * 4 * std::max(1, std::min(nb, 4));
+    return d->num_cus * 4;
 }
 
 // Front end of a batch: the same three stages a lone frame takes (k_fe_stage: {colour chain, normals + median or their

@@ -15,7 +15,7 @@ namespace lm {
 struct Knobs {
     int coarse_group = 4;          // LM_COARSE_GROUP: templates per workgroup of k_coarse (<= 4)
     int local_blocks = 0;          // LM_LOCAL_BLOCKS: grid of k_local (0 = default per CU count)
-    int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
+    int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default: 8 = kMaxBatch; lm_detector_set_batch)
     int serial = 2;                // LM_SERIAL: 2 = every kernel of a batch on ONE stream (default), 1 = the front end on its own stream beside the matching of the batch before, 0 = a stream per stage
     int coarse_bits = 1;           // LM_COARSE_BITS=0: coarse pass on the byte linear memories (k_coarse) instead of on the pair stream (k_coarse_bits)
     int bitplanes = 1;             // LM_BITPLANES=0: refinement on the byte strip planes with tiles (round 2-3's kernel) instead of on bit planes
@@ -28,12 +28,11 @@ struct Knobs {
     int dedupe_blocks = 0;         // LM_DEDUPE_BLOCKS: workgroups per frame of k_dedupe (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int fe_wgs_per_cu = kFeWaves;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
-    int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
-    int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
+    int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: 2; lm_detector_set_batch_queue)
+    int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: 64 workgroups per cloud up to 32 clouds, 32 beyond)
     int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
     int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
     int icp_maxshift_late = 4;
-    bool fe_fused_pipe = false;    // LM_FE_FUSED_PIPE=1: shared front-end launches also with frames in flight (measured slower)
 #ifdef LM_DIAG
     int coarse_dbg = 0;            // LM_COARSE_DBG: 1 = no tile grouping, 2 = no global atomic (wrong results)
     int local_dbg = 0;             // LM_LOCAL_DBG: 1 = tiles only, 2 = singles only (wrong results)
@@ -65,7 +64,6 @@ inline const Knobs& knobs() {
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
         v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
         v.icp_maxshift_late = geti("LM_ICP_MAXSHIFT_LATE", v.icp_maxshift_late);
-        v.fe_fused_pipe = geti("LM_FE_FUSED_PIPE", 0) == 1;
 #ifdef LM_DIAG
         v.coarse_dbg = geti("LM_COARSE_DBG", 0);
         v.local_dbg = geti("LM_LOCAL_DBG", 0);
