@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <system_error>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -1705,7 +1706,7 @@ int lm_launch_pending(lm_detector* d) {
         for (int b = 0; b < nb; ++b) {
             const int si = (first + b) % lm_detector::kSlots;
             if (!d->cbits_clean[si]) HIP_TRY(hipMemsetAsync(d->cbits_arena[si].p, 0, (size_t)d->cbits_npairs * 8, s));
-            d->cbits_clean[si] = true;
+            d->cbits_clean[si] = false;                  // dirty from the front end on, until k_local_bits (top_clear) is enqueued behind it: an error return in between must not leave it marked clean
         }
 #ifdef LM_DIAG
     static double lp_t[6]; static long lp_n;
@@ -1775,6 +1776,9 @@ int lm_launch_pending(lm_detector* d) {
             { LM_CLOCK("launch_local_bits");
             launch_local_bits(fb, bb, d->geom, d->d_entries.p, d->d_feat_word.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                               (uint32_t)dedupe_table_slots(d->buf_cand_cap), bits_grid(d, nb), d->bits_max_nf, ms); }
+            if (bb.top_clear_units)       // the pair streams this launch zeroes again are clean for their slots' next frames
+                for (int b = 0; b < nb; ++b)
+                    if (bb.top_clear[b]) d->cbits_clean[(first + b) % lm_detector::kSlots] = true;
             if (!d->bits_all_in)          // candidates whose windows leave their planes (marked in todo): k_local's per-candidate path
                 launch_local(fb_rest, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_feat_word.p, d->d_run_mask.p, d->d_feat_xy.p, d->d_work.p, d->buf_cand_cap, threshold, cap,
                              (uint32_t)dedupe_table_slots(d->buf_cand_cap), tile_cap, d->num_cus * 2, ms);
@@ -1915,14 +1919,39 @@ static void pool_main(lm_detector* d) {
         job();
     }
 }
+// Starts the helpers on first use.  Never more than the CPUs this process may run on leave free (a cgroup / affinity mask of a few cores, eight
+// ranks on one node), and a thread the system refuses (std::system_error: a container's thread limit) only shrinks the pool: the streamed path
+// works without helpers (the caller copies and sorts on its own).
 static bool pool_ready(lm_detector* d) {
     lm_detector::HostPool& P = d->pool;
     if (P.threads <= 0) return false;
     if (!P.started) {
+        int cpus = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        P.threads = std::max(0, std::min(P.threads, cpus - 1));        // one CPU stays with the calling thread
         P.stop = false;
-        for (int i = 0; i < P.threads; ++i) P.th.emplace_back(pool_main, d);
-        P.started = true;
+        int started = 0;
+        for (int i = 0; i < P.threads; ++i) {
+            try { P.th.emplace_back(pool_main, d); ++started; }
+            catch (const std::system_error&) { break; }
+        }
+        P.threads = started;
+        P.started = started > 0;
     }
+    return P.threads > 0;
+}
+// The calling thread takes a queued job itself (while it waits for the helpers: a helper that was descheduled must not hold the caller up)
+static bool pool_run_one(lm_detector* d) {
+    lm_detector::HostPool& P = d->pool;
+    if (P.posted.load(std::memory_order_acquire) <= 0) return false;
+    std::function<void()> job;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.jobs.empty()) return false;
+        job = std::move(P.jobs.front()); P.jobs.pop_front(); P.posted.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    job();
     return true;
 }
 static void pool_post(lm_detector* d, std::function<void()> job) {
@@ -1994,7 +2023,11 @@ static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t n
         pool_post(d, [=]() { copy_range(lo, hi); lp->fetch_sub(1, std::memory_order_release); });
     }
     copy_range(0, std::min(total, per));
-    while (left.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    // the slices nobody has taken yet are copied here; then a bounded spin for the ones in progress, then the CPU is given up between looks
+    for (int spin = 0; left.load(std::memory_order_acquire) != 0;) {
+        if (pool_run_one(d)) continue;
+        if (++spin < 4000) __builtin_ia32_pause(); else std::this_thread::yield();
+    }
     (void)posted;
 }
 
@@ -2027,8 +2060,9 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     size_t prepared_n = 0;
     bool have_prepared = false;
     if (sl.prep_queued) {                               // a helper thread owns the slot until it has marked it ready (a job of ~35 us, posted when the batch's first frame was collected)
-        for (int spin = 0; sl.ready.load(std::memory_order_acquire) == 0; ++spin) {
-            if (spin < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
+        for (int spin = 0; sl.ready.load(std::memory_order_acquire) == 0;) {    // (a job still queued — this slot's, possibly — is run here)
+            if (pool_run_one(d)) continue;
+            if (++spin < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
         }
         have_prepared = sl.ready.load(std::memory_order_acquire) == 1;
         prepared = sl.prep; prepared_n = sl.prep_n;

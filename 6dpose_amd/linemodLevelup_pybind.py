@@ -501,7 +501,8 @@ class Detector:
         _check(self._lib.lm_detector_set_batch_queue(self._h, int(batches)))
 
     def setAsyncCollect(self, on: bool) -> None:
-        """Streamed frames: prepare the result lists on a collector thread of the library instead of inside collect() (lm_detector_set_async_collect; off by default, LM_ASYNC_COLLECT=1 turns it on)."""
+        """Streamed frames: the result lists of a batch's later frames are prepared by the library's helper threads while the caller collects its first
+        (lm_detector_set_async_collect; on by default, LM_ASYNC_COLLECT=0 turns it off; LM_HOST_THREADS=0: no helper threads at all)."""
         _check(self._lib.lm_detector_set_async_collect(self._h, 1 if on else 0))
 
     def hostProfile(self, reset: bool = True) -> dict:

@@ -251,10 +251,12 @@ int lm_detector_flush(lm_detector *d);            /* launch the streamed frames 
 int lm_detector_set_batch(lm_detector *d, int frames);
 int lm_detector_get_batch(const lm_detector *d);
 int lm_detector_set_batch_queue(lm_detector *d, int batches);
-/* Streamed frames: a host thread of the library (one per detector) waits for each launched batch and prepares every frame's
- * Detector::match list (record conversion, canonical sort, unique) while the caller submits the next frames; lm_detector_collect
- * (sort_unique = 1) then only hands the list over.  Off by default (LM_ASYNC_COLLECT=1 / set_async_collect(d, 1) turn it on): it
- * pays when the calling thread is the bottleneck of the stream, and costs a little otherwise.  Results are identical either way. */
+/* Streamed frames come back in batches: when lm_detector_collect (sort_unique = 1) has seen the event of a batch, the records of ALL its
+ * frames are in pinned memory, and helper threads of the library (LM_HOST_THREADS, default 3, never more than the CPUs the process may use
+ * leave free, 0 = none; they make no HIP calls) prepare the Detector::match lists of the batch's later frames — record conversion, canonical
+ * sort, unique — while the caller takes the first; collecting those frames then only hands the list over.  The same threads copy slices of a
+ * submitted frame into the pinned staging buffer beside the caller.  On by default (LM_ASYNC_COLLECT=0 / set_async_collect(d, 0) turn the
+ * list preparation off); without helpers the caller does everything itself.  Results are identical either way. */
 int lm_detector_set_async_collect(lm_detector *d, int on);
 /* Host-side wall time (seconds, accumulated) the library spent on streamed frames: out8 = {frames, staging copy, H2D enqueue, slot
  * bookkeeping, batch launches, collect: waiting for the GPU, record conversion, canonical sort + unique}; reset != 0 clears it. */
