@@ -22,8 +22,12 @@ void upload_normal_lut(const uint8_t lut400[400]) {
 static __host__ __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 // n / d with m = div_magic(d) = ceil(2^32 / d): umulhi(n, m) is floor(n / d) or one more (the excess n e / (d 2^32), e = m d - 2^32 < d, stays
 // below 1 for every 32-bit n), so one comparison makes it exact for ANY n — an 8000 x 6000 frame puts n d past 2^32, where the bare product
-// was wrong for the last blocks of a job.
+// was wrong for the last blocks of a job.  The comparison itself cannot wrap: q d <= n + d, and every caller passes non-negative `int`
+// values (block / pixel / phase indices and image sizes), so n + d < 2^31 + 2^31 = 2^32 — asserted in the debug build below.
 static __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m, uint32_t d) {
+#ifdef LM_DIAG
+    if ((n | d) >> 31) __builtin_trap();                   // n, d < 2^31: q * d <= n + d < 2^32
+#endif
     if (!m) return n;
     const uint32_t q = __umulhi(n, m);
     return q - (q * d > n ? 1u : 0u);

@@ -626,7 +626,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(noisy_frames(N_FRAMES), banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         if world == 1 and not strong and not args.no_extras:
-            out["extras"]["strong_scaling_reference"] = strong_reference(det, quant, frames, args.templates, steps=max(20, args.steps), depth=PIPELINE_DEPTH)
+            sr = strong_reference(det, quant, frames, args.templates, steps=args.steps, depth=PIPELINE_DEPTH)
+            out["extras"]["strong_scaling_reference"] = sr
+            # One-GPU proxy of BASELINE's strong-scaling target (>= 6 x at 8 GPUs when sharding 16k templates): the 16k bank on this GPU against an
+            # eighth of it — the headline's workload — at EQUAL step counts and frames in flight.  It bounds the 8-GPU ratio from above: the exchange
+            # of the records and whatever eight host processes cost each other come on top.  Nothing here is a measured scaling curve.
+            out["extras"]["strong_scaling_proxy"] = {
+                "t_16k_one_gpu_ms": sr["ms_per_step"], "t_2k_share_ms": dt / K * 1e3, "steps": args.steps, "ratio": sr["ms_per_step"] / (dt / K * 1e3) if dt > 0 else None,
+                "target": 6.0, "note": "T(8 x 2000 templates on one GPU) / T(2000 templates on one GPU), same stream loop, same steps; an upper bound of the 8-GPU speed-up of configs[3], "
+                                       "not a measurement of it (no multi-GPU node has been available to any round)"}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out))
@@ -677,36 +685,61 @@ def parity_gate(det, frames, bank, classes, n_templates, n_frames=2):
     return out
 
 
-def stream_gate(det, host_frame, classes, bank, n_templates, depth, batch_queue, steps=(0, 1, 6, 11)):
+def stream_gate(det, host_frame, classes, bank, n_templates, depth, batch_queue, steps=(0, 1, 6, 11), region_steps=(0, 2, 3, 12, 18, 19), region_n=20):
     """The same comparison for the path the number is measured on: host frames through lm_detector_submit_frame, `depth` in flight, the
-    library's batching (several frames per kernel launch, frame -> XCD affinity) — the lists collect() returns for a few steps of one
-    stream against the oracle's lists for exactly those (stamped) frames.  Exits without a number on a mismatch."""
+    library's batching (several frames per kernel launch, frame -> XCD affinity) — the lists collect() returns for a few steps of a stream
+    against the oracle's lists for exactly those (stamped) frames.  Two passes: full batches only (batch queue 0: every frame shares its
+    launches), and the timed region's OWN launch rule (`batch_queue` as timed, a burst of `region_n` submits behind a fence: an early partial
+    batch, full batches, a short last one — the 3 + 8 + 8 + 1 of the driver's 20 steps).  Exits without a number on a mismatch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import linemod_oracle as lo
+    import torch
     od = lo.OracleDetector(NFEAT[0], T_LEVELS)
     pb = lo.PackedBank(n_templates, 2, *bank)
-    n = max(steps) + 1
-    kept, got, infl = {}, [], 0
-    det.setBatchQueue(0)                                      # full batches only: the gate must see frames that SHARE their launches, whatever the pace estimate says this early
-    for k in range(n):
-        rgb, dep = host_frame(k)
-        if k in steps:
-            kept[k] = (rgb.copy(), dep.copy())                # the pool frame is stamped again by later steps
-        det.submitFrame((rgb, dep), THRESHOLD, classes)
-        infl += 1
-        if infl == depth:
+
+    def burst(n, first):
+        infl = 0
+        for k in range(n):
+            det.submitFrame(host_frame(first + k), THRESHOLD, classes)
+            infl += 1
+            if infl == depth:
+                det.collect(sort_unique=True); infl -= 1
+        while infl:
+            det.collect(sort_unique=True); infl -= 1
+
+    def one_pass(bq, want_steps, n, first):
+        kept, got, infl = {}, [], 0
+        det.setBatchQueue(bq)
+        burst(depth + 5, first + 1000)                        # warm-up steps in a tight loop (the oracle runs of the pass before were a long pause: the library's pace estimate), ...
+        torch.cuda.synchronize()                              # ... then the burst behind a fence, like the timed region
+        for k in range(n):
+            rgb, dep = host_frame(first + k)
+            if k in want_steps:
+                kept[k] = (rgb.copy(), dep.copy())            # the pool frame is stamped again by later steps
+            det.submitFrame((rgb, dep), THRESHOLD, classes)
+            infl += 1
+            if infl == depth:
+                got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
+        while infl:
             got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
-    while infl:
-        got.append((det.collect(sort_unique=True), det.lastTimings()["batch_frames"])); infl -= 1
+        res, ok_all = [], True
+        for k in want_steps:
+            want, _, st, _, _, _ = oracle_matches(od, lo, pb, kept[k][0], kept[k][1], THRESHOLD)
+            ok = same_records(got[k][0], want)
+            res.append({"step": k, "matches": int(len(want)), "gpu_matches": int(len(got[k][0])), "frames_in_its_launch": int(got[k][1]), "equal": bool(ok)})
+            ok_all = ok_all and ok
+        return res, ok_all, [int(g[1]) for g in got]
+
+    out = {"ok": True, "frames_in_flight": depth}
+    # full batches only: the gate must see frames that SHARE their launches, whatever the pace estimate says this early
+    out["steps"], ok_a, _ = one_pass(0, steps, max(steps) + 1, 0)
+    # ... and the launch shapes of the timed region itself
+    reg, ok_b, shapes = one_pass(batch_queue, region_steps, region_n, 100)
+    out["timed_region_rule"] = {"batch_queue": batch_queue, "submits": region_n, "steps": reg, "frames_in_the_launch_of_each_step": shapes}
     det.setBatchQueue(batch_queue)
-    out = {"ok": True, "steps": [], "frames_in_flight": depth}
-    for k in steps:
-        want, _, st, _, _, _ = oracle_matches(od, lo, pb, kept[k][0], kept[k][1], THRESHOLD)
-        ok = same_records(got[k][0], want)
-        out["steps"].append({"step": k, "matches": int(len(want)), "gpu_matches": int(len(got[k][0])), "frames_in_its_launch": int(got[k][1]), "equal": bool(ok)})
-        out["ok"] = out["ok"] and ok
+    out["ok"] = ok_a and ok_b
     if not out["ok"]:
-        sys.stderr.write("bench.py: PARITY GATE FAILED on the streamed path - collect() differs from the CPU oracle: %s\n" % json.dumps(out["steps"]))
+        sys.stderr.write("bench.py: PARITY GATE FAILED on the streamed path - collect() differs from the CPU oracle: %s\n" % json.dumps(out))
         sys.exit(3)
     return out
 
@@ -796,8 +829,16 @@ def ceilings_of(pm):
             "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) if (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) else None}
 
 
-def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=8, depth=8):
-    """Seconds per frame of the live-stream path (a host frame per step, `depth` in flight) + mean timings."""
+def stream_shape(det, tm):
+    """What an extras leg ran on, so that its number can be set beside the headline's: kernel paths, frames per launch, device time per frame."""
+    nb = max(1.0, float(tm.get("batch_frames", 1.0)))
+    return {"paths": list(det.getPaths()), "frames_per_launch_mean": nb, "frames_in_flight": PIPELINE_DEPTH,
+            "kernels_ms_per_frame": {q: (tm.get(q + "_ms", 0.0) / nb) for q in ("frontend", "coarse", "local")}}
+
+
+def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=16, depth=None):
+    """Seconds per frame of the live-stream path (a host frame per step, `depth` in flight: the headline's PIPELINE_DEPTH unless given) + mean timings."""
+    depth = depth or PIPELINE_DEPTH or 16
     acc, n = {}, 0
     def go(k0, cnt, record):
         nonlocal n
@@ -820,7 +861,7 @@ def pipelined_host_stream(det, frames, classes, threshold, steps, warmup=8, dept
     return dt, {q: v / max(1, n) for q, v in acc.items()}
 
 
-def sparse_threshold_run(det, frames, classes, n_templates, steps=30):
+def sparse_threshold_run(det, frames, classes, n_templates, steps=50):
     """"a second run at a threshold chosen to give ~1 candidate/template".  The threshold is found by bisection
     on the coarse candidate count of frame 0; then the same live-stream loop as the headline."""
     lo_t, hi_t = THRESHOLD, 100.0
@@ -836,8 +877,8 @@ def sparse_threshold_run(det, frames, classes, n_templates, steps=30):
     thr = hi_t
     dt, tm = pipelined_host_stream(det, frames, classes, thr, steps)
     return {"threshold": thr, "coarse_candidates_per_template": tm.get("coarse_candidates", 0.0) / n_templates,
-            "ms_per_frame": dt * 1e3, "value": n_templates * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
-            "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "frontend_ms": tm.get("frontend_ms")}
+            "ms_per_frame": dt * 1e3, "value": n_templates * (W * H / 1e6) / dt, "unit": "templates*Mpx/s", "steps": steps,
+            "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "frontend_ms": tm.get("frontend_ms"), **stream_shape(det, tm)}
 
 
 def strong_reference(det0, quant, frames, per_object, steps=20, depth=8):
@@ -853,7 +894,7 @@ def strong_reference(det0, quant, frames, per_object, steps=20, depth=8):
         classes.append(cid)
     total = per_object * STRONG_OBJECTS
     dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps, warmup=16, depth=depth)
-    return {"templates_total": total, "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": depth, "value": total * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
+    return {"templates_total": total, "ms_per_step": dt * 1e3, "steps": steps, "value": total * (W * H / 1e6) / dt, "unit": "templates*Mpx/s", **stream_shape(det, tm),
             "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "coarse_candidates": tm.get("coarse_candidates"),
             "note": "same live-stream loop as the headline (host frame per step), `python bench.py --scaling strong` gives the same number as a bench line"}
 
@@ -1133,7 +1174,7 @@ def icp_cpu_baseline(hypotheses=4):
                                              "the kind of loop Open3D runs (KD-tree), one thread; not bit-compared"}}
 
 
-def real_fixture_leg(device, steps=40, target=2000):
+def real_fixture_leg(device, steps=50, target=2000):
     """the reference's own detect_test (linemodLevelup/test.cpp:111-130) - fixture frame 0000 read as BGR,
     Detector(127, {5, 8}), bank `127` (89 template pyramids at 1000 mm), threshold 75 - with the bank tiled to ~2k pyramids
     (copies under new template ids) so that it is the configs[1] size.  Parity-checked against the CPU oracle (all pyramids),
@@ -1160,7 +1201,7 @@ def real_fixture_leg(device, steps=40, target=2000):
     n = pb.num_pyramids
     return {"workload": "test.cpp:111-130 detect_test: fixture frame 0000 (BGR) x bank 127 tiled x%d = %d template pyramids, Detector(127,{5,8}), "
                         "threshold 75, 640x480" % (reps, n),
-            "templates": n, "ms_per_frame": dt * 1e3, "value": n * (W * H / 1e6) / dt, "unit": "templates*Mpx/s",
+            "templates": n, "ms_per_frame": dt * 1e3, "value": n * (W * H / 1e6) / dt, "unit": "templates*Mpx/s", "steps": steps, **stream_shape(det, tm),
             "coarse_candidates": tm.get("coarse_candidates"), "matches_pre_unique": tm.get("matches_pre_unique"), "matches_final": int(len(got)),
             "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "frontend_ms": tm.get("frontend_ms"),
             "equals_oracle": bool(equal), "top_match": ({"x": int(got[0]["x"]), "y": int(got[0]["y"]), "similarity": float(got[0]["similarity"]),

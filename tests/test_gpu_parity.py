@@ -536,6 +536,39 @@ def test_feature_count_boundaries_and_mixed_banks(lm):
                 same_records(det.collect(), want)
 
 
+def test_reference_feature_ceiling_8191_per_modality(lm):
+    """The reference's ceiling (LL.cpp:1291, 1816: 8191 features per modality = 32764 < 2^15 per u16 sum): template entries of 8191 + 8191 features at
+    BOTH pyramid levels — 16382 per entry, 2 features short of what the 14-bit counters of k_local_bits<10, .> / k_coarse_bits<10, .> hold — through
+    every kernel path and the oracle.  The features are those of planted 150- / 75-feature templates repeated, so that the scores keep their
+    structure (candidates around the planted position, raw sums up to 4 x 16382 = 65528)."""
+    W, H, T = 640, 480, [4, 8]
+    rgb, dep = synth.make_frame(31, W, H, 40)
+    od = lo.OracleDetector(64, T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    feat, offs, wh = synth.make_planted_bank(77, 10, [(p[0], p[1]) for p in pyr], T, (150, 75))
+    parts, noffs = [], [0]
+    for k in range(len(offs) - 1):
+        f = feat[offs[k]:offs[k + 1]]
+        f = np.tile(f, ((8191 + len(f) - 1) // len(f), 1))[:8191]
+        parts.append(f); noffs.append(noffs[-1] + len(f))
+    big = (np.ascontiguousarray(np.concatenate(parts), dtype=np.int32), np.asarray(noffs, np.int32), wh)
+    thr = 70.0
+    raw, st = oracle_matches(od, rgb, dep, big, T, thr, 0)
+    want = lo.canonical_sort_unique(raw)
+    assert len(want) > 0 and st["coarse_candidates"] >= 10
+    for paths in PATHS:
+        det = detector_on(lm, paths, 64, T, device=0)
+        det.addClassPacked("big", *big)
+        same_records(det.matchArray([rgb, dep], thr, ["big"]), want)
+        expect_paths(det, paths)
+        tm = det.lastTimings()
+        assert (tm["coarse_candidates"], tm["local_evals"], tm["matches_pre_unique"]) == (st["coarse_candidates"], st["local_evals"], len(raw)), paths
+        for _ in range(3):
+            det.submitFrame([rgb, dep], thr, ["big"])
+        for _ in range(3):
+            same_records(det.collect(), want)
+
+
 def test_sharded_equals_unsharded_on_one_device(lm):
     """N logical shards on one device through the same slice + merge code the multi-GPU path uses."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
