@@ -680,7 +680,7 @@ constexpr int kTileWords = 6144;                 // LDS pool of k_fe_bits (24 KB
 static_assert(kTileWords * 2 >= kBitsCells, "the pool holds bits_rows_body's cell words");
 static __host__ __device__ inline bool fe_top_tile_fits(int W, int T) { return (T == 4 || T == 8) && (W / T) % 8 == 0 && (3 * T - 1) * (W / 4 + T / 4) <= kTileWords; }
 static __host__ __device__ inline int fe_rows_block_rows(int NS, int T);
-static __host__ __device__ inline bool fe_rows_tile_fits(int W, int T) { return (T == 4 || T == 8) && W % 16 == 0 && fe_rows_block_rows(((W / T) + 15) / 16, T) > 0; }
+static __host__ __device__ inline bool fe_rows_tile_fits(int W, int T) { return (T == 4 || T == 5 || T == 8) && W % 16 == 0 && fe_rows_block_rows(((W / T) + 15) / 16, T) > 0; }   // (T = 5: the reference's default step, Detector() = {5, 8})
 
 static __device__ __forceinline__ unsigned long long transpose8x8(unsigned long long x) {      // byte i bit j <-> byte j bit i
     unsigned long long t;
@@ -830,11 +830,14 @@ static __device__ __forceinline__ void bits_rows_block_body(const int blk, const
                     }
                 }
                 d[4] = px(y, 4 * qd + 4);
-                if (kT == 8) d[5] = px(y, 4 * qd + 5);
+                if (kT > 5) d[5] = px(y, 4 * qd + 5);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 4; ++q) {                              // byte b of acc[q]: the OR of the kT pixels from pixel 4 q + b on (kT = 4 .. 8)
                     acc[q] |= d[q] | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1) | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2) | __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
-                    if (kT == 8) acc[q] |= d[q + 1] | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 1) | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 2) | __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 3);
+                    if (kT > 4) acc[q] |= d[q + 1];
+                    if (kT > 5) acc[q] |= __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 1);
+                    if (kT > 6) acc[q] |= __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 2);
+                    if (kT > 7) acc[q] |= __builtin_amdgcn_alignbyte(d[q + 2], d[q + 1], 3);
                 }
             }
             *reinterpret_cast<uint4*>(s_sp + rr * RW + 4 * qd) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
@@ -934,7 +937,11 @@ k_fe_bits(FeStage st, int total) {
         if (J.kind == kFeBitsRows) bits_rows_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, (J.Wd + 15) >> 4, J.m_wd, J.m_t, reinterpret_cast<uint16_t*>(s_tile));
         else if (J.kind == kFeTopBits) top_bits_body(bx, by, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t);
         else if (J.kind == kFeTopBitsAligned) top_bits_aligned_body(bx, J.lm[bz], J.W, J.H, J.a, J.Wd, J.Hd, J.m_wd, J.m_t, J.m_np);
-        else if (J.kind == kFeBitsRowsTile) { if (J.a == 8) bits_rows_block_body<8>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); else bits_rows_block_body<4>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile); }
+        else if (J.kind == kFeBitsRowsTile) {
+            if (J.a == 8) bits_rows_block_body<8>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile);
+            else if (J.a == 5) bits_rows_block_body<5>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile);
+            else bits_rows_block_body<4>(bx, by, J.b, J.lm[bz], J.W, J.H, J.Wd, J.Hd, (J.Wd + 15) >> 4, s_tile);
+        }
         else if (J.kind == kFeTopBitsTile) { if (J.a == 8) top_bits_tile_body<8>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); else top_bits_tile_body<4>(bx, J.lm[bz], J.W, J.H, J.Wd, J.Hd, s_tile); }
         if (blk + (int)gridDim.x < total) __syncthreads();      // the next block of rows reuses the cell words in LDS
     }
@@ -972,7 +979,7 @@ void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* co
     if (tiles && fe_rows_tile_fits(W, T)) {                // a workgroup per block of rows of cells and pixel-row phase
         const int Rb = fe_rows_block_rows((j.Wd + 15) / 16, T);
         const int k = knobs().fe_rows_cs;
-        j.b = (k == 1 || k == 2 || k == 4 || k == 8) && k <= T ? k : 2;      // column phases per workgroup (LM_FE_ROWS_CS; VGA level 0, per 8-frame batch: all four 23.7 us, two 21.1, one 25.9)
+        j.b = k >= 1 && k <= T && T % k == 0 ? k : (T % 2 == 0 ? 2 : 1);   // column phases per workgroup, a divisor of T (LM_FE_ROWS_CS; VGA level 0 at T = 4, per 8-frame batch: all four 23.7 us, two 21.1, one 25.9)
         j.kind = kFeBitsRowsTile; j.gx = (j.Hd + Rb - 1) / Rb; j.gy = T * (T / j.b);
     }
     j.lm[0] = LmJob{quant[0], mask[0], bits[0], nullptr}; j.lm[1] = LmJob{quant[1], mask[1], bits[1], nullptr};

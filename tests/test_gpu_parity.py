@@ -151,17 +151,17 @@ def _pair_stream(lm_colour, lm_normal, T, Wd, Hd, npairs):
     return out
 
 
-@pytest.mark.parametrize("case", ["T48", "T58", "3level", "1280", "small_T24", "masked"])
+@pytest.mark.parametrize("case", ["T48", "T58", "3level", "1280", "small_T24", "masked", "masked_T58"])
 def test_bit_planes_equal_the_packed_linear_memories(lm, case):
     """The encodings the bit-plane kernels read — strip records of every level below the top, pair stream of the top level —
     bit for bit against a numpy packing of the ORACLE's linear memories, as written directly by the front end (k_fe_bits: strip records from
     LDS cell words; the pair stream as whole dwords, or OR-ed together from shifted ballots) and as packed from the byte planes (k_pack_bits /
     k_pack_top)."""
     W, H, T = {"T48": (640, 480, [4, 8]), "T58": (640, 480, [5, 8]), "3level": (640, 480, [4, 4, 8]), "1280": (1280, 960, [4, 8]),
-               "small_T24": (320, 240, [2, 4]), "masked": (640, 480, [4, 8])}[case]
+               "small_T24": (320, 240, [2, 4]), "masked": (640, 480, [4, 8]), "masked_T58": (640, 480, [5, 8])}[case]
     rgb, dep = synth.make_frame(61, W, H, 40 if W <= 640 else 80)
     masks = []
-    if case == "masked":
+    if case.startswith("masked"):
         yy, xx = np.mgrid[0:H, 0:W]
         masks = [((xx // 37 + yy // 29) % 3 != 0).astype(np.uint8) * 255, ((xx // 23 + yy // 41) % 4 != 0).astype(np.uint8) * 255]
     nfeat = tuple(64 >> l for l in range(len(T)))
