@@ -145,22 +145,11 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     int prio[4] = {prio_greatest, prio_greatest, prio_least, 0};
     if (const char* pe = getenv("LM_STREAM_PRIO"))
         for (int i = 0; i < 4 && pe[i]; ++i) prio[i] = pe[i] == '1' ? prio_least : (pe[i] == '2' ? prio_greatest : 0);
-    // LM_CU_SPLIT=N (experiment): the front end and the coarse pass get CUs [0, N) to themselves, refinement and duplicate removal
-    // the rest (hipExtStreamCreateWithCUMask; no priorities on such streams)
-    int cu_split = 0;
-    if (const char* cs = getenv("LM_CU_SPLIT")) cu_split = atoi(cs);
     bool streams_ok = hipSetDevice(device) == hipSuccess;
-    if (streams_ok && cu_split > 0 && cu_split < 256) {
-        uint32_t lo[8] = {0}, hi[8] = {0};
-        for (int i = 0; i < 256; ++i) (i < cu_split ? lo : hi)[i >> 5] |= 1u << (i & 31);
-        streams_ok = hipExtStreamCreateWithCUMask(&d->stream, 8, lo) == hipSuccess && hipExtStreamCreateWithCUMask(&d->cstream, 8, lo) == hipSuccess &&
-                     hipExtStreamCreateWithCUMask(&d->mstream, 8, hi) == hipSuccess && hipExtStreamCreateWithCUMask(&d->xchg.stream, 8, hi) == hipSuccess;
-    } else if (streams_ok) {
+    if (streams_ok)
         streams_ok = hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio[0]) == hipSuccess &&
-                     hipStreamCreateWithPriority(&d->cstream, hipStreamNonBlocking, prio[1]) == hipSuccess &&
                      hipStreamCreateWithPriority(&d->mstream, hipStreamNonBlocking, prio[2]) == hipSuccess &&
                      hipStreamCreateWithPriority(&d->xchg.stream, hipStreamNonBlocking, prio[3]) == hipSuccess;
-    }
     if (!streams_ok) {
         delete d;
         return lm_set_error(LM_ERR_NO_DEVICE, "cannot initialise HIP device %d", device);
@@ -172,11 +161,9 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     else d->ingest.stream = nullptr;
     for (auto& ev : d->ev) (void)hipEventCreate(&ev);
     for (auto& sl : d->slot) {
-        for (auto& e : sl.ev) (void)hipEventCreateWithFlags(&e, knobs().stage_events == 2 ? hipEventDefault : hipEventDisableSystemFence);   // timing only: nobody synchronises on them, and a default record costs the queue a cache write-back + invalidate (5-6 us between two kernels; sl.done keeps the fence)
+        for (auto& e : sl.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);   // timing only: nobody synchronises on them, and a default record costs the queue a cache write-back + invalidate (5-6 us between two kernels; sl.done keeps the fence)
         (void)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&sl.fe_done, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&sl.local_done, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&sl.coarse_done, hipEventDisableTiming);
     }
     d->work_cls = std::make_shared<std::vector<int32_t>>();
     d->work_tid = std::make_shared<std::vector<int32_t>>();
@@ -207,7 +194,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& sl : d->slot) { free(sl.prep); sl.prep = nullptr; }
     (void)hipStreamSynchronize(d->stream);
     if (d->mstream) (void)hipStreamSynchronize(d->mstream);
-    if (d->cstream) (void)hipStreamSynchronize(d->cstream);
     d->frame_rgb.release(); d->frame_depth.release(); d->nrm_raw.release();
     for (int i = 0; i < lm_detector::kSlots; ++i) {
         if (d->ingest.pinned[i]) (void)hipHostFree(d->ingest.pinned[i]);
@@ -231,8 +217,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
         if (sl.h_distinct) (void)hipHostFree(sl.h_distinct);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.fe_done) (void)hipEventDestroy(sl.fe_done);
-        if (sl.local_done) (void)hipEventDestroy(sl.local_done);
-        if (sl.coarse_done) (void)hipEventDestroy(sl.coarse_done);
         for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
@@ -248,7 +232,6 @@ extern "C" void lm_detector_destroy(lm_detector* d) {
     for (auto& ev : d->ev) if (ev) (void)hipEventDestroy(ev);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->mstream) (void)hipStreamDestroy(d->mstream);
-    if (d->cstream) (void)hipStreamDestroy(d->cstream);
     delete d;
 }
 
@@ -1325,7 +1308,7 @@ static int build_work(lm_detector* d, const char* const* class_ids, int num_clas
     }
     // frames in flight still read the device-resident work list: let them finish before it is replaced
     if (d->n_submitted != d->n_collected) {
-        HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
+        HIP_TRY(hipStreamSynchronize(d->mstream));
         if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     }
     int rc = d->d_work.ensure(std::max<size_t>(1, d->work_pyr.size()));
@@ -1371,7 +1354,7 @@ static int ensure_slot_buffers(lm_detector* d, lm_detector::Slot& sl, uint32_t m
 }
 
 static int sync_all_streams(lm_detector* d) {
-    HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream)); HIP_TRY(hipStreamSynchronize(d->cstream));
+    HIP_TRY(hipStreamSynchronize(d->stream)); HIP_TRY(hipStreamSynchronize(d->mstream));
     if (d->xchg.stream) HIP_TRY(hipStreamSynchronize(d->xchg.stream));
     return LM_OK;
 }
@@ -1653,6 +1636,21 @@ static bool partial_batch_due(lm_detector* d, double at) {
     return d->gpu_free_at - at <= 1e-3 * d->launch_slack_ms;
 }
 
+// Ordering between the detector's two queues.  Every kernel of a batch runs on `mstream`; `stream` carries what the synchronous entry points
+// enqueue — a blocking upload, the device-to-device copy of lm_detector_select_frame, the clearing of new arenas, a training view.  A batch must see
+// all of that: whatever is still pending on `stream` when the batch is enqueued comes first.  (Nothing pending there — the steady state of a stream
+// of uploaded frames — needs no ordering: a query instead of a record, a cross-queue wait and the barrier packet the GPU would process for it.)
+// The other direction — work on `stream` that touches what a batch in flight reads or writes (level buffers, arenas, the resident frame) — is not
+// ordered by events: such entry points run only with nothing in flight (n_submitted == n_collected, checked where they start) or wait for the
+// batch's front end (select_frame: resident_reader).  A new caller that writes those buffers on `stream` has to do the same.
+static int order_after_default_stream(lm_detector* d, hipStream_t s) {
+    if (s == d->stream || hipStreamQuery(d->stream) == hipSuccess) return LM_OK;
+    (void)hipGetLastError();                                  // hipErrorNotReady is not an error
+    HIP_TRY(hipEventRecord(d->ev[5], d->stream));
+    HIP_TRY(hipStreamWaitEvent(s, d->ev[5], 0));
+    return LM_OK;
+}
+
 // Enqueue the whole device pipeline of the frames waiting in slots [pend_first, pend_first + pend_n): ONE front end, coarse pass,
 // refinement and duplicate removal for all of them (asynchronous).
 int lm_launch_pending(lm_detector* d) {
@@ -1674,7 +1672,7 @@ int lm_launch_pending(lm_detector* d) {
     int rc;
     for (int b = 0; b < nb; ++b)
         if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
-    hipStream_t ms = d->mstream, s = knobs().serial >= 2 ? ms : d->stream;
+    hipStream_t ms = d->mstream, s = ms;                      // every kernel of a batch on the matching stream (one queue; the end of a stage is the start of the next)
     // the frames' uploads (copy stream) before the front end
     for (int b = nb - 1; b >= 0; --b) {                       // (the copy stream is one in-order queue: the upload of the batch's last streamed frame covers the earlier ones)
         const int ring = d->slot[(first + b) % lm_detector::kSlots].ring;
@@ -1682,17 +1680,7 @@ int lm_launch_pending(lm_detector* d) {
         if (hipEventQuery(d->ingest.t1[ring]) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipStreamWaitEvent(s, d->ingest.t1[ring], 0)); }   // (already there: nothing to wait for)
         break;
     }
-    if (s != d->stream) {
-        // every kernel of the batch runs on the matching stream (LM_SERIAL=2): whatever was enqueued on `stream` before — a blocking upload, the
-        // device-to-device copy of lm_detector_select_frame, the clearing of new arenas, a training view — comes first
-        // (nothing pending there — the steady state of a stream of uploaded frames — needs no ordering: a query instead of a record, a cross-queue wait
-        // and the barrier packet the GPU would process for it)
-        if (hipStreamQuery(d->stream) != hipSuccess) {
-            (void)hipGetLastError();                          // hipErrorNotReady is not an error
-            HIP_TRY(hipEventRecord(d->ev[5], d->stream));
-            HIP_TRY(hipStreamWaitEvent(s, d->ev[5], 0));
-        }
-    }
+    if ((rc = order_after_default_stream(d, s))) return rc;
     HIP_TRY(hipEventRecord(lead.ev[0], s));
     const bool cbits = cbits_active(d, num_work);
     // The front end writes the bit planes directly where nothing reads the byte planes: below the top when no candidate can leave its planes
@@ -1740,14 +1728,12 @@ int lm_launch_pending(lm_detector* d) {
         if (top_ored && !d->fe_keep_top) bb.top_clear_units = (d->cbits_npairs * 8u + 15u) / 16u;
         if (!direct_top) launch_pack_top(tb, nb, d->cbits_byte0, d->cbits_npairs, s);
     }
-    // One queue for the whole batch (LM_SERIAL=2): the end of a stage IS the start of the next — one timing record between two kernels
-    // instead of two or three, and fe_done only when something outside the batch waits for this front end (a resident frame).
-    const bool one_queue = s == ms && knobs().stage_events != 2;
+    // One queue for the whole batch: the end of a stage IS the start of the next — one timing record between two kernels instead of two or
+    // three, and fe_done only when something outside the batch waits for this front end (a resident frame).
     bool resident_in = false;
     for (int b = 0; b < nb; ++b) resident_in = resident_in || d->slot[(first + b) % lm_detector::kSlots].ring < 0;
     HIP_TRY(hipEventRecord(lead.ev[1], s));
-    if (!one_queue || resident_in) HIP_TRY(hipEventRecord(lead.fe_done, s));
-    lead.t_coarse0 = one_queue ? 1 : 2; lead.t_local0 = one_queue ? 3 : 5;
+    if (resident_in) HIP_TRY(hipEventRecord(lead.fe_done, s));
     for (int b = 0; b < nb; ++b)                              // the resident frame is read by this front end: the next lm_detector_select_frame copy waits for it
         if (d->slot[(first + b) % lm_detector::kSlots].ring < 0) d->resident_reader = lead.fe_done;
     for (int b = 0; b < nb; ++b) {                            // a resident re-match of a streamed frame reads its ring entry: the entry's next upload waits for this front end
@@ -1758,7 +1744,6 @@ int lm_launch_pending(lm_detector* d) {
     }
     const uint32_t cap = std::min<uint32_t>(lead.match_cap, d->buf_cand_cap);
     auto enqueue_coarse = [&](hipStream_t st) -> int {
-        if (!one_queue) HIP_TRY(hipEventRecord(lead.ev[2], st));
         // the counters are zero on entry (reset by the slots' previous k_dedupe)
         { LM_CLOCK("launch_coarse");
         if (cbits) launch_coarse_bits(fb, tb, d->geom, d->d_entries.p, d->d_feat_off.p, d->d_work.p, num_work, threshold, d->buf_cand_cap, d->cbits_byte0, d->cbits_max_nf, st);
@@ -1768,7 +1753,6 @@ int lm_launch_pending(lm_detector* d) {
         return LM_OK;
     };
     auto enqueue_match = [&]() -> int {
-        if (!one_queue) HIP_TRY(hipEventRecord(lead.ev[5], ms));
         // persistent refinement grid over the tiles and then the remaining candidates of every frame of the batch; the counts are
         // read on the device (no host round trip), the records stored straight into the slots' pinned host memory; it also empties
         // the hash tables k_dedupe uses
@@ -1804,23 +1788,7 @@ int lm_launch_pending(lm_detector* d) {
             for (int b = 0; b < nb; ++b) HIP_TRY(hipMemsetAsync(fb.f[b].final_dev, 0, 8 * sizeof(unsigned long long), st));   // nothing searched: no records for NMS / exchange
         return LM_OK;
     };
-    // Dependent kernels on one queue start a few us apart, and neither the coarse pass of batch k+1 nor the duplicate removal of batch
-    // k needs anything the refinement of the neighbouring batch touches (per-slot candidates, counters, records, hash tables).  So
-    // with work already in flight each stage has its own stream — coarse(k+1) and dedupe(k) run beside local(k) / local(k+1) —
-    // while a lone launch (synchronous call, on-device pipeline, the first batch of a stream) keeps all three on the matching
-    // stream: no extra cross-stream hops on the latency path.  Cross-stream ordering and the host wait use eagerly recorded events.
-    if (d->n_launched != d->n_collected && knobs().serial == 0) {
-        HIP_TRY(hipStreamWaitEvent(d->cstream, lead.fe_done, 0));
-        if ((rc = enqueue_coarse(d->cstream))) return rc;
-        HIP_TRY(hipEventRecord(lead.coarse_done, d->cstream));
-        HIP_TRY(hipStreamWaitEvent(ms, lead.coarse_done, 0));
-        if ((rc = enqueue_match())) return rc;
-        HIP_TRY(hipEventRecord(lead.local_done, ms));
-        HIP_TRY(hipStreamWaitEvent(d->xchg.stream, lead.local_done, 0));
-        if ((rc = enqueue_dedupe(d->xchg.stream))) return rc;
-        HIP_TRY(hipEventRecord(lead.done, d->xchg.stream));
-    } else {
-        if (!one_queue) HIP_TRY(hipStreamWaitEvent(ms, lead.fe_done, 0));
+    {
 #ifdef LM_DIAG
         const double lp3 = lp_now();
 #endif
@@ -2168,8 +2136,8 @@ int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_
     tm.d2h_ms = 0.f;                                   // the records are stored straight into pinned memory by the refinement
     tm.batch_frames = sl.batch_n;
     if (hipEventElapsedTime(&tm.frontend_ms, lead.ev[0], lead.ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&tm.coarse_ms, lead.ev[lead.t_coarse0], lead.ev[3]) != hipSuccess ||
-        hipEventElapsedTime(&tm.local_ms, lead.ev[lead.t_local0], lead.ev[4]) != hipSuccess ||
+        hipEventElapsedTime(&tm.coarse_ms, lead.ev[1], lead.ev[3]) != hipSuccess ||
+        hipEventElapsedTime(&tm.local_ms, lead.ev[3], lead.ev[4]) != hipSuccess ||
         hipEventElapsedTime(&tm.total_ms, lead.ev[0], lead.ev[4]) != hipSuccess) {
         (void)hipGetLastError();
         tm.frontend_ms = tm.coarse_ms = tm.local_ms = tm.d2h_ms = tm.total_ms = 0.f;

@@ -67,7 +67,6 @@ struct lm_detector {
     int device = 0;
     hipStream_t stream = nullptr;       // frame upload / select + front end (and addTemplate)
     hipStream_t mstream = nullptr;      // refinement (a lone frame: all three matching kernels; + the pipeline's NMS / ICP): frame k, while `stream` prepares frame k+1
-    hipStream_t cstream = nullptr;      // coarse pass of frame k+1 beside the refinement of frame k (pipelined submits only)
     hipEvent_t ev[8] = {};
     int shard_rank = 0, shard_world = 1;
 
@@ -153,10 +152,7 @@ struct lm_detector {
         float prep_collect_ms = 0.f, prep_merge_ms = 0.f;
         hipEvent_t ev[6] = {};                      // stage timing: front end 0-1, coarse 2-3, refinement 5-4
         hipEvent_t done = nullptr;                  // recorded after the batch's last kernel: the only event the host waits on
-        int t_coarse0 = 2, t_local0 = 5;            // which of ev[] marks the start of the coarse pass / the refinement of the batch this slot leads (one queue: the end of the stage before)
         hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
-        hipEvent_t coarse_done = nullptr;           // coarse pass of this slot finished (eager, on `cstream`): `mstream` waits for it
-        hipEvent_t local_done = nullptr;            // refinement of this slot finished (eager, on `mstream`): the exchange stream (duplicate removal) waits for it
         bool pending = false;
         float threshold = 0.f, h2d_ms = 0.f;
         int num_work = 0;

@@ -16,12 +16,10 @@ struct Knobs {
     int coarse_group = 4;          // LM_COARSE_GROUP: templates per workgroup of k_coarse (<= 4)
     int local_blocks = 0;          // LM_LOCAL_BLOCKS: grid of k_local (0 = default per CU count)
     int frame_batch = 0;           // LM_FRAME_BATCH: frames per matching launch in stream mode (0 = default: 8 = kMaxBatch; lm_detector_set_batch)
-    int serial = 2;                // LM_SERIAL: 2 = every kernel of a batch on ONE stream (default), 1 = the front end on its own stream beside the matching of the batch before, 0 = a stream per stage
     int coarse_bits = 1;           // LM_COARSE_BITS=0: coarse pass on the byte linear memories (k_coarse) instead of on the pair stream (k_coarse_bits)
     int bitplanes = 1;             // LM_BITPLANES=0: refinement on the byte strip planes with tiles (round 2-3's kernel) instead of on bit planes
     int fe_bits = 1;               // LM_FE_BITS=0: the front end always writes the byte planes and k_pack_bits / k_pack_top pack them (1: bit planes directly when nothing reads the bytes)
     int fe_bits_split = 0;         // LM_FE_BITS_SPLIT=1: k_fe_bits as two launches (strip records, pair stream) so that a profile times them apart
-    int stage_events = 1;          // LM_STAGE_EVENTS=2: round 3's stage timing (records with a system-scope fence, start and end of every stage), for A/B
     int first_batch = 3;           // LM_FIRST_BATCH: frames an idle GPU waits for before a partial batch goes out WHILE THE CALLER SUBMITS IN A TIGHT LOOP (collect / flush launch what is left; sparse streams: every frame at once)
     int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
     int nt_copy = 1;               // LM_NT_COPY=0: the staging copy of a streamed frame with memcpy instead of non-temporal AVX2 stores
@@ -54,8 +52,6 @@ inline const Knobs& knobs() {
         v.coarse_bits = geti("LM_COARSE_BITS", 1);
         v.fe_bits = geti("LM_FE_BITS", 1);
         v.fe_bits_split = geti("LM_FE_BITS_SPLIT", 0);
-        v.serial = geti("LM_SERIAL", v.serial);
-        v.stage_events = geti("LM_STAGE_EVENTS", 1);
         v.first_batch = geti("LM_FIRST_BATCH", v.first_batch);
         v.dedupe_blocks = geti("LM_DEDUPE_BLOCKS", 0);
         v.nt_copy = geti("LM_NT_COPY", 1);
