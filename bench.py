@@ -575,10 +575,10 @@ def main():
                     "useful_valu_frac_with_window_shifts": (USEFUL_ADDER_OPS_PER_LANE_FEATURE + ALIGN_OPS_PER_LANE_FEATURE) / per,
                     "useful_valu_note": "adder operations the bit-sliced sums need per lane and feature (5.0: ISA of the 16-feature loop body, DESIGN.md 3.6) over the "
                                         "wave-level VALU instructions measured per lane and feature (SQ_INSTS_VALU / (pairs / 8)); round 3's kernel: 10 of 33",
-                    "what_bounds_it": "the vector L1: a wave load of k_local_bits is 8 candidates x 128 contiguous bytes at 8-byte alignment = ~22 64-byte accesses, and "
-                                      "the TCP serves about one access per cycle (`ceilings.tcp`; raw ratio and miss-stall share beside it); the VALU (carry-save "
-                                      "adders on bit-sliced counters) is at `ceilings.valu` of its issue slots since the window shifts and the address arithmetic "
-                                      "were cut (VERDICT r03 item 3)"})
+                    "what_bounds_it": "the number of wave loads: a wave load of k_local_bits (8 candidates x 128 contiguous bytes = 1 KB) takes 20-23 CU cycles whatever "
+                                      "the lanes or addresses (`cu_cycles_per_wave_load`; 16 = the 64 B per cycle of the L1 -> register path, `ceilings.l1_data`), with "
+                                      "the L2 -> L1 fills behind it (`ceilings.l2`, the miss-stall share).  Three schemes that share loads between neighbouring candidates "
+                                      "were built in round 5 — bit-exact, fewer wave loads, more L2 requests, none faster: profiles/r05_local_sharing/README.txt"})
         # every stage of a frame with the ceiling that binds it, from the same PMC passes (one fraction <= 1 per stage, recomputable from profiles/r04_pmc.txt)
         if pm_all:
             B_FRONT = W * H * 3 + W * H * 2 + 8 * 2 * (W * H + (W // 2) * (H // 2))      # 1.54 MB in + 6.14 MB of linear memories (8 labels x 2 modalities x 2 levels) out per VGA frame
@@ -803,9 +803,11 @@ ALIGN_OPS_PER_LANE_FEATURE = 2.0      # + the two v_alignbit that cut the lane's
 
 def ceilings_of(pm):
     """What a kernel's launch reached of each physical ceiling, from its PMC means:
-    tcp = vector-L1 (TCP) accesses per CU cycle — the TCP serves one 64-byte access per cycle (64 B x 256 CUs x ~2.25 GHz = the 36.9 TB/s
-          MI355X_MICROARCH.md gives for L2 + L1 reuse); the counter runs a few per cent past 1.0 on a saturated launch (1.01 measured), so the
-          fraction is capped at 1 and the raw ratio reported beside it; cycles stalled on pending misses are reported separately;
+    l1_data = the vector L1 -> register path: a wave load of 16 bytes per lane (what the matching kernels issue) is 1 KB at 64 B per CU cycle = 16 cycles,
+          so the fraction is 16 x wave loads over the CU cycles of the launch.  This is what binds k_local_bits: its time follows the NUMBER of wave loads
+          (profiles/r05_local_sharing/README.txt; 20-23 CU cycles per wave load in every lane layout tried);
+    tcp = vector-L1 (TCP) tag accesses per CU cycle, reported for reference only: round 4 read "one 64-byte access per cycle" as the ceiling, but the
+          counter stands at 1.09 per cycle on the faster grid of round 5 (22.4 accesses per wave load whatever the addresses), so it is not a limit;
     valu = wave-level VALU instructions x 4 cycles over the SIMD cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycle: profiles/r04_pmc.txt);
     l2 = L2 requests x 128 B (an upper bound on the bytes they move) per second over the L2 peak; hbm = memory-side bytes per second over the HBM peak."""
     kc = pm["GRBM_GUI_ACTIVE"] / 8.0
@@ -814,12 +816,13 @@ def ceilings_of(pm):
     us = kc / 2400.0
     hbm_bytes = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0
     tcp_raw = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kc)
-    c = {"tcp": min(1.0, tcp_raw),
+    c = {"l1_data": min(1.0, 16.0 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kc)),
+         "tcp": tcp_raw,
          "valu": 4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kc),
          "l2": (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) * 128.0 / (us * 1e-6) / 1e9 / L2_PEAK_GBS,
          "hbm": hbm_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    top = max(c, key=lambda q: c[q])
-    names = {"tcp": "vector L1 (TCP): 64-byte accesses per CU cycle (one per cycle = 36.9 TB/s over the chip)", "valu": "VALU issue slots (4 cycles per wave instruction)",
+    top = max((q for q in c if q != "tcp"), key=lambda q: c[q])
+    names = {"l1_data": "vector L1 -> register path: 16-byte-per-lane wave loads at 64 B per CU cycle (16 cycles each)", "valu": "VALU issue slots (4 cycles per wave instruction)",
              "l2": "L2 bandwidth (requests x 128 B against %.1f TB/s)" % (L2_PEAK_GBS / 1e3), "hbm": "HBM bandwidth (memory-side bytes against %.0f TB/s)" % (HBM_PEAK_GBS / 1e3)}
     return {"kernel_us_profiled": us, "dispatches_profiled": pm.get("dispatches"), "fractions": c, "binding": {"ceiling": names[top], "frac": c[top]},
             "tcp_accesses_per_cu_cycle_raw": tcp_raw, "tcp_miss_stall_cycles_per_cu_cycle": pm["TCP_PENDING_STALL_CYCLES_sum"] / (256.0 * kc),
