@@ -569,6 +569,54 @@ def test_reference_feature_ceiling_8191_per_modality(lm):
             same_records(det.collect(), want)
 
 
+def _random_geometries(seed, count):
+    """Seeded random frame sizes / pyramids / feature counts / thresholds the reference accepts (rows and columns of every level multiples of its T,
+    LL.cpp:1217-1218; rows x columns a multiple of 16, LL.cpp:1136): widths that are not multiples of 16 (no pixel tiles), odd steps, one to three levels."""
+    import math
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        L = int(rng.choice([1, 2, 2, 2, 3]))
+        T = [int(rng.choice([2, 4, 5, 8])) for _ in range(L)]
+        T[-1] = int(rng.choice([4, 5, 8, 16]))
+        base = 1
+        for l, t in enumerate(T):
+            base = math.lcm(base, t << l)
+        base = math.lcm(base, 4 << (L - 1))
+        a = int(rng.integers(max(1, 300 // base), max(2, 760 // base) + 1)); b = int(rng.integers(max(1, 220 // base), max(2, 560 // base) + 1))
+        W, H = base * a, base * b
+        if W < 300 or H < 220 or W > 800 or H > 600 or any(((W >> l) * (H >> l)) % 16 for l in range(L)):
+            continue
+        nf0 = int(rng.choice([24, 48, 64, 96, 150]))
+        out.append((W, H, T, tuple(max(8, nf0 >> l) for l in range(L)), float(rng.choice([55.0, 65.0, 75.0])), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_geometries(2025, 14), ids=lambda c: "%dx%d-T%s-nf%d" % (c[0], c[1], "_".join(map(str, c[2])), c[3][0]))
+def test_random_geometries_equal_the_oracle(lm, case):
+    """Differential test over geometries nobody chose by hand: the default path and two others drawn per case against the oracle, records and counts."""
+    W, H, T, nfeat, thr, sd = case
+    rgb, dep = synth.make_frame(sd % 1000, W, H, 30)
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(rgb, dep)
+    bank = synth.make_planted_bank(sd % 997, 40, [(p[0], p[1]) for p in pyr], T, nfeat)
+    raw, st = oracle_matches(od, rgb, dep, bank, T, thr, 0)
+    want = lo.canonical_sort_unique(raw)
+    rng = np.random.default_rng(sd)
+    for paths in [PATHS[0]] + [PATHS[i] for i in rng.choice(np.arange(1, len(PATHS)), 2, replace=False)]:
+        det = detector_on(lm, paths, nfeat[0], T, device=0)
+        det.addClassPacked("o", *bank)
+        same_records(det.matchArray([rgb, dep], thr, ["o"]), want)
+        tm = det.lastTimings()
+        assert (tm["coarse_candidates"], tm["local_evals"], tm["matches_pre_unique"]) == (st["coarse_candidates"], st["local_evals"], len(raw)), (case, paths)
+        for l in range(len(T)):                               # the quantised maps the match ran on
+            assert np.array_equal(det.readStage(l, 0).reshape(H >> l, W >> l), pyr[l][0]) and np.array_equal(det.readStage(l, 1).reshape(H >> l, W >> l), pyr[l][1]), (case, l)
+        for _ in range(3):                                    # and through the stream, three frames sharing a launch
+            det.submitFrame([rgb, dep], thr, ["o"])
+        for _ in range(3):
+            same_records(det.collect(), want)
+
+
 def test_sharded_equals_unsharded_on_one_device(lm):
     """N logical shards on one device through the same slice + merge code the multi-GPU path uses."""
     W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
