@@ -775,7 +775,7 @@ static __device__ __forceinline__ void top_bits_tile_body(const int ry, const Lm
     }
 }
 
-// The strip records of a level below the top from pixel tiles (T = 4 or 8, rows of a multiple of 16 pixels).  A workgroup takes a block of
+// The strip records of a level below the top from pixel tiles (T = 4, 5 or 8 — 5 is the reference's default step, LL.cpp:1663-1692 —, rows of a multiple of 16 pixels).  A workgroup takes a block of
 // R = 16 (or 8) rows of cells of one modality and one pixel-row phase rs; records are [label][phase][strip][row], so R rows of a
 // (label, phase, strip) are R x 8 contiguous bytes.
 //   A. a wave per row of cells, a lane per four dwords of the row: over the T pixel rows of the windows, the OR of T consecutive pixels starting

@@ -2,8 +2,8 @@
 // similarityLocal, LL.cpp:1788-1941 matchClass).  Pure integer byte work: every response is a
 // u8 in {0,1,4}, summed per template position.  Nothing here is a dense contraction, so no MFMA;
 // the linear memories of one frame (1.2 MB coarse + 4.9 MB fine at VGA) live in L2 / Infinity
-// Cache; the kernels are bound by the vector-L1 access rate (see "Gather discipline" below), not by
-// HBM and not by arithmetic.
+// Cache; the byte kernels (k_coarse, k_local) are bound by the vector-L1 access rate (see "Gather discipline" below), the bit-plane refinement
+// (k_local_bits, the default) by the number of 16-byte wave loads it issues — not by HBM and not by arithmetic.
 //
 // Data layout (built by frontend.hip / detector.cpp, offsets in FrameGeom):
 //   LM arena: per level, per modality: u8 [8 labels][T*T phases][(W/T)*(H/T)] + zero tail.
@@ -991,6 +991,10 @@ k_pack_bits(BitsBatch B, uint32_t sm_off0, uint32_t records, int NS, int Hd) {
 // origin, strip carry) and shift amounts; the group's lanes pick them up with two ds_bpermute per feature and add only their own row term.
 // Per lane and feature: 1 add, 2 v_alignbit, 5 adder operations (two dwords x 2.5).  Counters of kN = 4 + kHi bits: kHi = 5 serves entries
 // of up to 511 features, kHi = 10 up to 16383 (the reference allows 8191 per modality, LL.cpp:1291, 1816).
+// What bounds it (round 5, profiles/r05_local_sharing/README.txt): the number of wave loads — one takes 20-23 CU cycles whatever the lanes or addresses —, and
+// what keeps its L2 traffic down is that the 8 candidates of a wave are CONSECUTIVE candidates of one template (x-neighbours: ~5 distinct lines per wave load
+// instead of 23).  Three schemes that share loads between neighbouring candidates by regrouping them (vertical runs, interleaved pairs, same-lane pairs) were
+// built, bit-exact, and ran no faster: fewer wave loads, more L2 requests.  Hence: candidates in slot order, a grid of the resident workgroups.
 // All pyramid levels below the top are walked here (LL.cpp:1855: level by level, dropping a candidate as soon as it falls below the
 // threshold); a candidate whose windows leave their planes at some level (oversized template, features outside the frame) is marked in
 // `todo` and left, from the top, to k_local's per-candidate path.
