@@ -1490,7 +1490,7 @@ static int run_frontend_batch(lm_detector* d, int first, int nb, hipStream_t s, 
     return LM_OK;
 }
 
-// The bit-plane refinement (match.hip, DESIGN section 3.6): any pyramid with a level below the top; entries of up to 16383 features (two
+// The bit-plane refinement (match.hip, DESIGN section 3.1): any pyramid with a level below the top; entries of up to 16383 features (two
 // modalities of the reference's 8191, LL.cpp:1291).  LM_BITPLANES=0 / lm_detector_set_paths: the byte paths.
 static bool bits_active(const lm_detector* d, int num_work) {
     return knobs().bitplanes && d->refine_mode == 0 && num_work > 0 && d->geom.levels >= 2 && d->bits_max_nf <= 16383;
@@ -1672,7 +1672,7 @@ int lm_launch_pending(lm_detector* d) {
     int rc;
     for (int b = 0; b < nb; ++b)
         if ((rc = frame_slot(d, (first + b) % lm_detector::kSlots, tiled, tile_cap, &fb.f[b]))) return rc;
-    hipStream_t ms = d->mstream, s = ms;                      // every kernel of a batch on the matching stream (DESIGN 3.3: one queue; the end of a stage is the start of the next)
+    hipStream_t ms = d->mstream, s = ms;                      // every kernel of a batch on the matching stream (DESIGN 3.5: one queue; the end of a stage is the start of the next)
     // the frames' uploads (copy stream) before the front end
     for (int b = nb - 1; b >= 0; --b) {                       // (the copy stream is one in-order queue: the upload of the batch's last streamed frame covers the earlier ones)
         const int ring = d->slot[(first + b) % lm_detector::kSlots].ring;

@@ -163,7 +163,7 @@ struct lm_detector {
         std::shared_ptr<std::vector<int32_t>> work_cls, work_tid;
         std::chrono::steady_clock::time_point t0, t1;
     } slot[kSlots];
-    // Bit planes (match.hip, DESIGN section 3.6): both matching kernels read 1-bit response planes by default.
+    // Bit planes (match.hip, DESIGN section 3.1): both matching kernels read 1-bit response planes by default.
     DevBuf<uint8_t> cbits_arena[kSlots];            // pair stream of the top level's flat memories (k_coarse_bits)
     uint32_t cbits_byte0 = 0, cbits_npairs = 0;     // ... = arena bytes [byte0, byte0 + 32 npairs): the top level's two blocks with their zero tails
     DevBuf<uint8_t> bits_arena[kSlots];             // strip records of the levels below the top (the strip arena's layout at half the offsets; k_local_bits)

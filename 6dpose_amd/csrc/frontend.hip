@@ -544,7 +544,7 @@ void launch_build_lm(const uint8_t* const quant[2], const uint8_t* const mask[2]
     hipLaunchKernelGGL(k_build_lm, dim3((Wd * Hd + 255) / 256, T * T, 2), dim3(256), 0, s, j0, j1, W, H, T, Wd, Hd, NS, div_magic((uint32_t)Wd), div_magic((uint32_t)T));
 }
 
-// ---- the bit planes written directly (DESIGN.md section 3.6) -------------------------------------------------------------------------------
+// ---- the bit planes written directly (DESIGN.md section 3.1) -------------------------------------------------------------------------------
 // When nothing reads the byte planes of a level (bit-plane kernels for both passes, every window inside its plane) the linear-memory
 // stage does not write them at all: 8 response bytes per position and encoding (flat + strip-major: 9.8 MB per VGA frame at level 0)
 // become 2 bits per position and label (2.5 MB), and k_pack_bits / k_pack_top disappear from the batch.

@@ -45,7 +45,7 @@ void fe_job_pyrdown(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
 void fe_job_nn_down2(FeJob& j, const uint8_t* src, uint8_t* dst, int W, int H);
 void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const lm[2], uint8_t* const strips[2],
                      int W, int H, int T);
-// the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip; DESIGN.md section 3.6)
+// the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip; DESIGN.md section 3.1)
 bool fe_bits_rows_possible(int W, int T);     // the level's rows fit the stage's LDS
 void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T, bool tiles);   // tiles: from pixel tiles where the geometry allows (T = 4 or 8, the row fits the LDS pool)
 // (the writer of whole dwords when the label planes start on 64-position boundaries — fe_top_bits_kind —, else, or when forced, the one that ORs
@@ -130,7 +130,7 @@ struct FrameBatch {
     FrameSlot f[kMaxBatch];
 };
 
-// Bit planes (match.hip; DESIGN.md section 3.6).  Levels below the top: per frame of a batch the strip arena the records are packed from
+// Bit planes (match.hip; DESIGN.md section 3.1).  Levels below the top: per frame of a batch the strip arena the records are packed from
 // (launch_pack_bits; the front end writes them itself when nothing reads the strip bytes) and its bit arena — the strip arena's layout at
 // half the offsets: per plane row and strip an 8-byte record of 32 cells x {is 1, is 4} instead of a 16-byte row.
 struct BitsBatch { const uint8_t* strips[kMaxBatch]; uint8_t* bits[kMaxBatch];

@@ -911,7 +911,7 @@ k_local(FrameBatch fb, FrameGeom g, const TemplEntry* __restrict__ entries, cons
     }
 }
 
-// ---- Bit planes (DESIGN.md section 3.6): the default encoding of the response memories for both matching kernels --------------------------
+// ---- Bit planes (DESIGN.md section 3.1): the default encoding of the response memories for both matching kernels --------------------------
 // A response is 0, 1 or 4, so a position's sum is n1 + 4 n4 with n1 / n4 = the number of features whose response there is 1 / 4: two bits
 // per cell carry what the byte planes do, and the sums can be kept BIT-SLICED (one dword = 32 positions of one counter bit), features
 // entering through carry-save adders; integers are formed once per candidate / only for the hits.

@@ -573,7 +573,7 @@ def main():
                     "valu_per_lane_feature": per,
                     "useful_valu_frac": USEFUL_ADDER_OPS_PER_LANE_FEATURE / per,
                     "useful_valu_frac_with_window_shifts": (USEFUL_ADDER_OPS_PER_LANE_FEATURE + ALIGN_OPS_PER_LANE_FEATURE) / per,
-                    "useful_valu_note": "adder operations the bit-sliced sums need per lane and feature (5.0: ISA of the 16-feature loop body, DESIGN.md 3.6) over the "
+                    "useful_valu_note": "adder operations the bit-sliced sums need per lane and feature (5.0: ISA of the 16-feature loop body, DESIGN.md 3.1) over the "
                                         "wave-level VALU instructions measured per lane and feature (SQ_INSTS_VALU / (pairs / 8)); round 3's kernel: 10 of 33",
                     "what_bounds_it": "the number of wave loads: a wave load of k_local_bits (8 candidates x 128 contiguous bytes = 1 KB) takes 20-23 CU cycles whatever "
                                       "the lanes or addresses (`cu_cycles_per_wave_load`; 16 = the 64 B per cycle of the L1 -> register path, `ceilings.l1_data`), with "
@@ -795,7 +795,7 @@ def pmc_live(kernels, args, timeout=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-# VALU instructions per lane and feature the bit-sliced sums need (ISA of k_local_bits' 16-feature loop body, DESIGN.md section 3.6): two dwords x
+# VALU instructions per lane and feature the bit-sliced sums need (ISA of k_local_bits' 16-feature loop body, DESIGN.md section 3.1): two dwords x
 # 2.5 adder operations (7 carry-save adders per 8 inputs, one more per 16, a 5-level ripple per 16: 40 v_bitop3 per dword and 16 features)
 USEFUL_ADDER_OPS_PER_LANE_FEATURE = 5.0
 ALIGN_OPS_PER_LANE_FEATURE = 2.0      # + the two v_alignbit that cut the lane's two window rows out of their records

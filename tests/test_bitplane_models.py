@@ -1,6 +1,6 @@
 """The numpy models of the bit-plane kernels (profiles/bitplane_model.py: k_pack_bits + k_local_bits; profiles/bitplane_coarse_model.py: the
 coarse pass of make CBITS=1) against the byte evaluation and the oracle, on a sample of the bench workload.  CPU only: they state the
-layouts and the lane-level algorithms the HIP kernels implement (DESIGN.md section 3.6)."""
+layouts and the lane-level algorithms the HIP kernels implement (DESIGN.md section 3.1)."""
 import os
 import subprocess
 import sys

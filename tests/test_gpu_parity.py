@@ -153,7 +153,7 @@ def _pair_stream(lm_colour, lm_normal, T, Wd, Hd, npairs):
 
 @pytest.mark.parametrize("case", ["T48", "T58", "3level", "1280", "small_T24", "masked", "masked_T58"])
 def test_bit_planes_equal_the_packed_linear_memories(lm, case):
-    """The encodings the bit-plane kernels read (DESIGN 3.6) — strip records of every level below the top, pair stream of the top level —
+    """The encodings the bit-plane kernels read (DESIGN 3.1) — strip records of every level below the top, pair stream of the top level —
     bit for bit against a numpy packing of the ORACLE's linear memories, as written directly by the front end (k_fe_bits: strip records from
     LDS cell words; the pair stream as whole dwords, or OR-ed together from shifted ballots) and as packed from the byte planes (k_pack_bits /
     k_pack_top)."""
