@@ -801,6 +801,38 @@ def test_pipelined_submit_collect_equals_synchronous(lm):
         assert g.tobytes() == want[fi].tobytes()
 
 
+@pytest.mark.parametrize("mode", ["no_helpers", "one_cpu", "many_helpers"])
+def test_stream_with_and_without_helper_threads(lm, mode):
+    """The helper threads of the streamed path (HostPool: sliced staging copy, result lists of a batch's later frames) are an optimisation the results
+    never depend on: none at all (LM_HOST_THREADS=0), a process that may run on ONE CPU (the pool shrinks to nothing: never more helpers than the CPUs
+    the process may use leave free), and more helpers asked for than the default — the same lists as the synchronous call, batches shared."""
+    W, H, T, nfeat = 640, 480, [4, 8], (150, 75)
+    frames = [synth.make_frame(170 + i, W, H) for i in range(10)]
+    od = lo.OracleDetector(nfeat[0], T)
+    pyr = od.quantize_pyramid(*frames[0])
+    bank = synth.make_planted_bank(72, 100, [(p[0], p[1]) for p in pyr], T, nfeat)
+    ref = lm.Detector(nfeat[0], T, device=0)
+    ref.addClassPacked("o", *bank)
+    want = [ref.matchArray(list(f), 70.0, ["o"]) for f in frames]
+    old_env, old_aff = os.environ.get("LM_HOST_THREADS"), os.sched_getaffinity(0)
+    try:
+        if mode == "no_helpers": os.environ["LM_HOST_THREADS"] = "0"
+        if mode == "many_helpers": os.environ["LM_HOST_THREADS"] = "7"
+        if mode == "one_cpu": os.sched_setaffinity(0, {min(old_aff)})
+        det = lm.Detector(nfeat[0], T, device=0)                 # the pool is sized when the detector is created / first used
+        det.addClassPacked("o", *bank)
+        det.setBatch(4)
+        for rep in range(2):
+            for f in frames: det.submitFrame(list(f), 70.0, ["o"])
+            for w in want:
+                assert det.collect().tobytes() == w.tobytes()
+        del det
+    finally:
+        os.sched_setaffinity(0, old_aff)
+        if old_env is None: os.environ.pop("LM_HOST_THREADS", None)
+        else: os.environ["LM_HOST_THREADS"] = old_env
+
+
 def test_live_stream_ingest_equals_synchronous_and_the_oracle(lm):
     """SURVEY §8f N4 proper: a NEW host frame per step (linemod_ros/detect.py:83-138, linemod_and_levelup_test.py:314-327)
     through lm_detector_submit_frame — pinned ring + copy stream, up to lm_detector_max_in_flight() frames in flight, every frame different —
