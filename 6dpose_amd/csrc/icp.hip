@@ -20,6 +20,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "icp_kernels.h"
 #include "knobs.h"
 #include "lm_kernels.h"
@@ -276,7 +278,6 @@ static __device__ __forceinline__ int grid_coord(double v, double mn, double inv
 __global__ void __launch_bounds__(256)
 k_icp_bbox(IcpBuffers B, int W, int H) {
     const int h = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x == 0) B.bar[h] = 0;       // the round counter of k_icp_persist
     if (B.st[h].status != 0) return;                              // slot without a detection (pipeline)
     const uint16_t* img = B.models + (size_t)B.in[h].model_slot * W * H;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
@@ -1198,8 +1199,8 @@ static __device__ __forceinline__ bool solve6(double (&M)[6][7], double (&x)[6])
 // Sum of 32 per-lane values over the wave with 32 shuffles instead of 6 x 32: every step halves the
 // number of values a lane carries (lanes whose bit `off` is set keep the upper half).  Afterwards lane l
 // holds the wave total of value (l >> 1).
-template <int N, int OFF>
-static __device__ __forceinline__ void reduce_halve(double (&v)[32], int lane) {
+template <int N, int OFF, int M>
+static __device__ __forceinline__ void reduce_halve(double (&v)[M], int lane) {
     const bool hi = (lane & OFF) != 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1215,6 +1216,15 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
     reduce_halve<2, 4>(v, lane);
     reduce_halve<1, 2>(v, lane);
     return v[0] + shfl_xor_d(v[0], 1);
+}
+// The same for 16 values per lane: afterwards lane l holds the wave total of value (l >> 2).
+static __device__ __forceinline__ double wave_reduce16(double (&v)[16], int lane) {
+    reduce_halve<8, 32>(v, lane);
+    reduce_halve<4, 16>(v, lane);
+    reduce_halve<2, 8>(v, lane);
+    reduce_halve<1, 4>(v, lane);
+    const double a = v[0] + shfl_xor_d(v[0], 2);
+    return a + shfl_xor_d(a, 1);
 }
 
 // One ICP evaluation of one source slice.  Prologue (evaluations >= 1, every workgroup of the hypothesis
@@ -1234,11 +1244,7 @@ static __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane
 //       exact lexicographic minimum of (d, original index); a point of class c (<= 2^c columns) has 2^c lanes, one column
 //       each, and all classes are walked in one sweep of the workgroup's lanes;
 // and the slice's 32 partial sums (21 JtJ upper + 6 Jtr + sum d^2 + count, padded) for the next prologue.
-// kPersist: called from the loop of k_icp_persist instead of once per launch — the slices' partial sums then travel through
-// agent-scope atomics (the workgroups of a hypothesis sit on different XCDs whose L2s are not coherent with each other) and
-// the fitness history lives in the workgroup (fit_hist / rmse_hist -> LDS) instead of IcpState.  Returns true when the
-// hypothesis is finished (converged, or evaluation max_iter done).
-template <bool kPersist>
+// Returns true when the hypothesis is finished (converged, or evaluation max_iter done).
 static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpState& S, const int h, const int it, const int Gprev, const int max_shift, TgtRec* s_tgt,
                                                      unsigned short* s_cs, int* s_q, unsigned char* s_cls, const double max_dist,
                                                      const int max_iter, const double rel_tol, double* fit_hist, double* rmse_hist) {
@@ -1293,11 +1299,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             for (int u = 0; u < 8; ++u) {
                 const int gg = grp + 8 * u;
                 a8[u] = 0.0;
-                if (gg < Gprev) {
-                    if (kPersist) a8[u] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (size_t)gg * 32 + k),
-                                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    else a8[u] = part[(size_t)gg * 32 + k];
-                }
+                if (gg < Gprev) a8[u] = part[(size_t)gg * 32 + k];
             }
             double v = 0;
 #pragma unroll
@@ -1319,7 +1321,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             bool stop = false;
             if (it > 1 && fabs(fit_hist[it & 1] - fit) < rel_tol && fabs(rmse_hist[it & 1] - rmse) < rel_tol) stop = true;
             if (it - 1 == max_iter) stop = true;
-            if (kPersist || g == 0) { fit_hist[(it - 1) & 1] = fit; rmse_hist[(it - 1) & 1] = rmse; }
+            if (g == 0) { fit_hist[(it - 1) & 1] = fit; rmse_hist[(it - 1) & 1] = rmse; }
             if (g == 0) {
                 S.fitness = fit; S.rmse = rmse; S.n_corr = ncorr;
                 if (stop) S.stop = 1;
@@ -1648,8 +1650,7 @@ static __device__ __forceinline__ bool icp_eval_body(const IcpBuffers& B, IcpSta
             const long long tn = (long long)__builtin_amdgcn_s_memtime();
             v = tid == 29 ? (double)(tn - t0) : tid == 30 ? (double)t_a2 : (double)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7]);
         }
-        if (kPersist) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = v;
+        *dst = v;
     }
     if (g == 0 && tid == 0) {      // shader-cycle split of workgroup 0 (diagnostics): prologue, staging+transform, queue, search, sums
         const long long t4 = (long long)__builtin_amdgcn_s_memtime();
@@ -1667,54 +1668,638 @@ k_icp_eval(IcpBuffers B, int it, int prev_slices, int max_shift, double max_dist
     const int h = blockIdx.y;
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
-    (void)icp_eval_body<false>(B, S, h, it, prev_slices, max_shift, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
+    (void)icp_eval_body(B, S, h, it, prev_slices, max_shift, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, S.fit_hist, S.rmse_hist);
 }
 
-// The same evaluations as ONE launch: grid (slices, hypotheses) as above, every workgroup loops over the ICP rounds of its
-// hypothesis and meets the other slices of that hypothesis at a counter in HBM between rounds (arrive: agent-scope release
-// add after the slice's partial sums are stored; wait: acquire loads until all G slices of the round are there).  A hypothesis
-// that has converged leaves — after 6.5 rounds on average on the pipeline's workload, where the launch-per-round scheme
-// always pays for max_iter + 2 = 32 launches of ~10 us even when every hypothesis has stopped.  Workgroups are dispatched in
-// linear order (slices of hypothesis 0 first), so the hypotheses whose slices are resident always include complete ones:
-// waiting slices cannot starve the ones they wait for.  A wait that exceeds kBarrierTimeout (another kernel holding the
-// GPU for that long) marks the hypothesis kIcpPersistTimeout; the host then repeats the run with one launch per round.
-constexpr long long kBarrierTimeout = 200ll * 100000;       // wall_clock64 ticks (100 MHz): 200 ms
-__global__ void __launch_bounds__(kSearchWG, 3)
-k_icp_persist(IcpBuffers B, double max_dist, int max_iter, double rel_tol) {
-    __shared__ TgtRec s_tgt[kSlabPts];
-    __shared__ __attribute__((aligned(16))) unsigned short s_cs[kSlabCells + 8];
-    __shared__ int s_q[kLoopQueue];
-    __shared__ unsigned char s_cls[kLoopQueue];
-    __shared__ double s_hist[4];
-    __shared__ int s_abort;
-    const int h = blockIdx.y;
+// ---- k_icp_team: RegistrationICP as ONE launch — a team of workgroups per hypothesis, every evaluation inside the kernel -----------
+// The sliced launches above pay, per evaluation, a kernel launch and five or six dependent global round trips (the other slices'
+// partial sums, the points, their previous correspondences, the slab) for slices that hold ~32 points (profiles/r05_icp_account.txt:
+// 25-42 us per evaluation, 32 evaluations back to back).  Here nothing of a hypothesis leaves its CUs between the set-up and the final
+// state: every workgroup of the team keeps the whole target cloud (32-byte records, normals, certification radii) and the 16-bit
+// cell table in LDS for all evaluations, a source point lives in the registers of the thread that owns it (position, previous
+// correspondence, bound), the 29 sums are reduced inside the workgroup in a fixed order, and wave 0 — which owns no points —
+// finishes the evaluation (convergence test, 6x6 solve spread over its lanes, update).  The only traffic between the workgroups
+// of a team is the all-gather of their 29 partial sums per evaluation: agent-scope (sc1) stores of the sums, a drained flag per
+// workgroup, one poll instruction for all flags, G x 32 sc1 loads — ~1-2 us (MI355X_MICROARCH.md, hand-off price list) —, added
+// in workgroup order by every member, which then finishes the evaluation redundantly: no second exchange, identical updates.
+// Why a team and not one workgroup per hypothesis: measured (profiles/r06_icp_solo_first.txt), the updates of the bench's
+// hypotheses move the points by 5-20 mm per evaluation (sliding along the surface), so ~2100 points search in EVERY evaluation;
+// one CU needs 75-160 us for that, sixteen need 5-10.  A hypothesis stops on its own convergence and its CUs go idle.
+//
+// Which points must search.  The certification of k_icp_eval (4 d^2 < sep^2: the previous correspondence is closer than half the
+// distance to ITS nearest neighbour) holds for one point in ten at a voxel size of 2.5 mm.  A search here also leaves a bound
+// B = min(distance to the second nearest target it saw, radius it covered): every target other than the correspondence is at
+// least B away.  A rigid update moves a point by at most |R - I|_F * rho + |(R - I) c + t| (c, rho: centre and radius of the
+// workgroup's source points), and A = the sum of those bounds over the evaluations is kept by wave 0; a point whose
+// correspondence is at distance d1 now keeps it without a search while d1 < B - (A_now - A_at_search) — strict, so the
+// correspondence is the unique nearest target and index ties cannot arise.  While the updates are small the search radius is
+// d1 + a margin, so that B has room above d1; once a hypothesis settles only the points near a Voronoi boundary search.
+// Searching points go through a queue in LDS (ordered by cost class, 2^class lanes per point, one grid column per lane: the
+// sweep of k_icp_eval); the queue is worked off in windows when more points search than it holds.
+// A hypothesis whose clouds do not fit (slice > 3520 points, or target records + normals + table + a minimal queue > the LDS) is
+// left alone (stop stays 0): the host then runs the sliced launches for it.  So is one whose team waited kTeamTimeout for a
+// member (the GPU is shared and the grid was not resident at once).
+constexpr int kSoloWG = 768;                // 12 waves = 3 per SIMD: 168 VGPRs each (1024 threads: 128, and the points' state went to scratch)
+constexpr int kSoloOwners = kSoloWG - 64;   // threads that own source points (waves 1-11)
+constexpr int kSoloPts = 5;                 // source points per owner, in registers: n_src <= 3520
+constexpr int kSoloRaw = 160 * 1024 - 5120; // bytes of the carve-out (the rest: partial sums, update matrix, counters)
+constexpr int kSoloMinQueue = 128;          // the hypothesis is taken only if at least this many queue entries fit
+constexpr double kSoloMargin = 0.25;        // search radius beyond the previous correspondence, in units of max_dist
+constexpr long long kTeamTimeout = 100ll * 100000;          // wall_clock64 ticks (100 MHz): 100 ms
+struct __attribute__((aligned(8))) SoloQ { double x, y, z, bd; int bp; float lb; };   // a searching point: position, best squared distance so far, its target (-1: none); out: + bound
+
+static __device__ __forceinline__ double readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+static __device__ __forceinline__ double fast_rcp(double x) {      // v_rcp_f64 + two Newton steps (the IEEE division is ~40 dependent instructions)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
+// sin and cos of the small angles an ICP update consists of: Taylor polynomials below pi / 4 (truncation < 5e-17), libm beyond
+static __device__ __forceinline__ void sincos_small(const double a, double* sn, double* cs) {
+    if (fabs(a) < 0.78) {
+        const double z = a * a;
+        double s = -1.0 / 1307674368000.0;                          // x^15 / 15!
+        s = fma(s, z, 1.0 / 6227020800.0); s = fma(s, z, -1.0 / 39916800.0); s = fma(s, z, 1.0 / 362880.0); s = fma(s, z, -1.0 / 5040.0);
+        s = fma(s, z, 1.0 / 120.0); s = fma(s, z, -1.0 / 6.0);
+        *sn = fma(a * z, s, a);
+        double c = 1.0 / 20922789888000.0;                          // x^16 / 16!
+        c = fma(c, z, -1.0 / 87178291200.0); c = fma(c, z, 1.0 / 479001600.0); c = fma(c, z, -1.0 / 3628800.0); c = fma(c, z, 1.0 / 40320.0);
+        c = fma(c, z, -1.0 / 720.0); c = fma(c, z, 1.0 / 24.0); c = fma(c, z, -0.5);
+        *cs = fma(c, z, 1.0);
+    } else {
+        sincos(a, sn, cs);
+    }
+}
+
+// The 6x6 normal equations solved by ONE WAVE with the matrix spread over its lanes: lane 8 r + c holds [A | b](r, c) (r < 6, c < 7).
+// The algorithm of solve6 (partial pivoting, first largest pivot, one reciprocal per pivot), but a pivot step is a handful of
+// cross-lane reads instead of 35 dependent multiply-subtracts in one lane, and nothing of the matrix occupies registers of the
+// other waves.  `v`: lane k < 29 holds total k (21 JtJ upper, 6 Jtr, ..).
+static __device__ __forceinline__ bool solve6_lanes(const double v, const int lane, double (&x)[6]) {
+    const int r = lane >> 3, c = lane & 7;
+    const bool valid = r < 6 && c < 7;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int src = !valid ? 0 : c == 6 ? 21 + r : lo * 6 - ((lo * (lo - 1)) >> 1) + (hi - lo);
+    double a = __shfl(v, src, 64);
+    if (c == 6) a = -a;
+    if (!valid) a = 0.0;
+    bool ok = true;
+    double inv[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        double colp[6];
+#pragma unroll
+        for (int q = p; q < 6; ++q) colp[q] = readlane_d(a, 8 * q + p);
+        int piv = p;
+        double best = fabs(colp[p]), pp = colp[p];
+#pragma unroll
+        for (int q = p + 1; q < 6; ++q)
+            if (fabs(colp[q]) > best) { best = fabs(colp[q]); piv = q; pp = colp[q]; }
+        if (!(best > 0.0)) ok = false;
+        const int from = r == p ? piv : r == piv ? p : r;          // rows p and piv change places
+        a = __shfl(a, 8 * from + c, 64);
+        inv[p] = fast_rcp(pp);
+        const double f = __shfl(a, 8 * r + p, 64) * inv[p];
+        const double prow = __shfl(a, 8 * p + c, 64);
+        if (valid && r > p && c > p) a = fma(-f, prow, a);
+    }
+#pragma unroll
+    for (int q = 5; q >= 0; --q) {
+        double sacc = readlane_d(a, 8 * q + 6);
+#pragma unroll
+        for (int u = q + 1; u < 6; ++u) sacc = fma(-readlane_d(a, 8 * q + u), x[u], sacc);
+        x[q] = sacc * inv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ok = ok && isfinite(x[q]);
+    return ok;
+}
+
+// the products of one correspondence that the point-to-plane normal equations add up: HALF 0 = JtJ entries 0..15 (row-major upper
+// triangle), HALF 1 = JtJ 16..20, Jtr (6), d^2, 1 — two passes of 16 accumulators instead of one of 32 keep the registers for the points
+template <int HALF>
+static __device__ __forceinline__ void solo_accumulate(double (&acc)[16], const double px, const double py, const double pz, const TgtRec& q, const double* n3) {
+    const double nx = n3[0], ny = n3[1], nz = n3[2];
+    const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+    if (HALF == 0) {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) { if (k < 16) acc[k] = fma(J[a], J[b], acc[k]); ++k; }
+    } else {
+        const double bd = sqdist(px, py, pz, q.x, q.y, q.z);
+        const double r = (px - q.x) * nx + (py - q.y) * ny + (pz - q.z) * nz;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) { if (k >= 16) acc[k - 16] = fma(J[a], J[b], acc[k - 16]); ++k; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[5 + a] = fma(J[a], r, acc[5 + a]);
+        acc[11] += bd;
+        acc[12] += 1.0;
+    }
+}
+
+__global__ void __launch_bounds__(kSoloWG)
+k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int max_iter, double rel_tol) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSoloRaw];
+    __shared__ double s_part[kSoloWG / 64][32];
+    __shared__ double s_U[12];
+    __shared__ double s_T[12], s_hist[4], s_fin[2];             // wave 0's: transformation so far, fitness / rmse of the last two evaluations and of the last one
+    __shared__ double s_mot[6];                                  // A (motion bound summed over the evaluations), centre of the workgroup's source points, their radius
+    __shared__ long long s_clk[7];
+    __shared__ int s_cnt[kClasses];
+    __shared__ int s_stop, s_fin_i[2];
+    const int h = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     IcpState& S = B.st[h];
-    if (S.status != 0) return;                                  // the same for every slice of the hypothesis (set before this launch)
-    const unsigned int G = gridDim.x;
-    if (threadIdx.x == 0) s_abort = 0;
-    for (int it = 0; it <= max_iter + 1; ++it) {
-        if (it > 0) {                                           // evaluation it - 1 complete on every slice?
-            // The partial sums are agent-scope atomic stores and loads (they bypass the XCD-local caches), so the counter needs
-            // no release / acquire of its own — an agent-scope release is a write-back of the whole L2 (~30 us) — only that this
-            // slice's stores have completed: a wait on the memory counter before the workgroup barrier.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(&B.bar[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int want = G * (unsigned int)it;
-                const long long t0 = wall_clock64();
-                while (__hip_atomic_load(&B.bar[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (wall_clock64() - t0 > kBarrierTimeout) { s_abort = 1; break; }
-                }
-            }
-            __syncthreads();
-            if (s_abort) {
-                if (threadIdx.x == 0) __hip_atomic_store(&S.status, (int)kIcpPersistTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+    if (S.status != 0 || S.stop != 0) return;
+    const int ns = S.n_src, nt = S.n_tgt;
+    const int gx = S.gx, gy = S.gy, zq_max = S.zq_max, ncell = gx * gy;
+    // (every member of the team takes the same decision: it depends on the hypothesis only)
+    if ((ns + G - 1) / G > kSoloOwners * kSoloPts || nt > 8192 || ncell > kIcpCells - 1) return;
+    const int off_n = 32 * nt, off_sep = off_n + 24 * nt, off_cs = (off_sep + 4 * nt + 15) & ~15, off_q = (off_cs + 2 * (ncell + 1) + 15) & ~15;
+    if (off_q + kSoloMinQueue * (int)sizeof(SoloQ) > kSoloRaw) return;
+    const int Q = (kSoloRaw - off_q) / (int)sizeof(SoloQ);
+    const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);      // this workgroup's source points (voxel order: an x slab)
+    unsigned long long* xchg = B.xchg + ((size_t)h * kIcpMaxSplit) * 64;   // [parity: + count * kIcpMaxSplit * 64][member][64 granules {half of a sum, tag}]
+    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+
+    TgtRec* s_tgt = reinterpret_cast<TgtRec*>(s_raw);
+    double* s_nrm = reinterpret_cast<double*>(s_raw + off_n);
+    float* s_sep = reinterpret_cast<float*>(s_raw + off_sep);
+    unsigned short* s_cs = reinterpret_cast<unsigned short*>(s_raw + off_cs);
+    SoloQ* s_q = reinterpret_cast<SoloQ*>(s_raw + off_q);
+    {   // the target side, once: records, normals, certification radii (rounded down: a stricter test only searches more), cell table
+        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap);
+        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
+        for (int j = tid; j < nt * 2; j += kSoloWG) dst[j] = src[j];
+        const double* N = B.normals + (size_t)h * B.cap * 3;
+        for (int j = tid; j < nt * 3; j += kSoloWG) s_nrm[j] = N[j];
+        const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+        for (int j = tid; j < nt; j += kSoloWG) s_sep[j] = __double2float_rd(cov[(size_t)j * kIcpCovStride + 10]);
+        const uint4* csrc = reinterpret_cast<const uint4*>(B.cell_start16 + (size_t)h * kIcpCells16);
+        uint4* cdst = reinterpret_cast<uint4*>(s_cs);
+        for (int j = tid; j < (ncell + 8) / 8; j += kSoloWG) cdst[j] = csrc[j];
+        if (tid < kClasses) s_cnt[tid] = 0;
+    }
+    const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
+    const double r2 = max_dist * max_dist;
+    const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
+
+    // the source side: point i = i_lo + o + k * kSoloOwners belongs to owner o = tid - 64
+    const int o = tid - 64;
+    double px[kSoloPts], py[kSoloPts], pz[kSoloPts];
+    int prv[kSoloPts];
+    float lbf[kSoloPts];                                          // A at the last search + the bound that search left (every target other than prv is farther), rounded down
+    {
+        const double* Src = B.src + (size_t)h * B.cap * 3;
+        const double i0 = S.init[0], i1 = S.init[1], i2 = S.init[2];
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+#pragma unroll
+        for (int k = 0; k < kSoloPts; ++k) {
+            const int i = i_lo + o + k * kSoloOwners;
+            px[k] = 0; py[k] = 0; pz[k] = 0; prv[k] = -1; lbf[k] = 0.f;
+            if (o >= 0 && i < i_hi) {                              // pcd.Transform(init_guess)
+                const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
+                px[k] = 1.0 * x + 0.0 * y + 0.0 * z + i0;
+                py[k] = 0.0 * x + 1.0 * y + 0.0 * z + i1;
+                pz[k] = 0.0 * x + 0.0 * y + 1.0 * z + i2;
+                mn[0] = fmin(mn[0], px[k]); mn[1] = fmin(mn[1], py[k]); mn[2] = fmin(mn[2], pz[k]);
+                mx[0] = fmax(mx[0], px[k]); mx[1] = fmax(mx[1], py[k]); mx[2] = fmax(mx[2], pz[k]);
             }
         }
-        if (icp_eval_body<true>(B, S, h, it, (int)gridDim.x, 6, s_tgt, s_cs, s_q, s_cls, max_dist, max_iter, rel_tol, s_hist, s_hist + 2)) break;
+        // centre and radius of the source cloud (its bounding box: a rigid motion keeps |p - c|, c moves along in the finish stage)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { mn[q] = fmin(mn[q], shfl_xor_d(mn[q], off)); mx[q] = fmax(mx[q], shfl_xor_d(mx[q], off)); }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { s_part[wave][q] = mn[q]; s_part[wave][3 + q] = mx[q]; }
+        }
+    }
+    if (tid < 12) s_T[tid] = tid % 5 == 0 ? 1.0 : tid == 3 ? S.init[0] : tid == 7 ? S.init[1] : tid == 11 ? S.init[2] : 0.0;
+    if (tid < 4) s_hist[tid] = 0.0;
+    if (tid < 2) { s_fin[tid] = 0.0; s_fin_i[tid] = 0; }
+    if (tid < 7) s_clk[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double mn[3], mx[3], rho2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            mn[q] = s_part[1][q]; mx[q] = s_part[1][3 + q];
+            for (int w = 2; w < kSoloWG / 64; ++w) { mn[q] = fmin(mn[q], s_part[w][q]); mx[q] = fmax(mx[q], s_part[w][3 + q]); }
+            s_mot[1 + q] = 0.5 * (mn[q] + mx[q]);
+            rho2 += 0.25 * (mx[q] - mn[q]) * (mx[q] - mn[q]);
+        }
+        s_mot[0] = 0.0; s_mot[5] = 0.0;
+        s_mot[4] = sqrt(rho2) * (1.0 + 1e-9) + 1e-12;              // NaN for an empty / non-finite cloud: then no bound ever certifies
+    }
+    __syncthreads();
+
+    for (int it = 0;; ++it) {
+        const long long ta = (long long)__builtin_amdgcn_s_memtime();
+        // ---- finish evaluation it - 1: totals, Open3D's convergence test, ComputeTransformation, transformation = update * transformation ----
+        if (it > 0) {
+            if (wave == 0) {
+                // this workgroup's sums -> all-gather over the team -> the totals, added in workgroup order by every member
+                double v = 0;
+#pragma unroll
+                for (int w = 1; w < kSoloWG / 64; ++w) v += s_part[w][lane & 31];
+                bool timed_out = false;
+                const long long tx0 = (long long)__builtin_amdgcn_s_memtime();
+                if (G > 1) {
+                    // Tagged granules (MI355X_MICROARCH.md, hand-off price list): a sum travels as two 8-byte {half, tag} words, each written by ONE
+                    // sc1 store and valid by itself — no drained flag behind the data, no flag poll before the gather: the gather IS the poll.
+                    // tag = (run, evaluation): unique within the life of the buffer, so nothing is zeroed between runs; two buffers by
+                    // evaluation parity, because a member can be one evaluation ahead of the slowest reader of its granules, never two.
+                    const unsigned int tag = (run << 6) | (unsigned int)it;
+                    unsigned long long* mine = xchg + ((size_t)((it - 1) & 1) * B.count * kIcpMaxSplit + g) * 64;
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                    if (lane < 29) {
+                        __hip_atomic_store(mine + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(mine + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const unsigned long long* all = xchg + ((size_t)((it - 1) & 1) * B.count * kIcpMaxSplit) * 64;
+                    const long long t0w = wall_clock64();
+                    v = 0;
+                    for (int m0 = 0; m0 < G; m0 += 16) {              // 16 members (32 loads per lane) in flight at a time, added in member order
+                        unsigned long long lo[16], hi[16];
+                        for (;;) {
+                            bool miss = false;
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const int m = m0 + u < G ? m0 + u : G - 1;
+                                lo[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * (lane < 29 ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                hi[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * (lane < 29 ? lane : 0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) miss = miss || (unsigned int)(lo[u] >> 32) != tag || (unsigned int)(hi[u] >> 32) != tag;
+                            if (!__ballot(miss)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if (wall_clock64() - t0w > kTeamTimeout) { timed_out = true; break; }
+                        }
+                        if (timed_out) break;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (m0 + u < G) v += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                    }
+                }
+                if (lane == 0) s_clk[6] += (long long)__builtin_amdgcn_s_memtime() - tx0;
+                const int ncorr = (int)readlane_d(v, 28);
+                const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
+                const double rmse = ncorr ? sqrt(readlane_d(v, 27) / (double)ncorr) : 0.0;
+                bool stop = false;
+                const double fit2 = s_hist[it & 1], rmse2 = s_hist[2 + (it & 1)];       // of evaluation it - 2
+                if (it > 1 && fabs(fit2 - fit) < rel_tol && fabs(rmse2 - rmse) < rel_tol) stop = true;
+                if (it - 1 == max_iter) stop = true;
+                double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                if (!stop) {
+                    double x[6];
+                    if (ncorr >= 6 && solve6_lanes(v, lane, x)) {
+                        // the three sincos side by side in lanes 0-2
+                        double sn, cs;
+                        sincos_small(lane == 0 ? x[0] : lane == 1 ? x[1] : x[2], &sn, &cs);
+                        const double sx = readlane_d(sn, 0), cx = readlane_d(cs, 0), sy = readlane_d(sn, 1), cy = readlane_d(cs, 1), sz = readlane_d(sn, 2),
+                                     cz = readlane_d(cs, 2);
+                        // Rz(x2) * Ry(x1) * Rx(x0)
+                        U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
+                        U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
+                        U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int a = 0; a < 12; ++a) s_U[a] = U[a];
+                    s_stop = timed_out ? 2 : stop ? 1 : 0;
+                    s_hist[(it - 1) & 1] = fit; s_hist[2 + ((it - 1) & 1)] = rmse;
+                    s_fin[0] = fit; s_fin[1] = rmse; s_fin_i[0] = ncorr;
+                    if (!stop) s_fin_i[1] = it;
+                    // how far this update can move a point of the cloud: |R - I|_F * rho + |(R - I) c + t|; the centre moves along
+                    const double cx0 = s_mot[1], cy0 = s_mot[2], cz0 = s_mot[3];
+                    const double ncx = U[0] * cx0 + U[1] * cy0 + U[2] * cz0 + U[3], ncy = U[4] * cx0 + U[5] * cy0 + U[6] * cz0 + U[7],
+                                 ncz = U[8] * cx0 + U[9] * cy0 + U[10] * cz0 + U[11];
+                    double fro = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) { const double e = U[4 * a + b] - (a == b ? 1.0 : 0.0); fro += e * e; }
+                    const double step = sqrt(fro) * s_mot[4] + sqrt(sqdist(ncx, ncy, ncz, cx0, cy0, cz0));
+                    s_mot[0] += step * (1.0 + 1e-9) + 1e-12;
+                    s_mot[5] = step;
+                    s_mot[1] = ncx; s_mot[2] = ncy; s_mot[3] = ncz;
+                }
+                if (!stop && lane < 12) {                           // transformation = update * transformation: lane 4 r + c makes element (r, c)
+                    const int rr = lane >> 2, cc = lane & 3;
+                    const double tn = s_U[4 * rr] * s_T[cc] + s_U[4 * rr + 1] * s_T[4 + cc] + s_U[4 * rr + 2] * s_T[8 + cc] + (cc == 3 ? s_U[4 * rr + 3] : 0.0);
+                    s_T[lane] = tn;
+                }
+                if (lane < kClasses) s_cnt[lane] = 0;
+            }
+            __syncthreads();
+            if (s_stop) break;
+        }
+        if (it > max_iter) break;                                 // the last round only finishes evaluation max_iter
+        const long long tb = (long long)__builtin_amdgcn_s_memtime();
+
+        // ---- pcd.Transform(update), then which points must search ----
+        int cls[kSoloPts], rk[kSoloPts];
+        bool any = false;
+        const double A = s_mot[0];
+        // the room a search leaves above the correspondence it finds pays only when the updates are smaller than it (otherwise the next update voids the bound)
+        const double margin = s_mot[5] < 0.5 * kSoloMargin * max_dist ? kSoloMargin * max_dist : 0.0;
+        {
+            double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            if (it > 0) {
+#pragma unroll
+                for (int a = 0; a < 12; ++a) U[a] = s_U[a];
+            }
+#pragma unroll
+            for (int k = 0; k < kSoloPts; ++k) {
+                cls[k] = kClasses; rk[k] = 0;
+                if (o < 0 || i_lo + o + k * kSoloOwners >= i_hi) continue;
+                if (it > 0) {
+                    const double x = px[k], y = py[k], z = pz[k];
+                    px[k] = U[0] * x + U[1] * y + U[2] * z + U[3];
+                    py[k] = U[4] * x + U[5] * y + U[6] * z + U[7];
+                    pz[k] = U[8] * x + U[9] * y + U[10] * z + U[11];
+                }
+                const double room = ((double)lbf[k] - A) * (1.0 - 1e-9) - 1e-12;      // every target other than prv is farther than this (if positive)
+                bool need;
+                double rad, seed;
+                if (prv[k] >= 0) {
+                    const TgtRec q = s_tgt[prv[k]];
+                    const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
+                    need = !(d < r2 && ((room > 0.0 && d * (1.0 + 4e-9) < room * room) || 4.0 * d * (1.0 + 1e-9) < (double)s_sep[prv[k]]));
+                    seed = d < r2 ? d : r2;
+                    if (!(d < r2)) prv[k] = -2;                   // out of range now: searches max_dist (not the far margin), without a seed
+                } else {
+                    need = !(room > lb_need);                     // nearest target provably beyond max_dist: still no correspondence
+                    seed = far2;
+                }
+                if (need) {
+                    // A better start than the previous correspondence, which an update of several millimetres leaves far behind (the search
+                    // radius is the distance to the start): the targets of the point's own grid column next to its depth.  Any target will
+                    // do as a start — the search that follows is exact within the distance to it.
+                    {
+                        const int c = grid_coord(px[k], minx, inv, gx) * gy + grid_coord(py[k], miny, inv, gy);
+                        const int a = s_cs[c], b = s_cs[c + 1];
+                        if (b > a) {
+                            const int zq = zq_of(pz[k], minz, inv_z, zq_max);
+                            int lo = a, hi = b;                  // first target of the column at depth step >= zq
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_tgt[mid].zq < zq) lo = mid + 1; else hi = mid; }
+                            const int j0 = lo - 2 > a ? lo - 2 : a;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int j = j0 + v < b ? j0 + v : b - 1;
+                                const TgtRec q = s_tgt[j];
+                                const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
+                                if (d < seed && d < r2) { seed = d; prv[k] = j; }
+                            }
+                        }
+                    }
+                    rad = prv[k] >= 0 ? sqrt(seed) + margin : sqrt(seed);
+                    rad = rad * (1.0 + 1e-9) + 1e-12;
+                    const int nxc = grid_coord(px[k] + rad, minx, inv, gx) - grid_coord(px[k] - rad, minx, inv, gx) + 1;
+                    const int nyc = grid_coord(py[k] + rad, miny, inv, gy) - grid_coord(py[k] - rad, miny, inv, gy) + 1;
+                    const int ncol = nxc * nyc;
+                    cls[k] = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;   // lanes = 2^cls, one column each
+                    any = true;
+                }
+            }
+        }
+        // queue slots: rank inside the class over the workgroup — per wave one LDS atomic for all classes (lane c adds class c)
+        if (__ballot(any)) {
+            int wcnt[kClasses];
+#pragma unroll
+            for (int c = 0; c < kClasses; ++c) wcnt[c] = 0;
+#pragma unroll
+            for (int k = 0; k < kSoloPts; ++k)
+#pragma unroll
+                for (int c = 0; c < kClasses - 1; ++c) {
+                    const unsigned long long m = __ballot(cls[k] == c);
+                    if (cls[k] == c) rk[k] = wcnt[c] + __popcll(m & ((1ull << lane) - 1ull));
+                    wcnt[c] += __popcll(m);
+                }
+            int mine = 0;
+#pragma unroll
+            for (int c = 0; c < kClasses - 1; ++c) mine = lane == c ? wcnt[c] : mine;
+            int base = 0;
+            if (lane < kClasses && mine) base = atomicAdd(&s_cnt[lane], mine);
+#pragma unroll
+            for (int c = 0; c < kClasses - 1; ++c) {
+                const int bc = __builtin_amdgcn_readlane(base, c);
+#pragma unroll
+                for (int k = 0; k < kSoloPts; ++k) if (cls[k] == c) rk[k] += bc;
+            }
+        }
+        __syncthreads();
+        const long long tc = (long long)__builtin_amdgcn_s_memtime();
+
+        // ---- the searches: queue in class order, widest first; all classes in one sweep of the lanes ----
+        int cnt[kClasses], nq = 0;
+        long long d_scatter = 0, d_sweep = 0, d_read = 0;
+        int d_lanes = 0, d_shift = 0;
+#pragma unroll
+        for (int c = 0; c < kClasses; ++c) { cnt[c] = __builtin_amdgcn_readfirstlane(s_cnt[c]); nq += cnt[c]; }
+        if (nq > 0) {
+            int max_shift = shift_floor;                          // lanes per point: as many as keep the sweep within two passes of the workgroup
+#pragma unroll
+            for (int s = 4; s <= 6; ++s) {
+                int lanes = 0;
+#pragma unroll
+                for (int c = 0; c < kClasses; ++c) lanes += cnt[c] << (c < s ? c : s);
+                if (s > max_shift && lanes <= 2 * kSoloWG) max_shift = s;
+            }
+            int lane_end[kClasses], q_start[kClasses], total_lanes = 0, run = 0;
+#pragma unroll
+            for (int c = kClasses - 1; c >= 0; --c) {
+                q_start[c] = run; run += cnt[c];
+                total_lanes += cnt[c] << (c < max_shift ? c : max_shift);
+                lane_end[c] = total_lanes;
+            }
+            int pos[kSoloPts];
+#pragma unroll
+            for (int k = 0; k < kSoloPts; ++k) {
+                int qs = 0;
+#pragma unroll
+                for (int c = 0; c < kClasses; ++c) qs = cls[k] == c ? q_start[c] : qs;
+                pos[k] = cls[k] < kClasses ? qs + rk[k] : -1;
+            }
+            auto first_lane_of = [&](const int e) {               // queue position -> the first of its lanes
+                int lo = total_lanes;
+#pragma unroll
+                for (int c = kClasses - 1; c >= 0; --c) {
+                    const int first = c == kClasses - 1 ? 0 : lane_end[c + 1];
+                    if (e >= q_start[c] && e < q_start[c] + cnt[c]) lo = first + ((e - q_start[c]) << (c < max_shift ? c : max_shift));
+                }
+                return lo;
+            };
+            d_lanes = total_lanes; d_shift = max_shift;
+            for (int w0 = 0; w0 < nq; w0 += Q) {
+                const long long q0 = (long long)__builtin_amdgcn_s_memtime();
+                const int wend = w0 + Q < nq ? w0 + Q : nq;
+                if (w0 > 0) __syncthreads();                      // the previous window's results have been read
+#pragma unroll
+                for (int k = 0; k < kSoloPts; ++k)
+                    if (pos[k] >= w0 && pos[k] < wend) {              // the search starts from the previous correspondence if that is still in range
+                        SoloQ e;
+                        e.x = px[k]; e.y = py[k]; e.z = pz[k]; e.bd = prv[k] == -2 ? r2 : far2; e.bp = -1; e.lb = 0.f;
+                        if (prv[k] >= 0) {                            // (in range by construction: the previous correspondence or the start found above)
+                            const TgtRec q = s_tgt[prv[k]];
+                            e.bd = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
+                            e.bp = prv[k];
+                        }
+                        s_q[pos[k] - w0] = e;
+                    }
+                __syncthreads();
+                const long long q1 = (long long)__builtin_amdgcn_s_memtime();
+                const int tA = first_lane_of(w0) & ~63, tB = first_lane_of(wend);
+                for (int t0 = tA; t0 < tB; t0 += kSoloWG) {
+                    const int t = t0 + tid;
+                    int cq = 0, lane0 = lane_end[1], qs = q_start[0];
+#pragma unroll
+                    for (int c = kClasses - 1; c >= 1; --c) {
+                        const int first = c == kClasses - 1 ? 0 : lane_end[c + 1];
+                        if (t >= first && t < lane_end[c]) { cq = c; lane0 = first; qs = q_start[c]; }
+                    }
+                    const int lpp_shift = cq < max_shift ? cq : max_shift, lpp = 1 << lpp_shift;
+                    const int sub = (t - lane0) & (lpp - 1);
+                    const int e = qs + ((t - lane0) >> lpp_shift);
+                    const bool active = t < total_lanes && e >= w0 && e < wend;
+                    SoloQ& ent = s_q[active ? e - w0 : 0];
+                    const double qx = ent.x, qy = ent.y, qz = ent.z;
+                    double bd = ent.bd, b2 = 1e300;                 // best and second best squared distance (b2: over the targets other than bp)
+                    int bp = ent.bp;
+                    int bo = bp >= 0 ? s_tgt[bp].orig : INT_MAX;
+                    // the cube searched: every target within `reach` of the point lies in the columns it overlaps, cut to its depth range
+                    const double reach = bp >= 0 ? sqrt(bd) + margin : sqrt(bd);
+                    if (active && nt > 0 && qx == qx && qy == qy && qz == qz) {
+                        const double rad = reach * (1.0 + 1e-9) + 1e-12;
+                        const int xa = grid_coord(qx - rad, minx, inv, gx), xb = grid_coord(qx + rad, minx, inv, gx);
+                        const int ya = grid_coord(qy - rad, miny, inv, gy), yb = grid_coord(qy + rad, miny, inv, gy);
+                        const int zlo = zq_of(qz - rad, minz, inv_z, zq_max), zhi = zq_of(qz + rad, minz, inv_z, zq_max);
+                        const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
+                        const float inv_nxc = 1.0f / (float)nxc;
+                        for (int r = sub; r < ncol; r += lpp) {            // one column per lane and trip
+                            const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
+                            const int c = (xa + (r - yy * nxc)) * gy + ya + yy;
+                            int a = s_cs[c];
+                            const int b = s_cs[c + 1];
+                            if (b - a > 8) {                              // long run: first point at depth step >= zlo by bisection (the run is depth-ordered)
+                                int hi = b;
+                                while (a < hi) { const int mid = (a + hi) >> 1; if (s_tgt[mid].zq < zlo) a = mid + 1; else hi = mid; }
+                            }
+                            for (int j0 = a; j0 < b; j0 += 4) {           // four candidates per trip (independent LDS reads in flight)
+                                double d4[4];
+                                int j4[4], o4[4];
+                                bool more = true;
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    j4[v] = j0 + v < b ? j0 + v : b - 1;
+                                    const TgtRec rr = s_tgt[j4[v]];
+                                    d4[v] = sqdist(qx, qy, qz, rr.x, rr.y, rr.z);
+                                    o4[v] = rr.orig;
+                                    if (rr.zq > zhi) more = false;
+                                }
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    if (j4[v] == bp) continue;
+                                    if (d4[v] < bd || (d4[v] == bd && bp >= 0 && o4[v] < bo)) {
+                                        if (bp >= 0) b2 = fmin(b2, bd);
+                                        bd = d4[v]; bo = o4[v]; bp = j4[v];
+                                    } else b2 = fmin(b2, d4[v]);
+                                }
+                                if (!more) break;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {          // combine the lanes that shared the point (every lane makes every exchange)
+                        const double od = shfl_xor_d(bd, off), ob2 = shfl_xor_d(b2, off);
+                        const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
+                        if (off < lpp) {
+                            if (op >= 0 && (od < bd || (od == bd && oo < bo))) {
+                                if (bp >= 0 && bp != op) b2 = fmin(b2, bd);
+                                bd = od; bo = oo; bp = op;
+                            } else if (op >= 0 && op != bp) b2 = fmin(b2, od);
+                            b2 = fmin(b2, ob2);
+                        }
+                    }
+                    if (active && sub == 0) {
+                        if (bp >= 0 && !(bd < r2)) { b2 = fmin(b2, bd); bp = -1; }      // seen, but not a correspondence (d^2 < max_dist^2 required)
+                        if (bp < 0) b2 = fmin(b2, bd);               // without correspondence the bound is on every target (bd: the nearest seen, or the radius covered)
+                        const double bound = fmin(sqrt(b2), reach);  // every target other than bp is at least this far
+                        ent.bd = bd; ent.bp = bp; ent.lb = __double2float_rd(bound * (1.0 - 1e-9));
+                    }
+                }
+                __syncthreads();
+                const long long q2 = (long long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+                for (int k = 0; k < kSoloPts; ++k)
+                    if (pos[k] >= w0 && pos[k] < wend) {
+                        const SoloQ& e = s_q[pos[k] - w0];
+                        prv[k] = e.bp;
+                        lbf[k] = __double2float_rd((double)e.lb + A);
+                    }
+                d_scatter += q1 - q0; d_sweep += q2 - q1; d_read += (long long)__builtin_amdgcn_s_memtime() - q2;
+            }
+        }
+        const long long td = (long long)__builtin_amdgcn_s_memtime();
+
+        // ---- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences, reduced in a fixed order ----
+        bool has = false;
+#pragma unroll
+        for (int k = 0; k < kSoloPts; ++k) has = has || prv[k] >= 0;
+        if (!__ballot(has)) {                                     // a wave without correspondences (most waves of a team member): its sums are zero
+            if (lane < 32) s_part[wave][lane] = 0.0;
+        } else
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double acc[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int k = 0; k < kSoloPts; ++k) {
+                if (prv[k] < 0) continue;
+                const TgtRec q = s_tgt[prv[k]];
+                if (half == 0) solo_accumulate<0>(acc, px[k], py[k], pz[k], q, s_nrm + 3 * prv[k]);
+                else solo_accumulate<1>(acc, px[k], py[k], pz[k], q, s_nrm + 3 * prv[k]);
+            }
+            const double v = wave_reduce16(acc, lane);
+            if ((lane & 3) == 0) s_part[wave][half * 16 + (lane >> 2)] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const long long te = (long long)__builtin_amdgcn_s_memtime();
+            s_clk[0] += tb - ta; s_clk[1] += tc - tb; s_clk[2] += td - tc; s_clk[3] += te - td; s_clk[4] += nq; s_clk[5] += 1;
+            if (g == 0 && it < 32) {                             // per evaluation (read_debug kind 4, parity 0, row 32 + evaluation; B.partial is free while the team kernel runs)
+                double* row = B.partial + ((size_t)h * kIcpMaxSplit + 32 + it) * 32;
+#pragma unroll
+                for (int c = 0; c < kClasses; ++c) row[c] = (double)cnt[c];
+                row[8] = (double)d_lanes; row[9] = (double)d_shift; row[10] = (double)d_scatter; row[11] = (double)d_sweep; row[12] = (double)d_read;
+                row[13] = s_mot[0]; row[14] = (double)(tc - tb); row[15] = (double)(te - td); row[16] = (double)(tb - ta);
+            }
+        }
+    }
+    if (tid == 0 && g == 0 && s_stop != 2) {                    // (a team that timed out leaves stop == 0: the host runs the sliced launches)
+        for (int a = 0; a < 12; ++a) S.T[a] = s_T[a];
+        S.T[12] = 0.0; S.T[13] = 0.0; S.T[14] = 0.0; S.T[15] = 1.0;
+        S.fitness = s_fin[0]; S.rmse = s_fin[1]; S.n_corr = s_fin_i[0]; S.iterations = s_fin_i[1];
+        S.fit_hist[0] = s_hist[0]; S.fit_hist[1] = s_hist[1]; S.rmse_hist[0] = s_hist[2]; S.rmse_hist[1] = s_hist[3];
+        // diagnostics (shader cycles of wave 0 of member 0, which waits at the barriers for the other waves): exchange + finish, transform + queue, whole kernel, search, sums, evaluations, own searches, exchange alone
+        S.clk[0] += s_clk[0]; S.clk[1] += s_clk[1]; S.clk[2] += (long long)__builtin_amdgcn_s_memtime() - t_begin; S.clk[3] += s_clk[2]; S.clk[4] += s_clk[3];
+        S.clk[5] += s_clk[5]; S.clk[6] += s_clk[4]; S.clk[7] += s_clk[6];
+        S.stop = 1;
     }
 }
 
@@ -1755,8 +2340,35 @@ void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32
                        top_k);
 }
 
+// the sliced launches of evaluations [it_from, max_iter + 1]: evaluation `it` is finished (convergence test, solve, update) by the prologue
+// of launch it + 1.  The first evaluations have every hypothesis at work (768 workgroups = three per CU); by the sixth most have
+// converged and the ones that go on for all 30 are cut finer (their latency is what is left): 64 slices each
+static int icp_slices(int count, int it) {
+    const Knobs& kn = knobs();
+    int splits = 768 / count;                                        // enough workgroups to cover the chip, at least ~128 source points each at typical sizes
+    if (kn.icp_splits > 0) splits = kn.icp_splits;                     // tuning knob (profiles/)
+    if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
+    if (splits < 1) splits = 1;
+    return it < kIcpFineFrom || kn.icp_splits > 0 ? splits : kIcpMaxSplit;
+}
+
+void launch_icp_evals(const IcpBuffers& B, int count, int it_from, int it_to, double max_dist, int max_iter, double rel_tol, hipStream_t s) {
+    if (count <= 0) return;
+    const Knobs& kn = knobs();
+#ifdef LM_DIAG
+    if (kn.icp_maxiter_diag >= 0) max_iter = kn.icp_maxiter_diag;            // diagnostics only (profiles/): stop after a few evaluations
+#endif
+    if (it_to > max_iter + 1) it_to = max_iter + 1;
+    for (int it = it_from; it <= it_to; ++it) {
+        // lanes per searching point: at most 8 while every point searches (the first evaluations: more lanes only multiply the
+        // set-up), 16 afterwards (few searches left: their latency is what counts) — measured, profiles/r02_icp_experiments.txt
+        hipLaunchKernelGGL(k_icp_eval, dim3(icp_slices(count, it), count), dim3(kSearchWG), 0, s, B, it, it > 0 ? icp_slices(count, it - 1) : 1,
+                           it < kIcpFineFrom ? kn.icp_maxshift : kn.icp_maxshift_late, max_dist, max_iter, rel_tol);
+    }
+}
+
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
-                         double rel_tol, int knn, bool persistent, hipStream_t s) {
+                         double rel_tol, int knn, int solo_from, hipStream_t s) {
     if (count <= 0) return;
     const Knobs& kn = knobs();
 #ifdef LM_DIAG
@@ -1771,27 +2383,26 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
-    // splits per hypothesis: enough workgroups to cover the chip, at least ~128 source points each at typical sizes
-    int splits = 768 / count;
-    if (kn.icp_splits > 0) splits = kn.icp_splits;                     // tuning knob (profiles/)
-    if (splits > kIcpMaxSplit) splits = kIcpMaxSplit;
-    if (splits < 1) splits = 1;
-    if (persistent && B.bar) {
-        hipLaunchKernelGGL(k_icp_persist, dim3(splits, count), dim3(kSearchWG), 0, s, B, max_dist, max_iter, rel_tol);
+    if (solo_from != 0) {                                            // sliced launches only
+        launch_icp_evals(B, count, 0, max_iter + 1, max_dist, max_iter, rel_tol, s);
         return;
     }
-    // evaluation `it` is finished (convergence test, solve, update) by the prologue of launch it + 1
-    // the first evaluations have every hypothesis at work (768 workgroups = three per CU); by the sixth most have converged
-    // and the ones that go on for all 30 are cut finer (their latency is what is left): 64 slices each
-    int prev = splits;
-    for (int it = 0; it <= max_iter + 1; ++it) {
-        const int cur = it < kIcpFineFrom || kn.icp_splits > 0 ? splits : kIcpMaxSplit;
-        // lanes per searching point: at most 8 while every point searches (the first evaluations: more lanes only multiply the
-        // set-up), 16 afterwards (few searches left: their latency is what counts) — measured, profiles/r02_icp_experiments.txt
-        const int early = kn.icp_maxshift, late = kn.icp_maxshift_late;
-        hipLaunchKernelGGL(k_icp_eval, dim3(cur, count), dim3(kSearchWG), 0, s, B, it, prev, it < kIcpFineFrom ? early : late, max_dist, max_iter, rel_tol);
-        prev = cur;
-    }
+    // one launch for all evaluations: a team of workgroups per hypothesis, as many as the chip holds at once (one workgroup per CU: the
+    // team's members wait for each other, so the whole grid must be resident) — hypotheses k_icp_team cannot hold keep stop == 0 and
+    // the caller then runs launch_icp_evals for them
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
+        return n;
+    }();
+    int team = kn.icp_team > 0 ? kn.icp_team : 16;
+    if (team > cus / count) team = cus / count;
+    if (team > kIcpMaxSplit) team = kIcpMaxSplit;
+    if (team < 1) team = 1;
+    static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
+    unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+    if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+    hipLaunchKernelGGL(k_icp_team, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

@@ -28,12 +28,13 @@ struct lm_icp {
     IcpState* h_st = nullptr;      // pinned: the states uploaded before / read after a run
     IcpState* h_st2 = nullptr;     // pinned: read-back of lm_icp_run (h_st keeps the initial states for a repeated run)
     int h_cap = 0;
-    bool persist = false;          // LM_ICP_PERSIST=1: all ICP rounds in one launch (k_icp_persist: equal results; measured no faster than one launch
-                                   // per round — 1.79 vs 1.64 ms for 16 hypotheses — because a round's barrier costs what a launch costs); a barrier time-out turns it off
+    int solo_from = 0;             // 0: RegistrationICP as one launch (k_icp_team), the sliced launches only for hypotheses it leaves unfinished;
+                                   // -1 (LM_ICP_SLICED=1): one launch per evaluation (k_icp_eval, rounds 1-5)
 };
 
 
 // pose_refine.cpp
+bool lm_icp_unfinished(const lm::IcpState* st, int count);   // a hypothesis k_icp_solo left to the sliced launches (status 0, stop 0)
 int lm_icp_set_geometry(lm_icp* c, int W, int H);      // (re)allocates for a frame size; drops the slots when it changes
 int lm_icp_ensure_arenas(lm_icp* c, int count);        // arenas for `count` hypotheses
 int lm_icp_ensure_slots(lm_icp* c, int slots);         // resident model depth images

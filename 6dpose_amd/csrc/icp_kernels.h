@@ -33,7 +33,6 @@ enum IcpStatus {             // IcpState::status; every value has ONE meaning (t
     kIcpTooLarge = 3,        // cloud too large for 64-bit voxel keys
     kIcpNoDetection = 4,     // pipeline: hypothesis slot without a detection (k_icp_bind)
     kIcpNoView = 5,          // pipeline: the matched template has no rendered view (k_icp_bind)
-    kIcpPersistTimeout = 6,  // k_icp_persist gave up waiting for its other slices (the host repeats the run with one launch per round)
 };
 
 struct IcpState {            // one pose hypothesis (device-written, downloaded after the run)
@@ -80,13 +79,16 @@ struct IcpBuffers {
     double* strip_sum;       // [count][kIcpStrips][8] centroid sums per strip
     double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
-    unsigned int* bar;       // [count] rounds x slices that have arrived (k_icp_persist), zeroed by k_icp_bbox
+    unsigned long long* xchg;// [2][count][kIcpMaxSplit][64] the sums the members of a k_icp_team team publish: 8-byte granules {half of a sum, tag}
 };
 
 struct TopkSel;
 void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32_t* class_base, const float* view_K,
                      const int32_t* view_valid, int num_views, IcpIn* in, IcpState* st, int top_k, hipStream_t s);
+// solo_from == 0: RegistrationICP as one launch (k_icp_team: a team of workgroups per hypothesis, all evaluations inside); a hypothesis whose
+// clouds it cannot hold comes back with stop == 0 and the caller runs launch_icp_evals(0 .. max_iter + 1) for it.  Otherwise: sliced launches only.
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
-                         double rel_tol, int knn, bool persistent /*one launch for all ICP rounds (k_icp_persist)*/, hipStream_t s);
+                         double rel_tol, int knn, int solo_from, hipStream_t s);
+void launch_icp_evals(const IcpBuffers& B, int count, int it_from, int it_to, double max_dist, int max_iter, double rel_tol, hipStream_t s);
 
 }  // namespace lm

@@ -29,6 +29,7 @@ struct Knobs {
     int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: 2; lm_detector_set_batch_queue)
     int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: 64 workgroups per cloud up to 32 clouds, 32 beyond)
     int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
+    int icp_team = 0;              // LM_ICP_TEAM: workgroups per hypothesis of k_icp_team (0 = default: 16, at most CUs / hypotheses)
     int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
     int icp_maxshift_late = 4;
 #ifdef LM_DIAG
@@ -58,6 +59,7 @@ inline const Knobs& knobs() {
         v.fe_rows_cs = geti("LM_FE_ROWS_CS", 0);
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
+        v.icp_team = geti("LM_ICP_TEAM", 0);
         v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
         v.icp_maxshift_late = geti("LM_ICP_MAXSHIFT_LATE", v.icp_maxshift_late);
 #ifdef LM_DIAG

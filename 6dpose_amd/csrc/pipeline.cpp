@@ -240,7 +240,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
     int rc;
     if ((rc = lm_icp_ensure_arenas(c, top_k))) return rc;
     int overflows = 0;
-    for (;;) {                                                    // one pass normally; again after a candidate-buffer overflow (<= 3) or the one persist time-out
+    for (;;) {                                                    // one pass normally; again after a candidate-buffer overflow (<= 3) 
         HIP_TRY(hipEventRecord(p->e0, d->stream));
         if ((rc = lm_submit_frame(d, threshold, class_ids, num_class_ids))) return rc;
         // class position (caller's class_ids order, or sorted order) -> first view slot
@@ -268,7 +268,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         B.scene = d->cur_depth; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
         B.count = top_k;
         memcpy(B.sK, scene_K, sizeof(B.sK));
-        launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->persist, s);
+        launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, s);
         HIP_TRY(hipEventRecord(c->e1, s));
         HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)top_k * sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(p->h_sel, p->d_sel, (size_t)top_k * sizeof(TopkSel), hipMemcpyDeviceToHost, s));
@@ -281,11 +281,16 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
             continue;
         }
         if (rc) return rc;
-        bool timed_out = false;                                   // k_icp_persist gave up waiting for its other slices: one launch per round from now on
-        for (int i = 0; i < top_k; ++i) timed_out |= c->h_st[i].status == kIcpPersistTimeout;
-        if (!timed_out) break;
-        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected persist time-out status");
-        c->persist = false;                                       // its own retry, not counted as an overflow
+        if (lm_icp_unfinished(c->h_st, top_k)) {                  // clouds k_icp_team does not hold, or a team that timed out: the sliced launches run those hypotheses
+            if (c->solo_from != 0) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
+            launch_icp_evals(B, top_k, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, s);
+            HIP_TRY(hipEventRecord(c->e1, s));
+            HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)top_k * sizeof(IcpState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipGetLastError());
+            if (lm_icp_unfinished(c->h_st, top_k)) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
+        }
+        break;
     }
     if (p->h_nsel[1] != 0)
         return lm_set_error(LM_ERR_INVALID, "on-device NMS: a match field exceeds the packed record (template id >= 2^24, class position >= 128 or |x|,|y| >= 32768)");

@@ -45,7 +45,7 @@ namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.bar, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.xchg, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
@@ -94,7 +94,9 @@ int lm_icp_ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.cell_start16, (size_t)n * kIcpCells16 * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.keys, (size_t)n * 2 * cap2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&B.bar, (size_t)n * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc((void**)&B.xchg, (size_t)2 * n * lm::kIcpMaxSplit * 64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(B.xchg, 0, (size_t)2 * n * lm::kIcpMaxSplit * 64 * sizeof(unsigned long long)));      // tag 0 = never published (runs count from 1)
+    HIP_TRY(hipDeviceSynchronize());                                 // (the ICP stream does not wait for the null stream)
     HIP_TRY(hipMalloc((void**)&c->d_in, (size_t)n * sizeof(IcpIn)));
     HIP_TRY(hipMalloc((void**)&c->d_st, (size_t)n * sizeof(IcpState)));
     HIP_TRY(hipHostMalloc((void**)&c->h_in, (size_t)n * sizeof(IcpIn), hipHostMallocDefault));
@@ -164,6 +166,12 @@ void lm_icp_compose_result(const IcpState& st, const float* model_R, const float
     o.n_target = st.n_tgt;
 }
 
+bool lm_icp_unfinished(const IcpState* st, int count) {
+    for (int i = 0; i < count; ++i)
+        if (st[i].status == 0 && st[i].stop == 0) return true;
+    return false;
+}
+
 extern "C" int lm_icp_create(int device, lm_icp** out) {
     if (!out) return lm_set_error(LM_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -174,7 +182,7 @@ extern "C" int lm_icp_create(int device, lm_icp** out) {
     HIP_TRY(hipSetDevice(device));
     lm_icp* c = new lm_icp();
     c->device = device;
-    if (const char* e = getenv("LM_ICP_PERSIST")) c->persist = e[0] && e[0] != '0';
+    if (const char* e = getenv("LM_ICP_SLICED")) c->solo_from = e[0] && e[0] != '0' ? -1 : 0;
     if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->e0) != hipSuccess ||
         hipEventCreate(&c->e1) != hipSuccess) {
         delete c;
@@ -260,20 +268,19 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     B.scene = c->d_scene; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
     B.count = count;
     memcpy(B.sK, c->sK, sizeof(B.sK));
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
-        HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
-        HIP_TRY(hipEventRecord(c->e0, c->s));
-        launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->persist, c->s);
+    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
+    HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
+    HIP_TRY(hipEventRecord(c->e0, c->s));
+    launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, c->s);
+    for (int pass = 0; pass < 2; ++pass) {
         HIP_TRY(hipEventRecord(c->e1, c->s));
         HIP_TRY(hipMemcpyAsync(c->h_st2, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
         HIP_TRY(hipStreamSynchronize(c->s));
         HIP_TRY(hipGetLastError());
-        bool timed_out = false;
-        for (int i = 0; i < count; ++i) timed_out |= c->h_st2[i].status == kIcpPersistTimeout;
-        if (!timed_out) break;
-        if (!c->persist) return lm_set_error(LM_ERR_HIP, "ICP: unexpected persist time-out status");
-        c->persist = false;            // the persistent kernel waited too long for its other slices (GPU shared): one launch per round from now on
+        if (!lm_icp_unfinished(c->h_st2, count)) break;
+        // clouds k_icp_team does not hold (thousands of points per workgroup), or a team that timed out: the sliced launches run those hypotheses
+        if (pass == 1 || c->solo_from != 0) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
+        launch_icp_evals(B, count, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, c->s);
     }
     memcpy(c->h_st, c->h_st2, (size_t)count * sizeof(IcpState));
     c->last_count = count; c->last_flags = flags;
