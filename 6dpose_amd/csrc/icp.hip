@@ -1701,12 +1701,13 @@ k_icp_eval(IcpBuffers B, int it, int prev_slices, int max_shift, double max_dist
 // member (the GPU is shared and the grid was not resident at once).
 constexpr int kSoloWG = 768;                // 12 waves = 3 per SIMD: 168 VGPRs each (1024 threads: 128, and the points' state went to scratch)
 constexpr int kSoloOwners = kSoloWG - 64;   // threads that own source points (waves 1-11)
-constexpr int kSoloPts = 5;                 // source points per owner, in registers: n_src <= 3520
 constexpr int kSoloRaw = 160 * 1024 - 5120; // bytes of the carve-out (the rest: partial sums, update matrix, counters)
 constexpr int kSoloMinQueue = 128;          // the hypothesis is taken only if at least this many queue entries fit
 constexpr double kSoloMargin = 0.25;        // search radius beyond the previous correspondence, in units of max_dist
 constexpr long long kTeamTimeout = 100ll * 100000;          // wall_clock64 ticks (100 MHz): 100 ms
-struct __attribute__((aligned(8))) SoloQ { double x, y, z, bd; int bp; float lb; };   // a searching point: position, best squared distance so far, its target (-1: none); out: + bound
+// a searching point: position, best squared distance so far and its target (-1: none), and what to visit — the x rows of its cube as runs of
+// targets [ra, rb) (the columns of a row are consecutive cells), cum = chunks of four targets before a row; out: bd, bp, x = second best
+struct __attribute__((aligned(16))) SoloQ { double x, y, z, bd; int bp, chunks; unsigned short ra[8], rb[8], cum[8]; };
 
 static __device__ __forceinline__ double readlane_d(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -1809,6 +1810,7 @@ static __device__ __forceinline__ void solo_accumulate(double (&acc)[16], const 
     }
 }
 
+template <int KP>     // source points per owner thread, in registers
 __global__ void __launch_bounds__(kSoloWG)
 k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int max_iter, double rel_tol) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSoloRaw];
@@ -1825,7 +1827,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     const int ns = S.n_src, nt = S.n_tgt;
     const int gx = S.gx, gy = S.gy, zq_max = S.zq_max, ncell = gx * gy;
     // (every member of the team takes the same decision: it depends on the hypothesis only)
-    if ((ns + G - 1) / G > kSoloOwners * kSoloPts || nt > 8192 || ncell > kIcpCells - 1) return;
+    if ((ns + G - 1) / G > kSoloOwners * KP || nt > 8192 || ncell > kIcpCells - 1 || gx > 255 || gy > 255) return;
     const int off_n = 32 * nt, off_sep = off_n + 24 * nt, off_cs = (off_sep + 4 * nt + 15) & ~15, off_q = (off_cs + 2 * (ncell + 1) + 15) & ~15;
     if (off_q + kSoloMinQueue * (int)sizeof(SoloQ) > kSoloRaw) return;
     const int Q = (kSoloRaw - off_q) / (int)sizeof(SoloQ);
@@ -1857,15 +1859,15 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 
     // the source side: point i = i_lo + o + k * kSoloOwners belongs to owner o = tid - 64
     const int o = tid - 64;
-    double px[kSoloPts], py[kSoloPts], pz[kSoloPts];
-    int prv[kSoloPts];
-    float lbf[kSoloPts];                                          // A at the last search + the bound that search left (every target other than prv is farther), rounded down
+    double px[KP], py[KP], pz[KP];
+    int prv[KP];
+    float lbf[KP];                                          // A at the last search + the bound that search left (every target other than prv is farther), rounded down
     {
         const double* Src = B.src + (size_t)h * B.cap * 3;
         const double i0 = S.init[0], i1 = S.init[1], i2 = S.init[2];
         double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
 #pragma unroll
-        for (int k = 0; k < kSoloPts; ++k) {
+        for (int k = 0; k < KP; ++k) {
             const int i = i_lo + o + k * kSoloOwners;
             px[k] = 0; py[k] = 0; pz[k] = 0; prv[k] = -1; lbf[k] = 0.f;
             if (o >= 0 && i < i_hi) {                              // pcd.Transform(init_guess)
@@ -1931,27 +1933,33 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     }
                     const unsigned long long* all = xchg + ((size_t)((it - 1) & 1) * B.count * kIcpMaxSplit) * 64;
                     const long long t0w = wall_clock64();
+                    // lanes 0-31 gather members 0-7 of a group of 16, lanes 32-63 members 8-15 (16 loads per lane in flight); the sums are added
+                    // in member order inside a half, then first half + second half, group after group: the same order in every member of the team
+                    const int kk = (lane & 31) < 29 ? (lane & 31) : 0, half = lane >> 5;
                     v = 0;
-                    for (int m0 = 0; m0 < G; m0 += 16) {              // 16 members (32 loads per lane) in flight at a time, added in member order
-                        unsigned long long lo[16], hi[16];
+                    for (int m0 = 0; m0 < G; m0 += 16) {
+                        unsigned long long lo[8], hi[8];
                         for (;;) {
                             bool miss = false;
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) {
-                                const int m = m0 + u < G ? m0 + u : G - 1;
-                                lo[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * (lane < 29 ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                hi[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * (lane < 29 ? lane : 0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (int u = 0; u < 8; ++u) {
+                                const int m = m0 + half * 8 + u < G ? m0 + half * 8 + u : G - 1;
+                                lo[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                hi[u] = __hip_atomic_load(all + (size_t)m * 64 + 2 * kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) miss = miss || (unsigned int)(lo[u] >> 32) != tag || (unsigned int)(hi[u] >> 32) != tag;
+                            for (int u = 0; u < 8; ++u) miss = miss || (unsigned int)(lo[u] >> 32) != tag || (unsigned int)(hi[u] >> 32) != tag;
                             if (!__ballot(miss)) break;
                             __builtin_amdgcn_s_sleep(1);
                             if (wall_clock64() - t0w > kTeamTimeout) { timed_out = true; break; }
                         }
                         if (timed_out) break;
+                        double part = 0;
 #pragma unroll
-                        for (int u = 0; u < 16; ++u)
-                            if (m0 + u < G) v += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                        for (int u = 0; u < 8; ++u)
+                            if (m0 + half * 8 + u < G) part += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                        const double other = shfl_xor_d(part, 32);
+                        v += half == 0 ? part + other : other + part;      // (members 0-7) + (members 8-15), in both halves of the wave
                     }
                 }
                 if (lane == 0) s_clk[6] += (long long)__builtin_amdgcn_s_memtime() - tx0;
@@ -2012,11 +2020,15 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         const long long tb = (long long)__builtin_amdgcn_s_memtime();
 
         // ---- pcd.Transform(update), then which points must search ----
-        int cls[kSoloPts], rk[kSoloPts];
+        int cls[KP], rk[KP];
+        unsigned int box[KP];                                     // the columns a search visits (xa | ya << 8 | nxc << 16 | nyc << 24)
+        double seed[KP];                                          // squared distance the search starts from
         bool any = false;
         const double A = s_mot[0];
-        // the room a search leaves above the correspondence it finds pays only when the updates are smaller than it (otherwise the next update voids the bound)
-        const double margin = s_mot[5] < 0.5 * kSoloMargin * max_dist ? kSoloMargin * max_dist : 0.0;
+        // the room a search leaves above the correspondence it finds pays only when the updates are smaller than it (otherwise the next
+        // update voids the bound — then nothing is paid for bounds: no margin, and points without correspondence search max_dist, not beyond)
+        const bool calm = s_mot[5] < 0.5 * kSoloMargin * max_dist;
+        const double margin = calm ? kSoloMargin * max_dist : 0.0, none2 = calm ? far2 : r2;
         {
             double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
             if (it > 0) {
@@ -2024,8 +2036,8 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 for (int a = 0; a < 12; ++a) U[a] = s_U[a];
             }
 #pragma unroll
-            for (int k = 0; k < kSoloPts; ++k) {
-                cls[k] = kClasses; rk[k] = 0;
+            for (int k = 0; k < KP; ++k) {
+                cls[k] = kClasses; rk[k] = 0; box[k] = 0; seed[k] = none2;
                 if (o < 0 || i_lo + o + k * kSoloOwners >= i_hi) continue;
                 if (it > 0) {
                     const double x = px[k], y = py[k], z = pz[k];
@@ -2035,23 +2047,21 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 }
                 const double room = ((double)lbf[k] - A) * (1.0 - 1e-9) - 1e-12;      // every target other than prv is farther than this (if positive)
                 bool need;
-                double rad, seed;
                 if (prv[k] >= 0) {
                     const TgtRec q = s_tgt[prv[k]];
                     const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
                     need = !(d < r2 && ((room > 0.0 && d * (1.0 + 4e-9) < room * room) || 4.0 * d * (1.0 + 1e-9) < (double)s_sep[prv[k]]));
-                    seed = d < r2 ? d : r2;
-                    if (!(d < r2)) prv[k] = -2;                   // out of range now: searches max_dist (not the far margin), without a seed
+                    if (d < r2) seed[k] = d; else { seed[k] = r2; prv[k] = -1; }       // out of range now: searches max_dist, without a start
                 } else {
                     need = !(room > lb_need);                     // nearest target provably beyond max_dist: still no correspondence
-                    seed = far2;
                 }
                 if (need) {
                     // A better start than the previous correspondence, which an update of several millimetres leaves far behind (the search
                     // radius is the distance to the start): the targets of the point's own grid column next to its depth.  Any target will
                     // do as a start — the search that follows is exact within the distance to it.
+                    const int hx = grid_coord(px[k], minx, inv, gx), hy = grid_coord(py[k], miny, inv, gy);
                     {
-                        const int c = grid_coord(px[k], minx, inv, gx) * gy + grid_coord(py[k], miny, inv, gy);
+                        const int c = hx * gy + hy;
                         const int a = s_cs[c], b = s_cs[c + 1];
                         if (b > a) {
                             const int zq = zq_of(pz[k], minz, inv_z, zq_max);
@@ -2063,17 +2073,23 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                                 const int j = j0 + v < b ? j0 + v : b - 1;
                                 const TgtRec q = s_tgt[j];
                                 const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
-                                if (d < seed && d < r2) { seed = d; prv[k] = j; }
+                                if (d < seed[k] && d < r2) { seed[k] = d; prv[k] = j; }
                             }
                         }
                     }
-                    rad = prv[k] >= 0 ? sqrt(seed) + margin : sqrt(seed);
-                    rad = rad * (1.0 + 1e-9) + 1e-12;
-                    const int nxc = grid_coord(px[k] + rad, minx, inv, gx) - grid_coord(px[k] - rad, minx, inv, gx) + 1;
-                    const int nyc = grid_coord(py[k] + rad, miny, inv, gy) - grid_coord(py[k] - rad, miny, inv, gy) + 1;
+                    // every target within `reach` of the point lies in the columns overlapping the cube of that half-width, cut to its depth range
+                    const double reach = prv[k] >= 0 ? sqrt(seed[k]) + margin : sqrt(seed[k]);
+                    const double rad = reach * (1.0 + 1e-9) + 1e-12;
+                    const int xa = grid_coord(px[k] - rad, minx, inv, gx), xb = grid_coord(px[k] + rad, minx, inv, gx);
+                    const int ya = grid_coord(py[k] - rad, miny, inv, gy), yb = grid_coord(py[k] + rad, miny, inv, gy);
+                    const int nxc = xb - xa + 1, nyc = yb - ya + 1;
+                    box[k] = (unsigned int)xa | (unsigned int)ya << 8 | (unsigned int)nxc << 16 | (unsigned int)nyc << 24;
+                    // lanes = 2^cls, a chunk of four targets each; the class is set by the columns — a surface leaves about four targets in one — so that no
+                    // table is read here (the lanes take the chunks round robin, however many there are)
                     const int ncol = nxc * nyc;
-                    cls[k] = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;   // lanes = 2^cls, one column each
-                    any = true;
+                    cls[k] = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;
+                    any = px[k] == px[k] && py[k] == py[k] && pz[k] == pz[k] && nt > 0 ? true : any;
+                    if (!(px[k] == px[k] && py[k] == py[k] && pz[k] == pz[k] && nt > 0)) { cls[k] = kClasses; prv[k] = -1; lbf[k] = 0.f; }   // nothing to search
                 }
             }
         }
@@ -2083,7 +2099,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 #pragma unroll
             for (int c = 0; c < kClasses; ++c) wcnt[c] = 0;
 #pragma unroll
-            for (int k = 0; k < kSoloPts; ++k)
+            for (int k = 0; k < KP; ++k)
 #pragma unroll
                 for (int c = 0; c < kClasses - 1; ++c) {
                     const unsigned long long m = __ballot(cls[k] == c);
@@ -2099,7 +2115,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
             for (int c = 0; c < kClasses - 1; ++c) {
                 const int bc = __builtin_amdgcn_readlane(base, c);
 #pragma unroll
-                for (int k = 0; k < kSoloPts; ++k) if (cls[k] == c) rk[k] += bc;
+                for (int k = 0; k < KP; ++k) if (cls[k] == c) rk[k] += bc;
             }
         }
         __syncthreads();
@@ -2107,18 +2123,27 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 
         // ---- the searches: queue in class order, widest first; all classes in one sweep of the lanes ----
         int cnt[kClasses], nq = 0;
-        long long d_scatter = 0, d_sweep = 0, d_read = 0;
-        int d_lanes = 0, d_shift = 0;
+        long long d_scatter = 0, d_sweep = 0, d_read = 0, d_sw1 = 0, d_sw2 = 0, d_sw3 = 0;
+        int d_lanes = 0, d_shift = 0, d_rowlen = 0, d_rows = 0, d_nyc = 0;
 #pragma unroll
         for (int c = 0; c < kClasses; ++c) { cnt[c] = __builtin_amdgcn_readfirstlane(s_cnt[c]); nq += cnt[c]; }
         if (nq > 0) {
-            int max_shift = shift_floor;                          // lanes per point: as many as keep the sweep within two passes of the workgroup
-#pragma unroll
-            for (int s = 4; s <= 6; ++s) {
+            // lanes per point (2^min(class, max_shift)): a sweep costs its set-up however few columns a lane walks, so ONE sweep of the
+            // workgroup's lanes when the points allow it; many points (one workgroup per hypothesis): the schedule of k_icp_eval
+            auto lanes_at = [&](const int s) {
                 int lanes = 0;
 #pragma unroll
                 for (int c = 0; c < kClasses; ++c) lanes += cnt[c] << (c < s ? c : s);
-                if (s > max_shift && lanes <= 2 * kSoloWG) max_shift = s;
+                return lanes;
+            };
+            int max_shift = 0;
+            if (lanes_at(shift_floor) > kSoloWG) {
+                max_shift = shift_floor;
+#pragma unroll
+                for (int s = 4; s <= 6; ++s) if (s > max_shift && lanes_at(s) <= 2 * kSoloWG) max_shift = s;
+            } else {
+#pragma unroll
+                for (int s = 1; s <= 6; ++s) if (lanes_at(s) <= kSoloWG) max_shift = s;
             }
             int lane_end[kClasses], q_start[kClasses], total_lanes = 0, run = 0;
 #pragma unroll
@@ -2127,9 +2152,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 total_lanes += cnt[c] << (c < max_shift ? c : max_shift);
                 lane_end[c] = total_lanes;
             }
-            int pos[kSoloPts];
+            int pos[KP];
 #pragma unroll
-            for (int k = 0; k < kSoloPts; ++k) {
+            for (int k = 0; k < KP; ++k) {
                 int qs = 0;
 #pragma unroll
                 for (int c = 0; c < kClasses; ++c) qs = cls[k] == c ? q_start[c] : qs;
@@ -2150,15 +2175,22 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 const int wend = w0 + Q < nq ? w0 + Q : nq;
                 if (w0 > 0) __syncthreads();                      // the previous window's results have been read
 #pragma unroll
-                for (int k = 0; k < kSoloPts; ++k)
-                    if (pos[k] >= w0 && pos[k] < wend) {              // the search starts from the previous correspondence if that is still in range
+                for (int k = 0; k < KP; ++k)
+                    if (pos[k] >= w0 && pos[k] < wend) {
                         SoloQ e;
-                        e.x = px[k]; e.y = py[k]; e.z = pz[k]; e.bd = prv[k] == -2 ? r2 : far2; e.bp = -1; e.lb = 0.f;
-                        if (prv[k] >= 0) {                            // (in range by construction: the previous correspondence or the start found above)
-                            const TgtRec q = s_tgt[prv[k]];
-                            e.bd = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
-                            e.bp = prv[k];
+                        e.x = px[k]; e.y = py[k]; e.z = pz[k]; e.bd = seed[k]; e.bp = prv[k];
+                        const int xa = (int)(box[k] & 255u), ya = (int)(box[k] >> 8 & 255u), nxc = (int)(box[k] >> 16 & 255u), nyc = (int)(box[k] >> 24);
+                        int chunks = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {                     // (more than eight rows — a grid finer than the search radius allows — : one run from the first row's start to the last row's end)
+                            const bool on = r < nxc && nxc <= 8;
+                            int ra = 0, rb = 0;
+                            if (on) { const int c0 = (xa + r) * gy + ya; ra = s_cs[c0]; rb = s_cs[c0 + nyc]; }
+                            if (r == 0 && nxc > 8) { ra = s_cs[xa * gy + ya]; rb = s_cs[(xa + nxc - 1) * gy + ya + nyc]; }
+                            e.ra[r] = (unsigned short)ra; e.rb[r] = (unsigned short)rb; e.cum[r] = (unsigned short)chunks;
+                            chunks += (rb - ra + 3) >> 2;
                         }
+                        e.chunks = chunks;
                         s_q[pos[k] - w0] = e;
                     }
                 __syncthreads();
@@ -2166,6 +2198,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 const int tA = first_lane_of(w0) & ~63, tB = first_lane_of(wend);
                 for (int t0 = tA; t0 < tB; t0 += kSoloWG) {
                     const int t = t0 + tid;
+                    const long long w_0 = (long long)__builtin_amdgcn_s_memtime();
                     int cq = 0, lane0 = lane_end[1], qs = q_start[0];
 #pragma unroll
                     for (int c = kClasses - 1; c >= 1; --c) {
@@ -2181,75 +2214,100 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     double bd = ent.bd, b2 = 1e300;                 // best and second best squared distance (b2: over the targets other than bp)
                     int bp = ent.bp;
                     int bo = bp >= 0 ? s_tgt[bp].orig : INT_MAX;
-                    // the cube searched: every target within `reach` of the point lies in the columns it overlaps, cut to its depth range
-                    const double reach = bp >= 0 ? sqrt(bd) + margin : sqrt(bd);
-                    if (active && nt > 0 && qx == qx && qy == qy && qz == qz) {
-                        const double rad = reach * (1.0 + 1e-9) + 1e-12;
-                        const int xa = grid_coord(qx - rad, minx, inv, gx), xb = grid_coord(qx + rad, minx, inv, gx);
-                        const int ya = grid_coord(qy - rad, miny, inv, gy), yb = grid_coord(qy + rad, miny, inv, gy);
-                        const int zlo = zq_of(qz - rad, minz, inv_z, zq_max), zhi = zq_of(qz + rad, minz, inv_z, zq_max);
-                        const int nxc = xb - xa + 1, ncol = nxc * (yb - ya + 1);
-                        const float inv_nxc = 1.0f / (float)nxc;
-                        for (int r = sub; r < ncol; r += lpp) {            // one column per lane and trip
-                            const int yy = (int)(((float)r + 0.5f) * inv_nxc);       // r / nxc, exact for these small integers
-                            const int c = (xa + (r - yy * nxc)) * gy + ya + yy;
-                            int a = s_cs[c];
-                            const int b = s_cs[c + 1];
-                            if (b - a > 8) {                              // long run: first point at depth step >= zlo by bisection (the run is depth-ordered)
-                                int hi = b;
-                                while (a < hi) { const int mid = (a + hi) >> 1; if (s_tgt[mid].zq < zlo) a = mid + 1; else hi = mid; }
-                            }
-                            for (int j0 = a; j0 < b; j0 += 4) {           // four candidates per trip (independent LDS reads in flight)
-                                double d4[4];
-                                int j4[4], o4[4];
-                                bool more = true;
+                    const long long w_1 = (long long)__builtin_amdgcn_s_memtime() + (bo == 12345 ? 1 : 0);
+                    if (active) {
+                        // the four candidates of a chunk against the best so far — selects and bitwise logic only, and as a tree: the four first reduce
+                        // among themselves (two independent pairs), then once against the running best.  b2 collects every distance that does not
+                        // end up best, except a revisit of the start (same target)
+                        auto visit4 = [&](const int (&j4)[4], const double (&d4)[4], const int (&o4)[4]) {
+                            double cd[4], c2[2];
+                            int cj[4], co[4];
 #pragma unroll
-                                for (int v = 0; v < 4; ++v) {
-                                    j4[v] = j0 + v < b ? j0 + v : b - 1;
-                                    const TgtRec rr = s_tgt[j4[v]];
-                                    d4[v] = sqdist(qx, qy, qz, rr.x, rr.y, rr.z);
-                                    o4[v] = rr.orig;
-                                    if (rr.zq > zhi) more = false;
-                                }
-#pragma unroll
-                                for (int v = 0; v < 4; ++v) {
-                                    if (j4[v] == bp) continue;
-                                    if (d4[v] < bd || (d4[v] == bd && bp >= 0 && o4[v] < bo)) {
-                                        if (bp >= 0) b2 = fmin(b2, bd);
-                                        bd = d4[v]; bo = o4[v]; bp = j4[v];
-                                    } else b2 = fmin(b2, d4[v]);
-                                }
-                                if (!more) break;
+                            for (int v = 0; v < 4; ++v) {                   // a revisit of the running best, or of the slot before (the clamped tail), is no candidate
+                                const bool dup = (j4[v] == bp) | (v > 0 && j4[v] == j4[v > 0 ? v - 1 : 0]);
+                                cd[v] = dup ? 1e300 : d4[v]; cj[v] = j4[v]; co[v] = o4[v];
                             }
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {                   // pairs (0,1) and (2,3): winner in slot 2u, loser's distance in c2[u]
+                                const bool second = (cd[2 * u + 1] < cd[2 * u]) | ((cd[2 * u + 1] == cd[2 * u]) & (co[2 * u + 1] < co[2 * u]));
+                                c2[u] = second ? cd[2 * u] : cd[2 * u + 1];
+                                cd[2 * u] = second ? cd[2 * u + 1] : cd[2 * u]; cj[2 * u] = second ? cj[2 * u + 1] : cj[2 * u]; co[2 * u] = second ? co[2 * u + 1] : co[2 * u];
+                            }
+                            const bool second = (cd[2] < cd[0]) | ((cd[2] == cd[0]) & (co[2] < co[0]));
+                            const double lose = second ? cd[0] : cd[2];
+                            const double wd = second ? cd[2] : cd[0];
+                            const int wj = second ? cj[2] : cj[0], wo = second ? co[2] : co[0];
+                            double others = c2[0] < c2[1] ? c2[0] : c2[1];
+                            others = lose < others ? lose : others;
+                            const bool better = (wd < bd) | ((wd == bd) & (bp >= 0) & (wo < bo));    // (wd = 1e300: no candidate at all — never better)
+                            const double out = better ? (bp >= 0 ? bd : 1e300) : wd;
+                            others = out < others ? out : others;
+                            b2 = others < b2 ? others : b2;
+                            bd = better ? wd : bd; bo = better ? wo : bo; bp = better ? wj : bp;
+                        };
+                        const int chunks = ent.chunks;
+                        const uint4 w_ra = *reinterpret_cast<const uint4*>(ent.ra), w_rb = *reinterpret_cast<const uint4*>(ent.rb), w_cum = *reinterpret_cast<const uint4*>(ent.cum);
+                        const unsigned int a8[4] = {w_ra.x, w_ra.y, w_ra.z, w_ra.w}, b8[4] = {w_rb.x, w_rb.y, w_rb.z, w_rb.w}, c8[4] = {w_cum.x, w_cum.y, w_cum.z, w_cum.w};
+                        for (int q = sub; q < chunks; q += lpp) {          // one chunk of four targets per lane and trip
+                            int ra = (int)(a8[0] & 0xFFFFu), rb = (int)(b8[0] & 0xFFFFu), cu = 0;
+#pragma unroll
+                            for (int r = 1; r < 8; ++r) {                  // the row of chunk q: the last one whose first chunk is <= q (empty rows share their successor's)
+                                const int cr = (int)(r & 1 ? c8[r >> 1] >> 16 : c8[r >> 1] & 0xFFFFu);
+                                const bool in = q >= cr;
+                                ra = in ? (int)(r & 1 ? a8[r >> 1] >> 16 : a8[r >> 1] & 0xFFFFu) : ra;
+                                rb = in ? (int)(r & 1 ? b8[r >> 1] >> 16 : b8[r >> 1] & 0xFFFFu) : rb;
+                                cu = in ? cr : cu;
+                            }
+                            const int j0 = ra + 4 * (q - cu);
+                            double d4[4];
+                            int j4[4], o4[4];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {                   // (independent LDS reads in flight; the tail of a run repeats its last target)
+                                j4[v] = j0 + v < rb ? j0 + v : rb - 1;
+                                const TgtRec rr = s_tgt[j4[v]];
+                                d4[v] = sqdist(qx, qy, qz, rr.x, rr.y, rr.z);
+                                o4[v] = rr.orig;
+                            }
+                            visit4(j4, d4, o4);
                         }
                     }
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {          // combine the lanes that shared the point (every lane makes every exchange)
-                        const double od = shfl_xor_d(bd, off), ob2 = shfl_xor_d(b2, off);
-                        const int oo = __shfl_xor(bo, off, 64), op = __shfl_xor(bp, off, 64);
-                        if (off < lpp) {
-                            if (op >= 0 && (od < bd || (od == bd && oo < bo))) {
-                                if (bp >= 0 && bp != op) b2 = fmin(b2, bd);
-                                bd = od; bo = oo; bp = op;
-                            } else if (op >= 0 && op != bp) b2 = fmin(b2, od);
-                            b2 = fmin(b2, ob2);
-                        }
-                    }
+                    const long long w_2 = (long long)__builtin_amdgcn_s_memtime() + (bp == 123456789 ? 1 : 0);
+                    // combine the lanes that shared the point: an all-reduce over aligned groups of lpp lanes — inside a row of 16 lanes by DPP
+                    // (after the steps over 1 and 2 lanes a quad is uniform, after the half-row mirror a half row, ...), beyond it by permutes;
+                    // a wave whose widest group is narrower skips the rest (wave-uniform)
+                    auto merge = [&](const double od, const double ob2, const int oo, const int op, const bool in_group) {
+                        const bool take = in_group & (op >= 0) & ((od < bd) | ((od == bd) & (oo < bo)));
+                        const double second = take ? (((bp >= 0) & (bp != op)) ? bd : 1e300) : ((in_group & (op >= 0) & (op != bp)) ? od : 1e300);
+                        const double s2 = (second < ob2) | !in_group ? second : ob2;
+                        b2 = s2 < b2 ? s2 : b2;
+                        bd = take ? od : bd; bo = take ? oo : bo; bp = take ? op : bp;
+                    };
+                    if (__ballot(lpp > 1)) merge(dpp_mov<0xB1>(bd), dpp_mov<0xB1>(b2), dpp_mov<0xB1>(bo), dpp_mov<0xB1>(bp), lpp > 1);
+                    if (__ballot(lpp > 2)) merge(dpp_mov<0x4E>(bd), dpp_mov<0x4E>(b2), dpp_mov<0x4E>(bo), dpp_mov<0x4E>(bp), lpp > 2);
+                    if (__ballot(lpp > 4)) merge(dpp_mov<0x141>(bd), dpp_mov<0x141>(b2), dpp_mov<0x141>(bo), dpp_mov<0x141>(bp), lpp > 4);
+                    if (__ballot(lpp > 8)) merge(dpp_mov<0x140>(bd), dpp_mov<0x140>(b2), dpp_mov<0x140>(bo), dpp_mov<0x140>(bp), lpp > 8);
+                    if (__ballot(lpp > 16)) merge(shfl_xor_d(bd, 16), shfl_xor_d(b2, 16), __shfl_xor(bo, 16, 64), __shfl_xor(bp, 16, 64), lpp > 16);
+                    if (__ballot(lpp > 32)) merge(shfl_xor_d(bd, 32), shfl_xor_d(b2, 32), __shfl_xor(bo, 32, 64), __shfl_xor(bp, 32, 64), lpp > 32);
                     if (active && sub == 0) {
                         if (bp >= 0 && !(bd < r2)) { b2 = fmin(b2, bd); bp = -1; }      // seen, but not a correspondence (d^2 < max_dist^2 required)
                         if (bp < 0) b2 = fmin(b2, bd);               // without correspondence the bound is on every target (bd: the nearest seen, or the radius covered)
-                        const double bound = fmin(sqrt(b2), reach);  // every target other than bp is at least this far
-                        ent.bd = bd; ent.bp = bp; ent.lb = __double2float_rd(bound * (1.0 - 1e-9));
+                        ent.bd = bd; ent.bp = bp; ent.x = b2;        // (x: every lane of the point has read it)
                     }
+                    d_sw1 += w_1 - w_0; d_sw2 += w_2 - w_1; d_sw3 += (long long)__builtin_amdgcn_s_memtime() - w_2;
                 }
                 __syncthreads();
                 const long long q2 = (long long)__builtin_amdgcn_s_memtime();
 #pragma unroll
-                for (int k = 0; k < kSoloPts; ++k)
+                for (int k = 0; k < KP; ++k)
                     if (pos[k] >= w0 && pos[k] < wend) {
                         const SoloQ& e = s_q[pos[k] - w0];
+                        const bool had_start = prv[k] >= 0;
                         prv[k] = e.bp;
-                        lbf[k] = __double2float_rd((double)e.lb + A);
+                        lbf[k] = 0.f;
+                        if (calm) {                                   // every target other than the correspondence is at least this far: the second nearest seen, or the radius covered
+                            const double reach = had_start ? sqrt(seed[k]) + margin : sqrt(seed[k]);
+                            lbf[k] = __double2float_rd(fmin(sqrt(e.x), reach) * (1.0 - 1e-9) + A);
+                        }
                     }
                 d_scatter += q1 - q0; d_sweep += q2 - q1; d_read += (long long)__builtin_amdgcn_s_memtime() - q2;
             }
@@ -2259,7 +2317,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         // ---- JtJ / Jtr of TransformationEstimationPointToPlane over the correspondences, reduced in a fixed order ----
         bool has = false;
 #pragma unroll
-        for (int k = 0; k < kSoloPts; ++k) has = has || prv[k] >= 0;
+        for (int k = 0; k < KP; ++k) has = has || prv[k] >= 0;
         if (!__ballot(has)) {                                     // a wave without correspondences (most waves of a team member): its sums are zero
             if (lane < 32) s_part[wave][lane] = 0.0;
         } else
@@ -2269,7 +2327,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.0;
 #pragma unroll
-            for (int k = 0; k < kSoloPts; ++k) {
+            for (int k = 0; k < KP; ++k) {
                 if (prv[k] < 0) continue;
                 const TgtRec q = s_tgt[prv[k]];
                 if (half == 0) solo_accumulate<0>(acc, px[k], py[k], pz[k], q, s_nrm + 3 * prv[k]);
@@ -2288,6 +2346,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 for (int c = 0; c < kClasses; ++c) row[c] = (double)cnt[c];
                 row[8] = (double)d_lanes; row[9] = (double)d_shift; row[10] = (double)d_scatter; row[11] = (double)d_sweep; row[12] = (double)d_read;
                 row[13] = s_mot[0]; row[14] = (double)(tc - tb); row[15] = (double)(te - td); row[16] = (double)(tb - ta);
+                row[17] = (double)d_sw1; row[18] = (double)d_sw2; row[19] = (double)d_sw3; row[20] = (double)d_rowlen; row[21] = (double)d_rows; row[22] = (double)d_nyc;
             }
         }
     }
@@ -2402,7 +2461,11 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
     unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
     if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
-    hipLaunchKernelGGL(k_icp_team, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    // one source point per owner thread (slices of <= 704 points: every cloud of a few thousand points once the team has four members) keeps the
+    // kernel far inside its registers; batches so large that a team is one or two workgroups also get the five-points-per-thread build, which
+    // takes the hypotheses the first left (stop == 0) and costs ~2 us when there are none
+    hipLaunchKernelGGL(k_icp_team<1>, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (team < 4) hipLaunchKernelGGL(k_icp_team<5>, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

@@ -54,5 +54,5 @@ for sliced in (True, False):
                 if os.environ.get("TEAM_ROWS") and h in (0, 3):
                     for it in range(int(clk[5])):
                         r = rows[h][it]
-                        print("      eval %2d: classes %s lanes %4d shift %d | cycles: finish %6d move+queue %6d scatter %5d sweep %6d read %5d sums %6d | motion bound so far %.2f mm" % (
-                            it, [int(x) for x in r[:8]], r[8], r[9], r[16], r[14], r[10], r[11], r[12], r[15], r[13] * 1e3))
+                        print("      eval %2d: classes %s lanes %4d shift %d | cycles: finish %6d move+queue %6d scatter %5d sweep %6d (thread 0: set-up %d chunks %d merge %d) read %5d sums %6d | motion bound so far %.2f mm" % (
+                            it, [int(x) for x in r[:8]], r[8], r[9], r[16], r[14], r[10], r[11], r[17], r[18], r[19], r[12], r[15], r[13] * 1e3))
