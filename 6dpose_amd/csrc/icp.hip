@@ -1699,7 +1699,7 @@ k_icp_eval(IcpBuffers B, int it, int prev_slices, int max_shift, double max_dist
 // A hypothesis whose clouds do not fit (slice > 3520 points, or target records + normals + table + a minimal queue > the LDS) is
 // left alone (stop stays 0): the host then runs the sliced launches for it.  So is one whose team waited kTeamTimeout for a
 // member (the GPU is shared and the grid was not resident at once).
-constexpr int kSoloWG = 768;                // 12 waves = 3 per SIMD: 168 VGPRs each (1024 threads: 128, and the points' state went to scratch)
+constexpr int kSoloWG = 768;                // 12 waves = 3 per SIMD: 168 VGPRs each (1024 threads: 128, and the points' state went to scratch; 512: no more lanes than a search needs)
 constexpr int kSoloOwners = kSoloWG - 64;   // threads that own source points (waves 1-11)
 constexpr int kSoloRaw = 160 * 1024 - 5120; // bytes of the carve-out (the rest: partial sums, update matrix, counters)
 constexpr int kSoloMinQueue = 128;          // the hypothesis is taken only if at least this many queue entries fit
@@ -1708,6 +1708,17 @@ constexpr long long kTeamTimeout = 100ll * 100000;          // wall_clock64 tick
 // a searching point: position, best squared distance so far and its target (-1: none), and what to visit — the x rows of its cube as runs of
 // targets [ra, rb) (the columns of a row are consecutive cells), cum = chunks of four targets before a row; out: bd, bp, x = second best
 struct __attribute__((aligned(16))) SoloQ { double x, y, z, bd; int bp, chunks; unsigned short ra[8], rb[8], cum[8]; };
+
+constexpr unsigned long long kInfKey = 0x7FF0000000000000ull;   // +infinity as a distance key
+template <int CTRL> static __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, 0xF, 0xF, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, m, 64), hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 static __device__ __forceinline__ double readlane_d(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -1722,17 +1733,22 @@ static __device__ __forceinline__ double fast_rcp(double x) {      // v_rcp_f64 
     return r;
 }
 
+// A literal the compiler must materialise where it is used: as plain literals the f64 constants of the evaluation loop are hoisted out of
+// it into registers the kernel does not have, spilled, and reloaded from SCRATCH inside wave 0's chain (the polynomial below: 20 loads from
+// global memory per evaluation, ~3000 cycles; profiles/r06_finish_notes.txt).  A volatile asm is not moved.
+static __device__ __forceinline__ double here(double c) { asm volatile("" : "+v"(c)); return c; }
+
 // sin and cos of the small angles an ICP update consists of: Taylor polynomials below pi / 4 (truncation < 5e-17), libm beyond
 static __device__ __forceinline__ void sincos_small(const double a, double* sn, double* cs) {
     if (fabs(a) < 0.78) {
         const double z = a * a;
-        double s = -1.0 / 1307674368000.0;                          // x^15 / 15!
-        s = fma(s, z, 1.0 / 6227020800.0); s = fma(s, z, -1.0 / 39916800.0); s = fma(s, z, 1.0 / 362880.0); s = fma(s, z, -1.0 / 5040.0);
-        s = fma(s, z, 1.0 / 120.0); s = fma(s, z, -1.0 / 6.0);
+        double s = here(-1.0 / 1307674368000.0);                    // x^15 / 15!
+        s = fma(s, z, here(1.0 / 6227020800.0)); s = fma(s, z, here(-1.0 / 39916800.0)); s = fma(s, z, here(1.0 / 362880.0)); s = fma(s, z, here(-1.0 / 5040.0));
+        s = fma(s, z, here(1.0 / 120.0)); s = fma(s, z, here(-1.0 / 6.0));
         *sn = fma(a * z, s, a);
-        double c = 1.0 / 20922789888000.0;                          // x^16 / 16!
-        c = fma(c, z, -1.0 / 87178291200.0); c = fma(c, z, 1.0 / 479001600.0); c = fma(c, z, -1.0 / 3628800.0); c = fma(c, z, 1.0 / 40320.0);
-        c = fma(c, z, -1.0 / 720.0); c = fma(c, z, 1.0 / 24.0); c = fma(c, z, -0.5);
+        double c = here(1.0 / 20922789888000.0);                    // x^16 / 16!
+        c = fma(c, z, here(-1.0 / 87178291200.0)); c = fma(c, z, here(1.0 / 479001600.0)); c = fma(c, z, here(-1.0 / 3628800.0)); c = fma(c, z, here(1.0 / 40320.0));
+        c = fma(c, z, here(-1.0 / 720.0)); c = fma(c, z, here(1.0 / 24.0)); c = fma(c, z, -0.5);
         *cs = fma(c, z, 1.0);
     } else {
         sincos(a, sn, cs);
@@ -1755,15 +1771,21 @@ static __device__ __forceinline__ bool solve6_lanes(const double v, const int la
     double inv[6];
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
+        // the largest |a| of column p at or below the diagonal, the first one on equality: magnitudes compared as the integers their bit
+        // patterns are (sign bit cleared) — a dependent f64 compare + select costs a lone wave ~30 cycles, the integer pair a few
         double colp[6];
+        unsigned long long mag[6];
 #pragma unroll
-        for (int q = p; q < 6; ++q) colp[q] = readlane_d(a, 8 * q + p);
+        for (int q = p; q < 6; ++q) { colp[q] = readlane_d(a, 8 * q + p); mag[q] = (unsigned long long)__double_as_longlong(colp[q]) & 0x7FFFFFFFFFFFFFFFull; }
         int piv = p;
-        double best = fabs(colp[p]), pp = colp[p];
+        unsigned long long best = mag[p];
+        double pp = colp[p];
 #pragma unroll
-        for (int q = p + 1; q < 6; ++q)
-            if (fabs(colp[q]) > best) { best = fabs(colp[q]); piv = q; pp = colp[q]; }
-        if (!(best > 0.0)) ok = false;
+        for (int q = p + 1; q < 6; ++q) {
+            const bool gt = mag[q] > best && mag[q] <= 0x7FF0000000000000ull;   // (a NaN is never a pivot, as with fabs(..) > best)
+            best = gt ? mag[q] : best; piv = gt ? q : piv; pp = gt ? colp[q] : pp;
+        }
+        if (best == 0ull || best > 0x7FF0000000000000ull) ok = false;
         const int from = r == p ? piv : r == piv ? p : r;          // rows p and piv change places
         a = __shfl(a, 8 * from + c, 64);
         inv[p] = fast_rcp(pp);
@@ -1771,16 +1793,48 @@ static __device__ __forceinline__ bool solve6_lanes(const double v, const int la
         const double prow = __shfl(a, 8 * p + c, 64);
         if (valid && r > p && c > p) a = fma(-f, prow, a);
     }
+    // back substitution, column by column: once x[q] is known every right-hand side above it is updated at once (independent operations:
+    // two dependent ones per unknown instead of up to six)
+    double rhs[6], up[6][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        rhs[q] = readlane_d(a, 8 * q + 6);
+#pragma unroll
+        for (int u = q + 1; u < 6; ++u) up[q][u] = readlane_d(a, 8 * q + u);
+    }
 #pragma unroll
     for (int q = 5; q >= 0; --q) {
-        double sacc = readlane_d(a, 8 * q + 6);
+        x[q] = rhs[q] * inv[q];
 #pragma unroll
-        for (int u = q + 1; u < 6; ++u) sacc = fma(-readlane_d(a, 8 * q + u), x[u], sacc);
-        x[q] = sacc * inv[q];
+        for (int t = 0; t < q; ++t) rhs[t] = fma(-up[t][q], x[q], rhs[t]);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) ok = ok && isfinite(x[q]);
     return ok;
+}
+
+// TransformationEstimationPointToPlane::ComputeTransformation of one wave: the 6x6 solve, Rz * Ry * Rx and the translation -> U (3 x 4, row-major,
+// identity when there are fewer than six correspondences or the system is singular), written to `out` (LDS) by lane 0.  NOT inlined into
+// k_icp_team: inside the kernel's evaluation loop its constants are hoisted into registers the kernel does not have and come back from
+// scratch in the middle of wave 0's chain (~3000 cycles per evaluation; with 512 threads = 256 VGPRs the same code took 520).
+static __device__ __attribute__((noinline)) void team_update(const double v, const int ncorr, double* out) {
+    const int lane = threadIdx.x & 63;
+    double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double x[6];
+    if (ncorr >= 6 && solve6_lanes(v, lane, x)) {
+        // the three sincos side by side in lanes 0-2
+        double sn, cs;
+        sincos_small(lane == 0 ? x[0] : lane == 1 ? x[1] : x[2], &sn, &cs);
+        const double sx = readlane_d(sn, 0), cx = readlane_d(cs, 0), sy = readlane_d(sn, 1), cy = readlane_d(cs, 1), sz = readlane_d(sn, 2), cz = readlane_d(cs, 2);
+        // Rz(x2) * Ry(x1) * Rx(x0)
+        U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
+        U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
+        U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) out[a] = U[a];
+    }
 }
 
 // the products of one correspondence that the point-to-plane normal equations add up: HALF 0 = JtJ entries 0..15 (row-major upper
@@ -1818,7 +1872,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     __shared__ double s_U[12];
     __shared__ double s_T[12], s_hist[4], s_fin[2];             // wave 0's: transformation so far, fitness / rmse of the last two evaluations and of the last one
     __shared__ double s_mot[6];                                  // A (motion bound summed over the evaluations), centre of the workgroup's source points, their radius
-    __shared__ long long s_clk[7];
+    __shared__ long long s_clk[7], s_fclk[6];
     __shared__ int s_cnt[kClasses];
     __shared__ int s_stop, s_fin_i[2];
     const int h = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1855,6 +1909,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     }
     const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
     const double r2 = max_dist * max_dist;
+    const unsigned long long kr2 = (unsigned long long)__double_as_longlong(r2);
     const double far = max_dist * kFarMargin, far2 = far * far, lb_need = max_dist * (1.0 + 1e-9);
 
     // the source side: point i = i_lo + o + k * kSoloOwners belongs to owner o = tid - 64
@@ -1914,9 +1969,15 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         if (it > 0) {
             if (wave == 0) {
                 // this workgroup's sums -> all-gather over the team -> the totals, added in workgroup order by every member
-                double v = 0;
+                // (added as a tree: a chain of eleven dependent f64 additions is 440 cycles for a lone wave, four levels are 160; fixed order all the same)
+                double v;
+                {
+                    double pw[kSoloWG / 64 - 1];
 #pragma unroll
-                for (int w = 1; w < kSoloWG / 64; ++w) v += s_part[w][lane & 31];
+                    for (int w = 1; w < kSoloWG / 64; ++w) pw[w - 1] = s_part[w][lane & 31];
+                    static_assert(kSoloWG / 64 == 12, "the tree below adds the sums of eleven owner waves");
+                    v = (((pw[0] + pw[1]) + (pw[2] + pw[3])) + ((pw[4] + pw[5]) + (pw[6] + pw[7]))) + ((pw[8] + pw[9]) + pw[10]);
+                }
                 bool timed_out = false;
                 const long long tx0 = (long long)__builtin_amdgcn_s_memtime();
                 if (G > 1) {
@@ -1954,40 +2015,33 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                             if (wall_clock64() - t0w > kTeamTimeout) { timed_out = true; break; }
                         }
                         if (timed_out) break;
-                        double part = 0;
+                        double pm[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (m0 + half * 8 + u < G) part += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull)));
+                        for (int u = 0; u < 8; ++u) pm[u] = m0 + half * 8 + u < G ? __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xFFFFFFFFull))) : 0.0;
+                        const double part = ((pm[0] + pm[1]) + (pm[2] + pm[3])) + ((pm[4] + pm[5]) + (pm[6] + pm[7]));   // (a tree, as above)
                         const double other = shfl_xor_d(part, 32);
                         v += half == 0 ? part + other : other + part;      // (members 0-7) + (members 8-15), in both halves of the wave
                     }
                 }
                 if (lane == 0) s_clk[6] += (long long)__builtin_amdgcn_s_memtime() - tx0;
+                // ComputeTransformation first, Open3D's convergence test after it in program order: the two are independent chains of f64
+                // operations (the division and square root of the test alone are ~1000 cycles for a lone wave) and overlap this way; the
+                // update of an evaluation that turns out to be the last is computed in vain, once per hypothesis
+                const long long f0 = (long long)__builtin_amdgcn_s_memtime();
                 const int ncorr = (int)readlane_d(v, 28);
+                team_update(v, ncorr, s_U);
+                const long long f1 = (long long)__builtin_amdgcn_s_memtime(), f2 = f1;
+                double U[12];
+#pragma unroll
+                for (int a = 0; a < 12; ++a) U[a] = s_U[a];
                 const double fit = ncorr ? (double)ncorr / (double)ns : 0.0;
                 const double rmse = ncorr ? sqrt(readlane_d(v, 27) / (double)ncorr) : 0.0;
                 bool stop = false;
                 const double fit2 = s_hist[it & 1], rmse2 = s_hist[2 + (it & 1)];       // of evaluation it - 2
                 if (it > 1 && fabs(fit2 - fit) < rel_tol && fabs(rmse2 - rmse) < rel_tol) stop = true;
                 if (it - 1 == max_iter) stop = true;
-                double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-                if (!stop) {
-                    double x[6];
-                    if (ncorr >= 6 && solve6_lanes(v, lane, x)) {
-                        // the three sincos side by side in lanes 0-2
-                        double sn, cs;
-                        sincos_small(lane == 0 ? x[0] : lane == 1 ? x[1] : x[2], &sn, &cs);
-                        const double sx = readlane_d(sn, 0), cx = readlane_d(cs, 0), sy = readlane_d(sn, 1), cy = readlane_d(cs, 1), sz = readlane_d(sn, 2),
-                                     cz = readlane_d(cs, 2);
-                        // Rz(x2) * Ry(x1) * Rx(x0)
-                        U[0] = cz * cy; U[1] = cz * sy * sx - sz * cx; U[2] = cz * sy * cx + sz * sx; U[3] = x[3];
-                        U[4] = sz * cy; U[5] = sz * sy * sx + cz * cx; U[6] = sz * sy * cx - cz * sx; U[7] = x[4];
-                        U[8] = -sy;     U[9] = cy * sx;                U[10] = cy * cx;               U[11] = x[5];
-                    }
-                }
+                const long long f3 = (long long)__builtin_amdgcn_s_memtime() + (stop ? 1 : 0);
                 if (lane == 0) {
-#pragma unroll
-                    for (int a = 0; a < 12; ++a) s_U[a] = U[a];
                     s_stop = timed_out ? 2 : stop ? 1 : 0;
                     s_hist[(it - 1) & 1] = fit; s_hist[2 + ((it - 1) & 1)] = rmse;
                     s_fin[0] = fit; s_fin[1] = rmse; s_fin_i[0] = ncorr;
@@ -1996,11 +2050,12 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const double cx0 = s_mot[1], cy0 = s_mot[2], cz0 = s_mot[3];
                     const double ncx = U[0] * cx0 + U[1] * cy0 + U[2] * cz0 + U[3], ncy = U[4] * cx0 + U[5] * cy0 + U[6] * cz0 + U[7],
                                  ncz = U[8] * cx0 + U[9] * cy0 + U[10] * cz0 + U[11];
-                    double fro = 0.0;
+                    double e2[9];
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
 #pragma unroll
-                        for (int b = 0; b < 3; ++b) { const double e = U[4 * a + b] - (a == b ? 1.0 : 0.0); fro += e * e; }
+                        for (int b = 0; b < 3; ++b) { const double e = U[4 * a + b] - (a == b ? 1.0 : 0.0); e2[3 * a + b] = e * e; }
+                    const double fro = (((e2[0] + e2[1]) + (e2[2] + e2[3])) + ((e2[4] + e2[5]) + (e2[6] + e2[7]))) + e2[8];
                     const double step = sqrt(fro) * s_mot[4] + sqrt(sqdist(ncx, ncy, ncz, cx0, cy0, cz0));
                     s_mot[0] += step * (1.0 + 1e-9) + 1e-12;
                     s_mot[5] = step;
@@ -2012,6 +2067,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     s_T[lane] = tn;
                 }
                 if (lane < kClasses) s_cnt[lane] = 0;
+                if (lane == 0) { s_fclk[0] = f0 - ta; s_fclk[1] = f1 - f0; s_fclk[2] = f2 - f1; s_fclk[3] = f3 - f2; s_fclk[4] = (long long)__builtin_amdgcn_s_memtime() - f3; }
             }
             __syncthreads();
             if (s_stop) break;
@@ -2124,7 +2180,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         // ---- the searches: queue in class order, widest first; all classes in one sweep of the lanes ----
         int cnt[kClasses], nq = 0;
         long long d_scatter = 0, d_sweep = 0, d_read = 0, d_sw1 = 0, d_sw2 = 0, d_sw3 = 0;
-        int d_lanes = 0, d_shift = 0, d_rowlen = 0, d_rows = 0, d_nyc = 0;
+        int d_lanes = 0, d_shift = 0;
 #pragma unroll
         for (int c = 0; c < kClasses; ++c) { cnt[c] = __builtin_amdgcn_readfirstlane(s_cnt[c]); nq += cnt[c]; }
         if (nq > 0) {
@@ -2137,7 +2193,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 return lanes;
             };
             int max_shift = 0;
-            if (lanes_at(shift_floor) > kSoloWG) {
+            if (nq > kSoloWG) {
                 max_shift = shift_floor;
 #pragma unroll
                 for (int s = 4; s <= 6; ++s) if (s > max_shift && lanes_at(s) <= 2 * kSoloWG) max_shift = s;
@@ -2211,44 +2267,26 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const bool active = t < total_lanes && e >= w0 && e < wend;
                     SoloQ& ent = s_q[active ? e - w0 : 0];
                     const double qx = ent.x, qy = ent.y, qz = ent.z;
-                    double bd = ent.bd, b2 = 1e300;                 // best and second best squared distance (b2: over the targets other than bp)
+                    // Squared distances are compared and selected as the unsigned integers their bit patterns are (they are >= 0, so the order is the
+                    // same): a dependent f64 compare + select costs a lone wave ~30 cycles, the integer pair a few (profiles/r06_latency_microbench.txt).
+                    // kb: best so far, k2: second best (over the targets other than bp).  Equal distances (the lower ORIGINAL index wins) are not
+                    // resolved on this path: the chunk or the merge step that meets one is redone by the exact routine below (wave-uniform branch).
+                    unsigned long long kb = (unsigned long long)__double_as_longlong(ent.bd), k2 = kInfKey;
                     int bp = ent.bp;
-                    int bo = bp >= 0 ? s_tgt[bp].orig : INT_MAX;
-                    const long long w_1 = (long long)__builtin_amdgcn_s_memtime() + (bo == 12345 ? 1 : 0);
+                    const long long w_1 = (long long)__builtin_amdgcn_s_memtime() + (bp == 123456789 ? 1 : 0);
+                    auto exact_visit = [&](const int j, const unsigned long long k) {       // one candidate, ties by original index
+                        if (j == bp) return;
+                        const bool better = k < kb || (k == kb && bp >= 0 && s_tgt[j].orig < s_tgt[bp].orig);
+                        const unsigned long long second = better ? (bp >= 0 ? kb : kInfKey) : k;
+                        k2 = second < k2 ? second : k2;
+                        if (better) { kb = k; bp = j; }
+                    };
                     if (active) {
-                        // the four candidates of a chunk against the best so far — selects and bitwise logic only, and as a tree: the four first reduce
-                        // among themselves (two independent pairs), then once against the running best.  b2 collects every distance that does not
-                        // end up best, except a revisit of the start (same target)
-                        auto visit4 = [&](const int (&j4)[4], const double (&d4)[4], const int (&o4)[4]) {
-                            double cd[4], c2[2];
-                            int cj[4], co[4];
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) {                   // a revisit of the running best, or of the slot before (the clamped tail), is no candidate
-                                const bool dup = (j4[v] == bp) | (v > 0 && j4[v] == j4[v > 0 ? v - 1 : 0]);
-                                cd[v] = dup ? 1e300 : d4[v]; cj[v] = j4[v]; co[v] = o4[v];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {                   // pairs (0,1) and (2,3): winner in slot 2u, loser's distance in c2[u]
-                                const bool second = (cd[2 * u + 1] < cd[2 * u]) | ((cd[2 * u + 1] == cd[2 * u]) & (co[2 * u + 1] < co[2 * u]));
-                                c2[u] = second ? cd[2 * u] : cd[2 * u + 1];
-                                cd[2 * u] = second ? cd[2 * u + 1] : cd[2 * u]; cj[2 * u] = second ? cj[2 * u + 1] : cj[2 * u]; co[2 * u] = second ? co[2 * u + 1] : co[2 * u];
-                            }
-                            const bool second = (cd[2] < cd[0]) | ((cd[2] == cd[0]) & (co[2] < co[0]));
-                            const double lose = second ? cd[0] : cd[2];
-                            const double wd = second ? cd[2] : cd[0];
-                            const int wj = second ? cj[2] : cj[0], wo = second ? co[2] : co[0];
-                            double others = c2[0] < c2[1] ? c2[0] : c2[1];
-                            others = lose < others ? lose : others;
-                            const bool better = (wd < bd) | ((wd == bd) & (bp >= 0) & (wo < bo));    // (wd = 1e300: no candidate at all — never better)
-                            const double out = better ? (bp >= 0 ? bd : 1e300) : wd;
-                            others = out < others ? out : others;
-                            b2 = others < b2 ? others : b2;
-                            bd = better ? wd : bd; bo = better ? wo : bo; bp = better ? wj : bp;
-                        };
                         const int chunks = ent.chunks;
                         const uint4 w_ra = *reinterpret_cast<const uint4*>(ent.ra), w_rb = *reinterpret_cast<const uint4*>(ent.rb), w_cum = *reinterpret_cast<const uint4*>(ent.cum);
                         const unsigned int a8[4] = {w_ra.x, w_ra.y, w_ra.z, w_ra.w}, b8[4] = {w_rb.x, w_rb.y, w_rb.z, w_rb.w}, c8[4] = {w_cum.x, w_cum.y, w_cum.z, w_cum.w};
-                        for (int q = sub; q < chunks; q += lpp) {          // one chunk of four targets per lane and trip
+                        // the targets and squared distances (as keys) of chunk q; a chunk beyond the last one: nothing (keys = infinity)
+                        auto load_chunk = [&](const int q, unsigned long long (&k4)[4], int (&j4)[4]) {
                             int ra = (int)(a8[0] & 0xFFFFu), rb = (int)(b8[0] & 0xFFFFu), cu = 0;
 #pragma unroll
                             for (int r = 1; r < 8; ++r) {                  // the row of chunk q: the last one whose first chunk is <= q (empty rows share their successor's)
@@ -2259,39 +2297,79 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                                 cu = in ? cr : cu;
                             }
                             const int j0 = ra + 4 * (q - cu);
-                            double d4[4];
-                            int j4[4], o4[4];
+                            const bool live = q < chunks;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {                   // (independent LDS reads in flight; the tail of a run repeats its last target)
-                                j4[v] = j0 + v < rb ? j0 + v : rb - 1;
+                            for (int v = 0; v < 4; ++v) {                   // (independent LDS reads and distance chains in flight; the tail of a run repeats its last target)
+                                j4[v] = live ? (j0 + v < rb ? j0 + v : rb - 1) : 0;
                                 const TgtRec rr = s_tgt[j4[v]];
-                                d4[v] = sqdist(qx, qy, qz, rr.x, rr.y, rr.z);
-                                o4[v] = rr.orig;
+                                const unsigned long long k = (unsigned long long)__double_as_longlong(sqdist(qx, qy, qz, rr.x, rr.y, rr.z));
+                                k4[v] = (live & (j4[v] != bp) & !(v > 0 && j4[v] == j4[v > 0 ? v - 1 : 0])) ? k : kInfKey;     // a revisit of the start, or of the slot before, is no candidate
                             }
-                            visit4(j4, d4, o4);
+                        };
+                        // four candidates reduce among themselves as a tree (two independent pairs): winner (key, target), the smallest of the
+                        // three others, and whether two equal distances met at a node (a tie: the exact routine decides)
+                        auto reduce4 = [&](const unsigned long long (&c4)[4], const int (&j4)[4], unsigned long long& wk, int& wj, unsigned long long& others, bool& tie) {
+                            const bool s01 = c4[1] < c4[0], s23 = c4[3] < c4[2];
+                            const unsigned long long w01 = s01 ? c4[1] : c4[0], l01 = s01 ? c4[0] : c4[1], w23 = s23 ? c4[3] : c4[2], l23 = s23 ? c4[2] : c4[3];
+                            const int jw01 = s01 ? j4[1] : j4[0], jw23 = s23 ? j4[3] : j4[2];
+                            const bool sf = w23 < w01;
+                            wk = sf ? w23 : w01; wj = sf ? jw23 : jw01;
+                            const unsigned long long lk = sf ? w01 : w23;
+                            others = l01 < l23 ? l01 : l23;
+                            others = lk < others ? lk : others;
+                            tie = ((c4[0] == c4[1]) & (w01 != kInfKey)) | ((c4[2] == c4[3]) & (w23 != kInfKey)) | ((w01 == w23) & (wk != kInfKey));
+                        };
+                        for (int q = sub; q < chunks; q += lpp) {          // one chunk of four targets per lane and trip
+                            unsigned long long ka[4], wk, others;
+                            int ja[4], wj;
+                            bool t4;
+                            load_chunk(q, ka, ja);
+                            reduce4(ka, ja, wk, wj, others, t4);
+                            const bool tie = t4 | ((wk == kb) & (wk != kInfKey));
+                            if (__ballot(tie)) {                            // (never, in clouds off a sensor)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) if (ka[v] != kInfKey) exact_visit(ja[v], ka[v]);
+                            } else {                                        // once against the running best; k2 collects every distance that does not end up best
+                                const bool better = wk < kb;
+                                const unsigned long long out = better ? (bp >= 0 ? kb : kInfKey) : wk;
+                                others = out < others ? out : others;
+                                k2 = others < k2 ? others : k2;
+                                kb = better ? wk : kb; bp = better ? wj : bp;
+                            }
                         }
                     }
                     const long long w_2 = (long long)__builtin_amdgcn_s_memtime() + (bp == 123456789 ? 1 : 0);
                     // combine the lanes that shared the point: an all-reduce over aligned groups of lpp lanes — inside a row of 16 lanes by DPP
                     // (after the steps over 1 and 2 lanes a quad is uniform, after the half-row mirror a half row, ...), beyond it by permutes;
                     // a wave whose widest group is narrower skips the rest (wave-uniform)
-                    auto merge = [&](const double od, const double ob2, const int oo, const int op, const bool in_group) {
-                        const bool take = in_group & (op >= 0) & ((od < bd) | ((od == bd) & (oo < bo)));
-                        const double second = take ? (((bp >= 0) & (bp != op)) ? bd : 1e300) : ((in_group & (op >= 0) & (op != bp)) ? od : 1e300);
-                        const double s2 = (second < ob2) | !in_group ? second : ob2;
-                        b2 = s2 < b2 ? s2 : b2;
-                        bd = take ? od : bd; bo = take ? oo : bo; bp = take ? op : bp;
+                    auto merge = [&](const unsigned long long ok, const unsigned long long ok2, const int op, const bool in_group) {
+                        const bool tie = in_group & (ok == kb) & (op != bp) & (op >= 0) & (bp >= 0);
+                        if (__ballot(tie)) {                                // equal distances to two targets: the lower original index (exact, slow, never in practice)
+                            if (in_group) {
+                                const bool take = op >= 0 && (ok < kb || (ok == kb && bp >= 0 && op != bp && s_tgt[op].orig < s_tgt[bp].orig));
+                                const unsigned long long second = take ? (bp >= 0 && bp != op ? kb : kInfKey) : (op >= 0 && op != bp ? ok : kInfKey);
+                                k2 = second < k2 ? second : k2;
+                                k2 = ok2 < k2 ? ok2 : k2;
+                                if (take) { kb = ok; bp = op; }
+                            }
+                        } else {
+                            const bool take = in_group & (op >= 0) & (ok < kb);
+                            const unsigned long long second = take ? (((bp >= 0) & (bp != op)) ? kb : kInfKey) : ((in_group & (op >= 0) & (op != bp)) ? ok : kInfKey);
+                            const unsigned long long s2 = ((second < ok2) | !in_group) ? second : ok2;
+                            k2 = s2 < k2 ? s2 : k2;
+                            kb = take ? ok : kb; bp = take ? op : bp;
+                        }
                     };
-                    if (__ballot(lpp > 1)) merge(dpp_mov<0xB1>(bd), dpp_mov<0xB1>(b2), dpp_mov<0xB1>(bo), dpp_mov<0xB1>(bp), lpp > 1);
-                    if (__ballot(lpp > 2)) merge(dpp_mov<0x4E>(bd), dpp_mov<0x4E>(b2), dpp_mov<0x4E>(bo), dpp_mov<0x4E>(bp), lpp > 2);
-                    if (__ballot(lpp > 4)) merge(dpp_mov<0x141>(bd), dpp_mov<0x141>(b2), dpp_mov<0x141>(bo), dpp_mov<0x141>(bp), lpp > 4);
-                    if (__ballot(lpp > 8)) merge(dpp_mov<0x140>(bd), dpp_mov<0x140>(b2), dpp_mov<0x140>(bo), dpp_mov<0x140>(bp), lpp > 8);
-                    if (__ballot(lpp > 16)) merge(shfl_xor_d(bd, 16), shfl_xor_d(b2, 16), __shfl_xor(bo, 16, 64), __shfl_xor(bp, 16, 64), lpp > 16);
-                    if (__ballot(lpp > 32)) merge(shfl_xor_d(bd, 32), shfl_xor_d(b2, 32), __shfl_xor(bo, 32, 64), __shfl_xor(bp, 32, 64), lpp > 32);
+                    if (__ballot(lpp > 1)) merge(dpp_mov64<0xB1>(kb), dpp_mov64<0xB1>(k2), dpp_mov<0xB1>(bp), lpp > 1);
+                    if (__ballot(lpp > 2)) merge(dpp_mov64<0x4E>(kb), dpp_mov64<0x4E>(k2), dpp_mov<0x4E>(bp), lpp > 2);
+                    if (__ballot(lpp > 4)) merge(dpp_mov64<0x141>(kb), dpp_mov64<0x141>(k2), dpp_mov<0x141>(bp), lpp > 4);
+                    if (__ballot(lpp > 8)) merge(dpp_mov64<0x140>(kb), dpp_mov64<0x140>(k2), dpp_mov<0x140>(bp), lpp > 8);
+                    if (__ballot(lpp > 16)) merge(shfl_xor_u64(kb, 16), shfl_xor_u64(k2, 16), __shfl_xor(bp, 16, 64), lpp > 16);
+                    if (__ballot(lpp > 32)) merge(shfl_xor_u64(kb, 32), shfl_xor_u64(k2, 32), __shfl_xor(bp, 32, 64), lpp > 32);
                     if (active && sub == 0) {
-                        if (bp >= 0 && !(bd < r2)) { b2 = fmin(b2, bd); bp = -1; }      // seen, but not a correspondence (d^2 < max_dist^2 required)
-                        if (bp < 0) b2 = fmin(b2, bd);               // without correspondence the bound is on every target (bd: the nearest seen, or the radius covered)
-                        ent.bd = bd; ent.bp = bp; ent.x = b2;        // (x: every lane of the point has read it)
+                        if (bp >= 0 && !(kb < kr2)) { k2 = kb < k2 ? kb : k2; bp = -1; }      // seen, but not a correspondence (d^2 < max_dist^2 required)
+                        if (bp < 0) k2 = kb < k2 ? kb : k2;           // without correspondence the bound is on every target (kb: the nearest seen, or the radius covered)
+                        ent.bd = __longlong_as_double((long long)kb); ent.bp = bp; ent.x = __longlong_as_double((long long)k2);        // (x: every lane of the point has read it)
                     }
                     d_sw1 += w_1 - w_0; d_sw2 += w_2 - w_1; d_sw3 += (long long)__builtin_amdgcn_s_memtime() - w_2;
                 }
@@ -2346,9 +2424,14 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 for (int c = 0; c < kClasses; ++c) row[c] = (double)cnt[c];
                 row[8] = (double)d_lanes; row[9] = (double)d_shift; row[10] = (double)d_scatter; row[11] = (double)d_sweep; row[12] = (double)d_read;
                 row[13] = s_mot[0]; row[14] = (double)(tc - tb); row[15] = (double)(te - td); row[16] = (double)(tb - ta);
-                row[17] = (double)d_sw1; row[18] = (double)d_sw2; row[19] = (double)d_sw3; row[20] = (double)d_rowlen; row[21] = (double)d_rows; row[22] = (double)d_nyc;
+                row[17] = (double)d_sw1; row[18] = (double)d_sw2; row[19] = (double)d_sw3; row[20] = (double)s_fclk[0]; row[21] = (double)s_fclk[1]; row[22] = (double)s_fclk[2]; row[23] = (double)s_fclk[3]; row[24] = (double)s_fclk[4];
             }
         }
+    }
+    if (tid == 0) {                                             // per member (read_debug kind 4, parity 1, row = member): cycles in exchange + finish, move + queue, search, sums; evaluations, searches, exchange alone
+        double* row = B.partial + (((size_t)B.count + h) * kIcpMaxSplit + g) * 32;
+        for (int a = 0; a < 7; ++a) row[a] = (double)s_clk[a];
+        row[7] = (double)((long long)__builtin_amdgcn_s_memtime() - t_begin);
     }
     if (tid == 0 && g == 0 && s_stop != 2) {                    // (a team that timed out leaves stop == 0: the host runs the sliced launches)
         for (int a = 0; a < 12; ++a) S.T[a] = s_T[a];

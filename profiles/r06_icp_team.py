@@ -30,7 +30,10 @@ def poses(sliced, hypotheses):
     ctx.set_scene(scene, K); ctx.set_models(mds)
     res, ms = ctx.run(Ks, Rs, ts, xy)
     dbg = [ctx.read_debug(h, 3) for h in range(hypotheses)]
-    rows = [ctx.read_debug(h, 4).reshape(2, 64, 32)[0, 32:] for h in range(hypotheses)]
+    dbg4 = [ctx.read_debug(h, 4).reshape(2, 64, 32) for h in range(hypotheses)]
+    rows = [d[0, 32:] for d in dbg4]
+    global members
+    members = [d[1] for d in dbg4]
     ctx.close()
     return res, dbg, rows
 
@@ -51,8 +54,14 @@ for sliced in (True, False):
             if clk[5] > 0 and h < 4:
                 print("  hyp %2d evals %2d: workgroup 0, wave-0 cycles per evaluation: exchange %.0f, finish %.0f, transform+queue %.0f, search %.0f, sums %.0f | kernel %.0f cycles, own searches/eval %.1f" % (
                     h, clk[5], clk[7] / clk[5], (clk[0] - clk[7]) / clk[5], clk[1] / clk[5], clk[3] / clk[5], clk[4] / clk[5], clk[2], clk[6] / clk[5]))
+                if os.environ.get("TEAM_MEMBERS") and h in (0, 3):
+                    for g in range(16):
+                        m = members[h][g]
+                        if m[5] > 0:
+                            print("      member %2d: per evaluation: exchange %6.0f finish %6.0f move+queue %6.0f search %6.0f sums %6.0f | searches %.1f | kernel %.0f" % (
+                                g, m[6] / m[5], (m[0] - m[6]) / m[5], m[1] / m[5], m[2] / m[5], m[3] / m[5], m[4] / m[5], m[7]))
                 if os.environ.get("TEAM_ROWS") and h in (0, 3):
                     for it in range(int(clk[5])):
                         r = rows[h][it]
-                        print("      eval %2d: classes %s lanes %4d shift %d | cycles: finish %6d move+queue %6d scatter %5d sweep %6d (thread 0: set-up %d chunks %d merge %d) read %5d sums %6d | motion bound so far %.2f mm" % (
-                            it, [int(x) for x in r[:8]], r[8], r[9], r[16], r[14], r[10], r[11], r[17], r[18], r[19], r[12], r[15], r[13] * 1e3))
+                        print("      eval %2d: classes %s lanes %4d shift %d | cycles: finish %6d (sum+exchange %d solve %d sincos+U %d test %d writes+motion %d) move+queue %6d scatter %5d sweep %6d (thread 0: set-up %d chunks %d merge %d) read %5d sums %6d | motion bound so far %.2f mm" % (
+                            it, [int(x) for x in r[:8]], r[8], r[9], r[16], r[20], r[21], r[22], r[23], r[24], r[14], r[10], r[11], r[17], r[18], r[19], r[12], r[15], r[13] * 1e3))
