@@ -1864,7 +1864,7 @@ static __device__ __forceinline__ void solo_accumulate(double (&acc)[16], const 
     }
 }
 
-template <int KP>     // source points per owner thread, in registers
+template <int KP, bool SLAB>     // source points per owner thread (in registers); a slab of the target cloud in LDS, not all of it
 __global__ void __launch_bounds__(kSoloWG)
 k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int max_iter, double rel_tol) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSoloRaw];
@@ -1875,15 +1875,51 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     __shared__ long long s_clk[7], s_fclk[6];
     __shared__ int s_cnt[kClasses];
     __shared__ int s_stop, s_fin_i[2];
-    const int h = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_slab[5], s_ext[2];                          // the x columns staged [lo, hi], first target and number of targets staged, overflow; the columns this evaluation needs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int h = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    if (gridDim.y == 1 && B.count <= 64) {
+        // One-dimensional grid (up to 64 hypotheses): the workgroups are dealt out to the hypotheses still to do in proportion to their source
+        // points — a cloud of 10000 points next to one of 1500 gets seven times the members; with equal teams the large one sets the length
+        // of the launch while the CUs of the small ones idle.  Every wave of every workgroup computes the same table (lane = hypothesis).
+        int w = 0;
+        if (lane < B.count) { const IcpState& T = B.st[lane]; if (T.status == 0 && T.stop == 0) w = T.n_src > 0 ? T.n_src : 1; }
+        const int ncand = __popcll(__ballot(w > 0));
+        if (ncand == 0) return;
+        long long total = w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+        const int extra = (int)gridDim.x - ncand;
+        int members = w > 0 ? 1 + (int)((long long)extra * w / total) : 0;
+        members = members > kIcpMaxSplit ? kIcpMaxSplit : members;
+        int incl = members;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        const int start = incl - members, b = (int)blockIdx.x;
+        const unsigned long long mine = __ballot(b >= start && b < start + members);
+        if (!mine) return;                                      // (a workgroup the rounding left over)
+        h = __ffsll((long long)mine) - 1;
+        g = b - __shfl(start, h, 64);
+        G = __shfl(members, h, 64);
+    }
     IcpState& S = B.st[h];
     if (S.status != 0 || S.stop != 0) return;
     const int ns = S.n_src, nt = S.n_tgt;
     const int gx = S.gx, gy = S.gy, zq_max = S.zq_max, ncell = gx * gy;
     // (every member of the team takes the same decision: it depends on the hypothesis only)
-    if ((ns + G - 1) / G > kSoloOwners * KP || nt > 8192 || ncell > kIcpCells - 1 || gx > 255 || gy > 255) return;
-    const int off_n = 32 * nt, off_sep = off_n + 24 * nt, off_cs = (off_sep + 4 * nt + 15) & ~15, off_q = (off_cs + 2 * (ncell + 1) + 15) & ~15;
-    if (off_q + kSoloMinQueue * (int)sizeof(SoloQ) > kSoloRaw) return;
+    if ((ns + G - 1) / G > kSoloOwners * KP || nt > 65535 || ncell > kIcpCells - 1 || gx > 255 || gy > 255) {
+        if (g == 0 && tid == 0) { S.team_note[0] = (ns + G - 1) / G > kSoloOwners * KP ? 1 : 2; S.team_note[1] = ns; S.team_note[2] = nt; S.team_note[3] = KP; }
+        return;
+    }
+    // LDS: C target points (32-byte records, normals, certification radii), the whole 16-bit cell table (absolute sorted positions), the queue.
+    // A cloud of up to C points is resident whole; of a larger one the workgroup holds a SLAB — the targets of the x columns its source points can
+    // reach, a contiguous range [p0, p0 + np) of the sorted cloud — and stages it again when an update has moved its points out of it.
+    const int cs_bytes = (2 * (ncell + 1) + 15) & ~15;
+    constexpr bool slabbed = SLAB;
+    if (!SLAB && nt > ((kSoloRaw - cs_bytes - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3)) return;      // (the build with a slab takes it)
+    // (a slab leaves the normals in global memory — one gather per correspondence and evaluation — for 1.7 times the targets)
+    const int C = slabbed ? (kSoloRaw - cs_bytes - kSoloMinQueue * (int)sizeof(SoloQ)) / 36 & ~3 : (nt + 3) & ~3;
+    const int off_sep = 32 * C, off_n = off_sep + 4 * C, off_cs = off_n + (slabbed ? 0 : 24 * C), off_q = off_cs + cs_bytes;
     const int Q = (kSoloRaw - off_q) / (int)sizeof(SoloQ);
     const int i_lo = (int)((long long)ns * g / G), i_hi = (int)((long long)ns * (g + 1) / G);      // this workgroup's source points (voxel order: an x slab)
     unsigned long long* xchg = B.xchg + ((size_t)h * kIcpMaxSplit) * 64;   // [parity: + count * kIcpMaxSplit * 64][member][64 granules {half of a sum, tag}]
@@ -1894,18 +1930,24 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     float* s_sep = reinterpret_cast<float*>(s_raw + off_sep);
     unsigned short* s_cs = reinterpret_cast<unsigned short*>(s_raw + off_cs);
     SoloQ* s_q = reinterpret_cast<SoloQ*>(s_raw + off_q);
-    {   // the target side, once: records, normals, certification radii (rounded down: a stricter test only searches more), cell table
-        const uint4* src = reinterpret_cast<const uint4*>(B.tgt_rec + (size_t)h * B.cap);
+    const TgtRec* g_rec = B.tgt_rec + (size_t)h * B.cap;
+    const double* g_nrm = B.normals + (size_t)h * B.cap * 3;
+    const double* g_cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
+    // targets [q0, q0 + n) of the sorted cloud -> LDS slots 0..n (records, normals, certification radii rounded down: a stricter test only searches more)
+    auto stage = [&](const int q0, const int n) {
+        const uint4* src = reinterpret_cast<const uint4*>(g_rec + q0);
         uint4* dst = reinterpret_cast<uint4*>(s_tgt);
-        for (int j = tid; j < nt * 2; j += kSoloWG) dst[j] = src[j];
-        const double* N = B.normals + (size_t)h * B.cap * 3;
-        for (int j = tid; j < nt * 3; j += kSoloWG) s_nrm[j] = N[j];
-        const double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-        for (int j = tid; j < nt; j += kSoloWG) s_sep[j] = __double2float_rd(cov[(size_t)j * kIcpCovStride + 10]);
+        for (int j = tid; j < n * 2; j += kSoloWG) dst[j] = src[j];
+        if (!slabbed) for (int j = tid; j < n * 3; j += kSoloWG) s_nrm[j] = g_nrm[(size_t)q0 * 3 + j];
+        for (int j = tid; j < n; j += kSoloWG) s_sep[j] = __double2float_rd(g_cov[(size_t)(q0 + j) * kIcpCovStride + 10]);
+    };
+    {
         const uint4* csrc = reinterpret_cast<const uint4*>(B.cell_start16 + (size_t)h * kIcpCells16);
         uint4* cdst = reinterpret_cast<uint4*>(s_cs);
         for (int j = tid; j < (ncell + 8) / 8; j += kSoloWG) cdst[j] = csrc[j];
+        if (!slabbed) stage(0, nt);
         if (tid < kClasses) s_cnt[tid] = 0;
+        if (tid == 0) { s_slab[0] = slabbed ? 1 : 0; s_slab[1] = slabbed ? 0 : gx - 1; s_slab[2] = 0; s_slab[3] = slabbed ? 0 : nt; s_slab[4] = 0; s_ext[0] = INT_MAX; s_ext[1] = -1; }
     }
     const double minx = S.gminx, miny = S.gminy, minz = S.gminz, inv = S.inv_cell, inv_z = S.inv_z;
     const double r2 = max_dist * max_dist;
@@ -1977,6 +2019,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     for (int w = 1; w < kSoloWG / 64; ++w) pw[w - 1] = s_part[w][lane & 31];
                     static_assert(kSoloWG / 64 == 12, "the tree below adds the sums of eleven owner waves");
                     v = (((pw[0] + pw[1]) + (pw[2] + pw[3])) + ((pw[4] + pw[5]) + (pw[6] + pw[7]))) + ((pw[8] + pw[9]) + pw[10]);
+                    if (lane == 29) v = 0.0;                         // (sum 29: members that give the hypothesis up — none do at present)
                 }
                 bool timed_out = false;
                 const long long tx0 = (long long)__builtin_amdgcn_s_memtime();
@@ -1988,7 +2031,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const unsigned int tag = (run << 6) | (unsigned int)it;
                     unsigned long long* mine = xchg + ((size_t)((it - 1) & 1) * B.count * kIcpMaxSplit + g) * 64;
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                    if (lane < 29) {
+                    if (lane < 30) {
                         __hip_atomic_store(mine + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(mine + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -1996,7 +2039,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const long long t0w = wall_clock64();
                     // lanes 0-31 gather members 0-7 of a group of 16, lanes 32-63 members 8-15 (16 loads per lane in flight); the sums are added
                     // in member order inside a half, then first half + second half, group after group: the same order in every member of the team
-                    const int kk = (lane & 31) < 29 ? (lane & 31) : 0, half = lane >> 5;
+                    const int kk = (lane & 31) < 30 ? (lane & 31) : 0, half = lane >> 5;
                     v = 0;
                     for (int m0 = 0; m0 < G; m0 += 16) {
                         unsigned long long lo[8], hi[8];
@@ -2040,9 +2083,11 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 const double fit2 = s_hist[it & 1], rmse2 = s_hist[2 + (it & 1)];       // of evaluation it - 2
                 if (it > 1 && fabs(fit2 - fit) < rel_tol && fabs(rmse2 - rmse) < rel_tol) stop = true;
                 if (it - 1 == max_iter) stop = true;
+                const bool team_over = readlane_d(v, 29) > 0.0;
                 const long long f3 = (long long)__builtin_amdgcn_s_memtime() + (stop ? 1 : 0);
                 if (lane == 0) {
-                    s_stop = timed_out ? 2 : stop ? 1 : 0;
+                    s_stop = timed_out || team_over ? 2 : stop ? 1 : 0;
+                    s_ext[0] = INT_MAX; s_ext[1] = -1;
                     s_hist[(it - 1) & 1] = fit; s_hist[2 + ((it - 1) & 1)] = rmse;
                     s_fin[0] = fit; s_fin[1] = rmse; s_fin_i[0] = ncorr;
                     if (!stop) s_fin_i[1] = it;
@@ -2085,12 +2130,17 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         // update voids the bound — then nothing is paid for bounds: no margin, and points without correspondence search max_dist, not beyond)
         const bool calm = s_mot[5] < 0.5 * kSoloMargin * max_dist;
         const double margin = calm ? kSoloMargin * max_dist : 0.0, none2 = calm ? far2 : r2;
+        int p0 = s_slab[2];                                       // first target of the slab in LDS (0: the whole cloud)
+        bool in_lds = !SLAB || s_slab[4] == 0;                    // (a member whose points need more targets than the LDS holds reads them from global memory: slow, exact)
+        auto rec_at = [&](const int j) -> TgtRec { if (!SLAB) return s_tgt[j]; return in_lds ? s_tgt[j - p0] : g_rec[j]; };
+        auto sep_at = [&](const int j) -> double { if (!SLAB) return (double)s_sep[j]; return in_lds ? (double)s_sep[j - p0] : g_cov[(size_t)j * kIcpCovStride + 10]; };
         {
             double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
             if (it > 0) {
 #pragma unroll
                 for (int a = 0; a < 12; ++a) U[a] = s_U[a];
             }
+            int ext_lo = INT_MAX, ext_hi = -1;                    // the x columns this thread's points need in LDS
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 cls[k] = kClasses; rk[k] = 0; box[k] = 0; seed[k] = none2;
@@ -2104,14 +2154,54 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 const double room = ((double)lbf[k] - A) * (1.0 - 1e-9) - 1e-12;      // every target other than prv is farther than this (if positive)
                 bool need;
                 if (prv[k] >= 0) {
-                    const TgtRec q = s_tgt[prv[k]];
+                    const TgtRec q = rec_at(prv[k]);
                     const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
-                    need = !(d < r2 && ((room > 0.0 && d * (1.0 + 4e-9) < room * room) || 4.0 * d * (1.0 + 1e-9) < (double)s_sep[prv[k]]));
+                    need = !(d < r2 && ((room > 0.0 && d * (1.0 + 4e-9) < room * room) || 4.0 * d * (1.0 + 1e-9) < sep_at(prv[k])));
                     if (d < r2) seed[k] = d; else { seed[k] = r2; prv[k] = -1; }       // out of range now: searches max_dist, without a start
                 } else {
                     need = !(room > lb_need);                     // nearest target provably beyond max_dist: still no correspondence
                 }
-                if (need) {
+                if (!(px[k] == px[k] && py[k] == py[k] && pz[k] == pz[k] && nt > 0)) { need = false; prv[k] = -1; lbf[k] = 0.f; }   // nothing to search
+                if (need) cls[k] = -1;                            // (its class: below)
+                if (slabbed && (need || prv[k] >= 0)) {            // the columns its correspondence and its search can lie in
+                    const double R = (prv[k] >= 0 ? max_dist + margin : calm ? far : max_dist) * (1.0 + 1e-9) + 1e-12;
+                    const int lo = grid_coord(px[k] - R, minx, inv, gx), hi = grid_coord(px[k] + R, minx, inv, gx);
+                    ext_lo = lo < ext_lo ? lo : ext_lo; ext_hi = hi > ext_hi ? hi : ext_hi;
+                }
+            }
+            if (slabbed) {
+                // the slab: staged again (as wide as the LDS holds, around what is needed) when the points have left the columns it covers
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { ext_lo = min(ext_lo, __shfl_xor(ext_lo, off, 64)); ext_hi = max(ext_hi, __shfl_xor(ext_hi, off, 64)); }
+                if (lane == 0 && ext_hi >= ext_lo) { atomicMin(&s_ext[0], ext_lo); atomicMax(&s_ext[1], ext_hi); }
+                __syncthreads();
+                const int need_lo = s_ext[0], need_hi = s_ext[1], st_lo = s_slab[0], st_hi = s_slab[1];
+                if (need_hi >= need_lo && (need_lo < st_lo || need_hi > st_hi)) {
+                    __syncthreads();                              // (everyone has read the old slab)
+                    if (tid == 0) {
+                        auto count = [&](const int lo, const int hi) { return (int)s_cs[(hi + 1) * gy] - (int)s_cs[lo * gy]; };
+                        int e = 0;                                // widest symmetric margin that fits
+#pragma unroll
+                        for (int bit = 32; bit > 0; bit >>= 1) {
+                            const int t = e + bit, lo = need_lo - t > 0 ? need_lo - t : 0, hi = need_hi + t < gx - 1 ? need_hi + t : gx - 1;
+                            if (count(lo, hi) <= C) e = t;
+                        }
+                        const int lo = need_lo - e > 0 ? need_lo - e : 0, hi = need_hi + e < gx - 1 ? need_hi + e : gx - 1;
+                        const int n = count(lo, hi);
+                        if (n <= C) { s_slab[0] = lo; s_slab[1] = hi; s_slab[2] = s_cs[lo * gy]; s_slab[3] = n; s_slab[4] = 0; }
+                        else { s_slab[0] = 1; s_slab[1] = 0; s_slab[2] = 0; s_slab[3] = 0; s_slab[4] = 1; S.team_note[0] = 3; S.team_note[1] = g; S.team_note[2] = n; S.team_note[3] = C; }   // nothing staged: global mode until the points come together again
+                    }
+                    __syncthreads();
+                    stage(s_slab[2], s_slab[3]);
+                    __syncthreads();
+                    p0 = s_slab[2];
+                    in_lds = s_slab[4] == 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (cls[k] != -1) continue;
+                {
                     // A better start than the previous correspondence, which an update of several millimetres leaves far behind (the search
                     // radius is the distance to the start): the targets of the point's own grid column next to its depth.  Any target will
                     // do as a start — the search that follows is exact within the distance to it.
@@ -2122,12 +2212,12 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                         if (b > a) {
                             const int zq = zq_of(pz[k], minz, inv_z, zq_max);
                             int lo = a, hi = b;                  // first target of the column at depth step >= zq
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_tgt[mid].zq < zq) lo = mid + 1; else hi = mid; }
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec_at(mid).zq < zq) lo = mid + 1; else hi = mid; }
                             const int j0 = lo - 2 > a ? lo - 2 : a;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const int j = j0 + v < b ? j0 + v : b - 1;
-                                const TgtRec q = s_tgt[j];
+                                const TgtRec q = rec_at(j);
                                 const double d = sqdist(px[k], py[k], pz[k], q.x, q.y, q.z);
                                 if (d < seed[k] && d < r2) { seed[k] = d; prv[k] = j; }
                             }
@@ -2144,8 +2234,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     // table is read here (the lanes take the chunks round robin, however many there are)
                     const int ncol = nxc * nyc;
                     cls[k] = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;
-                    any = px[k] == px[k] && py[k] == py[k] && pz[k] == pz[k] && nt > 0 ? true : any;
-                    if (!(px[k] == px[k] && py[k] == py[k] && pz[k] == pz[k] && nt > 0)) { cls[k] = kClasses; prv[k] = -1; lbf[k] = 0.f; }   // nothing to search
+                    any = true;
                 }
             }
         }
@@ -2276,7 +2365,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const long long w_1 = (long long)__builtin_amdgcn_s_memtime() + (bp == 123456789 ? 1 : 0);
                     auto exact_visit = [&](const int j, const unsigned long long k) {       // one candidate, ties by original index
                         if (j == bp) return;
-                        const bool better = k < kb || (k == kb && bp >= 0 && s_tgt[j].orig < s_tgt[bp].orig);
+                        const bool better = k < kb || (k == kb && bp >= 0 && rec_at(j).orig < rec_at(bp).orig);
                         const unsigned long long second = better ? (bp >= 0 ? kb : kInfKey) : k;
                         k2 = second < k2 ? second : k2;
                         if (better) { kb = k; bp = j; }
@@ -2300,8 +2389,8 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                             const bool live = q < chunks;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {                   // (independent LDS reads and distance chains in flight; the tail of a run repeats its last target)
-                                j4[v] = live ? (j0 + v < rb ? j0 + v : rb - 1) : 0;
-                                const TgtRec rr = s_tgt[j4[v]];
+                                j4[v] = live ? (j0 + v < rb ? j0 + v : rb - 1) : p0;
+                                const TgtRec rr = rec_at(j4[v]);
                                 const unsigned long long k = (unsigned long long)__double_as_longlong(sqdist(qx, qy, qz, rr.x, rr.y, rr.z));
                                 k4[v] = (live & (j4[v] != bp) & !(v > 0 && j4[v] == j4[v > 0 ? v - 1 : 0])) ? k : kInfKey;     // a revisit of the start, or of the slot before, is no candidate
                             }
@@ -2346,7 +2435,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                         const bool tie = in_group & (ok == kb) & (op != bp) & (op >= 0) & (bp >= 0);
                         if (__ballot(tie)) {                                // equal distances to two targets: the lower original index (exact, slow, never in practice)
                             if (in_group) {
-                                const bool take = op >= 0 && (ok < kb || (ok == kb && bp >= 0 && op != bp && s_tgt[op].orig < s_tgt[bp].orig));
+                                const bool take = op >= 0 && (ok < kb || (ok == kb && bp >= 0 && op != bp && rec_at(op).orig < rec_at(bp).orig));
                                 const unsigned long long second = take ? (bp >= 0 && bp != op ? kb : kInfKey) : (op >= 0 && op != bp ? ok : kInfKey);
                                 k2 = second < k2 ? second : k2;
                                 k2 = ok2 < k2 ? ok2 : k2;
@@ -2407,9 +2496,12 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 if (prv[k] < 0) continue;
-                const TgtRec q = s_tgt[prv[k]];
-                if (half == 0) solo_accumulate<0>(acc, px[k], py[k], pz[k], q, s_nrm + 3 * prv[k]);
-                else solo_accumulate<1>(acc, px[k], py[k], pz[k], q, s_nrm + 3 * prv[k]);
+                const TgtRec q = rec_at(prv[k]);
+                double n3[3];
+                if (slabbed) { n3[0] = g_nrm[3 * (size_t)prv[k]]; n3[1] = g_nrm[3 * (size_t)prv[k] + 1]; n3[2] = g_nrm[3 * (size_t)prv[k] + 2]; }
+                else { n3[0] = s_nrm[3 * prv[k]]; n3[1] = s_nrm[3 * prv[k] + 1]; n3[2] = s_nrm[3 * prv[k] + 2]; }
+                if (half == 0) solo_accumulate<0>(acc, px[k], py[k], pz[k], q, n3);
+                else solo_accumulate<1>(acc, px[k], py[k], pz[k], q, n3);
             }
             const double v = wave_reduce16(acc, lane);
             if ((lane & 3) == 0) s_part[wave][half * 16 + (lane >> 2)] = v;
@@ -2544,11 +2636,15 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
     unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
     if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
-    // one source point per owner thread (slices of <= 704 points: every cloud of a few thousand points once the team has four members) keeps the
-    // kernel far inside its registers; batches so large that a team is one or two workgroups also get the five-points-per-thread build, which
-    // takes the hypotheses the first left (stop == 0) and costs ~2 us when there are none
-    hipLaunchKernelGGL(k_icp_team<1>, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (team < 4) hipLaunchKernelGGL(k_icp_team<5>, dim3(team, count), dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    // Three builds, each taking the hypotheses the ones before left (stop == 0); a launch with nothing to take costs ~2 us:
+    //   one source point per owner thread, the whole target cloud in LDS — clouds of a couple of thousand points per team member and
+    //   target clouds of <= ~2300 points: far inside its registers, every target access a plain LDS read;
+    //   two points per thread and a slab of the target cloud in LDS — anything up to 1408 points per member, any target cloud;
+    //   five points per thread — batches so large that a team is one or two workgroups.
+    const dim3 grid = count <= 64 && kn.icp_team == 0 ? dim3(cus) : dim3(team, count);   // (<= 64 hypotheses: the kernel deals the workgroups out itself, by cloud size)
+    hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (team < 4) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

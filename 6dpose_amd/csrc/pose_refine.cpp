@@ -340,6 +340,8 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             tmp.push_back((double)st.gx); tmp.push_back((double)st.gy); tmp.push_back(st.cell);
             tmp.push_back((double)st.iterations);
             for (int k = 0; k < 8; ++k) tmp.push_back((double)st.clk[k]);
+            for (int k = 0; k < 4; ++k) tmp.push_back((double)st.team_note[k]);
+            tmp.push_back((double)st.n_src); tmp.push_back((double)st.n_tgt);
             n = (int64_t)tmp.size();
             break;
         }

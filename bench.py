@@ -1031,7 +1031,10 @@ def pipeline_bench(det, frames, bank, classes, top_k=16, steps=20):
                 "refined": int(sum(1 for r in res if r["status"] == 0)),
                 "mean_fitness": float(np.mean([r["residual"] for r in res if r["status"] == 0])) if res else 0.0,
                 "icp_iters_per_sec_device": (acc["icp_iterations"] / steps) / (out["icp_ms"] * 1e-3) if out["icp_ms"] > 0 else 0.0,
-                "templates": n})
+                "templates": n,
+                "points_source": [int(r["n_source"]) for r in res if r["status"] == 0],
+                "points_target": [int(r["n_target"]) for r in res if r["status"] == 0],
+                "iterations": [int(r["iterations"]) for r in res if r["status"] == 0]})
     return out
 
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pose_refine or icp or pipeline" > gpurun_out/r06_run13_pytest.log 2>&1
+tail -5 gpurun_out/r06_run13_pytest.log
+timeout 300 python profiles/r06_icp_team.py 16 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_run13_icp_team.txt
+cut -c1-420 gpurun_out/r06_run13_icp_team.txt
+for sl in 1 0; do LM_ICP_SLICED=$sl timeout 300 python profiles/pipeline_only.py 10 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/r06_run13_pipeline.txt
+cut -c1-330 gpurun_out/r06_run13_pipeline.txt

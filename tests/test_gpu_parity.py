@@ -1302,7 +1302,10 @@ def test_pose_refine_batch_equals_single_calls(lm):
     for i in range(n - 1):
         pr = mod.poseRefine(device=0, scene_from_scene=True)
         pr.process(scene, mds[i], K_CAM, K_CAM, Rs[i].reshape(3, 3), ts[i], xy[i][0], xy[i][1])
-        assert np.array_equal(pr.getR(), res[i]["R"]) and np.array_equal(pr.getT().ravel(), res[i]["t"])
+        # the members of a hypothesis' team (k_icp_team) are dealt out by the sizes of the clouds in the batch, so the 29 sums of an evaluation are
+        # grouped differently in a batch of five and alone: equal to rounding, not bit for bit (the same batch is: see the slots test below)
+        assert pr.info["iterations"] == res[i]["iterations"]
+        assert np.abs(pr.getR() - res[i]["R"]).max() < 1e-11 and np.abs(pr.getT().ravel() - res[i]["t"]).max() < 1e-8
 
 
 def test_icp_device_intermediates_match_oracle(lm):
