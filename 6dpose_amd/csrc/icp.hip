@@ -991,7 +991,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
     return true;
 }
 
-__global__ void __launch_bounds__(kKnnWG)
+__global__ void __launch_bounds__(kKnnWG, 4)       // two workgroups per CU (their LDS allows it): 128 VGPRs — at 165 a CU held one, and the ~26 workgroups of a cloud ran in two rounds
 k_icp_knn(IcpBuffers B, int knn) {
     __shared__ TgtRec s_tgt[kKnnSlabPts];
     __shared__ int2 s_runs[kKnnWG / kKnnLanes][kKnnRuns];
@@ -1012,8 +1012,8 @@ k_icp_knn(IcpBuffers B, int knn) {
     const int k = knn < nt ? knn : nt;
     int R0 = (int)ceil(0.009 / cell);
     if (R0 < 1) R0 = 1;
-    // workgroups at work on this cloud: ~96 points each (a small cloud on all of the grid's workgroups would stage itself 64 times)
-    const int want = (nt + 95) / 96, nb = want < 16 ? 16 : want > (int)gridDim.x ? (int)gridDim.x : want;
+    // workgroups at work on this cloud: ~64 points each = one trip of the lane groups (a small cloud on all of the grid's workgroups would stage itself 64 times)
+    const int want = (nt + 63) / 64, nb = want < 16 ? 16 : want > (int)gridDim.x ? (int)gridDim.x : want;
     if ((int)blockIdx.x >= nb) return;
     const int q0 = (int)((long long)nt * blockIdx.x / nb), q1 = (int)((long long)nt * (blockIdx.x + 1) / nb);
     if (q0 >= q1) return;
@@ -1025,12 +1025,15 @@ k_icp_knn(IcpBuffers B, int knn) {
     const int p0 = cs[xlo * gy];
     int np = cs[(xhi + 1) * gy] - p0;
     if (np > kKnnSlabPts) np = 0;                                 // slab too large for LDS: every ring reads HBM
+    const long long k_t0 = (long long)__builtin_amdgcn_s_memtime();
     {
         const uint4* src = reinterpret_cast<const uint4*>(rec + p0);
         uint4* dst = reinterpret_cast<uint4*>(s_tgt);
         for (int j = threadIdx.x; j < np * 2; j += kKnnWG) dst[j] = src[j];
     }
     __syncthreads();
+    const long long k_t1 = (long long)__builtin_amdgcn_s_memtime();
+    long long k_main = 0, k_hard = 0;
     const int sub = threadIdx.x & (kKnnLanes - 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = q0; base < q1; base += kKnnHard) {
         const int end = base + kKnnHard < q1 ? base + kKnnHard : q1;
@@ -1044,6 +1047,7 @@ k_icp_knn(IcpBuffers B, int knn) {
             if (!done && sub == 0) s_hard[atomicAdd(&s_nhard, 1)] = pos;
         }
         __syncthreads();
+        const long long k_t2 = (long long)__builtin_amdgcn_s_memtime();
         // the points whose base ring held fewer than k candidates inside the guarantee radius (isolated points, flying pixels:
         // 2-15 % of a scene cloud, rings of hundreds to thousands of candidates): a wave each
         const int nhard = s_nhard;
@@ -1060,6 +1064,17 @@ k_icp_knn(IcpBuffers B, int knn) {
             else (void)knn_point<64>(pos, lane, runs, k, gx > gy ? gx : gy, INT_MAX, s_tgt, p0, np, T, rec, orig, cs, cov, gx, gy, minx, miny, inv, cell);
         }
         __syncthreads();
+        if (threadIdx.x == 0) {
+            const long long k_t3 = (long long)__builtin_amdgcn_s_memtime();
+            k_main += k_t2 - (base == q0 ? k_t1 : k_t2); k_hard += k_t3 - k_t2;
+            if (base == q0) k_main = k_t2 - k_t1;
+            atomicAdd((unsigned long long*)&B.st[h].knn_clk[3], (unsigned long long)nhard);
+        }
+    }
+    if (threadIdx.x == 0) {
+        atomicMax((unsigned long long*)&B.st[h].knn_clk[0], (unsigned long long)(k_t1 - k_t0));
+        atomicMax((unsigned long long*)&B.st[h].knn_clk[1], (unsigned long long)k_main);
+        atomicMax((unsigned long long*)&B.st[h].knn_clk[2], (unsigned long long)k_hard);
     }
 }
 

@@ -342,6 +342,7 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             for (int k = 0; k < 8; ++k) tmp.push_back((double)st.clk[k]);
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.team_note[k]);
             tmp.push_back((double)st.n_src); tmp.push_back((double)st.n_tgt);
+            for (int k = 0; k < 4; ++k) tmp.push_back((double)st.knn_clk[k]);
             n = (int64_t)tmp.size();
             break;
         }

@@ -54,6 +54,7 @@ for sliced in (True, False):
             if clk[5] > 0 and h < 4:
                 print("  hyp %2d evals %2d: workgroup 0, wave-0 cycles per evaluation: exchange %.0f, finish %.0f, transform+queue %.0f, search %.0f, sums %.0f | kernel %.0f cycles, own searches/eval %.1f" % (
                     h, clk[5], clk[7] / clk[5], (clk[0] - clk[7]) / clk[5], clk[1] / clk[5], clk[3] / clk[5], clk[4] / clk[5], clk[2], clk[6] / clk[5]))
+                print("           k_icp_knn: slowest workgroup: staging %d, 8-lane trips %d, whole-wave pass %d cycles; %d of %d points went to whole waves" % (d[39], d[40], d[41], d[42], d[38]))
                 if os.environ.get("TEAM_MEMBERS") and h in (0, 3):
                     for g in range(16):
                         m = members[h][g]
