@@ -137,11 +137,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of exactly --steps steps each; ms_per_step is their median")
     ap.add_argument("--templates", type=int, default=N_TEMPLATES, help="template pyramids per object")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("LM_BENCH_SCALING", "weak"),
                     help="N>1: weak = one object x --templates per GPU (configs[1] scaled up); strong = a fixed bank of 8 objects x "
                          "--templates (configs[3]) split over the GPUs.  N=1 --scaling strong runs that 16k bank on one GPU")
-    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch in stream mode (lm_detector_set_batch, 1..8; 0 = the library's default, 4)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch in stream mode (lm_detector_set_batch, 1..8; 0 = the library's default, 8)")
     ap.add_argument("--batch-queue", type=int, default=2, help="launched batches kept queued on the GPU before frames wait for a full batch (lm_detector_set_batch_queue)")
     ap.add_argument("--roofline-only", action="store_true", help="set-up + the roofline leg only (the command profiled under rocprofv3: every k_local / "
                                                                  "k_coarse launch of the run then is one of the measured launches, bar the set-up probe)")
@@ -439,7 +440,16 @@ def main():
         import cProfile, io, pstats
         pr = cProfile.Profile(); pr.enable(); timed(args.steps, args.warmup); pr.disable()
         st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14); sys.stderr.write(st.getvalue())
-    dt = timed(args.steps, args.warmup)              # THE timed region: a new host frame per step, H2D included
+    # THE timed region: exactly K steps (a new host frame per step, H2D included) between two fences — repeated, because at the driver's
+    # flags it is ~1.7 ms long and its run-to-run spread was as large as most optimisations: `ms_per_step` is the MEDIAN of the
+    # repeats (each: W warm-up steps, fence, K timed steps, fence; N > 1: the MAX over the ranks of each repeat), min / max / all in `repeats`
+    reps = max(1, args.repeats)
+    dts = [timed(args.steps, args.warmup) for _ in range(reps)]
+    dt = sorted(dts)[len(dts) // 2]
+    steady = None
+    if world == 1 and not args.no_extras and args.steps < 200:     # the same loop at 200 steps: the fill and drain of the frame pipeline amortised
+        steady = timed(200, args.warmup) / 200.0 * 1e3
+        timed(args.steps, args.warmup)                             # (leaves the per-step accumulators of a K-step region behind, as the fields below expect)
     n_final = last["n"]
     per_rank_ms = [t / K * 1e3 for t in rank_times["dt"]] if rank_times["dt"] else None
     mean = {k: acc[k] / K for k in keys}
@@ -475,6 +485,11 @@ def main():
             "metric": "templates*Mpixels matched/sec on 640x480 RGB-D",
             "value": value, "unit": "templates*Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "repeats": {"n": reps, "ms_per_step_min": min(dts) / K * 1e3, "ms_per_step_max": max(dts) / K * 1e3, "ms_per_step_all": [t / K * 1e3 for t in dts],
+                        "ms_per_step_is": "the median of n timed regions of exactly `steps` steps each"},
+            "ms_per_step_steady_200": steady,
+            "kernel_us_per_frame": (excl["frontend_ms"] + excl["coarse_ms"] + excl["local_ms"]) / BATCH * 1e3,
+            "kernel_us_per_frame_is": "front end + coarse pass + refinement kernels of one %d-frame launch set, each timed alone on the GPU (roofline leg), per frame" % BATCH,
             "dtype": "u8", "data": "synthetic",
             "parity_checked": bool(parity and parity["ok"]), "parity": parity,
             "config": {"workload": workload, "host_cpus": host_cpus,
@@ -531,15 +546,24 @@ def main():
                 cb = out["extras"]["icp"]["cpu_baseline"]
                 out["extras"]["icp"]["speedup_vs_cpu_numpy"] = (out["extras"]["icp"]["icp_iters_per_sec_device"] / cb["icp_iters_per_sec"]) if cb["icp_iters_per_sec"] else None
             pl = out["extras"]["pipeline"]
+            ic = out["extras"]["icp"]
+            gbs = ic["algorithmic_bytes"] / (ic["device_ms"] * 1e-3) / 1e9 if ic["device_ms"] > 0 else 0.0
+            tfs = ic["brute_force_flops"] / (ic["device_ms"] * 1e-3) / 1e12 if ic["device_ms"] > 0 else 0.0
             out["extras"]["roofline_icp"] = {
-                "bound": "latency of a chain of dependent launches (f64 VALU + LDS reads inside one): max_iteration + 2 = 32 "
-                         "k_icp_eval launches in stream order, each as long as its slowest slice",
-                "evaluation_launches": 32,
-                "us_per_launch_if_all_of_icp_ms_were_evaluations": pl["icp_ms"] * 1e3 / 32.0,
-                "measured_split": "profiles/r02_icp_experiments.txt + profiles/r02_kernel_stats_v5.txt: of 1.88 ms, 32 evaluations 1.15 ms (36 us each; "
-                                  "the slowest slice 15-25 us), kNN 0.28, voxel + grid sorts 0.33, normals 0.06, points + bbox 0.07",
-                "f64_flops_note": "a point-to-plane evaluation is ~200 f64 operations per source point: 16 x 7k points = 22 MFLOP per launch, "
-                                  "0.4 TFLOP/s of the 78 TFLOP/s f64 vector peak - the chain is nowhere near an arithmetic bound"}
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes": ic["algorithmic_bytes"], "device_ms": ic["device_ms"], "iterations": ic["iterations_total"],
+                "convention": "SURVEY 8d: per ICP iteration and hypothesis N_src * 24 B + N_tgt * 48 B (every point and normal once), summed over the iterations "
+                              "executed, over the device time of the whole poseRefine batch (clouds, voxel grid, kNN normals and all evaluations)",
+                "vs_f64_vector_peak": {"achieved": tfs, "peak": 78.6, "unit": "TFLOP/s", "frac": tfs / 78.6,
+                                       "convention": "SURVEY 8d: the flops of a brute-force nearest-neighbour search, N_src * N_tgt * 8 per iteration (the kernels "
+                                                     "search a grid and execute a small fraction of them)"},
+                "what_binds": "neither: the chain of DEPENDENT f64 operations of a single wave - a dependent f64 op costs a lone wave ~40 cycles on gfx950, an "
+                              "LDS read 70, a permute 78 (profiles/r06_latency_microbench.txt) - through 31 evaluations of the hypotheses that never converge: "
+                              "k_icp_team (one launch, a team of workgroups per hypothesis, clouds in LDS and registers) spends ~17 us per evaluation on "
+                              "exchange, 6x6 solve, transform + certification, search sweep and sums (profiles/r06_icp_*)",
+                "pipeline_leg": {"icp_ms": pl["icp_ms"], "iterations": pl["icp_iterations"],
+                                 "achieved": (sum(i * (a * 24 + b * 48) for i, a, b in zip(pl["iterations"], pl["points_source"], pl["points_target"])) / (pl["icp_ms"] * 1e-3) / 1e9) if pl["icp_ms"] > 0 else 0.0,
+                                 "unit": "GB/s"}}
         # PMC counters of the dominant kernel, measured NOW: separate rocprofv3 --pmc passes over `bench.py --roofline-only` (the
         # same launches as the roofline leg above), corrected as MI355X_MICROARCH.md (HBM) prescribes.  Without rocprofv3 (or with
         # --no-pmc) the numbers of the last committed pass (profiles/roofline_traffic.json) are quoted and labelled as such.
@@ -625,6 +649,10 @@ def main():
             os.sched_setaffinity(0, all_cpus)          # the CPU baseline (its all-cores variant) gets every core the process started with
             out["cpu_baseline"] = cpu_baseline(noisy_frames(N_FRAMES), banks[classes[0]], args.templates)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
+            out["speedup_vs_cpu_1thread_is"] = ("GPU frame (quantisation + matching + sort) over the CPU's MATCH LOOPS ONLY (the reference's lines from the quantised "
+                                                "maps on: OpenCV, which the reference's quantisation needs, is not in this image)")
+            iq = out["cpu_baseline"].get("incl_quantisation", {}).get("value")
+            out["speedup_vs_cpu_1thread_incl_quantisation"] = value / iq if iq else None
         if world == 1 and not strong and not args.no_extras:
             sr = strong_reference(det, quant, frames, args.templates, steps=args.steps, depth=PIPELINE_DEPTH)
             out["extras"]["strong_scaling_reference"] = sr
@@ -953,7 +981,10 @@ def icp_bench(device, hypotheses=16, reps=5):
                 "icp_iters_per_sec_device": iters / (dev_ms * 1e-3) if dev_ms > 0 else 0.0,
                 "icp_iters_per_sec_wall": iters / wall, "points_source_mean": float(np.mean([r["n_source"] for r in res])),
                 "points_target_mean": float(np.mean([r["n_target"] for r in res])),
-                "mean_fitness": float(np.mean([r["residual"] for r in res]))}
+                "mean_fitness": float(np.mean([r["residual"] for r in res])),
+                # per iteration and hypothesis N_src * 24 B + N_tgt * 48 B compulsory; a brute-force search is N_src * N_tgt * 8 flop
+                "algorithmic_bytes": float(sum(r["iterations"] * (r["n_source"] * 24 + r["n_target"] * 48) for r in res if r["residual"] >= 0)),
+                "brute_force_flops": float(sum(r["iterations"] * r["n_source"] * r["n_target"] * 8 for r in res if r["residual"] >= 0))}
     # (1) depth images resident in HBM (scene uploaded once per frame, model renderings in slots): the timed
     #     region is lm_icp_run = cloud preparation + normals + all ICP iterations on the device + result read-back
     ctx = lm.IcpContext(device=device, scene_from_scene=True)

@@ -90,7 +90,8 @@ void lm_detector_destroy(lm_detector *d);
 
 /* Detector::addTemplate (pybind11.cpp:29, LL.cpp:1943-1975).  Returns the new template_id (>=0),
  * -1 when no valid template could be extracted (the reference's own convention, LL.cpp:1964-1966),
- * or an LM_ERR_* code (< -1).  Quantisation runs on the GPU, the greedy feature selection on host. */
+ * or an LM_ERR_* code (< -1).  Quantisation runs on the GPU; so does the greedy feature selection when a mask is given
+ * (train.hip, checked against the reference's golden YAML), on the host for the maskless call. */
 int lm_detector_add_template(lm_detector *d, const uint8_t *rgb, const uint16_t *depth, const uint8_t *mask,
                              int width, int height, const char *class_id);
 
