@@ -191,6 +191,14 @@ def load_library():
     lib.lm_detector_exchange_merge_frame_strided.argtypes = [P, U64, P, I, I, ctypes.c_size_t]
     lib.lm_detector_exchange_pack_group.argtypes = [P, U64, I, P, I]
     lib.lm_detector_exchange_merge_group.argtypes = [P, U64, I, P, I, I]
+    lib.lm_comm_unique_id.argtypes = [P]
+    lib.lm_comm_create.argtypes = [P, I, I, I, ctypes.POINTER(P)]
+    lib.lm_comm_destroy.argtypes = [P]
+    lib.lm_comm_destroy.restype = None
+    lib.lm_comm_rank.argtypes = [P]
+    lib.lm_comm_world.argtypes = [P]
+    lib.lm_exchange_allgather.argtypes = [P, P, P, P, ctypes.c_size_t]
+    lib.lm_detector_exchange_group.argtypes = [P, P, U64, I, P, P, I]
     for f in (lib.lm_detector_frames_submitted, lib.lm_detector_frames_launched, lib.lm_detector_frames_collected):
         f.argtypes = [P]
         f.restype = U64
@@ -294,6 +302,41 @@ class Template:
 
     def __init__(self, width, height, pyramid_level, features):
         self.width, self.height, self.pyramid_level, self.features = width, height, pyramid_level, features
+
+
+class Comm:
+    """An RCCL communicator owned by the C library (lm_comm_*: librccl.so loaded with dlopen).  Rank 0 calls Comm.unique_id() and the
+    caller carries the 128 bytes to every rank (sharded.DeviceExchange uses torch.distributed's broadcast; a C++ caller MPI or a file)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        self._lib = load_library()
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        h = ctypes.c_void_p()
+        _check(self._lib.lm_comm_create(ctypes.c_char_p(bytes(unique_id)), rank, world, device, ctypes.byref(h)))
+        self._h = h
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def available() -> bool:
+        return bool(load_library().lm_comm_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _check(load_library().lm_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def close(self):
+        if self._h:
+            self._lib.lm_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Detector:
@@ -630,6 +673,10 @@ class Detector:
 
     def exchangeMergeFrame(self, frame_no: int, recv_ptr: int, world: int, capacity: int, rank_stride_bytes: int = 0) -> None:
         _check(self._lib.lm_detector_exchange_merge_frame_strided(self._h, frame_no, ctypes.c_void_p(recv_ptr), world, capacity, rank_stride_bytes))
+
+    def exchangeGroup(self, comm: "Comm", first: int, n: int, send_ptr: int, recv_ptr: int, capacity: int) -> None:
+        """pack + RCCL all-gather + merge of frames first .. first + n - 1, all issued by the library (lm_detector_exchange_group)."""
+        _check(self._lib.lm_detector_exchange_group(self._h, comm._h, first, n, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), capacity))
 
     def exchangePackGroup(self, first: int, n: int, send_ptr: int, capacity: int) -> None:
         _check(self._lib.lm_detector_exchange_pack_group(self._h, first, n, ctypes.c_void_p(send_ptr), capacity))

@@ -21,6 +21,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import os
+
 import numpy as np
 
 import linemodLevelup_pybind as lm
@@ -77,6 +79,14 @@ class DeviceExchange:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.collective = self.dist is not None and (self.world > 1 or force)
         self.device_collective = self.collective and dist.get_backend(group) == "nccl"
+        # the all-gather itself: issued by the C library (lm_exchange_allgather: its own RCCL communicator on the exchange stream — what a C++ caller
+        # of the library uses, no Python per group of frames on the data path beyond this call) when RCCL loads; else torch.distributed's
+        self.comm = None
+        if self.device_collective and os.environ.get("LM_EXCHANGE_COLLECTIVE", "c") != "torch" and lm.Comm.available():
+            import torch as _t
+            ident = [lm.Comm.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.comm = lm.Comm(ident[0], self.rank, self.world, device=_t.device(device).index or 0)
         if shard:                      # shard=False: the caller partitioned the bank itself (e.g. whole classes per rank)
             detector.setShard(self.rank, self.world)
         detector.setAsyncCollect(False)   # the merged list of all ranks comes from the device exchange: no per-rank host list to prepare
@@ -150,6 +160,9 @@ class DeviceExchange:
         cap = self.capacity
         send, recv = self.views[k][n]
         send_ptr, recv_ptr = self.ptrs[k]
+        if self.comm is not None:                                # pack, all-gather and merge enqueued by the library
+            self.det.exchangeGroup(self.comm, frames[0], n, send_ptr, recv_ptr, cap)
+            return
         self.det.exchangePackGroup(frames[0], n, send_ptr, cap)
         if not self.collective:
             recv_ptr = send_ptr

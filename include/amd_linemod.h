@@ -185,6 +185,27 @@ int lm_detector_exchange_collect(lm_detector *d, lm_match **out, size_t *n, int 
 /* the same into caller memory (capacity records; world * capacity always suffices): no allocation, one pass */
 int lm_detector_exchange_collect_into(lm_detector *d, lm_match *dst, size_t capacity, size_t *n, int *failed);
 
+/* The collective, issued by the library (BASELINE north_star: "RCCL all-gather over xGMI of per-GPU top-K matches"; the caller shape is the
+ * reference's C++ driver, linemodLevelup/test.cpp:111-130, one process per GPU).  librccl.so is loaded at run time (dlopen; LM_RCCL_LIB
+ * names another file), so single-GPU use needs no RCCL.  Rank 0 calls lm_comm_unique_id and carries the 128 bytes to the other ranks by
+ * whatever it has (MPI_Bcast, a file, a socket, torch.distributed's store): the library has no transport of its own.
+ *   lm_comm_available()                                1 if librccl.so could be loaded
+ *   lm_comm_create(id, rank, world, device, &comm)     ncclCommInitRank on this rank's device (collective: every rank calls it)
+ *   lm_exchange_allgather(d, comm, send, recv, bytes)  ncclAllGather of `bytes` per rank on lm_detector_exchange_stream(d): in stream order
+ *                                                      after the pack kernels of the frames it carries, before their merges; nothing blocks the host
+ *   lm_detector_exchange_group(d, comm, first, n, send, recv, capacity)
+ *                                                      pack_group + all-gather + merge_group of frames first .. first + n - 1 in one call
+ *                                                      (send: n blocks, recv: world x n blocks of lm_exchange_block_bytes(capacity), device memory) */
+typedef struct lm_comm lm_comm;
+int lm_comm_available(void);
+int lm_comm_unique_id(void *id128);
+int lm_comm_create(const void *id128, int rank, int world, int device, lm_comm **out);
+void lm_comm_destroy(lm_comm *c);
+int lm_comm_rank(const lm_comm *c);
+int lm_comm_world(const lm_comm *c);
+int lm_exchange_allgather(lm_detector *d, lm_comm *c, const void *send, void *recv, size_t bytes_per_rank);
+int lm_detector_exchange_group(lm_detector *d, lm_comm *c, uint64_t first, int n, void *send_blocks, void *recv_blocks, int capacity);
+
 /* Detector::match (pybind11.cpp:32-33, LL.cpp:1702-1777).  class_ids may be NULL/0 = all classes.
  * masks: NULL, or two pointers (colour, depth modality), each NULL or a [height][width] uint8 mask.
  * On success *out is a malloc'd array of *n matches in the canonical order of SURVEY §8a A12

@@ -1563,6 +1563,13 @@ if backend == "nccl":   # single rank: also push the records through the RCCL al
 ex = sharded.DeviceExchange(det, "cuda:0", force=True)
 dev_got = sharded.match_sharded(det, [rgb, dep], 75.0, ["c", "a", "b"], device=dev, exchange=ex)
 assert dev_got.tobytes() == got.tobytes(), (rank, len(dev_got), len(got))
+if backend == "nccl":   # the all-gather above was issued by the C library (lm_exchange_allgather, its own RCCL communicator); and once through torch's
+    assert ex.comm is not None and lm.Comm.available()
+    os.environ["LM_EXCHANGE_COLLECTIVE"] = "torch"
+    ex_t = sharded.DeviceExchange(det, "cuda:0", force=True)
+    assert ex_t.comm is None
+    assert sharded.match_sharded(det, [rgb, dep], 75.0, ["c", "a", "b"], device=dev, exchange=ex_t).tobytes() == got.tobytes()
+    del os.environ["LM_EXCHANGE_COLLECTIVE"]
 frames = [synth.make_frame(13 + k, W, H) for k in range(4)]
 for k, f in enumerate(frames):
     det.storeFrame(k, f)
@@ -1607,6 +1614,21 @@ def _run_workers(tmp_path, world, backend):
 def test_match_sharded_two_processes_one_gpu_gloo(lm, tmp_path):
     """world_size 2, both ranks computing on cuda:0, records exchanged over gloo: equals the unsharded result."""
     _run_workers(tmp_path, 2, "gloo")
+
+
+def test_cpp_caller_exchanges_through_the_librarys_own_rccl_collective(lm, tmp_path):
+    """tests/cpp/exchange_rccl_smoke.cpp — a C++ program shaped like the reference's test.cpp (train, match per frame), no Python: frames go
+    submit -> lm_detector_exchange_group (pack + ncclAllGather issued by the library on the exchange stream + merge) -> collect and must
+    equal lm_detector_match record by record.  World size 1 (one GPU here); the same binary is one rank of N."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "exchange_rccl_smoke")
+    subprocess.check_call([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "exchange_rccl_smoke.cpp"),
+                           "-L", os.path.join(root, "6dpose_amd"), "-lamdlinemod", "-Wl,-rpath," + os.path.join(root, "6dpose_amd"), "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"ok:" in r.stdout, r.stdout.decode()[-2000:]
 
 
 def test_match_sharded_rccl_single_rank(lm, tmp_path):
