@@ -924,8 +924,26 @@ def strong_reference(det0, quant, frames, per_object, steps=20, depth=8):
         det.addClassPacked(cid, *synth.make_planted_bank(1234 + o, per_object, quant, T_LEVELS, NFEAT))
         classes.append(cid)
     total = per_object * STRONG_OBJECTS
+    # parity on this leg's own bank and frame: two of its eight objects (first, last) against the CPU oracle, record by record
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import linemod_oracle as lo
+    od = lo.OracleDetector(NFEAT[0], T_LEVELS)
+    par = {"ok": True, "classes": []}
+    rgb0, dep0 = frames[0]
+    for o in (0, STRONG_OBJECTS - 1):
+        pb = lo.PackedBank(per_object, 2, *synth.make_planted_bank(1234 + o, per_object, quant, T_LEVELS, NFEAT))
+        want, _, st, _, _, _ = oracle_matches(od, lo, pb, rgb0, dep0, THRESHOLD)
+        got = det.matchArray([rgb0, dep0], THRESHOLD, [classes[o]])
+        ok = same_records(got, want) and int(det.lastTimings()["coarse_candidates"]) == int(st["coarse_candidates"])
+        par["classes"].append({"class": classes[o], "matches": int(len(want)), "coarse_candidates": int(st["coarse_candidates"]), "equal": bool(ok)})
+        par["ok"] = par["ok"] and ok
+    if not par["ok"]:
+        sys.stderr.write("bench.py: PARITY FAILED on the 16k bank: %s\n" % json.dumps(par))
+        sys.exit(3)
     dt, tm = pipelined_host_stream(det, frames, classes, THRESHOLD, steps, warmup=16, depth=depth)
     return {"templates_total": total, "ms_per_step": dt * 1e3, "steps": steps, "value": total * (W * H / 1e6) / dt, "unit": "templates*Mpx/s", **stream_shape(det, tm),
+            "workload": "configs[3] on ONE GPU: %d objects x %d templates, 640x480 stream" % (STRONG_OBJECTS, per_object), "parity": par,
+            "kernel_ms_per_launch": {q: tm.get(q) for q in ("frontend_ms", "coarse_ms", "local_ms")}, "frames_per_launch": tm.get("batch_frames"),
             "coarse_ms": tm.get("coarse_ms"), "local_ms": tm.get("local_ms"), "coarse_candidates": tm.get("coarse_candidates"),
             "note": "same live-stream loop as the headline (host frame per step), `python bench.py --scaling strong` gives the same number as a bench line"}
 

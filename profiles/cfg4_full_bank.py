@@ -43,6 +43,17 @@ def stream(cls, steps, depth=4, warm=4):
     return dt, {q: v / max(1, n) for q, v in acc.items()}, len(out)
 
 res = {"frame": [W, H], "objects": n_obj, "templates_per_object": per, "bank_build_s": t_bank}
+# parity on this configuration's own frame: one object's 3000 templates at 1280x960 against the CPU oracle (numpy quantisation +
+# oracle/match_oracle.c), record by record and the coarse candidate count
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import bench, linemod_oracle as lo
+od = lo.OracleDetector(NF[0], T)
+pb = lo.PackedBank(per, 2, *synth.make_planted_bank(500, per, quant, T, NF))
+want, _, st, _, _, _ = bench.oracle_matches(od, lo, pb, frames[0][0], frames[0][1], 75.0)
+got = det.matchArray(list(frames[0]), 75.0, [classes[0]])
+res["parity"] = {"class": classes[0], "matches": int(len(want)), "coarse_candidates": int(st["coarse_candidates"]),
+                 "equal": bool(bench.same_records(got, want) and int(det.lastTimings()["coarse_candidates"]) == int(st["coarse_candidates"]))}
+assert res["parity"]["equal"], res["parity"]
 for name, cls in (("whole_bank", classes), ("rank_share_8gpu", classes[:max(1, (n_obj + 7) // 8)])):
     dt, tm, nm = stream(cls, 12 if len(cls) > 8 else 30)
     nt = per * len(cls)
