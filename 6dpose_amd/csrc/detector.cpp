@@ -139,7 +139,8 @@ extern "C" int lm_detector_create(int num_features, const int* T, int num_levels
     //   coarse or front end at normal priority 0.223 / 0.230-0.237 (coarse shares a queue: half overlapped);
     //   exchange at low priority: its five dependent steps take ~50 us each and the frames in flight no longer hide the latency;
     //   GPU_MAX_HW_QUEUES=8: 0.223 / 0.40-0.50 (more queues than the hardware runs at once: they are time-sliced).
-    // LM_STREAM_PRIO="fcmx" overrides (digits: 0 normal, 1 low, 2 high).
+    // LM_STREAM_PRIO="f-mx" overrides (digits: 0 normal, 1 low, 2 high; position 0 = frame / front-end stream, 2 = matching stream, 3 = exchange
+    // stream; position 1 belonged to the coarse stream that round 5 removed and is ignored).
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     int prio[4] = {prio_greatest, prio_greatest, prio_least, 0};
@@ -335,6 +336,7 @@ static int upload_frame(lm_detector* d, const uint8_t* rgb, const uint16_t* dept
     d->frame_valid = false;
     if (d->n_submitted != d->n_collected)   // the front end's buffers (and, on a size change, the arenas) belong to the frames in flight
         return lm_set_error(LM_ERR_INVALID, "frames in flight: collect them before uploading another frame this way (lm_detector_submit_frame streams)");
+    LM_DIAG_IDLE(d, "upload_frame");
     int rc = setup_geometry(d, W, H, check_match_preconditions);
     if (rc) return rc;
     d->cur_rgb = d->frame_rgb.p; d->cur_depth = d->frame_depth.p;
@@ -623,6 +625,7 @@ extern "C" int lm_detector_add_templates_rendered(lm_detector* d, lm_mesh* m, co
         return lm_set_error(LM_ERR_INVALID, "null argument");
     if (m->device != d->device) return lm_set_error(LM_ERR_INVALID, "mesh and detector live on different devices");
     if (d->n_submitted != d->n_collected) return lm_set_error(LM_ERR_INVALID, "a frame is in flight: collect it first");
+    LM_DIAG_IDLE(d, "lm_detector_add_templates_rendered");
     if (width < 16 || height < 16) return lm_set_error(LM_ERR_INVALID, "unsupported frame size %dx%d", width, height);
     HIP_TRY(hipSetDevice(d->device));
     const size_t npx = (size_t)width * height;
@@ -1251,6 +1254,7 @@ extern "C" int lm_detector_select_frame(lm_detector* d, int slot) {
         if (d->n_submitted != d->n_collected)   // setup_geometry reallocates and clears the arenas the frames in flight are reading
             return lm_set_error(LM_ERR_INVALID, "frame size changes (%dx%d -> %dx%d) with frames in flight: collect them first", d->fW, d->fH, W, H);
         d->frame_valid = false;
+        LM_DIAG_IDLE(d, "lm_detector_select_frame (geometry change)");
         int rc = setup_geometry(d, W, H, true);
         if (rc) return rc;
     }
@@ -1372,8 +1376,7 @@ static int local_grid(lm_detector* d, int nb) {
     return d->num_cus * (tiles_wanted(d) ? 16 : 3) * std::max(1, std::min(nb, 4));
 }
 
-// Grid of k_local_bits: a wave serves 8 candidates (~2k groups per frame at configs[1]); 4 workgroups per CU and frame of the batch.
-// Grid of k_local_bits: the workgroups the chip holds at once (4 waves per SIMD = 4 workgroups of 256 per CU), whatever the batch: the waves stride over
+// Grid of k_local_bits (a wave serves 8 candidates, ~2k groups per frame at configs[1]): the workgroups the chip holds at once (4 waves per SIMD = 4 workgroups of 256 per CU), whatever the batch: the waves stride over
 // the items.  (Round 4 launched four times as many for batches of four and more frames; one wave per item and a dispatcher that has to place 4096
 // workgroups cost 3-4 %: 204-207 -> 197-199 us per 8-frame launch, profiles/r05_local_sharing/kernel_times_grid_sweep.txt.)
 static int bits_grid(lm_detector* d, int nb) {
@@ -1991,7 +1994,9 @@ static void staged_copy(lm_detector* d, uint8_t* dst, const uint8_t* a, size_t n
         pool_post(d, [=]() { copy_range(lo, hi); lp->fetch_sub(1, std::memory_order_release); });
     }
     copy_range(0, std::min(total, per));
-    // the slices nobody has taken yet are copied here; then a bounded spin for the ones in progress, then the CPU is given up between looks
+    // queued jobs nobody has taken yet are run here — the copy slices above, and whatever else is queued: a list-preparation job of another
+    // slot (~35 us, no HIP calls) may so run inside this submit; results do not depend on who runs a job —; then a bounded spin for the
+    // slices in progress, then the CPU is given up between looks
     for (int spin = 0; left.load(std::memory_order_acquire) != 0;) {
         if (pool_run_one(d)) continue;
         if (++spin < 4000) __builtin_ia32_pause(); else std::this_thread::yield();

@@ -150,7 +150,7 @@ struct lm_detector {
         lm_match* prep = nullptr;
         size_t prep_n = 0;
         float prep_collect_ms = 0.f, prep_merge_ms = 0.f;
-        hipEvent_t ev[6] = {};                      // stage timing: front end 0-1, coarse 2-3, refinement 5-4
+        hipEvent_t ev[6] = {};                      // stage timing: front end 0 -> 1, coarse 1 -> 3, refinement 3 -> 4 (2 and 5: not recorded since round 5)
         hipEvent_t done = nullptr;                  // recorded after the batch's last kernel: the only event the host waits on
         hipEvent_t fe_done = nullptr;               // front end of this slot finished (eager, on `stream`): `mstream` waits for it
         bool pending = false;
@@ -284,3 +284,22 @@ struct lm_detector {
 int lm_submit_frame(lm_detector* d, float threshold, const char* const* class_ids, int num_class_ids);
 int lm_collect_frame(lm_detector* d, int sort_unique, lm_match** out, size_t* n_out);   // sort_unique < 0: discard the records
 int lm_launch_pending(lm_detector* d);                                                  // launches the frames waiting for their batch to fill
+
+// A writer on the frame stream (`stream`) — upload, frame selection with a geometry change, training — touches level buffers, arenas and the
+// resident frame that a batch in flight on the matching stream reads.  Stream order only runs the other way (order_after_default_stream: batch
+// after `stream`), so these entry points must find nothing launched and uncollected; they check it at run time and refuse.  A DIAG build
+// (make DIAG=1) also aborts loudly if a future writer forgets the check.
+#ifdef LM_DIAG
+#include <stdio.h>
+#include <stdlib.h>
+#define LM_DIAG_IDLE(d, what)                                                                                                    \
+    do {                                                                                                                         \
+        if ((d)->n_launched != (d)->n_collected) {                                                                               \
+            fprintf(stderr, "LM_DIAG: %s writes on the frame stream with %llu batches' frames launched and %llu collected\n", (what), \
+                    (unsigned long long)(d)->n_launched, (unsigned long long)(d)->n_collected);                                 \
+            abort();                                                                                                             \
+        }                                                                                                                        \
+    } while (0)
+#else
+#define LM_DIAG_IDLE(d, what) do { } while (0)
+#endif

@@ -21,7 +21,7 @@ struct Knobs {
     int fe_bits = 1;               // LM_FE_BITS=0: the front end always writes the byte planes and k_pack_bits / k_pack_top pack them (1: bit planes directly when nothing reads the bytes)
     int fe_bits_split = 0;         // LM_FE_BITS_SPLIT=1: k_fe_bits as two launches (strip records, pair stream) so that a profile times them apart
     int first_batch = 3;           // LM_FIRST_BATCH: frames an idle GPU waits for before a partial batch goes out WHILE THE CALLER SUBMITS IN A TIGHT LOOP (collect / flush launch what is left; sparse streams: every frame at once)
-    int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (1, 2, 4, 8 <= T; 0 = default 2: the spread rows are built T / 2 times per row phase, for twice the workgroups)
+    int fe_rows_cs = 0;            // LM_FE_ROWS_CS: column phases per workgroup of the strip-record tile writer (a divisor of T: 1, 2, 4, 8 or 1, 5; 0 = default 2, or 1 where 2 does not divide T: the spread rows are built T / 2 times per row phase, for twice the workgroups)
     int nt_copy = 1;               // LM_NT_COPY=0: the staging copy of a streamed frame with memcpy instead of non-temporal AVX2 stores
     int dedupe_blocks = 0;         // LM_DEDUPE_BLOCKS: workgroups per frame of k_dedupe (0 = default: one per 256 candidates of the last frame, 64 .. two per CU)
     int fe_wgs_per_cu = kFeWaves;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)

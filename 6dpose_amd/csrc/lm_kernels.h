@@ -47,7 +47,7 @@ void fe_job_build_lm(FeJob& j, const uint8_t* const quant[2], const uint8_t* con
                      int W, int H, int T);
 // the bit planes straight from the quantised maps, when nothing reads the byte planes (frontend.hip)
 bool fe_bits_rows_possible(int W, int T);     // the level's rows fit the stage's LDS
-void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T, bool tiles);   // tiles: from pixel tiles where the geometry allows (T = 4 or 8, the row fits the LDS pool)
+void fe_job_bits_rows(FeJob& j, const uint8_t* const quant[2], const uint8_t* const mask[2], uint8_t* const bits[2], int W, int H, int T, bool tiles);   // tiles: from pixel tiles where the geometry allows (T = 4, 5 or 8, the row fits the LDS pool)
 // (the writer of whole dwords when the label planes start on 64-position boundaries — fe_top_bits_kind —, else, or when forced, the one that ORs
 // shifted ballots into a stream that must be zero beforehand)
 // mode: 0 = the cheapest writer the geometry allows (pixel tiles -> whole dwords per wave -> OR-ed ballots), 1 = the OR-ing writer, 2 = no tiles (tests)

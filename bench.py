@@ -611,7 +611,7 @@ def main():
             fe_parts = {}
             for k in ("k_fe_stage", "k_fe_bits", "k_pack_bits", "k_pack_top"):
                 if k in pm_all:
-                    cz = ceilings_of(pm_all[k])
+                    cz = ceilings_of(pm_all[k], wide_loads=False)
                     n = pm_all[k]["dispatches"] / max(1, pm_all[k_refine]["dispatches"] if k_refine in pm_all else 1)     # dispatches of this kernel per batch
                     fe_us += cz["kernel_us_profiled"] * n
                     fe_bytes += cz["hbm_bytes_per_dispatch"] * n
@@ -829,7 +829,7 @@ USEFUL_ADDER_OPS_PER_LANE_FEATURE = 5.0
 ALIGN_OPS_PER_LANE_FEATURE = 2.0      # + the two v_alignbit that cut the lane's two window rows out of their records
 
 
-def ceilings_of(pm):
+def ceilings_of(pm, wide_loads=True):
     """What a kernel's launch reached of each physical ceiling, from its PMC means:
     l1_data = the vector L1 -> register path: a wave load of 16 bytes per lane (what the matching kernels issue) is 1 KB at 64 B per CU cycle = 16 cycles,
           so the fraction is 16 x wave loads over the CU cycles of the launch.  This is what binds k_local_bits: its time follows the NUMBER of wave loads
@@ -844,12 +844,14 @@ def ceilings_of(pm):
     us = kc / 2400.0
     hbm_bytes = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0
     tcp_raw = pm["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kc)
-    c = {"l1_data": min(1.0, 16.0 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kc)),
+    # l1_data assumes every vector read is a 16-byte-per-lane wave load: true of k_local_bits / k_coarse_bits (wide_loads), not of the front end and the
+    # duplicate removal, whose loads are narrower - for those the ceiling is not applicable and is left out of the choice of the binding one
+    c = {"l1_data": min(1.0, 16.0 * pm["SQ_INSTS_VMEM_RD"] / (256.0 * kc)) if wide_loads else None,
          "tcp": tcp_raw,
          "valu": 4.0 * pm["SQ_INSTS_VALU"] / (1024.0 * kc),
          "l2": (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"]) * 128.0 / (us * 1e-6) / 1e9 / L2_PEAK_GBS,
          "hbm": hbm_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    top = max((q for q in c if q != "tcp"), key=lambda q: c[q])
+    top = max((q for q in c if q != "tcp" and c[q] is not None), key=lambda q: c[q])
     names = {"l1_data": "vector L1 -> register path: 16-byte-per-lane wave loads at 64 B per CU cycle (16 cycles each)", "valu": "VALU issue slots (4 cycles per wave instruction)",
              "l2": "L2 bandwidth (requests x 128 B against %.1f TB/s)" % (L2_PEAK_GBS / 1e3), "hbm": "HBM bandwidth (memory-side bytes against %.0f TB/s)" % (HBM_PEAK_GBS / 1e3)}
     return {"kernel_us_profiled": us, "dispatches_profiled": pm.get("dispatches"), "fractions": c, "binding": {"ceiling": names[top], "frac": c[top]},
