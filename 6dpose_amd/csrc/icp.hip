@@ -763,6 +763,19 @@ template <int CTRL> static __device__ __forceinline__ int dpp_mov(int v) { retur
 template <int CTRL> static __device__ __forceinline__ double dpp_mov(double v) {
     return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
 }
+constexpr unsigned long long kInfKey = 0x7FF0000000000000ull;   // +infinity as a distance key
+template <int CTRL> static __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v);
+template <int CTRL> static __device__ __forceinline__ unsigned long long dpp_mov(unsigned long long v) { return dpp_mov64<CTRL>(v); }
+template <int CTRL> static __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, 0xF, 0xF, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, m, 64), hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 static __device__ __forceinline__ int sum8(int v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v; }
 static __device__ __forceinline__ double sum8(double v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v; }
 static __device__ __forceinline__ double min8(double v) {
@@ -789,9 +802,11 @@ static __device__ __forceinline__ void knn_scan_run(const int a, const int b, co
         }
 #pragma unroll
         for (int v = 0; v < U; ++v) d4[v] = sqdist(px, py, pz, q4[v][0], q4[v][1], q4[v][2]);
+        // (the squared distance as the unsigned integer its bit pattern is: it is >= 0, so the order is the same, and a dependent integer
+        // compare + select costs a lone wave a few cycles where the f64 pair costs ~30 — profiles/r06_latency_microbench.txt)
 #pragma unroll
         for (int v = 0; v < U; ++v)
-            if (j0 + v * L < b) f(j0 + v * L, d4[v], q4[v][0], q4[v][1], q4[v][2]);
+            if (j0 + v * L < b) f(j0 + v * L, (unsigned long long)__double_as_longlong(d4[v]), q4[v][0], q4[v][1], q4[v][2]);
     }
 }
 // (two loops, not one loop with a choice of pointer inside: a pointer that may be LDS or HBM makes every load a FLAT load,
@@ -808,13 +823,21 @@ static __device__ __forceinline__ void knn_scan(const int2* runs, const int nx, 
 
 // One point, L lanes (8: the lane group of the main loop; 64: a whole wave, for the points whose ring has to grow).
 template <int L> struct Red;
+static __device__ __forceinline__ unsigned long long min8(unsigned long long v) {
+    unsigned long long o = dpp_mov64<0xB1>(v); v = o < v ? o : v;
+    o = dpp_mov64<0x4E>(v); v = o < v ? o : v;
+    o = dpp_mov64<0x141>(v); v = o < v ? o : v;
+    return v;
+}
 template <> struct Red<8> {
+    static __device__ __forceinline__ unsigned long long mn(unsigned long long v) { return min8(v); }
     static __device__ __forceinline__ int sum(int v) { return sum8(v); }
     static __device__ __forceinline__ double sum(double v) { return sum8(v); }
     static __device__ __forceinline__ int mn(int v) { return min8(v); }
     static __device__ __forceinline__ double mn(double v) { return min8(v); }
 };
 template <> struct Red<64> {
+    static __device__ __forceinline__ unsigned long long mn(unsigned long long v) { v = min8(v); for (int o = 8; o < 64; o <<= 1) { const unsigned long long t = shfl_xor_u64(v, o); v = t < v ? t : v; } return v; }
     static __device__ __forceinline__ int sum(int v) { v = sum8(v); for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o, 64); return v; }
     static __device__ __forceinline__ double sum(double v) { v = sum8(v); for (int o = 8; o < 64; o <<= 1) v += shfl_xor_d(v, o); return v; }
     static __device__ __forceinline__ int mn(int v) { v = min8(v); for (int o = 8; o < 64; o <<= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
@@ -838,6 +861,8 @@ template <> struct Red<512> {
     }
     static __device__ __forceinline__ int shfl_any(int v, int o) { return __shfl_xor(v, o, 64); }
     static __device__ __forceinline__ double shfl_any(double v, int o) { return shfl_xor_d(v, o); }
+    static __device__ __forceinline__ unsigned long long shfl_any(unsigned long long v, int o) { return shfl_xor_u64(v, o); }
+    static __device__ __forceinline__ unsigned long long mn(unsigned long long v) { return all(v, [](unsigned long long a, unsigned long long b) { return a < b ? a : b; }); }
     static __device__ __forceinline__ int sum(int v) { return all(v, [](int a, int b) { return a + b; }); }
     static __device__ __forceinline__ double sum(double v) { return all(v, [](double a, double b) { return a + b; }); }
     static __device__ __forceinline__ int mn(int v) { return all(v, [](int a, int b) { return a < b ? a : b; }); }
@@ -850,6 +875,8 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
                                                  const int* __restrict__ cs, double* __restrict__ cov, const int gx, const int gy, const double minx, const double miny,
                                                  const double inv, const double cell) {
     const double kInfD = __longlong_as_double(0x7FF0000000000000ll);
+    auto key = [](const double d) { return (unsigned long long)__double_as_longlong(d); };
+    auto val = [](const unsigned long long k) { return __longlong_as_double((long long)k); };
     const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
     const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
     int R = R0, nx, c0, c1, c2, c3, M;
@@ -869,10 +896,10 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         const double g = (double)R * cell * (1.0 - 1e-9);     // margin >> the rounding of grid_coord
         g2 = g * g;
         // pass 1: how many candidates are closer than g, g/sqrt(2), g/2, g/sqrt(8)
-        const double h1 = g2 * 0.5, h2 = g2 * 0.25, h3 = g2 * 0.125;
+        const unsigned long long kg = key(g2), k1 = key(g2 * 0.5), k2 = key(g2 * 0.25), k3 = key(g2 * 0.125);
         c0 = 0; c1 = 0; c2 = 0; c3 = 0; M = 0;
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
-            ++M; c0 += d < g2 ? 1 : 0; c1 += d < h1 ? 1 : 0; c2 += d < h2 ? 1 : 0; c3 += d < h3 ? 1 : 0;
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, unsigned long long d, double, double, double) {
+            ++M; c0 += d < kg ? 1 : 0; c1 += d < k1 ? 1 : 0; c2 += d < k2 ? 1 : 0; c3 += d < k3 ? 1 : 0;
         });
         c0 = Red<L>::sum(c0); c1 = Red<L>::sum(c1); c2 = Red<L>::sum(c2); c3 = Red<L>::sum(c3); M = Red<L>::sum(M);
         if (c0 >= k || all) break;
@@ -882,24 +909,26 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
     }
     // bracket: `cl` distances are < lo, `ch` are < hi, cl < k <= ch.  Selected in the end: d < v, and of the candidates at
     // d == v none (ties 0), all (1) or those up to original index last_o (2).
-    double lo = 0.0, hi = c0 >= k ? g2 : kInfD;
+    unsigned long long lo = 0ull, hi = c0 >= k ? key(g2) : key(kInfD);     // (keys: see knn_scan_run)
     int cl = 0, ch = c0 >= k ? c0 : M;
     if (c0 >= k) {
-        const double h1 = g2 * 0.5, h2 = g2 * 0.25, h3 = g2 * 0.125;
+        const unsigned long long h1 = key(g2 * 0.5), h2 = key(g2 * 0.25), h3 = key(g2 * 0.125);
         if (c1 >= k) { hi = h1; ch = c1; } else if (c1 > cl) { lo = h1; cl = c1; }
         if (c2 >= k) { hi = h2; ch = c2; } else if (c2 > cl) { lo = h2; cl = c2; }
         if (c3 >= k) { hi = h3; ch = c3; } else if (c3 > cl) { lo = h3; cl = c3; }
     }
-    double v = hi;
+    unsigned long long v = hi;
     int ties = ch == k ? 0 : -1, last_o = -1;
-    if (ties < 0 && hi < kInfD) {
+    if (ties < 0 && hi < key(kInfD)) {
         // pass 2: four thresholds around where the k-th smallest should be if the count is linear in between
-        const double w = hi - lo, f0 = ((double)(k - cl) + 0.5) / (double)(ch - cl + 1), df = 1.5 / (double)(ch - cl + 1);
-        double t[4] = {lo + w * (f0 - 3.0 * df), lo + w * (f0 - df), lo + w * (f0 + df), lo + w * (f0 + 3.0 * df)};
+        const double dlo = val(lo), dhi = val(hi);
+        const double w = dhi - dlo, f0 = ((double)(k - cl) + 0.5) / (double)(ch - cl + 1), df = 1.5 / (double)(ch - cl + 1);
+        const double td[4] = {dlo + w * (f0 - 3.0 * df), dlo + w * (f0 - df), dlo + w * (f0 + df), dlo + w * (f0 + 3.0 * df)};
+        unsigned long long t[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = t[q] > lo ? (t[q] < hi ? t[q] : hi) : lo;
+        for (int q = 0; q < 4; ++q) t[q] = key(td[q] > dlo ? (td[q] < dhi ? td[q] : dhi) : dlo);
         int n4[4] = {0, 0, 0, 0};
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, unsigned long long d, double, double, double) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) n4[q] += d < t[q] ? 1 : 0;
         });
@@ -913,42 +942,43 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
     }
     while (ties < 0) {
         // the kKnnFew smallest distinct distances in [lo, hi) this lane sees, with their multiplicities
-        double sv[kKnnFew];
+        const unsigned long long kInf = key(kInfD);
+        unsigned long long sv[kKnnFew];
         int sc[kKnnFew];
 #pragma unroll
-        for (int q = 0; q < kKnnFew; ++q) { sv[q] = kInfD; sc[q] = 0; }
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, double d, double, double, double) {
+        for (int q = 0; q < kKnnFew; ++q) { sv[q] = kInf; sc[q] = 0; }
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int, unsigned long long d, double, double, double) {
             if (d >= lo && d < hi) {
-                double x = d;
+                unsigned long long x = d;
                 int xc = 1;
 #pragma unroll
                 for (int q = 0; q < kKnnFew; ++q) {
-                    if (x == sv[q]) { sc[q] += xc; xc = 0; x = kInfD; }
-                    else if (x < sv[q]) { const double tt = sv[q]; const int tc = sc[q]; sv[q] = x; sc[q] = xc; x = tt; xc = tc; }
+                    if (x == sv[q]) { sc[q] += xc; xc = 0; x = kInf; }
+                    else if (x < sv[q]) { const unsigned long long tt = sv[q]; const int tc = sc[q]; sv[q] = x; sc[q] = xc; x = tt; xc = tc; }
                 }
             }
         });
         // merge the 8 lists smallest value first.  A lane whose list ran empty after being full may have dropped larger
         // values: nothing above the smallest such "last kept" value can be trusted (limit)
-        double limit = Red<L>::mn(sc[kKnnFew - 1] > 0 ? sv[kKnnFew - 1] : kInfD);
+        const unsigned long long limit = Red<L>::mn(sc[kKnnFew - 1] > 0 ? sv[kKnnFew - 1] : kInf);
         int cum = cl, less = -1, eq = 0;
         for (int it = 0; it < kKnnFew * L && less < 0; ++it) {
-            const double head = Red<L>::mn(sv[0]);
-            if (!(head < kInfD) || head > limit) break;
+            const unsigned long long head = Red<L>::mn(sv[0]);
+            if (!(head < kInf) || head > limit) break;
             const int mult = Red<L>::sum(sv[0] == head ? sc[0] : 0);
             if (cum + mult >= k) { v = head; less = cum; eq = mult; break; }
             cum += mult;
             if (sv[0] == head) {                                // pop
 #pragma unroll
                 for (int q = 0; q + 1 < kKnnFew; ++q) { sv[q] = sv[q + 1]; sc[q] = sc[q + 1]; }
-                sv[kKnnFew - 1] = kInfD; sc[kKnnFew - 1] = 0;
+                sv[kKnnFew - 1] = kInf; sc[kKnnFew - 1] = 0;
             }
             if (head == limit) break;                           // everything up to the limit is counted; beyond it lists are incomplete
         }
         if (less < 0) {                                          // the k-th is above what was collected: go on from there
             // every distance <= the last merged value is counted in cum; restart just above it
-            const double top = limit < kInfD ? limit : hi;       // (limit == inf: all lists complete, so cum == ch >= k cannot happen here)
-            lo = __longlong_as_double(__double_as_longlong(top) + 1ll); cl = cum;
+            const unsigned long long top = limit < kInf ? limit : hi;       // (limit == inf: all lists complete, so cum == ch >= k cannot happen here)
+            lo = top + 1ull; cl = cum;                            // (the next double above)
             continue;
         }
         if (less + eq == k) { ties = 1; break; }
@@ -956,7 +986,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
         for (int n = less; n < k; ++n) {
             int bo = INT_MAX;
             const int lo_o = last_o;
-        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, double d, double, double, double) {
+        knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, unsigned long long d, double, double, double) {
                 if (d == v) { const int o = orig[j]; if (o > lo_o && o < bo) bo = o; }
             });
             last_o = Red<L>::mn(bo);
@@ -965,9 +995,9 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
     double sum[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) sum[q] = 0.0;
-    double sep2 = 1e300;
+    unsigned long long sep2 = key(1e300);
     int taken = 0;
-    knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, double d, double qx, double qy, double qz) {
+    knn_scan<L>(runs, nx, sub, s_tgt, p0, np, rec, px, py, pz, [&](int j, unsigned long long d, double qx, double qy, double qz) {
         if (j != pos && d < sep2) sep2 = d;
         bool sel = d < v;
         if (ties && d == v) sel = ties == 1 || orig[j] <= last_o;
@@ -986,7 +1016,7 @@ static __device__ __forceinline__ bool knn_point(const int pos, const int sub, i
 #pragma unroll
         for (int q = 0; q < 9; ++q) c[q] = sum[q];
         c[9] = (double)taken;
-        c[10] = sep2;
+        c[10] = val(sep2);
     }
     return true;
 }
@@ -1724,17 +1754,6 @@ constexpr long long kTeamTimeout = 100ll * 100000;          // wall_clock64 tick
 // targets [ra, rb) (the columns of a row are consecutive cells), cum = chunks of four targets before a row; out: bd, bp, x = second best
 struct __attribute__((aligned(16))) SoloQ { double x, y, z, bd; int bp, chunks; unsigned short ra[8], rb[8], cum[8]; };
 
-constexpr unsigned long long kInfKey = 0x7FF0000000000000ull;   // +infinity as a distance key
-template <int CTRL> static __device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, 0xF, 0xF, false);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, 0xF, 0xF, false);
-    return ((unsigned long long)hi << 32) | lo;
-}
-static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)v, m, 64), hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), m, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 static __device__ __forceinline__ double readlane_d(double v, int l) {
     const long long b = __double_as_longlong(v);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), l);
@@ -1898,9 +1917,19 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         // points — a cloud of 10000 points next to one of 1500 gets seven times the members; with equal teams the large one sets the length
         // of the launch while the CUs of the small ones idle.  Every wave of every workgroup computes the same table (lane = hypothesis).
         int w = 0;
-        if (lane < B.count) { const IcpState& T = B.st[lane]; if (T.status == 0 && T.stop == 0) w = T.n_src > 0 ? T.n_src : 1; }
+        bool big = false;                                       // a cloud that needs the slab build
+        if (lane < B.count) {
+            const IcpState& T = B.st[lane];
+            if (T.status == 0 && T.stop == 0) {
+                w = T.n_src > 0 ? T.n_src : 1;
+                big = T.n_tgt > ((kSoloRaw - ((2 * (T.gx * T.gy + 1) + 15) & ~15) - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3);
+            }
+        }
         const int ncand = __popcll(__ballot(w > 0));
         if (ncand == 0) return;
+        // The build without a slab takes a batch only if it can take ALL of it: a batch of small and large clouds would otherwise run as two
+        // launches one after the other, each with most of the chip idle (the pipeline's 16 detections: 1.73 ms against 1.53 in one launch)
+        if (!SLAB && __ballot(big)) return;
         long long total = w;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -1930,8 +1959,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     // A cloud of up to C points is resident whole; of a larger one the workgroup holds a SLAB — the targets of the x columns its source points can
     // reach, a contiguous range [p0, p0 + np) of the sorted cloud — and stages it again when an update has moved its points out of it.
     const int cs_bytes = (2 * (ncell + 1) + 15) & ~15;
-    constexpr bool slabbed = SLAB;
-    if (!SLAB && nt > ((kSoloRaw - cs_bytes - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3)) return;      // (the build with a slab takes it)
+    const bool whole = nt <= ((kSoloRaw - cs_bytes - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3);      // the cloud fits with its normals: resident whole
+    if (!SLAB && !whole) return;                                 // (the build with a slab takes it)
+    const bool slabbed = SLAB && !whole;
     // (a slab leaves the normals in global memory — one gather per correspondence and evaluation — for 1.7 times the targets)
     const int C = slabbed ? (kSoloRaw - cs_bytes - kSoloMinQueue * (int)sizeof(SoloQ)) / 36 & ~3 : (nt + 3) & ~3;
     const int off_sep = 32 * C, off_n = off_sep + 4 * C, off_cs = off_n + (slabbed ? 0 : 24 * C), off_q = off_cs + cs_bytes;
@@ -2146,9 +2176,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         const bool calm = s_mot[5] < 0.5 * kSoloMargin * max_dist;
         const double margin = calm ? kSoloMargin * max_dist : 0.0, none2 = calm ? far2 : r2;
         int p0 = s_slab[2];                                       // first target of the slab in LDS (0: the whole cloud)
-        bool in_lds = !SLAB || s_slab[4] == 0;                    // (a member whose points need more targets than the LDS holds reads them from global memory: slow, exact)
-        auto rec_at = [&](const int j) -> TgtRec { if (!SLAB) return s_tgt[j]; return in_lds ? s_tgt[j - p0] : g_rec[j]; };
-        auto sep_at = [&](const int j) -> double { if (!SLAB) return (double)s_sep[j]; return in_lds ? (double)s_sep[j - p0] : g_cov[(size_t)j * kIcpCovStride + 10]; };
+        bool in_lds = !slabbed || s_slab[4] == 0;                    // (a member whose points need more targets than the LDS holds reads them from global memory: slow, exact)
+        auto rec_at = [&](const int j) -> TgtRec { if (!SLAB) return s_tgt[j]; if (__builtin_expect(in_lds, 1)) return s_tgt[j - p0]; return g_rec[j]; };
+        auto sep_at = [&](const int j) -> double { if (!SLAB) return (double)s_sep[j]; if (__builtin_expect(in_lds, 1)) return (double)s_sep[j - p0]; return g_cov[(size_t)j * kIcpCovStride + 10]; };
         {
             double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
             if (it > 0) {
@@ -2657,9 +2687,11 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     //   two points per thread and a slab of the target cloud in LDS — anything up to 1408 points per member, any target cloud;
     //   five points per thread — batches so large that a team is one or two workgroups.
     const dim3 grid = count <= 64 && kn.icp_team == 0 ? dim3(cus) : dim3(team, count);   // (<= 64 hypotheses: the kernel deals the workgroups out itself, by cloud size)
-    hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (team < 4) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    const int builds = kn.icp_builds > 0 ? kn.icp_builds : (1 | 2 | 4 | (team < 4 ? 8 : 0));
+    if (builds & 1) hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 2) hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 4) hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 8) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
 }
 
 }  // namespace lm

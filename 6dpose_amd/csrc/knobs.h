@@ -30,6 +30,8 @@ struct Knobs {
     int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: 64 workgroups per cloud up to 32 clouds, 32 beyond)
     int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
     int icp_team = 0;              // LM_ICP_TEAM: workgroups per hypothesis of k_icp_team (0 = default: 16, at most CUs / hypotheses)
+    int icp_builds = 0;            // LM_ICP_BUILDS: which builds of k_icp_team are launched, in this order (bits: 1 = one point per thread, whole cloud only; 2 = one point, slab;
+                                   // 4 = two points, slab; 8 = five points, slab; 0 = default 1 | 2 | 4, and 8 for batches whose teams are under four workgroups)
     int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
     int icp_maxshift_late = 4;
 #ifdef LM_DIAG
@@ -60,6 +62,7 @@ inline const Knobs& knobs() {
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
         v.icp_team = geti("LM_ICP_TEAM", 0);
+        v.icp_builds = geti("LM_ICP_BUILDS", 0);
         v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
         v.icp_maxshift_late = geti("LM_ICP_MAXSHIFT_LATE", v.icp_maxshift_late);
 #ifdef LM_DIAG
