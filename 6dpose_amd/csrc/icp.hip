@@ -480,6 +480,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         if (tid == 0) { if (which == 0) { S.n_src = 0; if (!scene_mode) S.n_tgt = 0; } else S.n_tgt = 0; }
         return;
     }
+    const long long v_t0 = (long long)__builtin_amdgcn_s_memtime();
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
     for (int i = tid; i < n; i += kWG) {
 #pragma unroll
@@ -496,6 +497,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         if (tid == 0) S.status = 3;
         return;
     }
+    const long long v_t1 = (long long)__builtin_amdgcn_s_memtime();
     const int npad = next_pow2(n < 2 ? 2 : n);
     const bool in_lds = npad <= kSortLds;
     const bool radix = n <= kRadixBig && bx + by + bz <= 32;       // voxel index in 32 bits: stable radix sort of the point indices
@@ -516,6 +518,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         else if (in_lds) s_keys[i] = key; else gk[i] = key;
     }
     __syncthreads();
+    const long long v_t2 = (long long)__builtin_amdgcn_s_memtime();
     const unsigned short* order = nullptr;
     if (radix && big) order = wg_radix_sort(s_rx, n, bx + by + bz, s_wave, [&](unsigned int id) { return gk32[id]; });
     else if (radix) order = wg_radix_sort(s_rx, n, bx + by + bz, s_wave, [&](unsigned int id) { return s_rx.key_lds[id]; });
@@ -526,6 +529,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
         if (radix) { const unsigned int id = order[i]; return ((unsigned long long)(big ? gk32[id] : s_rx.key_lds[id]) << bi) | id; }
         return in_lds ? s_keys[i] : gk[i];
     };
+    const long long v_t3 = (long long)__builtin_amdgcn_s_memtime();
     const unsigned long long imask = (1ull << bi) - 1ull;
     int nout = 0;
     if (radix) {
@@ -600,6 +604,10 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
     if (tid == 0) {
         if (which == 0) { S.n_src = nout; if (!scene_mode) S.n_tgt = nout; }
         else S.n_tgt = nout;
+        if (which == 0) {                                          // diagnostics (model cloud): cycles for extent, keys, sort, voxel means
+            const long long v_t4 = (long long)__builtin_amdgcn_s_memtime();
+            S.vox_clk[0] = v_t1 - v_t0; S.vox_clk[1] = v_t2 - v_t1; S.vox_clk[2] = v_t3 - v_t2; S.vox_clk[3] = v_t4 - v_t3;
+        }
     }
 }
 
@@ -2532,6 +2540,29 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         for (int k = 0; k < KP; ++k) has = has || prv[k] >= 0;
         if (!__ballot(has)) {                                     // a wave without correspondences (most waves of a team member): its sums are zero
             if (lane < 32) s_part[wave][lane] = 0.0;
+        } else if (KP <= 2) {
+            // one or two points per thread: all 29 sums at once (32 accumulators) and ONE halving reduction — the two passes of 16 below exist for the
+            // registers of the five-points build, and cost a second chain of six dependent exchanges
+            double acc[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (prv[k] < 0) continue;
+                const TgtRec q = rec_at(prv[k]);
+                double n3[3];
+                if (slabbed) { n3[0] = g_nrm[3 * (size_t)prv[k]]; n3[1] = g_nrm[3 * (size_t)prv[k] + 1]; n3[2] = g_nrm[3 * (size_t)prv[k] + 2]; }
+                else { n3[0] = s_nrm[3 * prv[k]]; n3[1] = s_nrm[3 * prv[k] + 1]; n3[2] = s_nrm[3 * prv[k] + 2]; }
+                double lo[16], hi[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { lo[u] = acc[u]; hi[u] = acc[16 + u]; }
+                solo_accumulate<0>(lo, px[k], py[k], pz[k], q, n3);
+                solo_accumulate<1>(hi, px[k], py[k], pz[k], q, n3);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { acc[u] = lo[u]; acc[16 + u] = hi[u]; }
+            }
+            const double v = wave_reduce32(acc, lane);              // lane l: the wave total of value l >> 1
+            if ((lane & 1) == 0) s_part[wave][lane >> 1] = v;
         } else
 #pragma unroll
         for (int half = 0; half < 2; ++half) {

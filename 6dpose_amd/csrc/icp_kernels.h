@@ -50,6 +50,7 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     int n_far;               // target points k_icp_knn left to k_icp_knn_far (their k nearest are more than 8 rings away)
     double fit_hist[2], rmse_hist[2];   // fitness / rmse of the last two evaluations, slot = evaluation parity
     int team_note[4];        // k_icp_team left the hypothesis to the sliced launches: reason (1 source slice too large, 2 grid, 3 slab overflow: + member, targets needed, capacity; 4 time-out), else 0
+    long long vox_clk[4];    // k_icp_voxel diagnostics (model cloud): cycles for the extent, the keys, the sort, the voxel means
     long long knn_clk[4];    // k_icp_knn diagnostics: slowest workgroup's cycles staging, in the 8-lane trips, in the whole-wave pass; points handed to whole waves
     long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };

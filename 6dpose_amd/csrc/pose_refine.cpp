@@ -343,6 +343,8 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.team_note[k]);
             tmp.push_back((double)st.n_src); tmp.push_back((double)st.n_tgt);
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.knn_clk[k]);
+            for (int k = 0; k < 4; ++k) tmp.push_back((double)st.vox_clk[k]);
+            tmp.push_back((double)st.n_model); tmp.push_back((double)st.n_scene);
             n = (int64_t)tmp.size();
             break;
         }

@@ -15,7 +15,8 @@ _close = lm.Pipeline.close
 def close_with_dump(self):
     for hyp in range(16):
         st = self.read_icp_debug(hyp, 3)
-        print("hyp %2d iterations %2d grid %dx%d team_note %s n_src %d n_tgt %d" % (hyp, st[24], st[21], st[22], [int(x) for x in st[33:37]], st[37], st[38]))
+        print("hyp %2d iterations %2d grid %dx%d team_note %s n_src %d n_tgt %d | voxel (model cloud of %d points): extent %d keys %d sort %d means %d cycles | knn: staging %d trips %d whole-wave %d, %d hard" % (
+            hyp, st[24], st[21], st[22], [int(x) for x in st[33:37]], st[37], st[38], st[47], st[43], st[44], st[45], st[46], st[39], st[40], st[41], st[42]))
     _close(self)
 lm.Pipeline.close = close_with_dump
 print(json.dumps(bench.pipeline_bench(det, frames, bank, ["obj00"], steps=2))[:300])
