@@ -2175,7 +2175,8 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 
         // ---- pcd.Transform(update), then which points must search ----
         int cls[KP], rk[KP];
-        unsigned int box[KP];                                     // the columns a search visits (xa | ya << 8 | nxc << 16 | nyc << 24)
+        unsigned int rows[KP][8];                                 // the x rows of the cube a search visits, as runs of targets: first | end << 16 (sorted positions)
+        int nchunks[KP];                                          // chunks of four targets in them
         double seed[KP];                                          // squared distance the search starts from
         bool any = false;
         const double A = s_mot[0];
@@ -2196,7 +2197,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
             int ext_lo = INT_MAX, ext_hi = -1;                    // the x columns this thread's points need in LDS
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                cls[k] = kClasses; rk[k] = 0; box[k] = 0; seed[k] = none2;
+                cls[k] = kClasses; rk[k] = 0; nchunks[k] = 0; seed[k] = none2;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rows[k][r] = 0;
                 if (o < 0 || i_lo + o + k * kSoloOwners >= i_hi) continue;
                 if (it > 0) {
                     const double x = px[k], y = py[k], z = pz[k];
@@ -2282,12 +2285,26 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     const int xa = grid_coord(px[k] - rad, minx, inv, gx), xb = grid_coord(px[k] + rad, minx, inv, gx);
                     const int ya = grid_coord(py[k] - rad, miny, inv, gy), yb = grid_coord(py[k] + rad, miny, inv, gy);
                     const int nxc = xb - xa + 1, nyc = yb - ya + 1;
-                    box[k] = (unsigned int)xa | (unsigned int)ya << 8 | (unsigned int)nxc << 16 | (unsigned int)nyc << 24;
-                    // lanes = 2^cls, a chunk of four targets each; the class is set by the columns — a surface leaves about four targets in one — so that no
-                    // table is read here (the lanes take the chunks round robin, however many there are)
-                    const int ncol = nxc * nyc;
-                    cls[k] = ncol <= 1 ? 0 : ncol <= 2 ? 1 : ncol <= 4 ? 2 : ncol <= 8 ? 3 : ncol <= 16 ? 4 : ncol <= 32 ? 5 : 6;
-                    any = true;
+                    // the rows as runs of targets (the columns (x, ya..yb) are consecutive cells), and their chunks of four: the class — lanes = 2^cls, a chunk
+                    // each — is set by the chunks themselves (by the columns, with ~4 targets assumed in one, tilted surfaces left some lanes three trips
+                    // and others none).  More than eight rows (a grid finer than the search radius allows): one run from the first row's start to the last row's end
+                    int chunks = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        int ra = 0, rb = 0;
+                        if (r < nxc && nxc <= 8) { const int c0 = (xa + r) * gy + ya; ra = s_cs[c0]; rb = s_cs[c0 + nyc]; }
+                        if (r == 0 && nxc > 8) { ra = s_cs[xa * gy + ya]; rb = s_cs[(xa + nxc - 1) * gy + ya + nyc]; }
+                        rows[k][r] = (unsigned int)ra | (unsigned int)rb << 16;
+                        chunks += (rb - ra + 3) >> 2;
+                    }
+                    nchunks[k] = chunks;
+                    if (chunks == 0) {                            // no target in the cube at all: the start (if any) is the nearest, everything else is beyond reach
+                        cls[k] = kClasses;
+                        lbf[k] = calm ? __double2float_rd(reach * (1.0 - 1e-9) + A) : 0.f;
+                    } else {
+                        cls[k] = chunks <= 1 ? 0 : chunks <= 2 ? 1 : chunks <= 4 ? 2 : chunks <= 8 ? 3 : chunks <= 16 ? 4 : chunks <= 32 ? 5 : 6;
+                        any = true;
+                    }
                 }
             }
         }
@@ -2377,14 +2394,10 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                     if (pos[k] >= w0 && pos[k] < wend) {
                         SoloQ e;
                         e.x = px[k]; e.y = py[k]; e.z = pz[k]; e.bd = seed[k]; e.bp = prv[k];
-                        const int xa = (int)(box[k] & 255u), ya = (int)(box[k] >> 8 & 255u), nxc = (int)(box[k] >> 16 & 255u), nyc = (int)(box[k] >> 24);
                         int chunks = 0;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) {                     // (more than eight rows — a grid finer than the search radius allows — : one run from the first row's start to the last row's end)
-                            const bool on = r < nxc && nxc <= 8;
-                            int ra = 0, rb = 0;
-                            if (on) { const int c0 = (xa + r) * gy + ya; ra = s_cs[c0]; rb = s_cs[c0 + nyc]; }
-                            if (r == 0 && nxc > 8) { ra = s_cs[xa * gy + ya]; rb = s_cs[(xa + nxc - 1) * gy + ya + nyc]; }
+                        for (int r = 0; r < 8; ++r) {
+                            const int ra = (int)(rows[k][r] & 0xFFFFu), rb = (int)(rows[k][r] >> 16);
                             e.ra[r] = (unsigned short)ra; e.rb[r] = (unsigned short)rb; e.cum[r] = (unsigned short)chunks;
                             chunks += (rb - ra + 3) >> 2;
                         }
