@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(kPtsWG)
 k_icp_points(IcpBuffers B, int W, int H, int flags) {
     __shared__ int s_wave[8];
     __shared__ double s_red[kPtsWG / 64][7];
+    __shared__ double s_ext[kPtsWG / 64][12];
     __shared__ int s_tot[2];
     const int h = blockIdx.y, strip = blockIdx.x, tid = threadIdx.x;
     IcpState& S = B.st[h];
@@ -383,6 +384,7 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
         return;
     }
 
+    if (strip == 0 && tid < 2 * kIcpSortGroups) B.sort_look[(size_t)h * 2 * kIcpSortGroups + tid] = 0;   // (k_icp_voxel_wide: voxel counts of the groups, not yet known)
     const double anchor = model[(size_t)(H / 2) * W + W / 2] / 1000.0;   // LL.cpp:62
     double* mp = B.model_pts + (size_t)h * B.cap * 3;
     double* sp = B.scene_pts + (size_t)h * B.cap * 3;
@@ -393,6 +395,7 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
         tot_m += a; tot_s += b2;
     }
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};     // model xyz, scene-near-anchor xyz, its count
+    double ext[12] = {1e300, 1e300, 1e300, -1e300, -1e300, -1e300, 1e300, 1e300, 1e300, -1e300, -1e300, -1e300};   // min, max of the strip's model points, of its scene points
     for (int base = p_lo; base < p_hi; base += kPtsWG) {
         const int p = base + tid;
         bool is_m = false, is_s = false;
@@ -410,6 +413,8 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
                 mx = (double)__fdiv_rn(__fsub_rn((float)mc, I.mK[2]), I.mK[0]) * mz;
                 my = (double)__fdiv_rn(__fsub_rn((float)mr, I.mK[5]), I.mK[4]) * mz;
                 acc[0] += mx; acc[1] += my; acc[2] += mz;
+                ext[0] = fmin(ext[0], mx); ext[1] = fmin(ext[1], my); ext[2] = fmin(ext[2], mz);
+                ext[3] = fmax(ext[3], mx); ext[4] = fmax(ext[4], my); ext[5] = fmax(ext[5], mz);
             }
             if (sd > 0) {
                 bool in_mask = md > 0;
@@ -426,6 +431,8 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
                     sx = (double)__fdiv_rn(__fsub_rn((float)sc, B.sK[2]), B.sK[0]) * sz;
                     sy = (double)__fdiv_rn(__fsub_rn((float)sr, B.sK[5]), B.sK[4]) * sz;
                     if (fabs(sz - anchor) < 0.4 && md > 0) { acc[3] += sx; acc[4] += sy; acc[5] += sz; acc[6] += 1.0; }
+                    ext[6] = fmin(ext[6], sx); ext[7] = fmin(ext[7], sy); ext[8] = fmin(ext[8], sz);
+                    ext[9] = fmax(ext[9], sx); ext[10] = fmax(ext[10], sy); ext[11] = fmax(ext[11], sz);
                 }
             }
         }
@@ -444,11 +451,24 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
         const double v = wave_sum(acc[k]);
         if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
     }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = ext[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = (k % 6) < 3 ? fmin(v, shfl_xor_d(v, o)) : fmax(v, shfl_xor_d(v, o));
+        if ((tid & 63) == 0) s_ext[tid >> 6][k] = v;
+    }
     __syncthreads();
     if (tid < 7) {
         double v = 0;
         for (int w = 0; w < kPtsWG / 64; ++w) v += s_red[w][tid];
         B.strip_sum[((size_t)h * kIcpStrips + strip) * 8 + tid] = v;
+    }
+    if (tid >= 64 && tid < 76) {                                   // the strip's extents: what k_icp_voxel_keys takes the voxel origin from (min / max are exact in any order)
+        const int k = tid - 64;
+        double v = s_ext[0][k];
+        for (int w = 1; w < kPtsWG / 64; ++w) v = (k % 6) < 3 ? fmin(v, s_ext[w][k]) : fmax(v, s_ext[w][k]);
+        B.strip_mm[((size_t)h * kIcpStrips + strip) * 12 + k] = v;
     }
     if (strip == 0 && tid == 0) { S.n_model = tot_m; S.n_scene = keep_scene ? tot_s : 0; }
 }
@@ -469,6 +489,7 @@ k_icp_voxel(IcpBuffers B, int flags, double voxel) {
     const int h = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
     IcpState& S = B.st[h];
     const bool scene_mode = (flags & 1) != 0;
+    if (S.vox_done[which] == kIcpSortGroups) return;               // k_icp_voxel_wide did this cloud
     if (S.status != 0) {
         if (tid == 0) { if (which == 0) { S.n_src = 0; if (!scene_mode) S.n_tgt = 0; } else S.n_tgt = 0; }
         return;
@@ -635,6 +656,7 @@ k_icp_grid(IcpBuffers B, int flags) {
     __shared__ double s_mm[6];
     const int h = blockIdx.x, tid = threadIdx.x;
     IcpState& S = B.st[h];
+    if (S.grid_done == kIcpSortGroups) return;                     // k_icp_grid_wide did this cloud
     if (tid == 0 && S.status == 0) {                               // init_guess: centroid difference (LL.cpp:91-104), strips added in order
         double t[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < kIcpStrips; ++k)
@@ -734,6 +756,337 @@ k_icp_grid(IcpBuffers B, int flags) {
     if (tid == 0) {
         S.gx = gx; S.gy = gy; S.zq_max = zq_max; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
         S.inv_z = inv_z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two sorts above, spread over the chip (round 6).  One workgroup sorting a cloud of 12-17k points took 120-200 us with 15 of 16 CUs
+// of the hypothesis' share idle.  k_icp_voxel_wide / k_icp_grid_wide give a cloud kIcpSortGroups workgroups, each a contiguous range of
+// the LEADING coordinate of the sort key (voxel index ix, grid column cx: equal shares of its span):
+//   a group walks the x coordinates of the whole cloud — every wave a contiguous piece: count, prefix over the waves, second walk — and
+//   takes the points of its range in input order with the key relative to its range; the cloud's extent comes from the strips of
+//   k_icp_points, not from a scan;
+//   it orders them in LDS: up to kRankMax points by counting, for every point, the points that go before it (one pass over the keys,
+//   broadcast reads), larger groups with the stable radix passes above;
+//   the grid group then writes its part of the sorted cloud (its first position = the points below its range, counted on the way) and the
+//   starts of its columns; the voxel group needs the number of voxels of the groups before it, which every group publishes as soon as its
+//   order stands (one agent-scope word each; a group waits only for lower block indices, which were dispatched before it).
+// The voxel means are those of k_icp_voxel bit for bit (same keys, stable order, the points of a voxel added up in input order); the grid
+// spans the extent of the cloud the target was down-sampled FROM (a bound of the means' extent that costs no scan).  The one-workgroup
+// kernels stay behind them for the clouds they leave: voxel index beyond 32 bits, a group of more than kGroupCap points, empty or rejected
+// hypotheses — IcpState::vox_done / grid_done say which.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGroupCap = 8192;     // points a group sorts (LDS: keys 32 KiB, point indices 32 KiB, two index lists 32 KiB, digit counts 16 KiB)
+constexpr int kRankMax = 1024;      // ... by counting
+constexpr unsigned int kLookFail = 0xFFFFFFFFu;
+constexpr long long kLookTimeout = 100ll * 100000;   // wall_clock64 ticks: 100 ms
+
+// Extent of one of the two back-projected clouds of a hypothesis from its strips; all threads of wave 0 call it, result in s_mm[6] (after a barrier).
+static __device__ __forceinline__ void strips_extent(const double* __restrict__ strip_mm /*[kIcpStrips][12]*/, const int which, double* s_mm) {
+    const int lane = threadIdx.x & 63;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    if (lane < kIcpStrips) {
+        const double* p = strip_mm + (size_t)lane * 12 + which * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = p[k]; mx[k] = p[3 + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fmin(mn[k], shfl_xor_d(mn[k], o)); mx[k] = fmax(mx[k], shfl_xor_d(mx[k], o)); }
+    if (lane == 0) { s_mm[0] = mn[0]; s_mm[1] = mn[1]; s_mm[2] = mn[2]; s_mm[3] = mx[0]; s_mm[4] = mx[1]; s_mm[5] = mx[2]; }
+}
+
+// The points whose leading coordinate lead(i) lies in [lo, hi), in input order: key_of(i, lead) -> s_key[j], i -> s_gid[j].  Returns their
+// number (nothing is written when it exceeds kGroupCap) and the number of points below lo.  1024 threads; s_wave: 32 ints.
+template <typename LeadF, typename KeyF>
+static __device__ __forceinline__ int group_collect(const int n, const long long lo, const long long hi, unsigned int* s_key, unsigned int* s_gid, int* s_wave,
+                                                    int& below_out, LeadF&& lead, KeyF&& key_of) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int piece = (((n + 15) >> 4) + 63) & ~63;               // of a wave: a multiple of 64, 16 pieces cover n
+    const int i0 = wave * piece, i1 = min(n, i0 + piece);
+    int mine = 0, below = 0;
+    for (int i = i0 + lane; i < i1; i += 64) { const long long v = lead(i); below += v < lo ? 1 : 0; mine += (v >= lo && v < hi) ? 1 : 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o, 64); below += __shfl_xor(below, o, 64); }
+    __syncthreads();
+    if (lane == 0) { s_wave[wave] = mine; s_wave[16 + wave] = below; }
+    __syncthreads();
+    int base = 0, m = 0, nb = 0;
+    for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wave) base += c; m += c; nb += s_wave[16 + w]; }
+    below_out = nb;
+    if (m > kGroupCap) return m;
+    for (int r = i0; r < i1; r += 64) {
+        const int i = r + lane;
+        const long long v = i < i1 ? lead(i) : lo - 1;
+        const bool in = v >= lo && v < hi;
+        const unsigned long long b = __ballot(in);
+        if (in) { const int j = base + __popcll(b & ((1ull << lane) - 1ull)); s_key[j] = key_of(i, v); s_gid[j] = (unsigned int)i; }
+        base += __popcll(b);
+    }
+    __syncthreads();
+    return m;
+}
+
+// Stable order of the m <= kGroupCap keys s_key[0..m) of `bits` bits: order[r] = index of the r-th.  s_idx: 2 x kGroupCap, s_cnt: 16 x 512.
+static __device__ __forceinline__ const unsigned short* group_sort(unsigned int* s_key, const int m, const int bits, unsigned short* s_idx, unsigned short* s_cnt, int* s_wave) {
+    const int tid = threadIdx.x;
+    const int ib = bits_for(m - 1);
+    if (m <= kRankMax && bits + ib <= 32) {
+        // rank of a point = the points before it by (key, input position), made one word: m / 4 broadcast reads of 16 bytes, 2 instructions per comparison
+        unsigned int* s_u = reinterpret_cast<unsigned int*>(s_cnt);
+        const int mpad = (m + 3) & ~3;
+        const unsigned int mine = tid < m ? (s_key[tid] << ib) | (unsigned int)tid : 0xFFFFFFFFu;
+        if (tid < mpad) s_u[tid] = mine;
+        __syncthreads();
+        if (tid < m) {
+            const uint4* q = reinterpret_cast<const uint4*>(s_u);
+            int rank = 0;
+#pragma unroll 4
+            for (int t = 0; t < (mpad >> 2); ++t) {
+                const uint4 v = q[t];
+                rank += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0) + (v.z < mine ? 1 : 0) + (v.w < mine ? 1 : 0);
+            }
+            s_idx[rank] = (unsigned short)tid;
+        }
+        __syncthreads();
+        return s_idx;
+    }
+    RadixView rx;
+    rx.key_lds = s_key; rx.idx[0] = s_idx; rx.idx[1] = s_idx + kGroupCap; rx.hist = s_cnt;
+    return wg_radix_sort(rx, m, bits, s_wave, [&](unsigned int id) { return s_key[id]; });
+}
+
+__global__ void __launch_bounds__(kWG)
+k_icp_voxel_wide(IcpBuffers B, int flags, double voxel) {
+    __shared__ __attribute__((aligned(16))) unsigned int s_key[kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned int s_gid[kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned short s_idx[2 * kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned short s_cnt[16 * 512];
+    __shared__ __attribute__((aligned(16))) double s_st[3 * kWG];
+    __shared__ unsigned int s_sv[kWG];
+    __shared__ int s_wave[32];
+    __shared__ double s_mm[6];
+    __shared__ int s_nv, s_base;
+    const int g = blockIdx.x, h = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
+    const int cloud = h * 2 + which;
+    IcpState& S = B.st[h];
+    const bool scene_mode = (flags & 1) != 0;
+    const int n = S.status == 0 ? (which ? S.n_scene : S.n_model) : 0;
+    if (n == 0) return;                                            // (k_icp_voxel sets the counts of these)
+    long long clk[6];
+    clk[0] = (long long)__builtin_amdgcn_s_memtime();
+    unsigned int* look = B.sort_look + (size_t)cloud * kIcpSortGroups;
+    if (tid < 64) strips_extent(B.strip_mm + (size_t)h * kIcpStrips * 12, which, s_mm);
+    if (tid == 64) s_nv = 0;
+    __syncthreads();
+    // the arithmetic of k_icp_voxel
+    const double mnx = s_mm[0] - voxel * 0.5, mny = s_mm[1] - voxel * 0.5, mnz = s_mm[2] - voxel * 0.5;
+    const double fx = floor(__ddiv_rn(s_mm[3] - mnx, voxel)), fy = floor(__ddiv_rn(s_mm[4] - mny, voxel)),
+                 fz = floor(__ddiv_rn(s_mm[5] - mnz, voxel));
+    const bool finite = fx >= 0 && fx < 4e18 && fy >= 0 && fy < 4e18 && fz >= 0 && fz < 4e18;
+    const int bx = finite ? bits_for((long long)fx) : 64, by = finite ? bits_for((long long)fy) : 64, bz = finite ? bits_for((long long)fz) : 64;
+    if (bx + by + bz > 32) return;                                 // every group alike: the cloud is k_icp_voxel's
+    const long long span = (long long)fx + 1;                      // ix = 0 .. fx
+    const long long lo = span * g / kIcpSortGroups, hi = span * (g + 1) / kIcpSortGroups;
+    const int bits = (hi > lo ? bits_for(hi - lo - 1) : 1) + by + bz;
+    const double* pts = (which ? B.scene_pts : B.model_pts) + (size_t)h * B.cap * 3;
+    double* out = (which ? B.tgt : B.src) + (size_t)h * B.cap * 3;
+    int below;
+    const int m = group_collect(n, lo, hi, s_key, s_gid, s_wave, below,
+        [&](int i) { return (long long)floor(__ddiv_rn(pts[3 * (size_t)i] - mnx, voxel)); },
+        [&](int i, long long ix) {
+            const unsigned long long iy = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 1] - mny, voxel));
+            const unsigned long long iz = (unsigned long long)(long long)floor(__ddiv_rn(pts[3 * (size_t)i + 2] - mnz, voxel));
+            return (unsigned int)(((((unsigned long long)(ix - lo)) << by) | iy) << bz | iz);
+        });
+    clk[1] = (long long)__builtin_amdgcn_s_memtime();
+    if (m > kGroupCap) {                                           // the groups behind must not wait for this one
+        if (tid == 0) __hip_atomic_store(look + g, kLookFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const unsigned short* order = m > 0 ? group_sort(s_key, m, bits, s_idx, s_cnt, s_wave) : s_idx;
+    clk[2] = (long long)__builtin_amdgcn_s_memtime();
+    // voxels of this group: published before the means are taken, so that the groups behind find it there
+    {
+        int heads = 0;
+        for (int i = tid; i < m; i += kWG) heads += (i == 0 || s_key[order[i - 1]] != s_key[order[i]]) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
+        if ((tid & 63) == 0 && heads) atomicAdd(&s_nv, heads);
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    if (tid == 0) __hip_atomic_store(look + g, (unsigned int)nv + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        unsigned int v = 1;
+        if (tid < g) {
+            const long long t0 = wall_clock64();
+            do { v = __hip_atomic_load(look + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (v == 0 && wall_clock64() - t0 < kLookTimeout);
+        }
+        const bool lost = __ballot(v == 0 || v == kLookFail) != 0ull;
+        int before = (int)v - 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+        if (tid == 0) s_base = lost ? -1 : before;
+    }
+    __syncthreads();
+    const int base_out = s_base;
+    clk[3] = (long long)__builtin_amdgcn_s_memtime();
+    if (base_out < 0) {                                            // a group before this one gave up or never came: the cloud is k_icp_voxel's
+        if (tid == 0) __hip_atomic_store(look + g, kLookFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int nout = base_out;
+    auto vox_of = [&](int i) -> unsigned int { return s_key[order[i]]; };
+    for (int base = 0; base < m; base += kWG) {                     // as k_icp_voxel: 1024 sorted positions side by side in LDS, the first thread of a voxel adds them up in input order
+        const int i = base + tid;
+        unsigned int v = 0;
+        if (i < m) {
+            const unsigned int id = order[i];
+            v = s_key[id];
+            const size_t p = s_gid[id];
+            s_st[3 * tid] = pts[3 * p]; s_st[3 * tid + 1] = pts[3 * p + 1]; s_st[3 * tid + 2] = pts[3 * p + 2];
+            s_sv[tid] = v;
+        }
+        __syncthreads();
+        const bool head = i < m && (i == 0 || (tid > 0 ? s_sv[tid - 1] : vox_of(i - 1)) != v);
+        int tot;
+        const int pos = nout + block_scan_flag(head, s_wave, tot);
+        nout += tot;
+        if (head) {
+            double sx = 0, sy = 0, sz = 0;
+            int cnt = 0;
+            for (int j = i; j < m; ++j) {
+                const int t = j - base;
+                if (t < kWG) {
+                    if (s_sv[t] != v) break;
+                    sx += s_st[3 * t]; sy += s_st[3 * t + 1]; sz += s_st[3 * t + 2];
+                } else {
+                    if (vox_of(j) != v) break;
+                    const size_t p = s_gid[order[j]];
+                    sx += pts[3 * p]; sy += pts[3 * p + 1]; sz += pts[3 * p + 2];
+                }
+                ++cnt;
+            }
+            const double cd = (double)cnt;
+            out[3 * (size_t)pos] = sx / cd; out[3 * (size_t)pos + 1] = sy / cd; out[3 * (size_t)pos + 2] = sz / cd;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (g == kIcpSortGroups - 1) {
+            if (which == 0) { S.n_src = nout; if (!scene_mode) S.n_tgt = nout; }
+            else S.n_tgt = nout;
+        }
+        atomicAdd(&S.vox_done[which], 1);
+        if (which == 0) {
+            clk[4] = (long long)__builtin_amdgcn_s_memtime();
+            for (int k = 0; k < 4; ++k) atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[k]), (unsigned long long)(clk[k + 1] - clk[k]));
+            atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[6]), (unsigned long long)m);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kWG)
+k_icp_grid_wide(IcpBuffers B, int flags) {
+    __shared__ __attribute__((aligned(16))) unsigned int s_key[kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned int s_gid[kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned short s_idx[2 * kGroupCap];
+    __shared__ __attribute__((aligned(16))) unsigned short s_cnt[16 * 512];
+    __shared__ int s_wave[32];
+    __shared__ double s_mm[6];
+    const int g = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    IcpState& S = B.st[h];
+    if (S.status != 0) return;
+    long long clk[5];
+    clk[0] = (long long)__builtin_amdgcn_s_memtime();
+    const int which = (flags & 1) ? 1 : 0;
+    if (g == 0 && tid >= 64 && tid < 128) {                        // init_guess: centroid difference (LL.cpp:91-104), strips added in order (as k_icp_grid)
+        double v[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) v[q] = lane < kIcpStrips ? B.strip_sum[((size_t)h * kIcpStrips + lane) * 8 + q] : 0.0;
+        double t[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < kIcpStrips; ++k)
+#pragma unroll
+            for (int q = 0; q < 7; ++q) t[q] += __shfl(v[q], k, 64);
+        if (lane == 0) {
+            const double n = (double)S.n_model;
+            S.init[0] = t[3] / t[6] - t[0] / n;
+            S.init[1] = t[4] / t[6] - t[1] / n;
+            S.init[2] = t[5] / t[6] - t[2] / n;
+        }
+    }
+    const int nt = S.n_tgt;
+    if (nt == 0 || nt >= (1 << kIdxBits)) return;                  // (k_icp_grid sets the state of these)
+    if (tid < 64) strips_extent(B.strip_mm + (size_t)h * kIcpStrips * 12, which, s_mm);
+    __syncthreads();
+    // the arithmetic of k_icp_grid, on the extent of the cloud the target was down-sampled from
+    const double minx = s_mm[0], miny = s_mm[1], minz = s_mm[2];
+    const double ext = fmax(s_mm[3] - minx, s_mm[4] - miny), extz = s_mm[5] - minz;
+    double cell = ext / (double)kIcpGrid;
+    if (!(cell > kCellMin)) cell = kCellMin;
+    double zres = extz / (double)((1 << kZBits) - 1);
+    if (!(zres > 1e-3)) zres = 1e-3;
+    const double inv = 1.0 / cell, inv_z = 1.0 / zres;
+    if (!(ext < 1e30) || !(extz < 1e30)) return;
+    const int gx = grid_coord(s_mm[3], minx, inv, kIcpGrid) + 1, gy = grid_coord(s_mm[4], miny, inv, kIcpGrid) + 1;
+    const int zq_max = zq_of(s_mm[5], minz, inv_z, (1 << kZBits) - 1);
+    const int z_bits = bits_for(zq_max);
+    const int lo = gx * g / kIcpSortGroups, hi = gx * (g + 1) / kIcpSortGroups;      // x columns of this group
+    const int bits = (hi > lo ? bits_for((long long)(hi - lo) * gy - 1) : 1) + z_bits;
+    const double* T = (which ? B.tgt : B.src) + (size_t)h * B.cap * 3;
+    int p0;
+    const int m = group_collect(nt, lo, hi, s_key, s_gid, s_wave, p0,
+        [&](int i) { return (long long)grid_coord(T[3 * (size_t)i], minx, inv, gx); },
+        [&](int i, long long cx) {
+            const int cy = grid_coord(T[3 * (size_t)i + 1], miny, inv, gy), zq = zq_of(T[3 * (size_t)i + 2], minz, inv_z, zq_max);
+            return ((unsigned int)(((int)cx - lo) * gy + cy) << z_bits) | (unsigned int)zq;
+        });
+    clk[1] = (long long)__builtin_amdgcn_s_memtime();
+    if (m > kGroupCap) return;                                     // grid_done stays short: k_icp_grid does the cloud
+    const unsigned short* order = m > 0 ? group_sort(s_key, m, bits, s_idx, s_cnt, s_wave) : s_idx;
+    clk[2] = (long long)__builtin_amdgcn_s_memtime();
+    double* Ts = B.tgt_sorted + (size_t)h * B.cap * 3;
+    int* orig = B.tgt_orig + (size_t)h * B.cap;
+    TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
+    int* cs = B.cell_start + (size_t)h * kIcpCells;
+    unsigned short* cs16 = B.cell_start16 + (size_t)h * kIcpCells16;
+    for (int j = tid; j < m; j += kWG) {
+        const unsigned int id = order[j];
+        const size_t i = s_gid[id], p = (size_t)p0 + j;
+        TgtRec r;
+        r.x = T[3 * i]; r.y = T[3 * i + 1]; r.z = T[3 * i + 2]; r.orig = (int)i;
+        r.zq = (int)(s_key[id] & ((1u << z_bits) - 1u));
+        Ts[3 * p] = r.x; Ts[3 * p + 1] = r.y; Ts[3 * p + 2] = r.z;
+        orig[p] = (int)i;
+        rec[p] = r;
+    }
+    clk[3] = (long long)__builtin_amdgcn_s_memtime();
+    // starts of this group's columns (column c of the grid = column c - lo * gy of the group); the last group also writes the end marker
+    const int c_lo = lo * gy, c_hi = hi * gy;
+    for (int c = c_lo + tid; c < c_hi; c += kWG) {
+        const unsigned int want = (unsigned int)(c - c_lo) << z_bits;
+        int a = 0, b = m;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (s_key[order[mid]] < want) a = mid + 1; else b = mid;
+        }
+        cs[c] = p0 + a;
+        cs16[c] = (unsigned short)(p0 + a);
+    }
+    if (g == kIcpSortGroups - 1 && tid == 0) { cs[gx * gy] = nt; cs16[gx * gy] = (unsigned short)nt; }
+    if (tid == 0) {
+        if (g == 0) {
+            S.gx = gx; S.gy = gy; S.zq_max = zq_max; S.gminx = minx; S.gminy = miny; S.gminz = minz; S.cell = cell; S.inv_cell = inv;
+            S.inv_z = inv_z;
+        }
+        atomicAdd(&S.grid_done, 1);
+        clk[4] = (long long)__builtin_amdgcn_s_memtime();
+        for (int k = 0; k < 4; ++k) atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[8 + k]), (unsigned long long)(clk[k + 1] - clk[k]));
+        atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[13]), (unsigned long long)m);
+        atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[14]), (unsigned long long)(c_hi - c_lo));
+        atomicMax(reinterpret_cast<unsigned long long*>(&S.sort_clk[15]), (unsigned long long)bits);
     }
 }
 
@@ -2701,7 +3054,11 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
     hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+    // voxel down-sampling and the search grid by kIcpSortGroups workgroups per cloud; the one-workgroup kernels behind them take what those
+    // left (IcpState::vox_done / grid_done) and cost ~2 us when there is nothing
+    if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_voxel_wide, dim3(kIcpSortGroups, count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
+    if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_grid_wide, dim3(kIcpSortGroups, count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);

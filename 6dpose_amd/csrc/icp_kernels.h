@@ -15,6 +15,7 @@ constexpr int kIcpCells = kIcpGrid * kIcpGrid + 1; // ... columns in x and y (+1
 constexpr int kIcpCells16 = 4104;                 // kIcpCells rounded up to a multiple of 8 (16-byte copies of the u16 table)
 constexpr int kIcpStrips = 48;                    // row strips of the bounding box in k_icp_points
 constexpr int kIcpMaxSplit = 64;                  // workgroups (source slices) per hypothesis in k_icp_search
+constexpr int kIcpSortGroups = 8;                 // workgroups that sort a cloud, each a contiguous range of the leading key coordinate (k_icp_voxel_wide / k_icp_grid_wide)
 constexpr int kIcpCovStride = 12;                 // 9 cumulants, neighbour count, squared nearest-neighbour separation, pad
 
 struct __attribute__((aligned(16))) TgtRec { double x, y, z; int orig; int zq; };    // target point as staged in LDS (32 B): xyz, original index, quantised depth
@@ -49,8 +50,12 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     int stop;                // RegistrationICP finished (converged or max_iteration)
     int n_far;               // target points k_icp_knn left to k_icp_knn_far (their k nearest are more than 8 rings away)
     double fit_hist[2], rmse_hist[2];   // fitness / rmse of the last two evaluations, slot = evaluation parity
+    int vox_done[2];         // groups of k_icp_voxel_wide that finished the model / scene cloud (kIcpSortGroups: k_icp_voxel has nothing to do)
+    int grid_done;           // the same for k_icp_grid_wide / k_icp_grid
+    int pad_done;
     int team_note[4];        // k_icp_team left the hypothesis to the sliced launches: reason (1 source slice too large, 2 grid, 3 slab overflow: + member, targets needed, capacity; 4 time-out), else 0
     long long vox_clk[4];    // k_icp_voxel diagnostics (model cloud): cycles for the extent, the keys, the sort, the voxel means
+    long long sort_clk[16];  // k_icp_voxel_wide (0-7, model cloud) / k_icp_grid_wide (8-15) diagnostics, slowest group per phase: cycles for picking its points, the sort, (voxels: count + wait for the groups before), writing, (grid: the column table); 6 / 13: largest group
     long long knn_clk[4];    // k_icp_knn diagnostics: slowest workgroup's cycles staging, in the 8-lane trips, in the whole-wave pass; points handed to whole waves
     long long clk[8];        // k_icp_loop shader cycles (thread 0): A1 certainty test, reduction, solve, transform, A2 search, accumulate, queued points, -
 };
@@ -80,6 +85,8 @@ struct IcpBuffers {
     double* nn_lb;           // [count][cap]     lower bound on the distance to the nearest target of a point without correspondence
     int* strip_cnt;          // [count][kIcpStrips][2] model / scene points per strip
     double* strip_sum;       // [count][kIcpStrips][8] centroid sums per strip
+    double* strip_mm;        // [count][kIcpStrips][12] min xyz, max xyz of the strip's model points, then of its scene points
+    unsigned int* sort_look; // [count][2][kIcpSortGroups] k_icp_voxel_wide: voxels of a group + 1 (0 = not yet known; zeroed by k_icp_points)
     double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity
     unsigned long long* keys;// [count][2][cap2] sort scratch for lists longer than the LDS capacity
     unsigned long long* xchg;// [2][count][kIcpMaxSplit][64] the sums the members of a k_icp_team team publish: 8-byte granules {half of a sum, tag}

@@ -45,7 +45,7 @@ namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.xchg, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.xchg, c->B.strip_mm, c->B.sort_look, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
@@ -90,6 +90,8 @@ int lm_icp_ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.partial, (size_t)2 * n * kIcpMaxSplit * 32 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.strip_cnt, (size_t)n * kIcpStrips * 2 * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.strip_sum, (size_t)n * kIcpStrips * 8 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.strip_mm, (size_t)n * kIcpStrips * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.sort_look, (size_t)n * 2 * lm::kIcpSortGroups * sizeof(unsigned int)));
     HIP_TRY(hipMalloc((void**)&B.tgt_rec, (size_t)n * cap * sizeof(TgtRec)));
     HIP_TRY(hipMalloc((void**)&B.cell_start16, (size_t)n * kIcpCells16 * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void**)&B.cell_start, (size_t)n * kIcpCells * sizeof(int)));
@@ -345,6 +347,7 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.knn_clk[k]);
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.vox_clk[k]);
             tmp.push_back((double)st.n_model); tmp.push_back((double)st.n_scene);
+            for (int k = 0; k < 16; ++k) tmp.push_back((double)st.sort_clk[k]);
             n = (int64_t)tmp.size();
             break;
         }
