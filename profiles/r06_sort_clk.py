@@ -28,5 +28,6 @@ for h in range(min(hyp, 4)):
     c = d[49:65]
     print("hyp %d n_model %d n_scene %d n_src %d n_tgt %d" % (h, d[19], d[20], d[37], d[38]))
     print("   voxel groups (model cloud): pick %d sort %d count+wait %d means %d | largest group %d points" % (c[0], c[1], c[2], c[3], c[6]))
+    print("   grid groups, inside pick: extent ready %d, counted %d, taken %d, (keys: the rest)" % (c[4], c[5], c[7]))
     print("   grid groups: pick %d sort %d write %d columns %d | largest group %d points, %d columns, %d key bits" % (c[8], c[9], c[10], c[11], c[13], c[14], c[15]))
 ctx.close()
