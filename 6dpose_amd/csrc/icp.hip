@@ -278,8 +278,17 @@ static __device__ __forceinline__ int grid_coord(double v, double mn, double inv
 __global__ void __launch_bounds__(256)
 k_icp_bbox(IcpBuffers B, int W, int H) {
     const int h = blockIdx.y;
-    if (B.st[h].status != 0) return;                              // slot without a detection (pipeline)
-    const uint16_t* img = B.models + (size_t)B.in[h].model_slot * W * H;
+    const int status = B.st[h].status, slot = B.in[h].model_slot;   // (both loads leave together)
+    if (status != 0) return;                                       // slot without a detection (pipeline)
+    // the box of a resident image is worked out once: a later run finds it in model_bbox (k_icp_points<false> of the first run put it there
+    // once this kernel was through; the host clears the state word when the image changes)
+    if (blockIdx.x == 0 && threadIdx.x < kIcpStrips) B.strip_pub[(size_t)h * kIcpStrips + threadIdx.x] = 0;   // (k_icp_points_fused: the strips' counts, not yet known)
+    const int* known = B.model_bbox + (size_t)slot * 8;
+    if (known[4] == 1) {
+        if (blockIdx.x == 0 && threadIdx.x < 4) B.st[h].bbox[threadIdx.x] = known[threadIdx.x];
+        return;
+    }
+    const uint16_t* img = B.models + (size_t)slot * W * H;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
     const bool vec = (W & 7) == 0;
     for (int y = blockIdx.x; y < H; y += gridDim.x) {
@@ -335,6 +344,10 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
     if (S.status != 0) return;
     const IcpIn I = B.in[h];
     const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
+    if (!kWrite && strip == 0 && tid == 0) {                       // k_icp_bbox is through: the box of this image is known from now on
+        int* known = B.model_bbox + (size_t)B.in[h].model_slot * 8;
+        if (known[4] == 0) { known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; __threadfence(); known[4] = 1; }
+    }
     if (x1 < 0) {                                                  // pass 1 never gets here: pass 0 set the status
         if (strip == 0 && tid == 0) { S.status = 2; S.n_model = 0; S.n_scene = 0; }
         return;
@@ -471,6 +484,179 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
         B.strip_mm[((size_t)h * kIcpStrips + strip) * 12 + k] = v;
     }
     if (strip == 0 && tid == 0) { S.n_model = tot_m; S.n_scene = keep_scene ? tot_s : 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_icp_points_fused: both passes of k_icp_points in one launch.  A strip classifies its pixels once (two bits per pixel and thread in
+// registers: the 9x9 dilation test is the expensive part), publishes its two counts as one agent-scope word and waits for the strips
+// before it (lower block indices, dispatched before it) — their sum is where its points start — then writes.  The last strip, which has
+// seen every count, sets n_model / n_scene.  k_icp_bbox clears the words (B.strip_pub) for the next run.
+// ---------------------------------------------------------------------------------------------
+constexpr long long kStripTimeout = 1000ll * 100000;            // wall_clock64 ticks: 1 s (then: status kIcpStalled)
+
+__global__ void __launch_bounds__(kPtsWG)
+k_icp_points_fused(IcpBuffers B, int W, int H, int flags) {
+    __shared__ int s_wave[8];
+    __shared__ double s_red[kPtsWG / 64][7];
+    __shared__ double s_ext[kPtsWG / 64][12];
+    __shared__ int s_tot[2];
+    __shared__ long long s_before[2];
+    const int h = blockIdx.y, strip = blockIdx.x, tid = threadIdx.x;
+    IcpState& S = B.st[h];
+    if (S.status != 0) return;
+    const IcpIn I = B.in[h];
+    const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
+    if (strip == 0 && tid == 0) {                                  // k_icp_bbox is through: the box of this image is known from now on
+        int* known = B.model_bbox + (size_t)I.model_slot * 8;
+        if (known[4] == 0) { known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; __threadfence(); known[4] = 1; }
+    }
+    if (strip == 0 && tid < 2 * kIcpSortGroups) B.sort_look[(size_t)h * 2 * kIcpSortGroups + tid] = 0;   // (k_icp_voxel_wide: voxel counts of the groups, not yet known)
+    if (x1 < 0) {
+        if (strip == 0 && tid == 0) { S.status = kIcpEmptyModel; S.n_model = 0; S.n_scene = 0; }
+        return;
+    }
+    const int bx0 = max(x0 - kDilate, 0), by0 = max(y0 - kDilate, 0);
+    const int bx1 = min(x1 + kDilate, W - 1), by1 = min(y1 + kDilate, H - 1);
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    if (I.dx + bw >= W || I.dy + bh >= H) {                       // LL.cpp:52-55
+        if (strip == 0 && tid == 0) { S.status = kIcpOutOfFrame; S.n_model = 0; S.n_scene = 0; }
+        return;
+    }
+    const uint16_t* model = B.models + (size_t)I.model_slot * W * H;
+    const uint16_t* scene = B.scene;
+    const int r_lo = (int)((long long)bh * strip / kIcpStrips), r_hi = (int)((long long)bh * (strip + 1) / kIcpStrips);
+    const int p_lo = r_lo * bw, p_hi = r_hi * bw;
+    const bool keep_scene = (flags & 1) != 0;
+    // model point where modelDepth > 0; scene point where sceneDepth > 0 under the dilated mask (LL.cpp:43-50, 66-90)
+    auto classify = [&](const int p, bool& is_m, bool& is_s) {
+        const int r = p / bw, c = p - r * bw;
+        const int mr = r + by0, mc = c + bx0;
+        const int sr = max(r + I.dy - kDilate, 0), sc = max(c + I.dx - kDilate, 0);
+        const uint16_t md = model[(size_t)mr * W + mc];
+        const uint16_t sd = scene[(size_t)sr * W + sc];
+        is_m = md > 0;
+        is_s = false;
+        if (sd > 0) {
+            bool in_mask = md > 0;
+            if (!in_mask) {                                       // dilate(modelDepth > 0, 9x9) at (mr, mc)
+                const int ya = max(mr - kDilate, 0), yb = min(mr + kDilate, H - 1);
+                const int xa = max(mc - kDilate, 0), xb = min(mc + kDilate, W - 1);
+                for (int yy = ya; yy <= yb && !in_mask; ++yy)
+                    for (int xx = xa; xx <= xb; ++xx)
+                        if (model[(size_t)yy * W + xx]) { in_mask = true; break; }
+            }
+            is_s = in_mask;
+        }
+    };
+    unsigned long long fm = 0, fs = 0;                             // the classes of this thread's first 64 pixels
+    int cm = 0, cs = 0;
+    {
+        int it = 0;
+        for (int p = p_lo + tid; p < p_hi; p += kPtsWG, ++it) {
+            bool is_m, is_s;
+            classify(p, is_m, is_s);
+            cm += is_m ? 1 : 0; cs += (is_s && keep_scene) ? 1 : 0;
+            if (it < 64) { fm |= (unsigned long long)is_m << it; fs |= (unsigned long long)is_s << it; }
+        }
+    }
+    if (tid < 2) s_tot[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cm += __shfl_xor(cm, o, 64); cs += __shfl_xor(cs, o, 64); }
+    if ((tid & 63) == 0) { atomicAdd(&s_tot[0], cm); atomicAdd(&s_tot[1], cs); }
+    __syncthreads();
+    unsigned long long* pub = B.strip_pub + (size_t)h * kIcpStrips;
+    if (tid == 0) __hip_atomic_store(pub + strip, (1ull << 63) | ((unsigned long long)s_tot[1] << 32) | (unsigned long long)s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        unsigned long long v = 1ull << 63;
+        if (tid < strip) {
+            const long long t0 = wall_clock64();
+            do { v = __hip_atomic_load(pub + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 63) && wall_clock64() - t0 < kStripTimeout);
+        }
+        const bool lost = __ballot(!(v >> 63)) != 0ull;
+        long long bm = (long long)(v & 0xFFFFFFFFull), bs = (long long)((v >> 32) & 0x7FFFFFFFull);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { bm += __shfl_xor(bm, o, 64); bs += __shfl_xor(bs, o, 64); }
+        if (tid == 0) { s_before[0] = lost ? -1 : bm; s_before[1] = bs; }
+    }
+    __syncthreads();
+    if (s_before[0] < 0) {                                         // a strip before this one never came
+        if (tid == 0) S.status = kIcpStalled;
+        return;
+    }
+    int nm = (int)s_before[0], nsn = (int)s_before[1];
+
+    const double anchor = model[(size_t)(H / 2) * W + W / 2] / 1000.0;   // LL.cpp:62
+    double* mp = B.model_pts + (size_t)h * B.cap * 3;
+    double* sp = B.scene_pts + (size_t)h * B.cap * 3;
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};     // model xyz, scene-near-anchor xyz, its count
+    double ext[12] = {1e300, 1e300, 1e300, -1e300, -1e300, -1e300, 1e300, 1e300, 1e300, -1e300, -1e300, -1e300};   // min, max of the strip's model points, of its scene points
+    int it = 0;
+    for (int base = p_lo; base < p_hi; base += kPtsWG, ++it) {
+        const int p = base + tid;
+        bool is_m = false, is_s = false;
+        double mx = 0, my = 0, mz = 0, sx = 0, sy = 0, sz = 0;
+        if (p < p_hi) {
+            if (it < 64) { is_m = (fm >> it) & 1ull; is_s = (fs >> it) & 1ull; }
+            else classify(p, is_m, is_s);
+            const int r = p / bw, c = p - r * bw;
+            const int mr = r + by0, mc = c + bx0;
+            const int sr = max(r + I.dy - kDilate, 0), sc = max(c + I.dx - kDilate, 0);
+            if (is_m) {
+                const uint16_t md = model[(size_t)mr * W + mc];
+                mz = md / 1000.0;
+                // (int - float) / float evaluated in float, then * double (LL.cpp:79-80)
+                mx = (double)__fdiv_rn(__fsub_rn((float)mc, I.mK[2]), I.mK[0]) * mz;
+                my = (double)__fdiv_rn(__fsub_rn((float)mr, I.mK[5]), I.mK[4]) * mz;
+                acc[0] += mx; acc[1] += my; acc[2] += mz;
+                ext[0] = fmin(ext[0], mx); ext[1] = fmin(ext[1], my); ext[2] = fmin(ext[2], mz);
+                ext[3] = fmax(ext[3], mx); ext[4] = fmax(ext[4], my); ext[5] = fmax(ext[5], mz);
+            }
+            if (is_s) {
+                const uint16_t sd = scene[(size_t)sr * W + sc];
+                sz = sd / 1000.0;
+                sx = (double)__fdiv_rn(__fsub_rn((float)sc, B.sK[2]), B.sK[0]) * sz;
+                sy = (double)__fdiv_rn(__fsub_rn((float)sr, B.sK[5]), B.sK[4]) * sz;
+                if (fabs(sz - anchor) < 0.4 && is_m) { acc[3] += sx; acc[4] += sy; acc[5] += sz; acc[6] += 1.0; }
+                ext[6] = fmin(ext[6], sx); ext[7] = fmin(ext[7], sy); ext[8] = fmin(ext[8], sz);
+                ext[9] = fmax(ext[9], sx); ext[10] = fmax(ext[10], sy); ext[11] = fmax(ext[11], sz);
+            }
+        }
+        int tot;
+        const int pm = nm + block_scan_flag(is_m, s_wave, tot);
+        nm += tot;
+        if (is_m) { mp[3 * (size_t)pm] = mx; mp[3 * (size_t)pm + 1] = my; mp[3 * (size_t)pm + 2] = mz; }
+        if (keep_scene) {
+            const int ps = nsn + block_scan_flag(is_s, s_wave, tot);
+            nsn += tot;
+            if (is_s) { sp[3 * (size_t)ps] = sx; sp[3 * (size_t)ps + 1] = sy; sp[3 * (size_t)ps + 2] = sz; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = ext[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = (k % 6) < 3 ? fmin(v, shfl_xor_d(v, o)) : fmax(v, shfl_xor_d(v, o));
+        if ((tid & 63) == 0) s_ext[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        double v = 0;
+        for (int w = 0; w < kPtsWG / 64; ++w) v += s_red[w][tid];
+        B.strip_sum[((size_t)h * kIcpStrips + strip) * 8 + tid] = v;
+    }
+    if (tid >= 64 && tid < 76) {
+        const int k = tid - 64;
+        double v = s_ext[0][k];
+        for (int w = 1; w < kPtsWG / 64; ++w) v = (k % 6) < 3 ? fmin(v, s_ext[w][k]) : fmax(v, s_ext[w][k]);
+        B.strip_mm[((size_t)h * kIcpStrips + strip) * 12 + k] = v;
+    }
+    if (strip == kIcpStrips - 1 && tid == 0) { S.n_model = nm; S.n_scene = keep_scene ? nsn : 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1565,6 +1751,8 @@ k_icp_knn(IcpBuffers B, int knn) {
         const long long k_t2 = (long long)__builtin_amdgcn_s_memtime();
         // the points whose base ring held fewer than k candidates inside the guarantee radius (isolated points, flying pixels:
         // 2-15 % of a scene cloud, rings of hundreds to thousands of candidates): a wave each
+        // (packing them onto the 8-lane groups once more, rings growing to 8, was measured: 117k cycles for that pass against 71k, and its
+        // code cost the main trip 17k cycles in spilled registers)
         const int nhard = s_nhard;
         for (int i = wave; i < nhard; i += kKnnWG / 64) {
             const int pos = s_hard[i];
@@ -3543,8 +3731,11 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
 #endif
     const int scene_mode = flags & 1;
     hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
-    hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
-    hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+    if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_points_fused, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+    else {
+        hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+        hipLaunchKernelGGL(k_icp_points<true>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
+    }
     // voxel down-sampling and the search grid by kIcpSortGroups workgroups per cloud; the one-workgroup kernels behind them take what those
     // left (IcpState::vox_done / grid_done) and cost ~2 us when there is nothing
     if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_voxel_wide, dim3(kIcpSortGroups, count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);

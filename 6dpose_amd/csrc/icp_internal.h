@@ -19,6 +19,7 @@ struct lm_icp {
     int last_count = 0, last_flags = 0;
     uint16_t* d_scene = nullptr;
     uint16_t* d_models = nullptr;
+    int* d_model_bbox = nullptr;   // [slots][8] bounding box of a resident model depth image (x0, y0, x1, y1, state: 0 = not known yet, -, -, -): icp.hip k_icp_bbox
     IcpIn* d_in = nullptr;
     IcpState* d_st = nullptr;
     IcpBuffers B{};

@@ -34,6 +34,7 @@ enum IcpStatus {             // IcpState::status; every value has ONE meaning (t
     kIcpTooLarge = 3,        // cloud too large for 64-bit voxel keys
     kIcpNoDetection = 4,     // pipeline: hypothesis slot without a detection (k_icp_bind)
     kIcpNoView = 5,          // pipeline: the matched template has no rendered view (k_icp_bind)
+    kIcpStalled = 6,         // a strip of k_icp_points_fused waited a second for the strips before it (the GPU was taken away from the launch?)
 };
 
 struct IcpState {            // one pose hypothesis (device-written, downloaded after the run)
@@ -63,6 +64,7 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
 struct IcpBuffers {
     const uint16_t* scene;   // [H][W]
     const uint16_t* models;  // [slots][H][W]
+    int* model_bbox;         // [slots][8] x0, y0, x1, y1 of modelDepth > 0 and a state word (0: not known; set by the first run that uses the slot, cleared by the host when the image changes)
     const IcpIn* in;         // [count]
     IcpState* st;            // [count]
     float sK[9];             // scene camera matrix
@@ -85,6 +87,7 @@ struct IcpBuffers {
     double* nn_lb;           // [count][cap]     lower bound on the distance to the nearest target of a point without correspondence
     int* strip_cnt;          // [count][kIcpStrips][2] model / scene points per strip
     double* strip_sum;       // [count][kIcpStrips][8] centroid sums per strip
+    unsigned long long* strip_pub; // [count][kIcpStrips] k_icp_points_fused: bit 63 = counted, scene points << 32 | model points (cleared by k_icp_bbox)
     double* strip_mm;        // [count][kIcpStrips][12] min xyz, max xyz of the strip's model points, then of its scene points
     unsigned int* sort_look; // [count][2][kIcpSortGroups] k_icp_voxel_wide: voxels of a group + 1 (0 = not yet known; zeroed by k_icp_points)
     double* partial;         // [2][count][kIcpMaxSplit][32] partial sums of one ICP evaluation, double-buffered by evaluation parity

@@ -161,6 +161,7 @@ extern "C" int lm_pipeline_set_views_rendered(lm_pipeline* p, lm_mesh* m, const 
             return rc;
         HIP_TRY(hipMemcpyAsync(p->icp->d_models + ((size_t)slot0 + c0) * npx, m->d_depth, (size_t)n * npx * sizeof(uint16_t),
                                hipMemcpyDeviceToDevice, m->s));
+        HIP_TRY(hipMemsetAsync(p->icp->d_model_bbox + ((size_t)slot0 + c0) * 8, 0, (size_t)n * 8 * sizeof(int), m->s));   // the boxes of these views are not known any more
         HIP_TRY(hipStreamSynchronize(m->s));
     }
     memcpy(&p->view_K[(size_t)slot0 * 9], Ks, (size_t)count * 9 * sizeof(float));
@@ -265,7 +266,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         launch_icp_bind(p->d_sel, p->d_nsel, p->d_class_base, p->d_view_K, p->d_view_valid, p->num_views, c->d_in, c->d_st, top_k, s);
         HIP_TRY(hipEventRecord(p->e2, s));
         IcpBuffers B = c->B;
-        B.scene = d->cur_depth; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
+        B.scene = d->cur_depth; B.models = c->d_models; B.model_bbox = c->d_model_bbox; B.in = c->d_in; B.st = c->d_st;
         B.count = top_k;
         memcpy(B.sK, scene_K, sizeof(B.sK));
         launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, s);
@@ -308,6 +309,7 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         o.status = st.status;
         if (st.status == 2) return lm_set_error(LM_ERR_INVALID, "rendered depth of template %d is empty", sl.template_id);
         if (st.status == 3) return lm_set_error(LM_ERR_INVALID, "detection %d: point cloud too large for 64-bit voxel keys", i);
+        if (st.status == lm::kIcpStalled) return lm_set_error(LM_ERR_HIP, "detection %d: the point kernels stalled (strips waited a second for each other)", i);
         if (st.status != 0) continue;                             // 1: window leaves the frame (LL.cpp:52-55); 5: no view for the template
         const int base = p->h_class_base[sl.class_index];
         const size_t v = (size_t)base + sl.template_id;

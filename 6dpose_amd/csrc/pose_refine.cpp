@@ -45,7 +45,7 @@ namespace {
 
 void free_arenas(lm_icp* c) {
     void* ptrs[] = {c->B.model_pts, c->B.scene_pts, c->B.src, c->B.tgt, c->B.tgt_sorted, c->B.tgt_orig, c->B.cell_start,
-                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.xchg, c->B.strip_mm, c->B.sort_look, c->d_in, c->d_st};
+                    c->B.cov, c->B.normals, c->B.work, c->B.prev_nn, c->B.nn_lb, c->B.partial, c->B.strip_cnt, c->B.strip_sum, c->B.tgt_rec, c->B.cell_start16, c->B.keys, c->B.xchg, c->B.strip_mm, c->B.strip_pub, c->B.sort_look, c->d_in, c->d_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->B = IcpBuffers{};
@@ -90,6 +90,7 @@ int lm_icp_ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.partial, (size_t)2 * n * kIcpMaxSplit * 32 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.strip_cnt, (size_t)n * kIcpStrips * 2 * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.strip_sum, (size_t)n * kIcpStrips * 8 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&B.strip_pub, (size_t)n * kIcpStrips * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&B.strip_mm, (size_t)n * kIcpStrips * 12 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.sort_look, (size_t)n * 2 * lm::kIcpSortGroups * sizeof(unsigned int)));
     HIP_TRY(hipMalloc((void**)&B.tgt_rec, (size_t)n * cap * sizeof(TgtRec)));
@@ -115,7 +116,8 @@ int lm_icp_set_geometry(lm_icp* c, int W, int H) {
     free_arenas(c);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_models) (void)hipFree(c->d_models);
-    c->d_scene = nullptr; c->d_models = nullptr; c->slots = 0; c->have_scene = false;
+    if (c->d_model_bbox) (void)hipFree(c->d_model_bbox);
+    c->d_scene = nullptr; c->d_models = nullptr; c->d_model_bbox = nullptr; c->slots = 0; c->have_scene = false;
     c->W = W; c->H = H;
     HIP_TRY(hipMalloc((void**)&c->d_scene, (size_t)W * H * sizeof(uint16_t)));
     return LM_OK;
@@ -133,6 +135,11 @@ int lm_icp_ensure_slots(lm_icp* c, int slots) {
         (void)hipFree(c->d_models);
     }
     c->d_models = p;
+    if (c->d_model_bbox) (void)hipFree(c->d_model_bbox);
+    c->d_model_bbox = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_model_bbox, (size_t)n * 8 * sizeof(int)));
+    HIP_TRY(hipMemset(c->d_model_bbox, 0, (size_t)n * 8 * sizeof(int)));   // (every box is worked out again by the first run that uses its slot)
+    HIP_TRY(hipDeviceSynchronize());
     c->slots = n;
     return LM_OK;
 }
@@ -201,6 +208,7 @@ extern "C" void lm_icp_destroy(lm_icp* c) {
     free_arenas(c);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_models) (void)hipFree(c->d_models);
+    if (c->d_model_bbox) (void)hipFree(c->d_model_bbox);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
@@ -239,6 +247,7 @@ extern "C" int lm_icp_set_models(lm_icp* c, int first_slot, int count, const uin
     uint8_t* stage = (uint8_t*)c->pinned + img;
     for (int i = 0; i < count; ++i) memcpy(stage + (size_t)i * img, model_depths[i], img);
     HIP_TRY(hipMemcpyAsync(c->d_models + (size_t)first_slot * c->W * c->H, stage, img * (size_t)count, hipMemcpyHostToDevice, c->s));
+    HIP_TRY(hipMemsetAsync(c->d_model_bbox + (size_t)first_slot * 8, 0, (size_t)count * 8 * sizeof(int), c->s));   // the boxes of these slots are not known any more
     return LM_OK;
 }
 
@@ -267,7 +276,7 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
         st.bbox[0] = INT_MAX; st.bbox[1] = INT_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
     }
     IcpBuffers B = c->B;
-    B.scene = c->d_scene; B.models = c->d_models; B.in = c->d_in; B.st = c->d_st;
+    B.scene = c->d_scene; B.models = c->d_models; B.model_bbox = c->d_model_bbox; B.in = c->d_in; B.st = c->d_st;
     B.count = count;
     memcpy(B.sK, c->sK, sizeof(B.sK));
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
@@ -290,6 +299,7 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     for (int i = 0; i < count; ++i) {
         const IcpState& st = c->h_st[i];
         if (st.status == 2) return lm_set_error(LM_ERR_INVALID, "model depth image is empty");
+        if (st.status == lm::kIcpStalled) return lm_set_error(LM_ERR_HIP, "hypothesis %d: the point kernels stalled (strips waited a second for each other)", i);
         if (st.status == 3)
             return lm_set_error(LM_ERR_INVALID, "hypothesis %d: point cloud too large for 64-bit voxel keys (depth spans tens of metres?)", i);
     }
