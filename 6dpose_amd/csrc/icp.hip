@@ -1427,6 +1427,7 @@ constexpr int kKnnSlabPts = 2048;  // target points staged per workgroup (32-byt
 constexpr int kKnnRuns = 16;       // x columns of a ring kept as separate runs (R <= 7; wider rings take whole x columns)
 constexpr int kKnnHard = 512;      // points per round of a workgroup, any of which may be handed to a whole wave
 constexpr int kKnnFarMax = 256;    // points per hypothesis k_icp_knn_far takes (more than that stay with their wave)
+constexpr int kKnnFarBlocks = 96;  // ... with this many workgroups per hypothesis
 constexpr int kKnnFew = 4;         // distinct distances a lane sorts in registers in a collecting pass
 
 // reductions over the 8 lanes of a point (xor 1, xor 2, mirror within the half row): every lane ends with the result
@@ -2125,11 +2126,16 @@ k_icp_knn_far(IcpBuffers B, int knn) {
     const int nfar = S.n_far < kKnnFarMax ? S.n_far : kKnnFarMax;
     if ((int)blockIdx.x >= nfar) return;
     const int nt = S.n_tgt;
-    const int pos = reinterpret_cast<const int*>(B.keys + (size_t)h * 2 * B.cap2)[blockIdx.x];
     const int big = S.gx > S.gy ? S.gx : S.gy;
-    (void)knn_point<512>(pos, (int)threadIdx.x, s_runs, knn < nt ? knn : nt, big, INT_MAX, nullptr, 0, 0, B.tgt_sorted + (size_t)h * B.cap * 3,
-                         B.tgt_rec + (size_t)h * B.cap, B.tgt_orig + (size_t)h * B.cap, B.cell_start + (size_t)h * kIcpCells,
-                         B.cov + (size_t)h * B.cap * kIcpCovStride, S.gx, S.gy, S.gminx, S.gminy, S.inv_cell, S.cell);
+    // (kKnnFarBlocks workgroups per cloud walk the list: a workgroup per possible entry was 4096 workgroups to dispatch for 16 clouds — 11 us
+    // when the lists are empty, as they are for clouds without depth outliers)
+    for (int i = blockIdx.x; i < nfar; i += gridDim.x) {
+        const int pos = reinterpret_cast<const int*>(B.keys + (size_t)h * 2 * B.cap2)[i];
+        (void)knn_point<512>(pos, (int)threadIdx.x, s_runs, knn < nt ? knn : nt, big, INT_MAX, nullptr, 0, 0, B.tgt_sorted + (size_t)h * B.cap * 3,
+                             B.tgt_rec + (size_t)h * B.cap, B.tgt_orig + (size_t)h * B.cap, B.cell_start + (size_t)h * kIcpCells,
+                             B.cov + (size_t)h * B.cap * kIcpCovStride, S.gx, S.gy, S.gminx, S.gminy, S.inv_cell, S.cell);
+        __syncthreads();                                             // (s_runs and the reduction scratch are the next point's)
+    }
 }
 
 // ---- 3x3 symmetric eigen decomposition (cyclic Jacobi), eigenvector of the smallest eigenvalue ----
@@ -3722,6 +3728,46 @@ void launch_icp_evals(const IcpBuffers& B, int count, int it_from, int it_to, do
     }
 }
 
+// RegistrationICP as one launch for all evaluations: a team of workgroups per hypothesis, as many as the chip holds at once (one workgroup per
+// CU: the team's members wait for each other, so the whole grid must be resident) — hypotheses k_icp_team cannot hold keep stop == 0.
+// Four builds, each taking the hypotheses the ones before left (stop == 0):
+//   1  one source point per owner thread, the whole target cloud in LDS — clouds of a couple of thousand points per team member and
+//      target clouds of <= ~2300 points: far inside its registers, every target access a plain LDS read;
+//   2  one point per thread, a slab of the target cloud in LDS when it does not fit whole (a batch with such a cloud is taken whole);
+//   4  two points per thread, slab — up to 1408 points per member;
+//   8  five points per thread — batches so large that a team is one or two workgroups.
+// A launch with nothing to take is not free (measured on the icp leg: the idle build 2 costs 3 us, the idle build 4 another 6-8), so up
+// to 64 hypotheses — where the kernel deals the workgroups out by cloud size and a member holds more than 704 points only when the batch
+// has more than ~170k source points — the first call launches builds 1 and 2 only; the caller tries `large` (4 and 8) on what is left
+// before it goes to the sliced launches.
+void launch_icp_team(const IcpBuffers& B, int count, int large, double max_dist, int max_iter, double rel_tol, hipStream_t s) {
+    if (count <= 0) return;
+    const Knobs& kn = knobs();
+#ifdef LM_DIAG
+    if (kn.icp_maxiter_diag >= 0) max_iter = kn.icp_maxiter_diag;
+#endif
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
+        return n;
+    }();
+    int team = kn.icp_team > 0 ? kn.icp_team : 16;
+    if (team > cus / count) team = cus / count;
+    if (team > kIcpMaxSplit) team = kIcpMaxSplit;
+    if (team < 1) team = 1;
+    static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
+    unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+    if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+    const bool dealt = count <= 64 && kn.icp_team == 0;              // (<= 64 hypotheses: the kernel deals the workgroups out itself, by cloud size)
+    const dim3 grid = dealt ? dim3(cus) : dim3(team, count);
+    int builds = kn.icp_builds > 0 ? kn.icp_builds : (dealt ? (large ? 4 | 8 : 1 | 2) : (large ? 0 : 1 | 2 | 4 | (team < 4 ? 8 : 0)));
+    if (kn.icp_builds > 0 && large) builds = 0;
+    if (builds & 1) hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 2) hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 4) hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    if (builds & 8) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+}
+
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, int solo_from, hipStream_t s) {
     if (count <= 0) return;
@@ -3744,38 +3790,13 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
     if (kn.knn_lanes == 8) hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     else hipLaunchKernelGGL(k_icp_knn16, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
-    hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarMax, count), dim3(512), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarBlocks, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     if (solo_from != 0) {                                            // sliced launches only
         launch_icp_evals(B, count, 0, max_iter + 1, max_dist, max_iter, rel_tol, s);
         return;
     }
-    // one launch for all evaluations: a team of workgroups per hypothesis, as many as the chip holds at once (one workgroup per CU: the
-    // team's members wait for each other, so the whole grid must be resident) — hypotheses k_icp_team cannot hold keep stop == 0 and
-    // the caller then runs launch_icp_evals for them
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
-        return n;
-    }();
-    int team = kn.icp_team > 0 ? kn.icp_team : 16;
-    if (team > cus / count) team = cus / count;
-    if (team > kIcpMaxSplit) team = kIcpMaxSplit;
-    if (team < 1) team = 1;
-    static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
-    unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
-    if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
-    // Three builds, each taking the hypotheses the ones before left (stop == 0); a launch with nothing to take costs ~2 us:
-    //   one source point per owner thread, the whole target cloud in LDS — clouds of a couple of thousand points per team member and
-    //   target clouds of <= ~2300 points: far inside its registers, every target access a plain LDS read;
-    //   two points per thread and a slab of the target cloud in LDS — anything up to 1408 points per member, any target cloud;
-    //   five points per thread — batches so large that a team is one or two workgroups.
-    const dim3 grid = count <= 64 && kn.icp_team == 0 ? dim3(cus) : dim3(team, count);   // (<= 64 hypotheses: the kernel deals the workgroups out itself, by cloud size)
-    const int builds = kn.icp_builds > 0 ? kn.icp_builds : (1 | 2 | 4 | (team < 4 ? 8 : 0));
-    if (builds & 1) hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 2) hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 4) hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 8) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    launch_icp_team(B, count, 0, max_dist, max_iter, rel_tol, s);
 }
 
 }  // namespace lm

@@ -282,15 +282,18 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
             continue;
         }
         if (rc) return rc;
-        if (lm_icp_unfinished(c->h_st, top_k)) {                  // clouds k_icp_team does not hold, or a team that timed out: the sliced launches run those hypotheses
+        for (int pass = 0; pass < 2 && lm_icp_unfinished(c->h_st, top_k); ++pass) {
+            // clouds the first team builds do not hold (more than 704 source points per workgroup): the builds with more points per thread;
+            // what those leave too, or a team that timed out: the sliced launches
             if (c->solo_from != 0) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
-            launch_icp_evals(B, top_k, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, s);
+            if (pass == 0) launch_icp_team(B, top_k, 1, kMaxDist, kMaxIter, kRelTol, s);
+            else launch_icp_evals(B, top_k, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, s);
             HIP_TRY(hipEventRecord(c->e1, s));
             HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)top_k * sizeof(IcpState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipGetLastError());
-            if (lm_icp_unfinished(c->h_st, top_k)) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
         }
+        if (lm_icp_unfinished(c->h_st, top_k)) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
         break;
     }
     if (p->h_nsel[1] != 0)

@@ -283,15 +283,17 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
     HIP_TRY(hipEventRecord(c->e0, c->s));
     launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, c->s);
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
         HIP_TRY(hipEventRecord(c->e1, c->s));
         HIP_TRY(hipMemcpyAsync(c->h_st2, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
         HIP_TRY(hipStreamSynchronize(c->s));
         HIP_TRY(hipGetLastError());
         if (!lm_icp_unfinished(c->h_st2, count)) break;
-        // clouds k_icp_team does not hold (thousands of points per workgroup), or a team that timed out: the sliced launches run those hypotheses
-        if (pass == 1 || c->solo_from != 0) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
-        launch_icp_evals(B, count, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, c->s);
+        // clouds the first team builds do not hold (more than 704 source points per workgroup): the builds with more points per thread;
+        // what those leave too, or a team that timed out: the sliced launches
+        if (pass == 2 || c->solo_from != 0) return lm_set_error(LM_ERR_HIP, "ICP: a hypothesis was left unfinished");
+        if (pass == 0) launch_icp_team(B, count, 1, kMaxDist, kMaxIter, kRelTol, c->s);
+        else launch_icp_evals(B, count, 0, kMaxIter + 1, kMaxDist, kMaxIter, kRelTol, c->s);
     }
     memcpy(c->h_st, c->h_st2, (size_t)count * sizeof(IcpState));
     c->last_count = count; c->last_flags = flags;

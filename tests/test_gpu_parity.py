@@ -1370,11 +1370,12 @@ def test_icp_normals_of_a_cloud_with_depth_outliers(lm):
     ctx.close()
 
 
-@pytest.mark.parametrize("half_w,half_h", [(110, 100), (80, 75)])
+@pytest.mark.parametrize("half_w,half_h", [(110, 100), (80, 75), (150, 120)])
 def test_icp_large_clouds_take_the_global_sort_path(lm, half_w, half_h):
-    """> 16k points per cloud: the voxel / grid sorts keep their keys in HBM (radix sort, up to 32k points: the 159 x 149 =
-    23.7k-pixel case) or leave LDS altogether (bitonic network through the HBM scratch: 219 x 199 = 43.6k pixels).  The
-    down-sampled cloud must still equal the oracle's, and registering the cloud to itself (verbatim mode, LL.cpp:109) is
+    """> 16k points per cloud: eight workgroups sort a cloud of up to 8 x 8192 points between them (159 x 149 = 23.7k and 219 x 199 =
+    43.6k pixels); beyond that (299 x 239 = 71k) one workgroup does, its keys in HBM (bitonic network through the scratch) — and the
+    team of 64 workgroups then holds more than 704 source points each, which takes the second team launch (two points per thread).
+    The down-sampled cloud must still equal the oracle's, and registering the cloud to itself (verbatim mode, LL.cpp:109) is
     the identity."""
     import linemodLevelup_pybind as mod
     H, W = 480, 640
