@@ -1782,339 +1782,11 @@ k_icp_knn(IcpBuffers B, int knn) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_icp_knn16 (round 6): the same neighbour search with the candidates of a ring held in REGISTERS.  knn_point above walks the ring
-// once per pass — 5-7 walks per point, each recomputing every squared distance — and the kernel's time is the time of ONE such point
-// (a cloud of the icp leg is one trip of the lane groups: ~70k cycles), then once more for the points whose ring had to grow, a whole
-// wave each (~70k again, most of it 64-lane reductions through the LDS crossbar).  Here
-//   SIXTEEN LANES per point (one DPP row: every reduction is four row operations), four points per wave;
-//   one walk: candidate e of the ring (its columns' runs laid end to end) goes to lane e mod 16, slot e / 16 — 8 slots hold rings of up to
-//   128 candidates, 16 slots 256 — as the bit pattern of its squared distance (the oracle's expression) plus its sorted position;
-//   every pass of the selection (the counting brackets, the few-smallest merge, the ties by original index: knn_point's, unchanged) then
-//   runs over the slots; the cumulants of the selected re-read their records;
-//   a point whose ring holds fewer than k candidates inside the guarantee radius goes onto a list with the next ring (R0 + 1, then
-//   x 1.5, then doubling up to 8) and the list is worked off the same way, packed 32 points a trip — no point waits in a wave for a
-//   neighbour whose ring grows; rings beyond 256 candidates are left to whole waves and knn_point, rings beyond 8 to k_icp_knn_far.
-// Neighbour sets are exact as before (the ring schedule does not enter the result); the cumulants add the same neighbours in another
-// order (last bits).
-// MEASURED (icp leg, 16 clouds of ~1.7k points): 198 us against k_icp_knn's 91 — the kernel is not bound by the latency of a point but by
-// instruction issue (216 CUs x 4 waves per SIMD busy), and the selection over 8 slots compiles to ~3.5k instructions per point and lane
-// group (64-bit compares and selects, the four-deep insertion of the few-smallest lists as branches) where the walk it saves costs ~300 each;
-// three rounds of trips instead of one add their barriers.  Kept behind LM_KNN_LANES=16 (tests pass on it); the default stays k_icp_knn.
-// ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ int sum16(int v) { v = sum8(v); v += dpp_mov<0x140>(v); return v; }
-static __device__ __forceinline__ double sum16(double v) { v = sum8(v); v += dpp_mov<0x140>(v); return v; }
-static __device__ __forceinline__ int min16(int v) { v = min8(v); return min(v, dpp_mov<0x140>(v)); }
-static __device__ __forceinline__ unsigned long long min16(unsigned long long v) { v = min8(v); const unsigned long long o = dpp_mov64<0x140>(v); return o < v ? o : v; }
-
-constexpr int kKnn16Lanes = 16;
-constexpr int kKnn16Groups = kKnnWG / kKnn16Lanes;     // 32 points per trip of a workgroup
-
-// One point, one ring (its runs are in `runs`, M candidates in all), 16 lanes, S slots per lane (M <= 16 S).  False: fewer than k candidates
-// inside the guarantee radius (g2 = its square) and the ring is not the whole grid — nothing written.
-template <int S>
-static __device__ __forceinline__ bool knn_ring16(const int pos, const int sub, const int2* runs, const int nx, const int M, const bool all, const double g2, const int k,
-                                                  const TgtRec* s_tgt, const int p0, const int np, const TgtRec* __restrict__ rec, const int* __restrict__ orig,
-                                                  double* __restrict__ cov, const double px, const double py, const double pz) {
-    const double kInfD = __longlong_as_double(0x7FF0000000000000ll);
-    auto key = [](const double d) { return (unsigned long long)__double_as_longlong(d); };
-    auto val = [](const unsigned long long kk) { return __longlong_as_double((long long)kk); };
-    const unsigned long long kInf = key(kInfD);
-    // the walk: slot s of this lane is candidate sub + 16 s of the runs laid end to end
-    int jj[S];
-    {
-        int xi = 0, pre = 0;
-        int2 ab = runs[0];
-        int end = ab.y - ab.x;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int e = sub + kKnn16Lanes * s;
-            while (e >= end && xi + 1 < nx) { ++xi; ab = runs[xi]; pre = end; end += ab.y - ab.x; }
-            jj[s] = e < end ? ab.x + (e - pre) : -1;
-        }
-    }
-    unsigned long long dk[S];
-    bool inside = true;
-#pragma unroll
-    for (int s = 0; s < S; ++s) inside = inside && (jj[s] < 0 || (jj[s] >= p0 && jj[s] < p0 + np));
-    if (__all(inside)) {                                           // (one loop per address space: a pointer that may be either makes every load a FLAT load)
-        const TgtRec* s_rel = s_tgt - p0;
-        double q[S][3];
-#pragma unroll
-        for (int s = 0; s < S; ++s) { const TgtRec& r = s_rel[jj[s] >= 0 ? jj[s] : p0]; q[s][0] = r.x; q[s][1] = r.y; q[s][2] = r.z; }
-#pragma unroll
-        for (int s = 0; s < S; ++s) dk[s] = jj[s] >= 0 ? key(sqdist(px, py, pz, q[s][0], q[s][1], q[s][2])) : kInf;
-    } else {
-        double q[S][3];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int j = jj[s] >= 0 ? jj[s] : pos;
-            const double2 xy = *reinterpret_cast<const double2*>(&rec[j].x);
-            q[s][0] = xy.x; q[s][1] = xy.y; q[s][2] = rec[j].z;
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) dk[s] = jj[s] >= 0 ? key(sqdist(px, py, pz, q[s][0], q[s][1], q[s][2])) : kInf;
-    }
-    // pass 1: how many candidates are closer than g, g/sqrt(2), g/2, g/sqrt(8)
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    {
-        const unsigned long long kg = key(g2), k1 = key(g2 * 0.5), k2 = key(g2 * 0.25), k3 = key(g2 * 0.125);
-#pragma unroll
-        for (int s = 0; s < S; ++s) { c0 += dk[s] < kg ? 1 : 0; c1 += dk[s] < k1 ? 1 : 0; c2 += dk[s] < k2 ? 1 : 0; c3 += dk[s] < k3 ? 1 : 0; }
-        c0 = sum16(c0); c1 = sum16(c1); c2 = sum16(c2); c3 = sum16(c3);
-    }
-    if (c0 < k && !all) return false;
-    // bracket and selection: knn_point's, over the slots
-    unsigned long long lo = 0ull, hi = c0 >= k ? key(g2) : kInf;
-    int cl = 0, ch = c0 >= k ? c0 : M;
-    if (c0 >= k) {
-        const unsigned long long h1 = key(g2 * 0.5), h2 = key(g2 * 0.25), h3 = key(g2 * 0.125);
-        if (c1 >= k) { hi = h1; ch = c1; } else if (c1 > cl) { lo = h1; cl = c1; }
-        if (c2 >= k) { hi = h2; ch = c2; } else if (c2 > cl) { lo = h2; cl = c2; }
-        if (c3 >= k) { hi = h3; ch = c3; } else if (c3 > cl) { lo = h3; cl = c3; }
-    }
-    unsigned long long v = hi;
-    int ties = ch == k ? 0 : -1, last_o = -1;
-    if (ties < 0 && hi < kInf) {
-        const double dlo = val(lo), dhi = val(hi);
-        const double w = dhi - dlo, f0 = ((double)(k - cl) + 0.5) / (double)(ch - cl + 1), df = 1.5 / (double)(ch - cl + 1);
-        const double td[4] = {dlo + w * (f0 - 3.0 * df), dlo + w * (f0 - df), dlo + w * (f0 + df), dlo + w * (f0 + 3.0 * df)};
-        unsigned long long t[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = key(td[q] > dlo ? (td[q] < dhi ? td[q] : dhi) : dlo);
-        int n4[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) n4[q] += dk[s] < t[q] ? 1 : 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = sum16(n4[q]);
-            if (n < k) { if (n >= cl && t[q] > lo) { lo = t[q]; cl = n; } }
-            else if (t[q] < hi) { hi = t[q]; ch = n; }
-        }
-        if (ch == k) { ties = 0; v = hi; }
-    }
-    while (ties < 0) {
-        unsigned long long sv[kKnnFew];
-        int sc[kKnnFew];
-#pragma unroll
-        for (int q = 0; q < kKnnFew; ++q) { sv[q] = kInf; sc[q] = 0; }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const unsigned long long d = dk[s];
-            if (d >= lo && d < hi) {
-                unsigned long long x = d;
-                int xc = 1;
-#pragma unroll
-                for (int q = 0; q < kKnnFew; ++q) {
-                    if (x == sv[q]) { sc[q] += xc; xc = 0; x = kInf; }
-                    else if (x < sv[q]) { const unsigned long long tt = sv[q]; const int tc = sc[q]; sv[q] = x; sc[q] = xc; x = tt; xc = tc; }
-                }
-            }
-        }
-        const unsigned long long limit = min16(sc[kKnnFew - 1] > 0 ? sv[kKnnFew - 1] : kInf);
-        int cum = cl, less = -1, eq = 0;
-        for (int it = 0; it < kKnnFew * kKnn16Lanes && less < 0; ++it) {
-            const unsigned long long head = min16(sv[0]);
-            if (!(head < kInf) || head > limit) break;
-            const int mult = sum16(sv[0] == head ? sc[0] : 0);
-            if (cum + mult >= k) { v = head; less = cum; eq = mult; break; }
-            cum += mult;
-            if (sv[0] == head) {
-#pragma unroll
-                for (int q = 0; q + 1 < kKnnFew; ++q) { sv[q] = sv[q + 1]; sc[q] = sc[q + 1]; }
-                sv[kKnnFew - 1] = kInf; sc[kKnnFew - 1] = 0;
-            }
-            if (head == limit) break;
-        }
-        if (less < 0) {
-            const unsigned long long top = limit < kInf ? limit : hi;
-            lo = top + 1ull; cl = cum;
-            continue;
-        }
-        if (less + eq == k) { ties = 1; break; }
-        ties = 2;
-        for (int n = less; n < k; ++n) {
-            int bo = INT_MAX;
-            const int lo_o = last_o;
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (dk[s] == v) { const int o = orig[jj[s]]; if (o > lo_o && o < bo) bo = o; }
-            last_o = min16(bo);
-        }
-    }
-    // the cumulants of the selected points (their records read again) and the distance to the nearest other point
-    double sum[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) sum[q] = 0.0;
-    unsigned long long sep2 = key(1e300);
-    int taken = 0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const unsigned long long d = dk[s];
-        const int j = jj[s];
-        if (j >= 0 && j != pos && d < sep2) sep2 = d;
-        bool sel = d < v;
-        if (ties && d == v) sel = ties == 1 || orig[j] <= last_o;
-        if (sel) {
-            double qx, qy, qz;
-            if (j >= p0 && j < p0 + np) { const TgtRec& r = s_tgt[j - p0]; qx = r.x; qy = r.y; qz = r.z; }
-            else { const double2 xy = *reinterpret_cast<const double2*>(&rec[j].x); qx = xy.x; qy = xy.y; qz = rec[j].z; }
-            sum[0] += qx; sum[1] += qy; sum[2] += qz;
-            sum[3] += qx * qx; sum[4] += qx * qy; sum[5] += qx * qz; sum[6] += qy * qy; sum[7] += qy * qz; sum[8] += qz * qz;
-            ++taken;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) sum[q] = sum16(sum[q]);
-    taken = sum16(taken);
-    sep2 = min16(sep2);
-    if (sub == 0) {
-        double* c = cov + (size_t)pos * kIcpCovStride;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) c[q] = sum[q];
-        c[9] = (double)taken;
-        c[10] = val(sep2);
-    }
-    return true;
-}
-
-// (not inlined: the rare paths of k_icp_knn16 — their registers are then theirs, not the kernel's)
-struct KnnCloud { const TgtRec* s_tgt; int p0, np; const double* T; const TgtRec* rec; const int* orig; const int* cs; double* cov; int gx, gy; double minx, miny, inv, cell; };
-static __device__ __attribute__((noinline)) bool knn_point_wave(const int pos, const int lane, int2* runs, const int k, const int R0, const int Rmax, const KnnCloud& C) {
-    return knn_point<64>(pos, lane, runs, k, R0, Rmax, C.s_tgt, C.p0, C.np, C.T, C.rec, C.orig, C.cs, C.cov, C.gx, C.gy, C.minx, C.miny, C.inv, C.cell);
-}
-static __device__ __attribute__((noinline)) bool knn_ring16_large(const int pos, const int sub, const int2* runs, const int nx, const int M, const bool all, const double g2,
-                                                                 const int k, const KnnCloud& C, const double px, const double py, const double pz) {
-    return knn_ring16<16>(pos, sub, runs, nx, M, all, g2, k, C.s_tgt, C.p0, C.np, C.rec, C.orig, C.cov, px, py, pz);
-}
-
-__global__ void __launch_bounds__(kKnnWG, 4)
-k_icp_knn16(IcpBuffers B, int knn) {
-    __shared__ TgtRec s_tgt[kKnnSlabPts];
-    __shared__ int2 s_runs[kKnn16Groups][kKnnRuns];
-    __shared__ int s_list[2][kKnnHard];                            // points still to do: sorted position | ring << 24, this round's and the next one's
-    __shared__ int s_wide[kKnnHard];                               // points whose ring holds more candidates than the slots: whole waves
-    __shared__ int s_n[3];
-    const int h = blockIdx.y;
-    const IcpState& S = B.st[h];
-    if (S.status != 0 || S.n_tgt == 0) return;
-    const int nt = S.n_tgt;
-    const double* T = B.tgt_sorted + (size_t)h * B.cap * 3;
-    const int* orig = B.tgt_orig + (size_t)h * B.cap;
-    const int* cs = B.cell_start + (size_t)h * kIcpCells;
-    const TgtRec* rec = B.tgt_rec + (size_t)h * B.cap;
-    double* cov = B.cov + (size_t)h * B.cap * kIcpCovStride;
-    int* far_list = reinterpret_cast<int*>(B.keys + (size_t)h * 2 * B.cap2);   // the sort scratch is free by now
-    const int gx = S.gx, gy = S.gy;
-    const double minx = S.gminx, miny = S.gminy, inv = S.inv_cell, cell = S.cell;
-    const int k = knn < nt ? knn : nt;
-    int R0 = (int)ceil(0.009 / cell);
-    if (R0 < 1) R0 = 1;
-    // workgroups at work on this cloud: ~64 points each = two trips of the lane groups
-    const int want = (nt + 63) / 64, nb = want < 16 ? 16 : want > (int)gridDim.x ? (int)gridDim.x : want;
-    if ((int)blockIdx.x >= nb) return;
-    const int q0 = (int)((long long)nt * blockIdx.x / nb), q1 = (int)((long long)nt * (blockIdx.x + 1) / nb);
-    if (q0 >= q1) return;
-    // the slab: the columns the rings R0 + 1 of this workgroup's points reach (R0 if that is too much for the LDS)
-    int xlo = max(grid_coord(T[3 * (size_t)q0], minx, inv, gx) - (R0 + 1), 0);
-    int xhi = min(grid_coord(T[3 * (size_t)(q1 - 1)], minx, inv, gx) + (R0 + 1), gx - 1);
-    if (cs[(xhi + 1) * gy] - cs[xlo * gy] > kKnnSlabPts) { xlo = min(xlo + 1, xhi); xhi = max(xhi - 1, xlo); }
-    if (nt <= kKnnSlabPts) { xlo = 0; xhi = gx - 1; }             // a small cloud is staged whole: grown rings stay in LDS too
-    const int p0 = cs[xlo * gy];
-    int np = cs[(xhi + 1) * gy] - p0;
-    if (np > kKnnSlabPts) np = 0;                                 // slab too large for LDS: every ring reads HBM
-    const long long k_t0 = (long long)__builtin_amdgcn_s_memtime();
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(rec + p0);
-        uint4* dst = reinterpret_cast<uint4*>(s_tgt);
-        for (int j = threadIdx.x; j < np * 2; j += kKnnWG) dst[j] = src[j];
-    }
-    __syncthreads();
-    const long long k_t1 = (long long)__builtin_amdgcn_s_memtime();
-    long long k_rounds = 0, k_wide = 0;
-    int later = 0;
-    KnnCloud C;
-    C.s_tgt = s_tgt; C.p0 = p0; C.np = np; C.T = T; C.rec = rec; C.orig = orig; C.cs = cs; C.cov = cov; C.gx = gx; C.gy = gy; C.minx = minx; C.miny = miny; C.inv = inv; C.cell = cell;
-    const int sub = threadIdx.x & (kKnn16Lanes - 1), grp = threadIdx.x / kKnn16Lanes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int2* runs = s_runs[grp];
-    for (int base = q0; base < q1; base += kKnnHard) {
-        const int end = base + kKnnHard < q1 ? base + kKnnHard : q1;
-        const long long k_t2 = (long long)__builtin_amdgcn_s_memtime();
-        if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-        __syncthreads();
-        int cur = 0, ncur = end - base;
-        for (int round = 0; ncur > 0; ++round) {
-            const int nxt = cur ^ 1;
-            for (int i = grp; i < ncur; i += kKnn16Groups) {
-                const int item = round == 0 ? ((base + i) | (R0 << 24)) : s_list[cur][i];
-                const int pos = item & 0xFFFFFF, R = (int)((unsigned int)item >> 24);
-                const double px = T[3 * (size_t)pos], py = T[3 * (size_t)pos + 1], pz = T[3 * (size_t)pos + 2];
-                const int cx = grid_coord(px, minx, inv, gx), cy = grid_coord(py, miny, inv, gy);
-                const int xa = max(cx - R, 0), xb = min(cx + R, gx - 1), ya = max(cy - R, 0), yb = min(cy + R, gy - 1);
-                const bool all = xa == 0 && ya == 0 && xb == gx - 1 && yb == gy - 1;
-                int nx = xb - xa + 1, len = 0;
-                if (nx > kKnnRuns) {                              // a ring that wide: whole x columns, which are one run
-                    nx = 1;
-                    if (sub == 0) { const int2 ab = make_int2(cs[xa * gy], cs[(xb + 1) * gy]); runs[0] = ab; len = ab.y - ab.x; }
-                } else if (sub < nx) {
-                    const int2 ab = make_int2(cs[(xa + sub) * gy + ya], cs[(xa + sub) * gy + yb + 1]);
-                    runs[sub] = ab; len = ab.y - ab.x;
-                }
-                const int M = sum16(len);                          // (within a wave the LDS operations are in order)
-                const double g = (double)R * cell * (1.0 - 1e-9);   // margin >> the rounding of grid_coord
-                int state;                                          // 1 done, 0 the ring has to grow, -1 more candidates than slots
-                if (M <= 8 * kKnn16Lanes) state = knn_ring16<8>(pos, sub, runs, nx, M, all, g * g, k, s_tgt, p0, np, rec, orig, cov, px, py, pz) ? 1 : 0;
-                else if (M <= 16 * kKnn16Lanes) state = knn_ring16_large(pos, sub, runs, nx, M, all, g * g, k, C, px, py, pz) ? 1 : 0;
-                else state = -1;
-                if (sub == 0 && state != 1) {
-                    // isolated points: grow geometrically, not ring by ring
-                    const int Rn = R <= R0 ? R + 1 : (R == R0 + 1 ? R + (R >> 1) + (R == 1 ? 1 : 0) : 2 * R);
-                    if (state < 0) s_wide[atomicAdd(&s_n[2], 1)] = item;
-                    else if (Rn <= 8) s_list[nxt][atomicAdd(&s_n[nxt], 1)] = pos | (Rn << 24);
-                    else {                                         // more than 8 rings from its k-th neighbour: the whole cloud, a workgroup of k_icp_knn_far
-                        const int slot = atomicAdd(&B.st[h].n_far, 1);
-                        if (slot < kKnnFarMax) far_list[slot] = pos; else s_wide[atomicAdd(&s_n[2], 1)] = pos | (255 << 24);
-                    }
-                }
-            }
-            __syncthreads();
-            ncur = s_n[nxt];
-            __syncthreads();
-            if (threadIdx.x == 0) s_n[cur] = 0;
-            if (round == 0) later += ncur;
-            cur = nxt;
-            __syncthreads();
-        }
-        const long long k_t3 = (long long)__builtin_amdgcn_s_memtime();
-        // rings of more than 256 candidates (and what k_icp_knn_far has no room for): whole waves, knn_point
-        const int nwide = s_n[2];
-        for (int i = wave; i < nwide; i += kKnnWG / 64) {
-            const int item = s_wide[i], pos = item & 0xFFFFFF, R = (int)((unsigned int)item >> 24);
-            int2* wr = s_runs[wave * (64 / kKnn16Lanes)];
-            if (R == 255) { (void)knn_point_wave(pos, lane, wr, k, gx > gy ? gx : gy, INT_MAX, C); continue; }
-            if (knn_point_wave(pos, lane, wr, k, R, 8, C)) continue;
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(&B.st[h].n_far, 1);
-            slot = __shfl(slot, 0, 64);
-            if (slot < kKnnFarMax) { if (lane == 0) far_list[slot] = pos; }
-            else (void)knn_point_wave(pos, lane, wr, k, gx > gy ? gx : gy, INT_MAX, C);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const long long k_t4 = (long long)__builtin_amdgcn_s_memtime();
-            k_rounds += k_t3 - k_t2; k_wide += k_t4 - k_t3;
-        }
-    }
-    if (threadIdx.x == 0) {
-        atomicMax((unsigned long long*)&B.st[h].knn_clk[0], (unsigned long long)(k_t1 - k_t0));
-        atomicMax((unsigned long long*)&B.st[h].knn_clk[1], (unsigned long long)k_rounds);
-        atomicMax((unsigned long long*)&B.st[h].knn_clk[2], (unsigned long long)k_wide);
-        atomicAdd((unsigned long long*)&B.st[h].knn_clk[3], (unsigned long long)later);
-    }
-}
-
+// (Round 6 built this search twice more with the candidates of a ring held in registers — one walk instead of 5-7, the selection passes over
+// the slots; 16 lanes x 8-16 slots per point, then 8 lanes x 16 slots with whole waves x 8 slots for grown rings — exact on every test and
+// slower both times: 198 and 130 us against 85 on the icp leg's clouds.  The kernel is bound by instruction issue, not by the walks: a pass
+// is 4 sixty-four-bit compares + adds per slot whether the key comes out of a register or out of eight f64 operations, and the unrolled
+// slots cost the idle ones in full.  profiles/r06_knn_notes.txt.)
 // The points k_icp_knn could not finish within 8 rings: a workgroup each, the whole cloud as one coalesced run (one wave
 // streaming 12k records four times over took ~1 M cycles, and a blob of such points sits in ONE workgroup of k_icp_knn).
 __global__ void __launch_bounds__(512)
@@ -3788,8 +3460,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     hipLaunchKernelGGL(k_icp_voxel, dim3(count, scene_mode ? 2 : 1), dim3(kWG), 0, s, B, flags, voxel);
     if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_grid_wide, dim3(kIcpSortGroups, count), dim3(kWG), 0, s, B, flags);
     hipLaunchKernelGGL(k_icp_grid, dim3(count), dim3(kWG), 0, s, B, flags);
-    if (kn.knn_lanes == 8) hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
-    else hipLaunchKernelGGL(k_icp_knn16, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
+    hipLaunchKernelGGL(k_icp_knn, dim3(kn.knn_blocks > 0 ? kn.knn_blocks : (count <= 32 ? 64 : 32), count), dim3(kKnnWG), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_knn_far, dim3(kKnnFarBlocks, count), dim3(512), 0, s, B, knn);
     hipLaunchKernelGGL(k_icp_normals, dim3(count <= 32 ? 64 : 16, count), dim3(256), 0, s, B);
     if (solo_from != 0) {                                            // sliced launches only

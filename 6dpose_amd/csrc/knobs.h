@@ -27,7 +27,6 @@ struct Knobs {
     int fe_wgs_per_cu = kFeWaves;         // LM_FE_WGS_PER_CU: persistent workgroups per CU of a front-end stage (0 = one workgroup per tile)
     int launch_slack_us = 0;       // LM_LAUNCH_SLACK_US: a partial batch goes out when the GPU's estimated backlog is shorter than this (0 = default 150)
     int batch_queue = 0;           // LM_BATCH_QUEUE: launched batches to keep queued on the GPU before streamed frames wait for a full batch (0 = default: 2; lm_detector_set_batch_queue)
-    int knn_lanes = 8;             // LM_KNN_LANES=16: k_icp_knn16 (sixteen lanes per point, the ring's candidates in registers; exact, measured 2x slower: icp.hip) instead of k_icp_knn
     int knn_blocks = 0;            // LM_KNN_BLOCKS: grid.x of k_icp_knn (0 = default: 64 workgroups per cloud up to 32 clouds, 32 beyond)
     int icp_splits = 0;            // LM_ICP_SPLITS: slices per hypothesis of k_icp_eval (0 = default schedule)
     int icp_team = 0;              // LM_ICP_TEAM: workgroups per hypothesis of k_icp_team (0 = default: 16, at most CUs / hypotheses)
@@ -62,7 +61,6 @@ inline const Knobs& knobs() {
         v.nt_copy = geti("LM_NT_COPY", 1);
         v.fe_rows_cs = geti("LM_FE_ROWS_CS", 0);
         v.knn_blocks = geti("LM_KNN_BLOCKS", 0);
-        v.knn_lanes = geti("LM_KNN_LANES", 8);
         v.icp_splits = geti("LM_ICP_SPLITS", 0);
         v.icp_team = geti("LM_ICP_TEAM", 0);
         v.icp_builds = geti("LM_ICP_BUILDS", 0);
