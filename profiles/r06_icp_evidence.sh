@@ -32,7 +32,7 @@ import glob, shutil, os
 dbs = glob.glob("$OUT/pmc*/**/*_results.db", recursive=True)
 os.makedirs("$OUT/pmc_dbs", exist_ok=True)
 for n, f in enumerate(dbs): shutil.copy(f, "$OUT/pmc_dbs/%d_results.db" % n)
-rocpd_pmc.main("$OUT/pmc_dbs/*_results.db", "$OUT/pmc_icp.txt", kernels=("k_icp_team", "k_icp_knn", "k_icp_voxel", "k_icp_grid", "k_icp_normals"))
+rocpd_pmc.main("$OUT/pmc_dbs/*_results.db", "$OUT/pmc_icp.txt", kernels=("k_icp_team", "k_icp_knn", "k_icp_voxel_wide", "k_icp_grid_wide", "k_icp_points_fused", "k_icp_normals"))
 PY
 TEAM_MEMBERS=1 TEAM_ROWS=1 timeout 300 python profiles/r06_icp_team.py 16 2>&1 | grep -v amdgpu.ids > $OUT/team_phases.txt
 find $OUT -name "*_results.db" -delete; rm -rf $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc_dbs $OUT/trace_icp $OUT/trace_pipe $OUT/trace_icp_sliced
