@@ -322,6 +322,54 @@ k_icp_bbox(IcpBuffers B, int W, int H) {
     }
 }
 
+// k_icp_model_boxes: the same rectangle for resident model images AT UPLOAD (lm_icp_set_models, the pipeline's view upload): a workgroup
+// per image writes model_bbox[slot] = x0, y0, x1, y1, 1.  A run whose slots all came that way does not launch k_icp_bbox at all: reading a
+// 614 KB image per hypothesis and run was 12 us of every run for a fact that changes when the image does.
+__global__ void __launch_bounds__(256)
+k_icp_model_boxes(const uint16_t* __restrict__ models, int* __restrict__ model_bbox, int first_slot, int W, int H) {
+    __shared__ int s_box[4][4];
+    const int slot = first_slot + (int)blockIdx.x;
+    const uint16_t* img = models + (size_t)slot * W * H;
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+    const bool vec = (W & 7) == 0;
+    for (int y = 0; y < H; ++y) {
+        const uint16_t* row = img + (size_t)y * W;
+        for (int x = threadIdx.x * 8; x < W; x += 256 * 8) {
+            uint16_t px[8];
+            if (vec) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + x);
+                px[0] = v.x & 0xFFFF; px[1] = v.x >> 16; px[2] = v.y & 0xFFFF; px[3] = v.y >> 16;
+                px[4] = v.z & 0xFFFF; px[5] = v.z >> 16; px[6] = v.w & 0xFFFF; px[7] = v.w >> 16;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) px[k] = x + k < W ? row[x + k] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (px[k]) {
+                    x0 = min(x0, x + k); x1 = max(x1, x + k);
+                    y0 = min(y0, y); y1 = max(y1, y);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { x0 = min(x0, s_box[w][0]); y0 = min(y0, s_box[w][1]); x1 = max(x1, s_box[w][2]); y1 = max(y1, s_box[w][3]); }
+        int* known = model_bbox + (size_t)slot * 8;
+        known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; known[4] = 1;
+    }
+}
+
+void launch_icp_model_boxes(const uint16_t* models, int* model_bbox, int first_slot, int count, int W, int H, hipStream_t s) {
+    if (count > 0) hipLaunchKernelGGL(k_icp_model_boxes, dim3(count), dim3(256), 0, s, models, model_bbox, first_slot, W, H);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_icp_points (LL.cpp:52-104): raster scan of the dilated bounding box; model point where
 // modelDepth > 0, scene point where the dilated mask is set and sceneDepth (window shifted by
@@ -505,10 +553,13 @@ k_icp_points_fused(IcpBuffers B, int W, int H, int flags) {
     IcpState& S = B.st[h];
     if (S.status != 0) return;
     const IcpIn I = B.in[h];
-    const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
-    if (strip == 0 && tid == 0) {                                  // k_icp_bbox is through: the box of this image is known from now on
-        int* known = B.model_bbox + (size_t)I.model_slot * 8;
-        if (known[4] == 0) { known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; __threadfence(); known[4] = 1; }
+    // the box of the model image: worked out when the image was uploaded (k_icp_model_boxes), else by k_icp_bbox of this run
+    const int* known = B.model_bbox + (size_t)I.model_slot * 8;
+    const bool boxed = known[4] == 1;
+    const int x0 = boxed ? known[0] : S.bbox[0], y0 = boxed ? known[1] : S.bbox[1], x1 = boxed ? known[2] : S.bbox[2], y1 = boxed ? known[3] : S.bbox[3];
+    if (strip == 0 && tid == 0 && !boxed) {                        // (k_icp_bbox is through: known from now on)
+        int* kn = B.model_bbox + (size_t)I.model_slot * 8;
+        kn[0] = x0; kn[1] = y0; kn[2] = x1; kn[3] = y1; __threadfence(); kn[4] = 1;
     }
     if (strip == 0 && tid < 2 * kIcpSortGroups) B.sort_look[(size_t)h * 2 * kIcpSortGroups + tid] = 0;   // (k_icp_voxel_wide: voxel counts of the groups, not yet known)
     if (x1 < 0) {
@@ -1143,6 +1194,7 @@ k_icp_voxel_wide(IcpBuffers B, int flags, double voxel) {
     const int cloud = h * 2 + which;
     IcpState& S = B.st[h];
     const bool scene_mode = (flags & 1) != 0;
+    if (g == 0 && which == 0 && tid < kIcpStrips) B.strip_pub[(size_t)h * kIcpStrips + tid] = 0;   // (k_icp_points_fused is through: its strips' counts are the next run's to publish)
     const int n = S.status == 0 ? (which ? S.n_scene : S.n_model) : 0;
     if (n == 0) return;                                            // (k_icp_voxel sets the counts of these)
     long long clk[6];
@@ -3448,7 +3500,7 @@ void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags
     if (kn.icp_maxiter_diag >= 0) max_iter = kn.icp_maxiter_diag;            // diagnostics only (profiles/): stop after a few evaluations
 #endif
     const int scene_mode = flags & 1;
-    hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);
+    if (!(flags & 0x100) || !kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_bbox, dim3(32, count), dim3(256), 0, s, B, W, H);   // (0x100: every slot's box is in model_bbox)
     if (kn.icp_wide_sort) hipLaunchKernelGGL(k_icp_points_fused, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);
     else {
         hipLaunchKernelGGL(k_icp_points<false>, dim3(kIcpStrips, count), dim3(kPtsWG), 0, s, B, W, H, flags);

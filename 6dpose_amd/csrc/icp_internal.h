@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/amd_linemod.h"
 #include "icp_kernels.h"
+#include <vector>
 
 using lm::IcpBuffers;
 using lm::IcpIn;
@@ -19,7 +20,8 @@ struct lm_icp {
     int last_count = 0, last_flags = 0;
     uint16_t* d_scene = nullptr;
     uint16_t* d_models = nullptr;
-    int* d_model_bbox = nullptr;   // [slots][8] bounding box of a resident model depth image (x0, y0, x1, y1, state: 0 = not known yet, -, -, -): icp.hip k_icp_bbox
+    int* d_model_bbox = nullptr;   // [slots][8] bounding box of a resident model depth image (x0, y0, x1, y1, state: 1 = known, -, -, -): worked out at upload (k_icp_model_boxes)
+    std::vector<uint8_t> slot_boxed;   // host view of the state words: 1 = the slot's box was worked out at upload
     IcpIn* d_in = nullptr;
     IcpState* d_st = nullptr;
     IcpBuffers B{};

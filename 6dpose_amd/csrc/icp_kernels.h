@@ -102,6 +102,8 @@ void launch_icp_bind(const TopkSel* sel, const int32_t* nsel_status, const int32
 // clouds it cannot hold comes back with stop == 0 and the caller runs launch_icp_evals(0 .. max_iter + 1) for it.  Otherwise: sliced launches only.
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,
                          double rel_tol, int knn, int solo_from, hipStream_t s);
+// bit 0x100 of launch_icp_pipeline's flags: every model slot the hypotheses use had its box worked out at upload (launch_icp_model_boxes)
+void launch_icp_model_boxes(const uint16_t* models, int* model_bbox, int first_slot, int count, int W, int H, hipStream_t s);
 void launch_icp_evals(const IcpBuffers& B, int count, int it_from, int it_to, double max_dist, int max_iter, double rel_tol, hipStream_t s);
 // the team kernel alone: large == 0 what launch_icp_pipeline launches at its end; large == 1 the builds for more than 704 source points per
 // workgroup, which the caller tries on unfinished hypotheses (stop == 0) before launch_icp_evals

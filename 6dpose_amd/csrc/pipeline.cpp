@@ -161,7 +161,8 @@ extern "C" int lm_pipeline_set_views_rendered(lm_pipeline* p, lm_mesh* m, const 
             return rc;
         HIP_TRY(hipMemcpyAsync(p->icp->d_models + ((size_t)slot0 + c0) * npx, m->d_depth, (size_t)n * npx * sizeof(uint16_t),
                                hipMemcpyDeviceToDevice, m->s));
-        HIP_TRY(hipMemsetAsync(p->icp->d_model_bbox + ((size_t)slot0 + c0) * 8, 0, (size_t)n * 8 * sizeof(int), m->s));   // the boxes of these views are not known any more
+        lm::launch_icp_model_boxes(p->icp->d_models, p->icp->d_model_bbox, slot0 + c0, n, p->W, p->H, m->s);   // the boxes of the new views, once (LL.cpp:43-50)
+        for (int i = 0; i < n; ++i) p->icp->slot_boxed[(size_t)slot0 + c0 + i] = 1;
         HIP_TRY(hipStreamSynchronize(m->s));
     }
     memcpy(&p->view_K[(size_t)slot0 * 9], Ks, (size_t)count * 9 * sizeof(float));
@@ -269,7 +270,8 @@ extern "C" int lm_pipeline_run(lm_pipeline* p, float threshold, const char* cons
         B.scene = d->cur_depth; B.models = c->d_models; B.model_bbox = c->d_model_bbox; B.in = c->d_in; B.st = c->d_st;
         B.count = top_k;
         memcpy(B.sK, scene_K, sizeof(B.sK));
-        launch_icp_pipeline(B, top_k, p->W, p->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, s);
+        // (k_icp_bind only binds views that were uploaded, and both upload paths work out the boxes: 0x100 = no k_icp_bbox)
+        launch_icp_pipeline(B, top_k, p->W, p->H, (flags & 0xFF) | 0x100, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, s);
         HIP_TRY(hipEventRecord(c->e1, s));
         HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, (size_t)top_k * sizeof(IcpState), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(p->h_sel, p->d_sel, (size_t)top_k * sizeof(TopkSel), hipMemcpyDeviceToHost, s));

@@ -91,6 +91,7 @@ int lm_icp_ensure_arenas(lm_icp* c, int count) {
     HIP_TRY(hipMalloc((void**)&B.strip_cnt, (size_t)n * kIcpStrips * 2 * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&B.strip_sum, (size_t)n * kIcpStrips * 8 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.strip_pub, (size_t)n * kIcpStrips * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(B.strip_pub, 0, (size_t)n * kIcpStrips * sizeof(unsigned long long)));                      // (0 = not counted yet; every run leaves them cleared for the next)
     HIP_TRY(hipMalloc((void**)&B.strip_mm, (size_t)n * kIcpStrips * 12 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&B.sort_look, (size_t)n * 2 * lm::kIcpSortGroups * sizeof(unsigned int)));
     HIP_TRY(hipMalloc((void**)&B.tgt_rec, (size_t)n * cap * sizeof(TgtRec)));
@@ -118,6 +119,7 @@ int lm_icp_set_geometry(lm_icp* c, int W, int H) {
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_model_bbox) (void)hipFree(c->d_model_bbox);
     c->d_scene = nullptr; c->d_models = nullptr; c->d_model_bbox = nullptr; c->slots = 0; c->have_scene = false;
+    c->slot_boxed.clear();
     c->W = W; c->H = H;
     HIP_TRY(hipMalloc((void**)&c->d_scene, (size_t)W * H * sizeof(uint16_t)));
     return LM_OK;
@@ -135,11 +137,16 @@ int lm_icp_ensure_slots(lm_icp* c, int slots) {
         (void)hipFree(c->d_models);
     }
     c->d_models = p;
-    if (c->d_model_bbox) (void)hipFree(c->d_model_bbox);
-    c->d_model_bbox = nullptr;
-    HIP_TRY(hipMalloc((void**)&c->d_model_bbox, (size_t)n * 8 * sizeof(int)));
-    HIP_TRY(hipMemset(c->d_model_bbox, 0, (size_t)n * 8 * sizeof(int)));   // (every box is worked out again by the first run that uses its slot)
+    int* boxes = nullptr;
+    HIP_TRY(hipMalloc((void**)&boxes, (size_t)n * 8 * sizeof(int)));
+    HIP_TRY(hipMemset(boxes, 0, (size_t)n * 8 * sizeof(int)));
+    if (c->d_model_bbox) {
+        HIP_TRY(hipMemcpy(boxes, c->d_model_bbox, (size_t)c->slots * 8 * sizeof(int), hipMemcpyDeviceToDevice));
+        (void)hipFree(c->d_model_bbox);
+    }
     HIP_TRY(hipDeviceSynchronize());
+    c->d_model_bbox = boxes;
+    c->slot_boxed.resize((size_t)n, 0);
     c->slots = n;
     return LM_OK;
 }
@@ -247,7 +254,8 @@ extern "C" int lm_icp_set_models(lm_icp* c, int first_slot, int count, const uin
     uint8_t* stage = (uint8_t*)c->pinned + img;
     for (int i = 0; i < count; ++i) memcpy(stage + (size_t)i * img, model_depths[i], img);
     HIP_TRY(hipMemcpyAsync(c->d_models + (size_t)first_slot * c->W * c->H, stage, img * (size_t)count, hipMemcpyHostToDevice, c->s));
-    HIP_TRY(hipMemsetAsync(c->d_model_bbox + (size_t)first_slot * 8, 0, (size_t)count * 8 * sizeof(int), c->s));   // the boxes of these slots are not known any more
+    lm::launch_icp_model_boxes(c->d_models, c->d_model_bbox, first_slot, count, c->W, c->H, c->s);   // the boxes of the new images, once (LL.cpp:43-50)
+    for (int i = 0; i < count; ++i) c->slot_boxed[(size_t)first_slot + i] = 1;
     return LM_OK;
 }
 
@@ -282,7 +290,9 @@ extern "C" int lm_icp_run(lm_icp* c, int count, const int32_t* model_slots, cons
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, (size_t)count * sizeof(IcpIn), hipMemcpyHostToDevice, c->s));
     HIP_TRY(hipMemcpyAsync(c->d_st, c->h_st, (size_t)count * sizeof(IcpState), hipMemcpyHostToDevice, c->s));
     HIP_TRY(hipEventRecord(c->e0, c->s));
-    launch_icp_pipeline(B, count, c->W, c->H, flags, kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, c->s);
+    bool boxed = true;                                               // every slot's box was worked out when its image was uploaded: no k_icp_bbox
+    for (int i = 0; i < count; ++i) boxed = boxed && c->slot_boxed[(size_t)(model_slots ? model_slots[i] : i)] != 0;
+    launch_icp_pipeline(B, count, c->W, c->H, (flags & 0xFF) | (boxed ? 0x100 : 0), kVoxel, kMaxDist, kMaxIter, kRelTol, kKnn, c->solo_from, c->s);
     for (int pass = 0; pass < 3; ++pass) {
         HIP_TRY(hipEventRecord(c->e1, c->s));
         HIP_TRY(hipMemcpyAsync(c->h_st2, c->d_st, (size_t)count * sizeof(IcpState), hipMemcpyDeviceToHost, c->s));
