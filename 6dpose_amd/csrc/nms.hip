@@ -70,41 +70,51 @@ static __device__ __forceinline__ NmsKey unpack_key(const Key128& p, bool canoni
     k.y = (int32_t)((p.lo >> 48) & 0xFFFF) - 32768; k.x = (int32_t)((p.lo >> 32) & 0xFFFF) - 32768; k.slot = (int32_t)(uint32_t)p.lo;
     return k;
 }
-static __device__ __forceinline__ Key128 shfl_key128(const Key128& k, int off) {
+// The larger of a lane's key and the key of the lane a DPP pattern pairs it with; after the four patterns (swap 1, swap 2, mirror of the
+// half row, mirror of the row) every lane holds the maximum of its row of 16.  (Was: six butterfly steps through ds_bpermute, four dwords
+// each — 24 trips through the LDS crossbar per selection, two selections per round of the greedy loop.)
+template <int CTRL>
+static __device__ __forceinline__ Key128 dpp_key128(const Key128& k) {
+    auto mv = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); };
     Key128 o;
-    o.hi = ((unsigned long long)(uint32_t)__shfl_xor((int)(k.hi >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k.hi, off, 64);
-    o.lo = ((unsigned long long)(uint32_t)__shfl_xor((int)(k.lo >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k.lo, off, 64);
+    o.hi = ((unsigned long long)mv((uint32_t)(k.hi >> 32)) << 32) | mv((uint32_t)k.hi);
+    o.lo = ((unsigned long long)mv((uint32_t)(k.lo >> 32)) << 32) | mv((uint32_t)k.lo);
+    return o;
+}
+static __device__ __forceinline__ Key128 row_max_key128(Key128 k) {
+    Key128 o;
+    o = dpp_key128<0xB1>(k); if (key_less(k, o)) k = o;
+    o = dpp_key128<0x4E>(k); if (key_less(k, o)) k = o;
+    o = dpp_key128<0x141>(k); if (key_less(k, o)) k = o;
+    o = dpp_key128<0x140>(k); if (key_less(k, o)) k = o;
+    return k;
+}
+static __device__ __forceinline__ Key128 readlane_key128(const Key128& k, const int l) {
+    auto rl = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
+    Key128 o;
+    o.hi = ((unsigned long long)rl((uint32_t)(k.hi >> 32)) << 32) | rl((uint32_t)k.hi);
+    o.lo = ((unsigned long long)rl((uint32_t)(k.lo >> 32)) << 32) | rl((uint32_t)k.lo);
     return o;
 }
 
-// Workgroup-wide maximum of the packed keys (`valid` = this thread has one); slot < 0 in the result = none.  Wave reduction,
-// the 16 wave results reduced again by the first wave, result broadcast through LDS.
-static __device__ __forceinline__ NmsKey block_select_max(const NmsKey& mine, const bool canonical, Key128* s_keys /*[kNmsWG / 64 + 1]*/) {
+// Workgroup-wide maximum of the packed keys (`valid` = this thread has one); slot < 0 in the result = none.  Rows of 16 lanes by DPP, the four
+// rows of a wave through readlane, the 16 wave results through LDS — every wave reduces them itself, so two barriers do.
+static __device__ __forceinline__ NmsKey block_select_max(const NmsKey& mine, const bool canonical, Key128* s_keys /*[kNmsWG / 64]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Key128 k = pack_key(mine, canonical);
-    bool have = mine.slot >= 0;
+    const bool have = mine.slot >= 0;
     if (!have) { k.hi = 0; k.lo = 0; }
-    // a valid key is never all-zero in lo (slot >= 0 but y + 32768 >= 0 ... ) — validity travels as an extra flag in bit 31 of lo's slot field
-    k.lo = have ? (k.lo | 0x80000000ull) : 0ull;                     // slots are < 2^31: the flag makes every valid key larger than "none"
+    // validity travels as an extra flag in bit 31 of lo's slot field: slots are < 2^31, the flag makes every valid key larger than "none"
+    k.lo = have ? (k.lo | 0x80000000ull) : 0ull;
+    k = row_max_key128(k);
+    Key128 w = readlane_key128(k, 0);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const Key128 o = shfl_key128(k, off);
-        if (key_less(k, o)) k = o;
-    }
+    for (int r = 1; r < 4; ++r) { const Key128 o = readlane_key128(k, 16 * r); if (key_less(w, o)) w = o; }
+    __syncthreads();                                                 // (the previous selection's results have been read)
+    if (lane == 0) s_keys[wave] = w;
     __syncthreads();
-    if (lane == 0) s_keys[wave] = k;
-    __syncthreads();
-    if (wave == 0) {
-        Key128 w = lane < kNmsWG / 64 ? s_keys[lane] : Key128{0, 0};
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const Key128 o = shfl_key128(w, off);
-            if (key_less(w, o)) w = o;
-        }
-        if (lane == 0) s_keys[kNmsWG / 64] = w;
-    }
-    __syncthreads();
-    Key128 best = s_keys[kNmsWG / 64];
+    Key128 best = lane < kNmsWG / 64 ? s_keys[lane] : Key128{0, 0};
+    best = readlane_key128(row_max_key128(best), 0);
     NmsKey r;
     if (!(best.lo & 0x80000000ull)) { r.slot = -1; r.sim = 0; r.tid = r.cls = r.x = r.y = 0; return r; }
     best.lo &= ~0x80000000ull;
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(kNmsWG)
 k_topk_nms(int top_k, double thresh, int4* __restrict__ rec, const uint32_t* __restrict__ ctr, TopkSel* __restrict__ sel,
            int32_t* __restrict__ nsel_status) {
     __shared__ int4 s_rec[kNmsLds];
-    __shared__ Key128 s_keys[kNmsWG / 64 + 1];
+    __shared__ Key128 s_keys[kNmsWG / 64];
     const int tid = threadIdx.x;
     if (ctr[1] == 0) {                                                             // a field does not fit the packed record
         if (tid == 0) { nsel_status[0] = 0; nsel_status[1] = 1; }
