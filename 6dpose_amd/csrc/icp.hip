@@ -285,7 +285,7 @@ k_icp_bbox(IcpBuffers B, int W, int H) {
     if (blockIdx.x == 0 && threadIdx.x < kIcpStrips) B.strip_pub[(size_t)h * kIcpStrips + threadIdx.x] = 0;   // (k_icp_points_fused: the strips' counts, not yet known)
     const int* known = B.model_bbox + (size_t)slot * 8;
     if (known[4] == 1) {
-        if (blockIdx.x == 0 && threadIdx.x < 4) B.st[h].bbox[threadIdx.x] = known[threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x < 4) B.st[h].bbox[threadIdx.x] = threadIdx.x < 2 ? INT_MAX - known[threadIdx.x] : known[threadIdx.x] - 1;
         return;
     }
     const uint16_t* img = B.models + (size_t)slot * W * H;
@@ -322,17 +322,17 @@ k_icp_bbox(IcpBuffers B, int W, int H) {
     }
 }
 
-// k_icp_model_boxes: the same rectangle for resident model images AT UPLOAD (lm_icp_set_models, the pipeline's view upload): a workgroup
-// per image writes model_bbox[slot] = x0, y0, x1, y1, 1.  A run whose slots all came that way does not launch k_icp_bbox at all: reading a
-// 614 KB image per hypothesis and run was 12 us of every run for a fact that changes when the image does.
+// k_icp_model_boxes: the same rectangle for resident model images AT UPLOAD (lm_icp_set_models, the pipeline's view upload): 32 workgroups
+// per image, model_bbox[slot] = INT_MAX - x0, INT_MAX - y0, x1 + 1, y1 + 1 (so that a cleared record is the empty box and every word
+// only grows: atomicMax), state 1.  A run whose slots all came that way does not launch k_icp_bbox at all: reading a 614 KB image per
+// hypothesis and run was 12 us of every run for a fact that changes when the image does.
 __global__ void __launch_bounds__(256)
 k_icp_model_boxes(const uint16_t* __restrict__ models, int* __restrict__ model_bbox, int first_slot, int W, int H) {
-    __shared__ int s_box[4][4];
-    const int slot = first_slot + (int)blockIdx.x;
+    const int slot = first_slot + (int)blockIdx.y;
     const uint16_t* img = models + (size_t)slot * W * H;
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
     const bool vec = (W & 7) == 0;
-    for (int y = 0; y < H; ++y) {
+    for (int y = blockIdx.x; y < H; y += gridDim.x) {
         const uint16_t* row = img + (size_t)y * W;
         for (int x = threadIdx.x * 8; x < W; x += 256 * 8) {
             uint16_t px[8];
@@ -357,17 +357,17 @@ k_icp_model_boxes(const uint16_t* __restrict__ models, int* __restrict__ model_b
         x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
         x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { x0 = min(x0, s_box[w][0]); y0 = min(y0, s_box[w][1]); x1 = max(x1, s_box[w][2]); y1 = max(y1, s_box[w][3]); }
-        int* known = model_bbox + (size_t)slot * 8;
-        known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; known[4] = 1;
+    int* known = model_bbox + (size_t)slot * 8;
+    if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+        atomicMax(&known[0], INT_MAX - x0); atomicMax(&known[1], INT_MAX - y0); atomicMax(&known[2], x1 + 1); atomicMax(&known[3], y1 + 1);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) known[4] = 1;        // (read by the kernels of a later launch)
 }
 
 void launch_icp_model_boxes(const uint16_t* models, int* model_bbox, int first_slot, int count, int W, int H, hipStream_t s) {
-    if (count > 0) hipLaunchKernelGGL(k_icp_model_boxes, dim3(count), dim3(256), 0, s, models, model_bbox, first_slot, W, H);
+    if (count <= 0) return;
+    (void)hipMemsetAsync(model_bbox + (size_t)first_slot * 8, 0, (size_t)count * 8 * sizeof(int), s);
+    hipLaunchKernelGGL(k_icp_model_boxes, dim3(32, count), dim3(256), 0, s, models, model_bbox, first_slot, W, H);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,7 +394,7 @@ k_icp_points(IcpBuffers B, int W, int H, int flags) {
     const int x0 = S.bbox[0], y0 = S.bbox[1], x1 = S.bbox[2], y1 = S.bbox[3];
     if (!kWrite && strip == 0 && tid == 0) {                       // k_icp_bbox is through: the box of this image is known from now on
         int* known = B.model_bbox + (size_t)B.in[h].model_slot * 8;
-        if (known[4] == 0) { known[0] = x0; known[1] = y0; known[2] = x1; known[3] = y1; __threadfence(); known[4] = 1; }
+        if (known[4] == 0) { known[0] = INT_MAX - x0; known[1] = INT_MAX - y0; known[2] = x1 + 1; known[3] = y1 + 1; __threadfence(); known[4] = 1; }
     }
     if (x1 < 0) {                                                  // pass 1 never gets here: pass 0 set the status
         if (strip == 0 && tid == 0) { S.status = 2; S.n_model = 0; S.n_scene = 0; }
@@ -556,10 +556,11 @@ k_icp_points_fused(IcpBuffers B, int W, int H, int flags) {
     // the box of the model image: worked out when the image was uploaded (k_icp_model_boxes), else by k_icp_bbox of this run
     const int* known = B.model_bbox + (size_t)I.model_slot * 8;
     const bool boxed = known[4] == 1;
-    const int x0 = boxed ? known[0] : S.bbox[0], y0 = boxed ? known[1] : S.bbox[1], x1 = boxed ? known[2] : S.bbox[2], y1 = boxed ? known[3] : S.bbox[3];
+    const int x0 = boxed ? INT_MAX - known[0] : S.bbox[0], y0 = boxed ? INT_MAX - known[1] : S.bbox[1], x1 = boxed ? known[2] - 1 : S.bbox[2],
+              y1 = boxed ? known[3] - 1 : S.bbox[3];
     if (strip == 0 && tid == 0 && !boxed) {                        // (k_icp_bbox is through: known from now on)
         int* kn = B.model_bbox + (size_t)I.model_slot * 8;
-        kn[0] = x0; kn[1] = y0; kn[2] = x1; kn[3] = y1; __threadfence(); kn[4] = 1;
+        kn[0] = INT_MAX - x0; kn[1] = INT_MAX - y0; kn[2] = x1 + 1; kn[3] = y1 + 1; __threadfence(); kn[4] = 1;
     }
     if (strip == 0 && tid < 2 * kIcpSortGroups) B.sort_look[(size_t)h * 2 * kIcpSortGroups + tid] = 0;   // (k_icp_voxel_wide: voxel counts of the groups, not yet known)
     if (x1 < 0) {

@@ -64,7 +64,7 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
 struct IcpBuffers {
     const uint16_t* scene;   // [H][W]
     const uint16_t* models;  // [slots][H][W]
-    int* model_bbox;         // [slots][8] x0, y0, x1, y1 of modelDepth > 0 and a state word (0: not known; set by the first run that uses the slot, cleared by the host when the image changes)
+    int* model_bbox;         // [slots][8] box of modelDepth > 0 of a resident image as INT_MAX - x0, INT_MAX - y0, x1 + 1, y1 + 1 (all zero = empty) and a state word (1: known; worked out at upload by k_icp_model_boxes, or by the first run that uses the slot)
     const IcpIn* in;         // [count]
     IcpState* st;            // [count]
     float sK[9];             // scene camera matrix
