@@ -1401,6 +1401,89 @@ def test_icp_large_clouds_take_the_global_sort_path(lm, half_w, half_h):
     ctx.close()
 
 
+_ICP_PATHS_SCRIPT = r"""
+import sys, json, os
+import numpy as np
+root = sys.argv[1]
+sys.path[:0] = [root, os.path.join(root, "6dpose_amd"), os.path.join(root, "tests")]
+import synth, linemodLevelup_pybind as mod
+K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1], np.float32)
+rng = np.random.default_rng(3)
+base = synth.synth_model_depth(41)
+scene = np.where(base > 0, base + 3, 0).astype(np.uint16)
+scene = np.where(scene > 0, scene + rng.integers(-1, 2, scene.shape), 0).astype(np.uint16)
+mds, xy = [], []
+for h in range(6):
+    md = synth.synth_model_depth(41 + h % 3)
+    ys, xs = np.nonzero(md)
+    mds.append(md); xy.append((int(xs.min()) + h % 2, int(ys.min()) - h % 2))
+n = len(mds)
+Ks = np.tile(K.reshape(1, 9), (n, 1)); Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1)); ts = np.tile(np.array([[0, 0, 1000]], np.float32), (n, 1))
+ctx = mod.IcpContext(device=0, scene_from_scene=True)
+ctx.set_scene(scene, K); ctx.set_models(mds)
+res, _ = ctx.run(Ks, Rs, ts, xy)
+res2, _ = ctx.run(Ks, Rs, ts, xy)
+out = {"R": [r["R"].tolist() for r in res], "t": [r["t"].tolist() for r in res], "it": [int(r["iterations"]) for r in res],
+       "again": all(np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) for a, b in zip(res, res2)),
+       "src": [ctx.read_debug(h, 0).tolist() for h in range(2)], "tgt": [ctx.read_debug(h, 1).tolist() for h in range(2)]}
+ctx.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_icp_preparation_paths_agree(lm, tmp_path):
+    """The round-6 preparation (voxel down-sampling and search grid by eight workgroups per cloud, one point launch, boxes at upload) against the
+    kernels of rounds 2-5 (`LM_ICP_WIDE_SORT=0`: one workgroup per cloud, two point launches, k_icp_bbox per run), each in its own process (the
+    knob is read once): the down-sampled clouds are equal bit for bit, the poses to rounding (the search grid of the new path spans the
+    extent of the cloud the target was down-sampled from, so the neighbour sums of the normals add up in another order), the iteration
+    counts are equal, and a run repeats itself bit for bit on either path."""
+    import subprocess, sys, json
+    script = tmp_path / "icp_paths.py"
+    script.write_text(_ICP_PATHS_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for wide in ("1", "0"):
+        env = dict(os.environ, LM_ICP_WIDE_SORT=wide)
+        r = subprocess.run([sys.executable, str(script), root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+        text = r.stdout.decode()
+        assert r.returncode == 0, text[-2000:]
+        outs.append(json.loads([l for l in text.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    a, b = outs
+    assert a["again"] and b["again"]
+    assert a["it"] == b["it"] and max(a["it"]) > 5
+    for h in range(2):
+        assert np.array_equal(np.array(a["src"][h]), np.array(b["src"][h])) and np.array_equal(np.array(a["tgt"][h]), np.array(b["tgt"][h]))
+    assert np.abs(np.array(a["R"]) - np.array(b["R"])).max() < 1e-9 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-6
+
+
+def test_icp_more_hypotheses_than_the_kernel_deals_out(lm):
+    """More than 64 hypotheses: k_icp_team runs on a fixed grid (a team of cus / count workgroups per hypothesis, here three) instead of dealing
+    the workgroups out by cloud size, and its builds with two and five source points per thread take the hypotheses a workgroup of which
+    holds more than 704 points.  The poses must equal those of the same hypotheses run in batches of eight (teams of 16+)."""
+    import linemodLevelup_pybind as mod
+    base = synth.synth_model_depth(50)
+    scene = _perturbed_scene(base, K_CAM.astype(np.float64), 1.0, (1.5, -1.0, 2.0), 50)
+    mds = [synth.synth_model_depth(50 + s) for s in range(4)]
+    n = 72
+    slots = [h % 4 for h in range(n)]
+    xy = []
+    for h in range(n):
+        ys, xs = np.nonzero(mds[slots[h]])
+        xy.append((int(xs.min()) + (h % 5) - 2, int(ys.min()) + (h % 3) - 1))
+    Ks = np.tile(K_CAM.reshape(1, 9), (n, 1)); Rs = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    ts = np.tile(np.array([[0, 0, 1000]], np.float32), (n, 1))
+    ctx = mod.IcpContext(device=0, scene_from_scene=True)
+    ctx.set_scene(scene, K_CAM)
+    ctx.set_models(mds)
+    got, _ = ctx.run(Ks, Rs, ts, xy, model_slots=slots)
+    for b in range(0, n, 8):
+        want, _ = ctx.run(Ks[b:b + 8], Rs[b:b + 8], ts[b:b + 8], xy[b:b + 8], model_slots=slots[b:b + 8])
+        for g, w in zip(got[b:b + 8], want):
+            assert g["iterations"] == w["iterations"] and g["n_source"] == w["n_source"] and g["n_target"] == w["n_target"]
+            assert np.abs(g["R"] - w["R"]).max() < 1e-10 and np.abs(g["t"] - w["t"]).max() < 1e-7
+    ctx.close()
+
+
 def test_icp_context_slots_shared_by_hypotheses(lm):
     """Hypotheses may share a resident model slot; results equal the one-image-per-hypothesis batch call."""
     import linemodLevelup_pybind as mod

@@ -323,3 +323,22 @@ def test_magic_division_with_one_correction_is_exact():
     for d in (3, 5, 7, 160, 19200, 65535, 1 << 20):
         wrong_without_correction |= check(rng.integers(0, 1 << 31, 200000), d)
     assert wrong_without_correction, "the cases must include some the uncorrected product gets wrong"
+
+
+def test_floor_of_a_quotient_without_the_division():
+    """k_icp_voxel_wide (csrc/icp.hip, floor_quotient) takes floor(a / v) from a * (1 / v) wherever the fraction of that product is further than
+    1e-6 from an integer and divides only otherwise: the two floors must agree on every value the shortcut accepts — voxel indices of points
+    up to a few metres from the cloud's corner at the reference's 2.5 mm voxels and at sizes around it, including quotients that sit exactly
+    on and next to integers."""
+    rng = np.random.default_rng(11)
+    for v in (0.0025, 0.002, 0.005, 0.0031, 1.0 / 3.0):
+        inv = 1.0 / v
+        a = np.concatenate([rng.uniform(0.0, 4.0, 400000), np.arange(0, 2000) * v, np.nextafter(np.arange(1, 2000) * v, 0.0), np.nextafter(np.arange(1, 2000) * v, 10.0),
+                            rng.integers(0, 1600, 100000) * v + rng.uniform(-1e-12, 1e-12, 100000)])
+        a = a[a >= 0]
+        q = a * inv
+        f = np.floor(q)
+        d = q - f
+        accepted = (d > 1e-6) & (d < 1.0 - 1e-6)
+        assert accepted[:400000].mean() > 0.99                               # (the random points; the rest are the constructed boundary cases)
+        assert np.array_equal(f[accepted], np.floor(a[accepted] / v))
