@@ -2669,9 +2669,25 @@ static __device__ __forceinline__ void solo_accumulate(double (&acc)[16], const 
     }
 }
 
+// Workgroups of a hypothesis of w source points when `extra` workgroups beyond one each are dealt out in proportion to the points (total = all
+// points still at work): never more than one per min_points points (knobs: icp_team_min_points) — below that another member costs the team more (it gathers one
+// more row of sums every evaluation) than it saves (the searches of a member are already a fraction of its evaluation).
+static __device__ __forceinline__ int team_members(const int w, const long long total, const int extra, const int min_points) {
+    int m = 1 + (int)((long long)extra * w / total);
+    const int cap = (w + min_points - 1) / min_points;
+    m = m > cap ? cap : m;
+    m = m > kIcpMaxSplit ? kIcpMaxSplit : m;
+    return m < 1 ? 1 : m;
+}
+
+// a target cloud that does not fit the LDS whole (with its normals): the slab build takes the hypothesis
+static __device__ __forceinline__ bool team_needs_slab(const int n_tgt, const int gx, const int gy) {
+    return n_tgt > ((kSoloRaw - ((2 * (gx * gy + 1) + 15) & ~15) - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3);
+}
+
 template <int KP, bool SLAB>     // source points per owner thread (in registers); a slab of the target cloud in LDS, not all of it
 __global__ void __launch_bounds__(kSoloWG)
-k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int max_iter, double rel_tol) {
+k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int max_iter, double rel_tol, int cut_index, int min_points) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kSoloRaw];
     __shared__ double s_part[kSoloWG / 64][32];
     __shared__ double s_U[12];
@@ -2681,8 +2697,10 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     __shared__ int s_cnt[kClasses];
     __shared__ int s_stop, s_fin_i[2];
     __shared__ int s_slab[5], s_ext[2];                          // the x columns staged [lo, hi], first target and number of targets staged, overflow; the columns this evaluation needs
+    __shared__ int s_it0, s_cut_at;                              // the evaluation index this launch starts the hypothesis at (> 0: resumed) and the one it is cut after (0: none) — here, not in registers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int h = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    int cut_at = 0;                                             // evaluation index after whose finish stage the hypotheses still at work leave the launch (0: none)
     if (gridDim.y == 1 && B.count <= 64) {
         // One-dimensional grid (up to 64 hypotheses): the workgroups are dealt out to the hypotheses still to do in proportion to their source
         // points — a cloud of 10000 points next to one of 1500 gets seven times the members; with equal teams the large one sets the length
@@ -2693,7 +2711,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
             const IcpState& T = B.st[lane];
             if (T.status == 0 && T.stop == 0) {
                 w = T.n_src > 0 ? T.n_src : 1;
-                big = T.n_tgt > ((kSoloRaw - ((2 * (T.gx * T.gy + 1) + 15) & ~15) - kSoloMinQueue * (int)sizeof(SoloQ)) / 60 & ~3);
+                big = team_needs_slab(T.n_tgt, T.gx, T.gy);
             }
         }
         const int ncand = __popcll(__ballot(w > 0));
@@ -2705,8 +2723,13 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
         const int extra = (int)gridDim.x - ncand;
-        int members = w > 0 ? 1 + (int)((long long)extra * w / total) : 0;
-        members = members > kIcpMaxSplit ? kIcpMaxSplit : members;
+        const int members = w > 0 ? team_members(w, total, extra, min_points) : 0;
+        // cramped: the hypotheses could use half as many workgroups again as there are (one per min_points source points each)
+        int want = w > 0 ? (w + min_points - 1) / min_points : 0;
+        want = want > kIcpMaxSplit ? kIcpMaxSplit : want;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) want += __shfl_xor(want, off, 64);
+        if (cut_index > 0 && 2 * want >= 3 * (int)gridDim.x) cut_at = cut_index;
         int incl = members;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
@@ -2721,6 +2744,8 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     if (S.status != 0 || S.stop != 0) return;
     const int ns = S.n_src, nt = S.n_tgt;
     const int gx = S.gx, gy = S.gy, zq_max = S.zq_max, ncell = gx * gy;
+    const int it0 = S.resume_it;                                 // > 0: suspended by an earlier launch of the round after the finish stage of this evaluation index
+    if (g == 0 && tid == 0) S.team_size = G;                       // (diagnostics)
     // (every member of the team takes the same decision: it depends on the hypothesis only)
     if ((ns + G - 1) / G > kSoloOwners * KP || nt > 65535 || ncell > kIcpCells - 1 || gx > 255 || gy > 255) {
         if (g == 0 && tid == 0) { S.team_note[0] = (ns + G - 1) / G > kSoloOwners * KP ? 1 : 2; S.team_note[1] = ns; S.team_note[2] = nt; S.team_note[3] = KP; }
@@ -2777,7 +2802,12 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     float lbf[KP];                                          // A at the last search + the bound that search left (every target other than prv is farther), rounded down
     {
         const double* Src = B.src + (size_t)h * B.cap * 3;
-        const double i0 = S.init[0], i1 = S.init[1], i2 = S.init[2];
+        // (a hypothesis an earlier launch of the round suspended goes on from the transformation it had reached: launch_icp_team)
+        double T0[12] = {1.0, 0.0, 0.0, S.init[0], 0.0, 1.0, 0.0, S.init[1], 0.0, 0.0, 1.0, S.init[2]};
+        if (it0 > 0) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) T0[a] = S.T[a];
+        }
         double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
@@ -2785,9 +2815,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
             px[k] = 0; py[k] = 0; pz[k] = 0; prv[k] = -1; lbf[k] = 0.f;
             if (o >= 0 && i < i_hi) {                              // pcd.Transform(init_guess)
                 const double x = Src[3 * (size_t)i], y = Src[3 * (size_t)i + 1], z = Src[3 * (size_t)i + 2];
-                px[k] = 1.0 * x + 0.0 * y + 0.0 * z + i0;
-                py[k] = 0.0 * x + 1.0 * y + 0.0 * z + i1;
-                pz[k] = 0.0 * x + 0.0 * y + 1.0 * z + i2;
+                px[k] = T0[0] * x + T0[1] * y + T0[2] * z + T0[3];
+                py[k] = T0[4] * x + T0[5] * y + T0[6] * z + T0[7];
+                pz[k] = T0[8] * x + T0[9] * y + T0[10] * z + T0[11];
                 mn[0] = fmin(mn[0], px[k]); mn[1] = fmin(mn[1], py[k]); mn[2] = fmin(mn[2], pz[k]);
                 mx[0] = fmax(mx[0], px[k]); mx[1] = fmax(mx[1], py[k]); mx[2] = fmax(mx[2], pz[k]);
             }
@@ -2802,9 +2832,9 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
             for (int q = 0; q < 3; ++q) { s_part[wave][q] = mn[q]; s_part[wave][3 + q] = mx[q]; }
         }
     }
-    if (tid < 12) s_T[tid] = tid % 5 == 0 ? 1.0 : tid == 3 ? S.init[0] : tid == 7 ? S.init[1] : tid == 11 ? S.init[2] : 0.0;
-    if (tid < 4) s_hist[tid] = 0.0;
-    if (tid < 2) { s_fin[tid] = 0.0; s_fin_i[tid] = 0; }
+    if (tid < 12) s_T[tid] = it0 > 0 ? S.T[tid] : tid % 5 == 0 ? 1.0 : tid == 3 ? S.init[0] : tid == 7 ? S.init[1] : tid == 11 ? S.init[2] : 0.0;
+    if (tid < 4) s_hist[tid] = it0 > 0 ? (tid < 2 ? S.fit_hist[tid] : S.rmse_hist[tid - 2]) : 0.0;
+    if (tid < 2) { s_fin[tid] = 0.0; s_fin_i[tid] = tid == 1 ? it0 : 0; }
     if (tid < 7) s_clk[tid] = 0;
     __syncthreads();
     if (tid == 0) {
@@ -2821,10 +2851,12 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
     }
     __syncthreads();
 
-    for (int it = 0;; ++it) {
+    if (tid == 0) { s_it0 = it0; s_cut_at = cut_at; }      // (visible after the barrier above the loop... the one below)
+    __syncthreads();
+    for (int it = s_it0;; ++it) {
         const long long ta = (long long)__builtin_amdgcn_s_memtime();
         // ---- finish evaluation it - 1: totals, Open3D's convergence test, ComputeTransformation, transformation = update * transformation ----
-        if (it > 0) {
+        if (it > s_it0) {
             if (wave == 0) {
                 // this workgroup's sums -> all-gather over the team -> the totals, added in workgroup order by every member
                 // (added as a tree: a chain of eleven dependent f64 additions is 440 cycles for a lone wave, four levels are 160; fixed order all the same)
@@ -2900,9 +2932,15 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
                 if (it > 1 && fabs(fit2 - fit) < rel_tol && fabs(rmse2 - rmse) < rel_tol) stop = true;
                 if (it - 1 == max_iter) stop = true;
                 const bool team_over = readlane_d(v, 29) > 0.0;
+                // The launch is CUT here for a batch that is cramped (launch_icp_team): most hypotheses of such a batch converge within a couple of
+                // evaluations and their workgroups would idle while the ones that go on keep the small team they were dealt.  Every hypothesis
+                // still at work after the finish stage of evaluation index `cut_at` leaves the launch (transformation, the last two fitness /
+                // rmse values and the count go to IcpState) and the next launch deals the chip out among those.  The rule depends on the sizes
+                // of the clouds and on the evaluation index only — not on which team is how far at the time —, so a run repeats itself.
+                const bool team_cut = it == s_cut_at;          // (0: never — the finish stage runs from index 1 on)
                 const long long f3 = (long long)__builtin_amdgcn_s_memtime() + (stop ? 1 : 0);
                 if (lane == 0) {
-                    s_stop = timed_out || team_over ? 2 : stop ? 1 : 0;
+                    s_stop = timed_out || team_over ? 2 : stop ? 1 : team_cut ? 3 : 0;
                     s_ext[0] = INT_MAX; s_ext[1] = -1;
                     s_hist[(it - 1) & 1] = fit; s_hist[2 + ((it - 1) & 1)] = rmse;
                     s_fin[0] = fit; s_fin[1] = rmse; s_fin_i[0] = ncorr;
@@ -2953,7 +2991,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         auto sep_at = [&](const int j) -> double { if (!SLAB) return (double)s_sep[j]; if (__builtin_expect(in_lds, 1)) return (double)s_sep[j - p0]; return g_cov[(size_t)j * kIcpCovStride + 10]; };
         {
             double U[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-            if (it > 0) {
+            if (it > s_it0) {
 #pragma unroll
                 for (int a = 0; a < 12; ++a) U[a] = s_U[a];
             }
@@ -2964,7 +3002,7 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
 #pragma unroll
                 for (int r = 0; r < 8; ++r) rows[k][r] = 0;
                 if (o < 0 || i_lo + o + k * kSoloOwners >= i_hi) continue;
-                if (it > 0) {
+                if (it > s_it0) {
                     const double x = px[k], y = py[k], z = pz[k];
                     px[k] = U[0] * x + U[1] * y + U[2] * z + U[3];
                     py[k] = U[4] * x + U[5] * y + U[6] * z + U[7];
@@ -3377,6 +3415,16 @@ k_icp_team(IcpBuffers B, unsigned int run, int shift_floor, double max_dist, int
         for (int a = 0; a < 7; ++a) row[a] = (double)s_clk[a];
         row[7] = (double)((long long)__builtin_amdgcn_s_memtime() - t_begin);
     }
+    if (s_stop == 3) {                                          // suspended: the next launch of the round goes on from here (every member holds the same state)
+        if (g == 0 && tid < 12) S.T[tid] = s_T[tid];
+        if (g == 0 && tid == 0) {
+            S.fit_hist[0] = s_hist[0]; S.fit_hist[1] = s_hist[1]; S.rmse_hist[0] = s_hist[2]; S.rmse_hist[1] = s_hist[3];
+            S.resume_it = s_fin_i[1];                              // (the evaluation index of this finish stage)
+            S.clk[0] += s_clk[0]; S.clk[1] += s_clk[1]; S.clk[2] += (long long)__builtin_amdgcn_s_memtime() - t_begin; S.clk[3] += s_clk[2]; S.clk[4] += s_clk[3];
+            S.clk[5] += s_clk[5]; S.clk[6] += s_clk[4]; S.clk[7] += s_clk[6];
+        }
+        return;
+    }
     if (tid == 0 && g == 0 && s_stop != 2) {                    // (a team that timed out leaves stop == 0: the host runs the sliced launches)
         for (int a = 0; a < 12; ++a) S.T[a] = s_T[a];
         S.T[12] = 0.0; S.T[13] = 0.0; S.T[14] = 0.0; S.T[15] = 1.0;
@@ -3481,16 +3529,31 @@ void launch_icp_team(const IcpBuffers& B, int count, int large, double max_dist,
     if (team > kIcpMaxSplit) team = kIcpMaxSplit;
     if (team < 1) team = 1;
     static std::atomic<unsigned int> runs{0};                         // tags of the team's granules (see k_icp_team): unique per launch of the process, 0 = never published
-    unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
-    if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
     const bool dealt = count <= 64 && kn.icp_team == 0;              // (<= 64 hypotheses: the kernel deals the workgroups out itself, by cloud size)
     const dim3 grid = dealt ? dim3(cus) : dim3(team, count);
     int builds = kn.icp_builds > 0 ? kn.icp_builds : (dealt ? (large ? 4 | 8 : 1 | 2) : (large ? 0 : 1 | 2 | 4 | (team < 4 ? 8 : 0)));
     if (kn.icp_builds > 0 && large) builds = 0;
-    if (builds & 1) hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 2) hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 4) hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
-    if (builds & 8) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol);
+    // A SECOND LAUNCH for a cramped batch (dealt grids): most hypotheses of a batch converge within a couple of evaluations and their
+    // workgroups then idle while the ones that go on for all 30 keep the team they were dealt at the start (the pipeline's 16 detections: 12
+    // done after two evaluations, the launch as long as 31 evaluations of a hypothesis on 8 workgroups).  When the clouds of a batch could
+    // use half as many workgroups again as the chip has, the first launch ends after evaluation kn.icp_cut_index for everyone still at work
+    // (k_icp_team: the state goes to IcpState) and the second — the slab build alone, which holds whole clouds too — deals the chip out
+    // among those and runs them to the end; it costs ~3 us when the batch was not cramped.  Same arithmetic, the sums of an evaluation
+    // grouped by the new team size (rounding); the rule looks at cloud sizes and evaluation indices only, so a run repeats itself bit for bit.
+    const int relaunch = dealt && !large && kn.icp_builds == 0 ? kn.icp_relaunch : 0;
+    for (int ph = 0; ph <= relaunch; ++ph) {
+        unsigned int run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+        if (run == 0) run = (runs.fetch_add(1) + 1) & 0x3FFFFFFu;
+        const int allow = ph < relaunch ? kn.icp_cut_index * (ph + 1) * (ph + 1) : 0, b = ph == 0 ? builds : 2;   // (cut indices 3, 12, 27 ...)
+        if ((b & 3) == 3) {
+            hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+            hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+        }
+        else if (b & 1) hipLaunchKernelGGL((k_icp_team<1, false>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+        else if (b & 2) hipLaunchKernelGGL((k_icp_team<1, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+        if (b & 4) hipLaunchKernelGGL((k_icp_team<2, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+        if (b & 8) hipLaunchKernelGGL((k_icp_team<5, true>), grid, dim3(kSoloWG), 0, s, B, run, kn.icp_maxshift, max_dist, max_iter, rel_tol, allow, kn.icp_team_min_points);
+    }
 }
 
 void launch_icp_pipeline(const IcpBuffers& B, int count, int W, int H, int flags, double voxel, double max_dist, int max_iter,

@@ -53,7 +53,8 @@ struct IcpState {            // one pose hypothesis (device-written, downloaded 
     double fit_hist[2], rmse_hist[2];   // fitness / rmse of the last two evaluations, slot = evaluation parity
     int vox_done[2];         // groups of k_icp_voxel_wide that finished the model / scene cloud (kIcpSortGroups: k_icp_voxel has nothing to do)
     int grid_done;           // the same for k_icp_grid_wide / k_icp_grid
-    int pad_done;
+    int team_size;           // k_icp_team: workgroups at work on the hypothesis in the current launch
+    int resume_it;           // k_icp_team: > 0 = the hypothesis was suspended after the finish stage of this evaluation index (T, fit_hist, rmse_hist hold what the next launch goes on from)
     int team_note[4];        // k_icp_team left the hypothesis to the sliced launches: reason (1 source slice too large, 2 grid, 3 slab overflow: + member, targets needed, capacity; 4 time-out), else 0
     long long vox_clk[4];    // k_icp_voxel diagnostics (model cloud): cycles for the extent, the keys, the sort, the voxel means
     long long sort_clk[16];  // k_icp_voxel_wide (0-7, model cloud) / k_icp_grid_wide (8-15) diagnostics, slowest group per phase: cycles for picking its points, the sort, (voxels: count + wait for the groups before), writing, (grid: the column table); 6 / 13: largest group

@@ -32,6 +32,9 @@ struct Knobs {
     int icp_team = 0;              // LM_ICP_TEAM: workgroups per hypothesis of k_icp_team (0 = default: 16, at most CUs / hypotheses)
     int icp_builds = 0;            // LM_ICP_BUILDS: which builds of k_icp_team are launched, in this order (bits: 1 = one point per thread, whole cloud only; 2 = one point, slab;
                                    // 4 = two points, slab; 8 = five points, slab; 0 = default 1 | 2 | 4, and 8 for batches whose teams are under four workgroups)
+    int icp_team_min_points = 128; // LM_ICP_TEAM_MIN_POINTS: a hypothesis is never dealt more than one workgroup per this many source points
+    int icp_cut_index = 3;         // LM_ICP_CUT_INDEX: the evaluation index after which a cramped batch leaves k_icp_team's first launch
+    int icp_relaunch = 1;          // LM_ICP_RELAUNCH=0: k_icp_team as one launch; n: up to n more launches for hypotheses the teams suspend to have the chip dealt out again
     int icp_wide_sort = 1;         // LM_ICP_WIDE_SORT=0: voxel down-sampling and the search grid by one workgroup per cloud (k_icp_voxel / k_icp_grid alone), as before round 6
     int icp_maxshift = 3;          // LM_ICP_MAXSHIFT / _LATE: log2 lanes per searching point, early / late evaluations
     int icp_maxshift_late = 4;
@@ -65,6 +68,10 @@ inline const Knobs& knobs() {
         v.icp_team = geti("LM_ICP_TEAM", 0);
         v.icp_builds = geti("LM_ICP_BUILDS", 0);
         v.icp_wide_sort = geti("LM_ICP_WIDE_SORT", 1);
+        v.icp_relaunch = geti("LM_ICP_RELAUNCH", 1);
+        v.icp_cut_index = geti("LM_ICP_CUT_INDEX", 3);
+        v.icp_team_min_points = geti("LM_ICP_TEAM_MIN_POINTS", 128);
+        if (v.icp_team_min_points < 1) v.icp_team_min_points = 1;
         v.icp_maxshift = geti("LM_ICP_MAXSHIFT", v.icp_maxshift);
         v.icp_maxshift_late = geti("LM_ICP_MAXSHIFT_LATE", v.icp_maxshift_late);
 #ifdef LM_DIAG

@@ -370,6 +370,7 @@ extern "C" int64_t lm_icp_read_debug(lm_icp* c, int hypothesis, int kind, double
             for (int k = 0; k < 4; ++k) tmp.push_back((double)st.vox_clk[k]);
             tmp.push_back((double)st.n_model); tmp.push_back((double)st.n_scene);
             for (int k = 0; k < 16; ++k) tmp.push_back((double)st.sort_clk[k]);
+            tmp.push_back((double)st.team_size); tmp.push_back((double)st.resume_it);
             n = (int64_t)tmp.size();
             break;
         }
