@@ -1456,15 +1456,18 @@ def test_icp_preparation_paths_agree(lm, tmp_path):
     assert np.abs(np.array(a["R"]) - np.array(b["R"])).max() < 1e-9 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-6
 
 
-def test_icp_more_hypotheses_than_the_kernel_deals_out(lm):
-    """More than 64 hypotheses: k_icp_team runs on a fixed grid (a team of cus / count workgroups per hypothesis, here three) instead of dealing
-    the workgroups out by cloud size, and its builds with two and five source points per thread take the hypotheses a workgroup of which
-    holds more than 704 points.  The poses must equal those of the same hypotheses run in batches of eight (teams of 16+)."""
+@pytest.mark.parametrize("n", [72, 40])
+def test_icp_more_hypotheses_than_the_kernel_deals_out(lm, n):
+    """72 hypotheses (more than 64): k_icp_team runs on a fixed grid (a team of cus / count workgroups per hypothesis, here three) instead of
+    dealing the workgroups out by cloud size, and its builds with two and five source points per thread take the hypotheses a workgroup of
+    which holds more than 704 points.  40 hypotheses of ~2k points: a CRAMPED batch (its clouds could use 40 x 17 workgroups, the chip has
+    256), which leaves the first launch after evaluation 3; the second launch deals the chip out among the hypotheses still at work and goes
+    on from the state they left in IcpState.  Either way the poses must equal those of the same hypotheses run in batches of eight (teams
+    of 16+, one launch), and a run must repeat itself bit for bit."""
     import linemodLevelup_pybind as mod
     base = synth.synth_model_depth(50)
     scene = _perturbed_scene(base, K_CAM.astype(np.float64), 1.0, (1.5, -1.0, 2.0), 50)
     mds = [synth.synth_model_depth(50 + s) for s in range(4)]
-    n = 72
     slots = [h % 4 for h in range(n)]
     xy = []
     for h in range(n):
@@ -1476,6 +1479,9 @@ def test_icp_more_hypotheses_than_the_kernel_deals_out(lm):
     ctx.set_scene(scene, K_CAM)
     ctx.set_models(mds)
     got, _ = ctx.run(Ks, Rs, ts, xy, model_slots=slots)
+    again, _ = ctx.run(Ks, Rs, ts, xy, model_slots=slots)
+    assert all(np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and a["iterations"] == b["iterations"] for a, b in zip(got, again))
+    assert max(g["iterations"] for g in got) > 6                  # (some hypotheses go on well beyond the cut)
     for b in range(0, n, 8):
         want, _ = ctx.run(Ks[b:b + 8], Rs[b:b + 8], ts[b:b + 8], xy[b:b + 8], model_slots=slots[b:b + 8])
         for g, w in zip(got[b:b + 8], want):
