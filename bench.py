@@ -559,8 +559,9 @@ def main():
                                                      "search a grid and execute a small fraction of them)"},
                 "what_binds": "neither: the chain of DEPENDENT f64 operations of a single wave - a dependent f64 op costs a lone wave ~40 cycles on gfx950, an "
                               "LDS read 70, a permute 78 (profiles/r06_latency_microbench.txt) - through 31 evaluations of the hypotheses that never converge: "
-                              "k_icp_team (one launch, a team of workgroups per hypothesis, clouds in LDS and registers) spends ~17 us per evaluation on "
-                              "exchange, 6x6 solve, transform + certification, search sweep and sums (profiles/r06_icp_*)",
+                              "k_icp_team (a team of workgroups per hypothesis, clouds in LDS and registers; one launch, two for a batch whose clouds could use "
+                              "more workgroups than the chip has) spends ~17 us per evaluation on exchange, 6x6 solve, transform + certification, search "
+                              "sweep and sums (profiles/r06_icp_*)",
                 "pipeline_leg": {"icp_ms": pl["icp_ms"], "iterations": pl["icp_iterations"],
                                  "achieved": (sum(i * (a * 24 + b * 48) for i, a, b in zip(pl["iterations"], pl["points_source"], pl["points_target"])) / (pl["icp_ms"] * 1e-3) / 1e9) if pl["icp_ms"] > 0 else 0.0,
                                  "unit": "GB/s"}}
